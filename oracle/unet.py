@@ -1,0 +1,659 @@
+"""CPU oracle: pure-PyTorch restatement of the SVD spatio-temporal UNet.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package (`svd_xtend_amd/`) may import this
+module; only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg use it, and
+only as the checker.
+
+PARITY UNPINNED.  The arithmetic of this path lives in `diffusers` (un-vendored, un-pinned:
+`check_min_version("0.24.0.dev0")` /root/reference/train_svd.py:59, `"0.29.1"`
+/root/reference/train_svd_lora.py:63; import path `diffusers.models.unets.unet_3d_blocks`
+/root/reference/src/unet_spatio_temporal_condition.py:13 implies >= 0.26) which is NOT installed here
+and cannot be installed (no network).  The reference ships no tests, golden vectors or fixtures
+(SURVEY.md section 4).  This file therefore restates the published diffusers algorithm block by block,
+following the reference's own call sites, and is self-pinned only by structural checks
+(tests/test_oracle.py): parameter count == 1,524,623,082, trainable-by-name count == 397,620,480,
+the diffusers state-dict key set, LoRA r=64 delta == 26,558,464.
+
+Every class cites the reference line that instantiates it and the diffusers module it restates.
+Module / parameter names are exactly diffusers' so `state_dict()` keys match a real SVD checkpoint.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------------------
+# embeddings  (diffusers.models.embeddings; used at src/unet_spatio_temporal_condition.py:138-144)
+# --------------------------------------------------------------------------------------------------
+class Timesteps(nn.Module):
+    """Sinusoidal embedding, `Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)`
+    (src/unet_spatio_temporal_condition.py:138, :143).  Always computes in fp32, output [cos, sin]."""
+
+    def __init__(self, num_channels: int, flip_sin_to_cos: bool = True, downscale_freq_shift: float = 0.0):
+        super().__init__()
+        self.num_channels = num_channels
+        self.flip_sin_to_cos = flip_sin_to_cos
+        self.downscale_freq_shift = downscale_freq_shift
+
+    def forward(self, timesteps: torch.Tensor) -> torch.Tensor:
+        half = self.num_channels // 2
+        exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=timesteps.device)
+        exponent = exponent / (half - self.downscale_freq_shift)
+        emb = torch.exp(exponent)
+        emb = timesteps[:, None].float() * emb[None, :]
+        emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+        if self.flip_sin_to_cos:
+            emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+        return emb
+
+
+class TimestepEmbedding(nn.Module):
+    """`Linear -> SiLU -> Linear` (src/unet_spatio_temporal_condition.py:141, :144)."""
+
+    def __init__(self, in_channels: int, time_embed_dim: int, out_dim: Optional[int] = None):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, out_dim if out_dim is not None else time_embed_dim)
+
+    def forward(self, sample: torch.Tensor) -> torch.Tensor:
+        return self.linear_2(self.act(self.linear_1(sample)))
+
+
+# --------------------------------------------------------------------------------------------------
+# attention  (diffusers.models.attention_processor.Attention + AttnProcessor2_0,
+#             diffusers.models.attention.{FeedForward, GEGLU, BasicTransformerBlock,
+#             TemporalBasicTransformerBlock}); reached through get_down_block/get_up_block/mid,
+#             src/unet_spatio_temporal_condition.py:170-192, 219-234
+# --------------------------------------------------------------------------------------------------
+class Attention(nn.Module):
+    """q/k/v without bias, `to_out.0` with bias, scale = dim_head**-0.5, dropout 0."""
+
+    def __init__(self, query_dim: int, heads: int, dim_head: int, cross_attention_dim: Optional[int] = None):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        self.dim_head = dim_head
+        kv_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(kv_dim, inner, bias=False)
+        self.to_v = nn.Linear(kv_dim, inner, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim, bias=True), nn.Dropout(0.0)])
+
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None):
+        ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        b, s, _ = hidden_states.shape
+        q = self.to_q(hidden_states).view(b, s, self.heads, self.dim_head).transpose(1, 2)
+        k = self.to_k(ctx).view(b, -1, self.heads, self.dim_head).transpose(1, 2)
+        v = self.to_v(ctx).view(b, -1, self.heads, self.dim_head).transpose(1, 2)
+        # explicit softmax(QK^T * scale) V  == F.scaled_dot_product_attention (AttnProcessor2_0)
+        scores = torch.matmul(q, k.transpose(-1, -2)) * (self.dim_head ** -0.5)
+        probs = scores.softmax(dim=-1)
+        out = torch.matmul(probs, v)
+        out = out.transpose(1, 2).reshape(b, s, self.heads * self.dim_head)
+        out = self.to_out[0](out)
+        return self.to_out[1](out)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in: int, dim_out: int):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x, gate = self.proj(x).chunk(2, dim=-1)
+        return x * F.gelu(gate)  # exact (erf) GELU
+
+
+class FeedForward(nn.Module):
+    """`net = [GEGLU(dim, 4*dim), Dropout, Linear(4*dim, dim_out)]` (keys net.0.proj / net.2)."""
+
+    def __init__(self, dim: int, dim_out: Optional[int] = None, mult: int = 4):
+        super().__init__()
+        inner = dim * mult
+        dim_out = dim if dim_out is None else dim_out
+        self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(0.0), nn.Linear(inner, dim_out)])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        for m in self.net:
+            x = m(x)
+        return x
+
+
+class BasicTransformerBlock(nn.Module):
+    """Spatial block: x += attn1(LN(x)); x += attn2(LN(x), ehs); x += FF(LN(x)).  LN eps 1e-5."""
+
+    def __init__(self, dim: int, num_attention_heads: int, attention_head_dim: int, cross_attention_dim: int):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-5)
+        self.attn1 = Attention(dim, num_attention_heads, attention_head_dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-5)
+        self.attn2 = Attention(dim, num_attention_heads, attention_head_dim, cross_attention_dim)
+        self.norm3 = nn.LayerNorm(dim, eps=1e-5)
+        self.ff = FeedForward(dim)
+
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor) -> torch.Tensor:
+        hidden_states = self.attn1(self.norm1(hidden_states)) + hidden_states
+        hidden_states = self.attn2(self.norm2(hidden_states), encoder_hidden_states) + hidden_states
+        hidden_states = self.ff(self.norm3(hidden_states)) + hidden_states
+        return hidden_states
+
+
+class TemporalBasicTransformerBlock(nn.Module):
+    """The trainable set of train_svd.py:761-766 ('temporal_transformer_block' in name)."""
+
+    def __init__(self, dim: int, time_mix_inner_dim: int, num_attention_heads: int, attention_head_dim: int,
+                 cross_attention_dim: int):
+        super().__init__()
+        self.is_res = dim == time_mix_inner_dim
+        self.norm_in = nn.LayerNorm(dim)
+        self.ff_in = FeedForward(dim, dim_out=time_mix_inner_dim)
+        self.norm1 = nn.LayerNorm(time_mix_inner_dim)
+        self.attn1 = Attention(time_mix_inner_dim, num_attention_heads, attention_head_dim)
+        self.norm2 = nn.LayerNorm(time_mix_inner_dim)
+        self.attn2 = Attention(time_mix_inner_dim, num_attention_heads, attention_head_dim, cross_attention_dim)
+        self.norm3 = nn.LayerNorm(time_mix_inner_dim)
+        self.ff = FeedForward(time_mix_inner_dim)
+
+    def forward(self, hidden_states: torch.Tensor, num_frames: int, encoder_hidden_states: torch.Tensor):
+        batch_frames, seq_length, channels = hidden_states.shape
+        batch_size = batch_frames // num_frames
+        hidden_states = hidden_states[None, :].reshape(batch_size, num_frames, seq_length, channels)
+        hidden_states = hidden_states.permute(0, 2, 1, 3).reshape(batch_size * seq_length, num_frames, channels)
+
+        residual = hidden_states
+        hidden_states = self.ff_in(self.norm_in(hidden_states))
+        if self.is_res:
+            hidden_states = hidden_states + residual
+        hidden_states = self.attn1(self.norm1(hidden_states)) + hidden_states
+        hidden_states = self.attn2(self.norm2(hidden_states), encoder_hidden_states) + hidden_states
+        ff_output = self.ff(self.norm3(hidden_states))
+        hidden_states = ff_output + hidden_states if self.is_res else ff_output
+
+        hidden_states = hidden_states[None, :].reshape(batch_size, seq_length, num_frames, channels)
+        hidden_states = hidden_states.permute(0, 2, 1, 3).reshape(batch_size * num_frames, seq_length, channels)
+        return hidden_states
+
+
+# --------------------------------------------------------------------------------------------------
+# resnet  (diffusers.models.resnet.{ResnetBlock2D, TemporalResnetBlock, AlphaBlender,
+#          SpatioTemporalResBlock, Downsample2D, Upsample2D})
+# --------------------------------------------------------------------------------------------------
+class AlphaBlender(nn.Module):
+    """merge_strategy="learned_with_images", alpha0 = 0.5; image_only_indicator is all-zero on this
+    path (src/unet_spatio_temporal_condition.py:430) so alpha = sigmoid(mix_factor)."""
+
+    def __init__(self, alpha: float = 0.5):
+        super().__init__()
+        self.mix_factor = nn.Parameter(torch.tensor([alpha], dtype=torch.float32))
+
+    def forward(self, x_spatial: torch.Tensor, x_temporal: torch.Tensor, image_only_indicator: torch.Tensor):
+        alpha = torch.where(image_only_indicator.bool(),
+                            torch.ones(1, 1, device=image_only_indicator.device),
+                            torch.sigmoid(self.mix_factor)[..., None])
+        if x_spatial.ndim == 5:      # (batch, channel, frames, height, width)
+            alpha = alpha[:, None, :, None, None]
+        elif x_spatial.ndim == 3:    # (batch*frames, height*width, channels)
+            alpha = alpha.reshape(-1)[:, None, None]
+        alpha = alpha.to(x_spatial.dtype)
+        return alpha * x_spatial + (1.0 - alpha) * x_temporal
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, temb_channels: int, eps: float):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(32, in_channels, eps=eps, affine=True)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, stride=1, padding=1)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels)
+        self.norm2 = nn.GroupNorm(32, out_channels, eps=eps, affine=True)
+        self.dropout = nn.Dropout(0.0)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, stride=1, padding=1)
+        self.nonlinearity = nn.SiLU()
+        self.conv_shortcut = None
+        if in_channels != out_channels:
+            self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1, stride=1, padding=0, bias=True)
+
+    def forward(self, input_tensor: torch.Tensor, temb: torch.Tensor) -> torch.Tensor:
+        h = self.conv1(self.nonlinearity(self.norm1(input_tensor)))
+        t = self.time_emb_proj(self.nonlinearity(temb))[:, :, None, None]
+        h = h + t
+        h = self.conv2(self.dropout(self.nonlinearity(self.norm2(h))))
+        if self.conv_shortcut is not None:
+            input_tensor = self.conv_shortcut(input_tensor)
+        return input_tensor + h
+
+
+class TemporalResnetBlock(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, temb_channels: int, eps: float):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(32, in_channels, eps=eps, affine=True)
+        self.conv1 = nn.Conv3d(in_channels, out_channels, (3, 1, 1), stride=1, padding=(1, 0, 0))
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels)
+        self.norm2 = nn.GroupNorm(32, out_channels, eps=eps, affine=True)
+        self.dropout = nn.Dropout(0.0)
+        self.conv2 = nn.Conv3d(out_channels, out_channels, (3, 1, 1), stride=1, padding=(1, 0, 0))
+        self.nonlinearity = nn.SiLU()
+        self.conv_shortcut = None
+        if in_channels != out_channels:
+            self.conv_shortcut = nn.Conv3d(in_channels, out_channels, 1, stride=1, padding=0)
+
+    def forward(self, input_tensor: torch.Tensor, temb: torch.Tensor) -> torch.Tensor:
+        h = self.conv1(self.nonlinearity(self.norm1(input_tensor)))
+        t = self.time_emb_proj(self.nonlinearity(temb))[:, :, :, None, None]   # [B,T,C,1,1]
+        t = t.permute(0, 2, 1, 3, 4)
+        h = h + t
+        h = self.conv2(self.dropout(self.nonlinearity(self.norm2(h))))
+        if self.conv_shortcut is not None:
+            input_tensor = self.conv_shortcut(input_tensor)
+        return input_tensor + h
+
+
+class SpatioTemporalResBlock(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, temb_channels: int, eps: float):
+        super().__init__()
+        self.spatial_res_block = ResnetBlock2D(in_channels, out_channels, temb_channels, eps)
+        self.temporal_res_block = TemporalResnetBlock(out_channels, out_channels, temb_channels, eps)
+        self.time_mixer = AlphaBlender(0.5)
+
+    def forward(self, hidden_states: torch.Tensor, temb: torch.Tensor, image_only_indicator: torch.Tensor):
+        num_frames = image_only_indicator.shape[-1]
+        hidden_states = self.spatial_res_block(hidden_states, temb)
+        batch_frames, channels, height, width = hidden_states.shape
+        batch_size = batch_frames // num_frames
+        x5 = hidden_states[None, :].reshape(batch_size, num_frames, channels, height, width).permute(0, 2, 1, 3, 4)
+        temb5 = temb.reshape(batch_size, num_frames, -1)
+        x_t = self.temporal_res_block(x5, temb5)
+        out = self.time_mixer(x_spatial=x5, x_temporal=x_t, image_only_indicator=image_only_indicator)
+        return out.permute(0, 2, 1, 3, 4).reshape(batch_frames, channels, height, width)
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, channels: int):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, channels: int):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+# --------------------------------------------------------------------------------------------------
+# transformer_temporal.TransformerSpatioTemporalModel
+# --------------------------------------------------------------------------------------------------
+class TransformerSpatioTemporalModel(nn.Module):
+    def __init__(self, num_attention_heads: int, attention_head_dim: int, in_channels: int,
+                 num_layers: int, cross_attention_dim: int):
+        super().__init__()
+        inner_dim = num_attention_heads * attention_head_dim
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6)
+        self.proj_in = nn.Linear(in_channels, inner_dim)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner_dim, num_attention_heads, attention_head_dim, cross_attention_dim)
+            for _ in range(num_layers)])
+        self.temporal_transformer_blocks = nn.ModuleList([
+            TemporalBasicTransformerBlock(inner_dim, inner_dim, num_attention_heads, attention_head_dim,
+                                          cross_attention_dim)
+            for _ in range(num_layers)])
+        self.time_pos_embed = TimestepEmbedding(in_channels, in_channels * 4, out_dim=in_channels)
+        self.time_proj = Timesteps(in_channels, True, 0)
+        self.time_mixer = AlphaBlender(0.5)
+        self.proj_out = nn.Linear(inner_dim, in_channels)
+
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                image_only_indicator: torch.Tensor) -> torch.Tensor:
+        batch_frames, _, height, width = hidden_states.shape
+        num_frames = image_only_indicator.shape[-1]
+        batch_size = batch_frames // num_frames
+
+        time_context = encoder_hidden_states
+        first = time_context[None, :].reshape(batch_size, num_frames, -1, time_context.shape[-1])[:, 0]
+        # NB: (HW, B) flatten order vs the block's (B, HW) order: identical only at B == 1 (diffusers quirk)
+        time_context = first[None, :].broadcast_to(height * width, batch_size, 1, time_context.shape[-1])
+        time_context = time_context.reshape(height * width * batch_size, 1, time_context.shape[-1])
+
+        residual = hidden_states
+        hidden_states = self.norm(hidden_states)
+        inner_dim = hidden_states.shape[1]
+        hidden_states = hidden_states.permute(0, 2, 3, 1).reshape(batch_frames, height * width, inner_dim)
+        hidden_states = self.proj_in(hidden_states)
+
+        num_frames_emb = torch.arange(num_frames, device=hidden_states.device).repeat(batch_size, 1).reshape(-1)
+        t_emb = self.time_proj(num_frames_emb).to(dtype=hidden_states.dtype)
+        emb = self.time_pos_embed(t_emb)[:, None, :]
+
+        for block, temporal_block in zip(self.transformer_blocks, self.temporal_transformer_blocks):
+            hidden_states = block(hidden_states, encoder_hidden_states=encoder_hidden_states)
+            hidden_states_mix = hidden_states + emb
+            hidden_states_mix = temporal_block(hidden_states_mix, num_frames=num_frames,
+                                               encoder_hidden_states=time_context)
+            hidden_states = self.time_mixer(x_spatial=hidden_states, x_temporal=hidden_states_mix,
+                                            image_only_indicator=image_only_indicator)
+
+        hidden_states = self.proj_out(hidden_states)
+        hidden_states = hidden_states.reshape(batch_frames, height, width, inner_dim).permute(0, 3, 1, 2).contiguous()
+        return hidden_states + residual
+
+
+# --------------------------------------------------------------------------------------------------
+# unet_3d_blocks  (src/unet_spatio_temporal_condition.py:13)
+# --------------------------------------------------------------------------------------------------
+class CrossAttnDownBlockSpatioTemporal(nn.Module):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers, transformer_layers_per_block,
+                 num_attention_heads, cross_attention_dim, add_downsample):
+        super().__init__()
+        resnets, attentions = [], []
+        for i in range(num_layers):
+            resnets.append(SpatioTemporalResBlock(in_channels if i == 0 else out_channels, out_channels,
+                                                  temb_channels, eps=1e-6))
+            attentions.append(TransformerSpatioTemporalModel(num_attention_heads, out_channels // num_attention_heads,
+                                                             out_channels, transformer_layers_per_block,
+                                                             cross_attention_dim))
+        self.attentions = nn.ModuleList(attentions)
+        self.resnets = nn.ModuleList(resnets)
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+    def forward(self, hidden_states, temb, encoder_hidden_states, image_only_indicator):
+        output_states = ()
+        for resnet, attn in zip(self.resnets, self.attentions):
+            hidden_states = resnet(hidden_states, temb, image_only_indicator)
+            hidden_states = attn(hidden_states, encoder_hidden_states, image_only_indicator)
+            output_states = output_states + (hidden_states,)
+        if self.downsamplers is not None:
+            for d in self.downsamplers:
+                hidden_states = d(hidden_states)
+            output_states = output_states + (hidden_states,)
+        return hidden_states, output_states
+
+
+class DownBlockSpatioTemporal(nn.Module):
+    has_cross_attention = False
+
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers, add_downsample):
+        super().__init__()
+        self.resnets = nn.ModuleList([
+            SpatioTemporalResBlock(in_channels if i == 0 else out_channels, out_channels, temb_channels, eps=1e-5)
+            for i in range(num_layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+    def forward(self, hidden_states, temb, image_only_indicator):
+        output_states = ()
+        for resnet in self.resnets:
+            hidden_states = resnet(hidden_states, temb, image_only_indicator)
+            output_states = output_states + (hidden_states,)
+        if self.downsamplers is not None:
+            for d in self.downsamplers:
+                hidden_states = d(hidden_states)
+            output_states = output_states + (hidden_states,)
+        return hidden_states, output_states
+
+
+class UNetMidBlockSpatioTemporal(nn.Module):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, temb_channels, transformer_layers_per_block, num_attention_heads,
+                 cross_attention_dim, num_layers: int = 1):
+        super().__init__()
+        resnets = [SpatioTemporalResBlock(in_channels, in_channels, temb_channels, eps=1e-5)]
+        attentions = []
+        for _ in range(num_layers):
+            attentions.append(TransformerSpatioTemporalModel(num_attention_heads, in_channels // num_attention_heads,
+                                                             in_channels, transformer_layers_per_block,
+                                                             cross_attention_dim))
+            resnets.append(SpatioTemporalResBlock(in_channels, in_channels, temb_channels, eps=1e-5))
+        self.attentions = nn.ModuleList(attentions)
+        self.resnets = nn.ModuleList(resnets)
+
+    def forward(self, hidden_states, temb, encoder_hidden_states, image_only_indicator):
+        hidden_states = self.resnets[0](hidden_states, temb, image_only_indicator)
+        for attn, resnet in zip(self.attentions, self.resnets[1:]):
+            hidden_states = attn(hidden_states, encoder_hidden_states, image_only_indicator)
+            hidden_states = resnet(hidden_states, temb, image_only_indicator)
+        return hidden_states
+
+
+class UpBlockSpatioTemporal(nn.Module):
+    has_cross_attention = False
+
+    def __init__(self, in_channels, prev_output_channel, out_channels, temb_channels, num_layers, add_upsample):
+        super().__init__()
+        resnets = []
+        for i in range(num_layers):
+            res_skip = in_channels if (i == num_layers - 1) else out_channels
+            res_in = prev_output_channel if i == 0 else out_channels
+            resnets.append(SpatioTemporalResBlock(res_in + res_skip, out_channels, temb_channels, eps=1e-6))
+        self.resnets = nn.ModuleList(resnets)
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+
+    def forward(self, hidden_states, res_hidden_states_tuple, temb, image_only_indicator):
+        for resnet in self.resnets:
+            res = res_hidden_states_tuple[-1]
+            res_hidden_states_tuple = res_hidden_states_tuple[:-1]
+            hidden_states = torch.cat([hidden_states, res], dim=1)
+            hidden_states = resnet(hidden_states, temb, image_only_indicator)
+        if self.upsamplers is not None:
+            for u in self.upsamplers:
+                hidden_states = u(hidden_states)
+        return hidden_states
+
+
+class CrossAttnUpBlockSpatioTemporal(nn.Module):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, out_channels, prev_output_channel, temb_channels, num_layers,
+                 transformer_layers_per_block, num_attention_heads, cross_attention_dim, add_upsample):
+        super().__init__()
+        resnets, attentions = [], []
+        for i in range(num_layers):
+            res_skip = in_channels if (i == num_layers - 1) else out_channels
+            res_in = prev_output_channel if i == 0 else out_channels
+            resnets.append(SpatioTemporalResBlock(res_in + res_skip, out_channels, temb_channels, eps=1e-6))
+            attentions.append(TransformerSpatioTemporalModel(num_attention_heads, out_channels // num_attention_heads,
+                                                             out_channels, transformer_layers_per_block,
+                                                             cross_attention_dim))
+        self.attentions = nn.ModuleList(attentions)
+        self.resnets = nn.ModuleList(resnets)
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+
+    def forward(self, hidden_states, res_hidden_states_tuple, temb, encoder_hidden_states, image_only_indicator):
+        for resnet, attn in zip(self.resnets, self.attentions):
+            res = res_hidden_states_tuple[-1]
+            res_hidden_states_tuple = res_hidden_states_tuple[:-1]
+            hidden_states = torch.cat([hidden_states, res], dim=1)
+            hidden_states = resnet(hidden_states, temb, image_only_indicator)
+            hidden_states = attn(hidden_states, encoder_hidden_states, image_only_indicator)
+        if self.upsamplers is not None:
+            for u in self.upsamplers:
+                hidden_states = u(hidden_states)
+        return hidden_states
+
+
+# --------------------------------------------------------------------------------------------------
+# top level  (restates src/unet_spatio_temporal_condition.py:71-246 construction, :357-490 forward)
+# --------------------------------------------------------------------------------------------------
+SVD_CONFIG = dict(
+    in_channels=8, out_channels=4,
+    down_block_types=("CrossAttnDownBlockSpatioTemporal",) * 3 + ("DownBlockSpatioTemporal",),
+    up_block_types=("UpBlockSpatioTemporal",) + ("CrossAttnUpBlockSpatioTemporal",) * 3,
+    block_out_channels=(320, 640, 1280, 1280), addition_time_embed_dim=256,
+    projection_class_embeddings_input_dim=768, layers_per_block=2, cross_attention_dim=1024,
+    transformer_layers_per_block=1, num_attention_heads=(5, 10, 20, 20), num_frames=25)
+
+# small config with the same topology (head_dim stays 64) for fast CPU tests
+TINY_CONFIG = dict(SVD_CONFIG, block_out_channels=(64, 128, 128, 128), addition_time_embed_dim=32,
+                   projection_class_embeddings_input_dim=96, cross_attention_dim=64,
+                   num_attention_heads=(1, 2, 2, 2), num_frames=4)
+
+
+class UNetSpatioTemporalConditionOracle(nn.Module):
+    def __init__(self, sample_size=None, in_channels=8, out_channels=4,
+                 down_block_types=SVD_CONFIG["down_block_types"], up_block_types=SVD_CONFIG["up_block_types"],
+                 block_out_channels=(320, 640, 1280, 1280), addition_time_embed_dim=256,
+                 projection_class_embeddings_input_dim=768, layers_per_block=2, cross_attention_dim=1024,
+                 transformer_layers_per_block=1, num_attention_heads=(5, 10, 20, 20), num_frames=25):
+        super().__init__()
+        n = len(down_block_types)
+        self.config = SimpleNamespace(
+            sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
+            down_block_types=tuple(down_block_types), up_block_types=tuple(up_block_types),
+            block_out_channels=tuple(block_out_channels), addition_time_embed_dim=addition_time_embed_dim,
+            projection_class_embeddings_input_dim=projection_class_embeddings_input_dim,
+            layers_per_block=layers_per_block, cross_attention_dim=cross_attention_dim,
+            transformer_layers_per_block=transformer_layers_per_block,
+            num_attention_heads=num_attention_heads, num_frames=num_frames)
+        if isinstance(num_attention_heads, int):
+            num_attention_heads = (num_attention_heads,) * n
+        if isinstance(cross_attention_dim, int):
+            cross_attention_dim = (cross_attention_dim,) * n
+        if isinstance(layers_per_block, int):
+            layers_per_block = [layers_per_block] * n
+        if isinstance(transformer_layers_per_block, int):
+            transformer_layers_per_block = [transformer_layers_per_block] * n
+
+        self.conv_in = nn.Conv2d(in_channels, block_out_channels[0], kernel_size=3, padding=1)
+        time_embed_dim = block_out_channels[0] * 4
+        self.time_proj = Timesteps(block_out_channels[0], True, 0)
+        self.time_embedding = TimestepEmbedding(block_out_channels[0], time_embed_dim)
+        self.add_time_proj = Timesteps(addition_time_embed_dim, True, 0)
+        self.add_embedding = TimestepEmbedding(projection_class_embeddings_input_dim, time_embed_dim)
+
+        self.down_blocks = nn.ModuleList([])
+        self.up_blocks = nn.ModuleList([])
+        output_channel = block_out_channels[0]
+        for i, t in enumerate(down_block_types):
+            input_channel, output_channel = output_channel, block_out_channels[i]
+            final = i == n - 1
+            if t == "CrossAttnDownBlockSpatioTemporal":
+                blk = CrossAttnDownBlockSpatioTemporal(input_channel, output_channel, time_embed_dim,
+                                                       layers_per_block[i], transformer_layers_per_block[i],
+                                                       num_attention_heads[i], cross_attention_dim[i], not final)
+            elif t == "DownBlockSpatioTemporal":
+                blk = DownBlockSpatioTemporal(input_channel, output_channel, time_embed_dim, layers_per_block[i],
+                                              not final)
+            else:
+                raise ValueError(f"{t} does not exist.")
+            self.down_blocks.append(blk)
+
+        self.mid_block = UNetMidBlockSpatioTemporal(block_out_channels[-1], time_embed_dim,
+                                                    transformer_layers_per_block[-1], num_attention_heads[-1],
+                                                    cross_attention_dim[-1])
+
+        rev_ch = list(reversed(block_out_channels))
+        rev_heads = list(reversed(num_attention_heads))
+        rev_layers = list(reversed(layers_per_block))
+        rev_cross = list(reversed(cross_attention_dim))
+        rev_tl = list(reversed(transformer_layers_per_block))
+        output_channel = rev_ch[0]
+        for i, t in enumerate(up_block_types):
+            final = i == n - 1
+            prev_output_channel, output_channel = output_channel, rev_ch[i]
+            input_channel = rev_ch[min(i + 1, n - 1)]
+            if t == "UpBlockSpatioTemporal":
+                blk = UpBlockSpatioTemporal(input_channel, prev_output_channel, output_channel, time_embed_dim,
+                                            rev_layers[i] + 1, not final)
+            elif t == "CrossAttnUpBlockSpatioTemporal":
+                blk = CrossAttnUpBlockSpatioTemporal(input_channel, output_channel, prev_output_channel,
+                                                     time_embed_dim, rev_layers[i] + 1, rev_tl[i], rev_heads[i],
+                                                     rev_cross[i], not final)
+            else:
+                raise ValueError(f"{t} does not exist.")
+            self.up_blocks.append(blk)
+
+        self.conv_norm_out = nn.GroupNorm(num_channels=block_out_channels[0], num_groups=32, eps=1e-5)
+        self.conv_act = nn.SiLU()
+        self.conv_out = nn.Conv2d(block_out_channels[0], out_channels, kernel_size=3, padding=1)
+
+    def forward(self, sample, timestep, encoder_hidden_states, added_time_ids, return_dict: bool = True):
+        timesteps = timestep
+        if not torch.is_tensor(timesteps):
+            dtype = torch.float64 if isinstance(timestep, float) else torch.int64
+            timesteps = torch.tensor([timesteps], dtype=dtype, device=sample.device)
+        elif timesteps.ndim == 0:
+            timesteps = timesteps[None].to(sample.device)
+        batch_size, num_frames = sample.shape[:2]
+        timesteps = timesteps.expand(batch_size)
+
+        t_emb = self.time_proj(timesteps).to(dtype=sample.dtype)
+        emb = self.time_embedding(t_emb)
+        time_embeds = self.add_time_proj(added_time_ids.flatten()).reshape((batch_size, -1)).to(emb.dtype)
+        emb = emb + self.add_embedding(time_embeds)
+
+        sample = sample.flatten(0, 1)
+        emb = emb.repeat_interleave(num_frames, dim=0)
+        encoder_hidden_states = encoder_hidden_states.repeat_interleave(num_frames, dim=0)
+
+        sample = self.conv_in(sample)
+        image_only_indicator = torch.zeros(batch_size, num_frames, dtype=sample.dtype, device=sample.device)
+
+        down_block_res_samples = (sample,)
+        for blk in self.down_blocks:
+            if blk.has_cross_attention:
+                sample, res = blk(sample, emb, encoder_hidden_states, image_only_indicator)
+            else:
+                sample, res = blk(sample, emb, image_only_indicator)
+            down_block_res_samples += res
+
+        sample = self.mid_block(sample, emb, encoder_hidden_states, image_only_indicator)
+
+        for blk in self.up_blocks:
+            res = down_block_res_samples[-len(blk.resnets):]
+            down_block_res_samples = down_block_res_samples[:-len(blk.resnets)]
+            if blk.has_cross_attention:
+                sample = blk(sample, res, emb, encoder_hidden_states, image_only_indicator)
+            else:
+                sample = blk(sample, res, emb, image_only_indicator)
+
+        sample = self.conv_out(self.conv_act(self.conv_norm_out(sample)))
+        sample = sample.reshape(batch_size, num_frames, *sample.shape[1:])
+        if not return_dict:
+            return (sample,)
+        return SimpleNamespace(sample=sample)
+
+
+def scaled_init_(model: nn.Module, seed: int = 0, gain: float = 1.0) -> None:
+    """Deterministic random init used for every synthetic-weight experiment (no checkpoints offline).
+
+    Weights ~ N(0, gain/fan_in) drawn on the CPU generator in `named_parameters()` order, biases small
+    N(0, 0.02^2), norm affine = (1 + 0.1 N, 0.1 N), mix_factor kept at 0.5.  Each tensor uses its own
+    generator seeded from (seed, index) so a subset of tensors can be regenerated independently and
+    the product model and the oracle can be filled identically without holding both in memory.
+    """
+    for idx, (name, p) in enumerate(model.named_parameters()):
+        fill_param_(name, p, seed, idx)
+
+
+def fill_param_(name: str, p: torch.Tensor, seed: int, idx: int, gain: float = 1.0) -> None:
+    g = torch.Generator(device="cpu").manual_seed((seed * 1000003 + idx) % (2 ** 31 - 1))
+    with torch.no_grad():
+        if name.endswith("mix_factor"):
+            p.fill_(0.5)
+        elif p.ndim == 1:
+            if "norm" in name and name.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            elif "norm" in name:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+        else:
+            fan_in = p[0].numel()
+            p.copy_(torch.randn(p.shape, generator=g) * math.sqrt(gain / fan_in))
+
+
+def trainable_names(model: nn.Module) -> Sequence[str]:
+    """train_svd.py:761-766."""
+    return [n for n, _ in model.named_parameters() if "temporal_transformer_block" in n]
