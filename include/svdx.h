@@ -1,0 +1,165 @@
+/* svdx.h -- C-ABI of libsvdx.so: the MI355X (gfx950) kernels behind the SVD UNet training step.
+ *
+ * Drop-in boundary.  The reference has no FFI of its own: its hot path is the Python call
+ * `unet(inp_noisy_latents, timesteps, encoder_hidden_states, added_time_ids)` at
+ * /root/reference/train_svd.py:1021, `accelerator.backward(loss)` at :1044 and `optimizer.step()` at
+ * :1047, all of which dispatch into ATen/cuDNN/cuBLAS/flash-SDPA kernels through diffusers modules
+ * (/root/reference/src/unet_spatio_temporal_condition.py:7-13).  This header is what a ctypes binding
+ * of those kernels binds instead; each entry cites the reference/diffusers operation it replaces.
+ *
+ * Conventions
+ *  - Activations are row-major [rows, C] with rows = (b, t, y, x) flattened ("(B*T, HW, C)" layout),
+ *    stored in `dtype` (SVDX_F16 / SVDX_BF16); statistics, biases, master weights, grads are float.
+ *  - All memory is owned by the caller (PyTorch's caching allocator).  The library never allocates or
+ *    frees device memory, never synchronises, never retains a pointer past the call; every launch goes
+ *    to the explicit `stream` (a hipStream_t passed as void*), so all calls are hipGraph-capturable.
+ *  - Return 0 on success, negative on error; the message is retrievable with svdx_last_error()
+ *    (thread-local: forward runs on the Python main thread, backward may run on another).
+ */
+#ifndef SVDX_H
+#define SVDX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVDX_F16 0
+#define SVDX_BF16 1
+
+#define SVDX_OUT_ACT 0      /* store in activation dtype            */
+#define SVDX_OUT_F32 1      /* store float                          */
+#define SVDX_OUT_F32_ATOMIC 2 /* atomicAdd float (grad accumulation, split-K) */
+
+#define SVDX_GATHER_PLAIN 0
+#define SVDX_GATHER_CONV3X3 1     /* 3x3, pad 1, stride 1|2, optional nearest x2 upsampled source */
+#define SVDX_GATHER_CONV3X3_DGRAD2 2 /* data-gradient of the stride-2 3x3 conv (transposed conv) */
+#define SVDX_GATHER_TEMPORAL3 3   /* Conv3d kernel (3,1,1) pad (1,0,0) over the frame axis */
+
+/* Implicit-GEMM A-operand addressing: row m of the GEMM is an output pixel, K = taps*cin,
+ * k = tap*cin + ci.  Replaces cuDNN/MIOpen conv2d/conv3d reached from diffusers ResnetBlock2D /
+ * TemporalResnetBlock / Downsample2D / Upsample2D. */
+typedef struct svdx_gather {
+    int mode;
+    int n_img;      /* images (B*T) for modes 1,2; batch B for mode 3 */
+    int hi, wi;     /* logical source height/width (after the optional x2 upsample)      */
+    int ho, wo;     /* output height/width; GEMM rows M = n_img*ho*wo (mode 3: B*T*hw)     */
+    int cin;        /* channels per tap                                                    */
+    int stride;     /* mode 1: 1 or 2                                                      */
+    int ups;        /* mode 1: source stored at (hi/2, wi/2), read through nearest x2      */
+    int t, hw;      /* mode 3: frames per clip, rows per frame                             */
+    int lda;        /* row stride of the source tensor in elements                         */
+} svdx_gather;
+
+int         svdx_version(void);
+int         svdx_last_error(char* buf, size_t n);
+/* 1 when the binary was built for gfx950 and a device is usable */
+int         svdx_device_ok(void);
+
+/* ---- GEMM family: nn.Linear / conv2d / conv3d fwd and data-grad, weight-grad (NT form) ------------
+ * acc[m,n] = sum_k Aeff[m,k] * B[n,k];  v = alpha*acc + bias[n] + rowvec[g(m)*rv_ld + n] + res[m*ldres+n]
+ * g(m) = rv_mod ? m % rv_mod : m / rv_rows_per_group.   B is [N,K] row-major (ldb).
+ * out_mode ACT: C[m*ldc+n] = (dtype)v ; F32: float store ; F32_ATOMIC: atomicAdd (split_k >= 1). */
+int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+              const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
+              const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
+              int out_mode, float alpha, int split_k, int variant, int dtype, void* stream);
+
+/* Skinny linears (M <= 64): time/added-id embedding MLPs, time_emb_proj, time_pos_embed, the KV-length-1
+ * cross-attention.  X, Y float; W in dtype.
+ * trans=0: Y[m,n] (+)= sum_k act(X[m,k]) W[n*ldw+k] + bias[n];  trans=1: Y[m,k] (+)= sum_n X[m,n] W[n*ldw+k]. */
+int svdx_small_linear(const float* X, const void* W, const float* bias, float* Y, int M, int N, int K,
+                      int ldw, int trans, int silu_in, int accumulate, int dtype, void* stream);
+/* dW[n*K+k] += scale * sum_m dY[m,n] X[m,k]   (all float; weight-grad of a skinny linear) */
+int svdx_outer_acc(const float* dY, const float* X, float* dW, int M, int N, int K, float scale, void* stream);
+/* out[i, :] = [cos(t_i f_j), sin(t_i f_j)], f_j = exp(-ln(1e4) j / (dim/2))  (diffusers Timesteps,
+ * flip_sin_to_cos=True, shift 0; src/unet_spatio_temporal_condition.py:138,143) */
+int svdx_timestep_embed(const float* t, float* out, int n, int dim, void* stream);
+
+/* ---- GroupNorm(32) (+SiLU) over n_s samples of `rows` rows x C channels (2-D: sample = frame;
+ *      3-D: sample = clip, rows = T*HW).  stats[n_s, G, 2] = (sum, sumsq). -------------------------- */
+int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int C, int G, int dtype, void* stream);
+int svdx_gn_apply(const void* x, const float* stats, const float* gamma, const float* beta, void* y,
+                  int n_s, int rows, int C, int G, float eps, int silu, int dtype, void* stream);
+/* bstats[n_s,G,2] = (sum dz*gamma, sum dz*gamma*xhat), dz = dy * silu'(z) when silu */
+int svdx_gn_bwd_stats(const void* dy, const void* x, const float* stats, const float* gamma, const float* beta,
+                      float* bstats, int n_s, int rows, int C, int G, float eps, int silu, int dtype, void* stream);
+int svdx_gn_bwd_apply(const void* dy, const void* x, const float* stats, const float* bstats,
+                      const float* gamma, const float* beta, const void* add, void* dx,
+                      int n_s, int rows, int C, int G, float eps, int silu, int dtype, void* stream);
+
+/* ---- LayerNorm over C; stats[rows,2] = (mean, rstd) ------------------------------------------------- */
+int svdx_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                int rows, int C, float eps, int dtype, void* stream);
+/* dx = LN'(dy) (+ add);  dgamma/dbeta (float, atomicAdd, may be NULL) */
+int svdx_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* add,
+                void* dx, float* dgamma, float* dbeta, int rows, int C, int dtype, void* stream);
+
+/* ---- spatial self-attention (head_dim 64), flash form; replaces F.scaled_dot_product_attention in
+ *      diffusers AttnProcessor2_0.  q,k element (n,s,h,d) at (n*S+s)*ld + h*64 + d;
+ *      vt/kt/qt/dot are head-transposed copies [nb, heads, 64, s_pad] made by svdx_head_transpose. ---- */
+int svdx_head_transpose(const void* in, int ld, void* out, int nb, int heads, int S, int s_pad, int dtype, void* stream);
+int svdx_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int nb, int heads, int S,
+                  int ld, int ld_o, int s_pad, float scale, int dtype, void* stream);
+/* D[n,h,s] = sum_d o*do */
+int svdx_attn_bwd_prep(const void* o, const void* d_o, float* D, int nb, int heads, int S, int ld_o, int dtype, void* stream);
+int svdx_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* d_o, const void* qt, const void* dot,
+                      const float* lse, const float* D, void* dk, void* dv, int nb, int heads, int S,
+                      int ld, int ld_o, int ld_d, int s_pad, float scale, int dtype, void* stream);
+int svdx_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o,
+                     const float* lse, const float* D, void* dq, int nb, int heads, int S,
+                     int ld, int ld_o, int ld_d, int s_pad, float scale, int dtype, void* stream);
+
+/* ---- temporal self-attention across frames: element (b,t,p,h,d) at
+ *      ((b*T+t)*HW+p)*ld + h*64 + d -- addressed in place, no (B*T,HW,C)<->(B*HW,T,C) transpose. ------ */
+int svdx_tattn_fwd(const void* q, const void* k, const void* v, void* o, int B, int T, int HW, int heads,
+                   int ld, int ld_o, float scale, int dtype, void* stream);
+int svdx_tattn_bwd(const void* q, const void* k, const void* v, const void* d_o, void* dq, void* dk, void* dv,
+                   int B, int T, int HW, int heads, int ld, int ld_o, int ld_d, float scale, int dtype, void* stream);
+
+/* ---- elementwise / data movement -------------------------------------------------------------------- */
+int svdx_geglu_fwd(const void* pre, void* out, int M, int F, int dtype, void* stream);       /* out = pre[:, :F] * gelu(pre[:, F:]) */
+int svdx_geglu_bwd(const void* dout, const void* pre, void* dpre, int M, int F, int dtype, void* stream);
+int svdx_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+/* alpha = sigmoid(*mix_factor) (diffusers AlphaBlender, image_only_indicator == 0) */
+int svdx_blend(const void* a, const void* b, const float* mix_factor, void* out, int64_t n, int dtype, void* stream);
+int svdx_blend_bwd(const void* dy, const float* mix_factor, void* da, void* db, int64_t n, int dtype, void* stream);
+int svdx_add_rowvec(const void* x, const float* vec, void* out, int rows, int C, int rv_ld,
+                    int rows_per_group, int mod, int dtype, void* stream);
+/* out[g, c] (+)= sum over rows of group g (float; zeroed first unless accumulate) */
+int svdx_colsum(const void* x, float* out, int rows, int C, int ldx, int n_groups, int rows_per_group, int mod,
+                int accumulate, int dtype, void* stream);
+/* out[c*ld_out + r] = in[r*ld_in + c]; columns r in [rows, ld_out) zero-filled */
+int svdx_transpose(const void* in, int ld_in, void* out, int ld_out, int rows, int cols, int dtype, void* stream);
+int svdx_concat2(const void* a, int Ca, const void* b, int Cb, void* out, int rows, int dtype, void* stream);
+int svdx_split2(const void* in, void* a, int Ca, void* b, int Cb, int rows, int dtype, void* stream);
+/* bwd of nearest x2: out[n,y,x,:] = sum of the 2x2 block of in[n,2y..,2x..,:] */
+int svdx_sum2x2(const void* in, void* out, int n_img, int h, int w, int C, int dtype, void* stream);
+int svdx_cast_from_f32(const float* in, void* out, int64_t n, int dtype, void* stream);
+/* out[c*R + r] = (dtype) in[r*Ccols + c] */
+int svdx_cast_transpose_from_f32(const float* in, void* out, int R, int Ccols, int dtype, void* stream);
+/* NCHW float <-> rows: out[(n*H*W + y*W + x)*ld + c] (channels >= C zero-filled up to ld on the way in) */
+int svdx_nchw_to_rows(const float* in, void* out, int n_img, int C, int H, int W, int ld, float mul, int dtype, void* stream);
+int svdx_rows_to_nchw(const void* in, float* out, int n_img, int C, int H, int W, int ld, int dtype, void* stream);
+int svdx_zero(void* p, size_t bytes, void* stream);
+
+/* ---- EDM loss (train_svd.py:1025-1036) fused with its gradient.  pred rows [B*T*HW, ld]; noisy/target
+ *      float NCHW-per-frame [B,T,4,H,W]; sigma[B].  loss (float, accumulated; zero it first) and
+ *      dpred rows = loss_scale * dLoss/dpred, loss_scale read from opt_state[1]. ----------------------- */
+int svdx_edm_loss(const void* pred, int ld, const float* noisy, const float* target, const float* sigma,
+                  float* loss, void* dpred, int B, int T, int C, int HW, const float* opt_state,
+                  int dtype, void* stream);
+
+/* ---- optimizer: AdamW (train_svd.py:767-773) + GradScaler semantics (accelerate fp16), all on device.
+ *      opt_state float[8]: 0 step, 1 loss_scale, 2 growth_tracker, 3 found_inf, 4 inv_scale, 5 bc1, 6 bc2, 7 skip */
+int svdx_check_finite(const float* g, int64_t n, float* opt_state, void* stream);
+int svdx_optim_prep(float* opt_state, float beta1, float beta2, float growth, float backoff, int growth_interval,
+                    int dynamic, void* stream);
+int svdx_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+               float eps, float wd, float grad_mul, const float* opt_state, void* p_act, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVDX_H */

@@ -1,0 +1,315 @@
+"""ctypes binding of libsvdx.so -- the only place the host code touches the HIP kernels.
+
+Every function here is a 1:1 wrapper of an `extern "C"` entry declared in include/svdx.h: it passes raw
+device pointers, sizes and the current HIP stream.  There is NO CPU fallback and no alternative
+implementation in the product: if the shared library is missing, was not built for gfx950, or no GPU is
+visible, the first call raises.  (tests/ can install an emulation backend through
+`_set_backend_for_tests` to exercise the host-side orchestration on a CPU-only box; nothing in the
+package does.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsvdx.so")
+
+F16, BF16 = 0, 1
+OUT_ACT, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
+GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3 = 0, 1, 2, 3
+
+
+class SvdxError(RuntimeError):
+    pass
+
+
+class _GatherC(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in
+                ("mode", "n_img", "hi", "wi", "ho", "wo", "cin", "stride", "ups", "t", "hw", "lda")]
+
+
+@dataclass(frozen=True)
+class Gather:
+    """Implicit-GEMM addressing of the A operand (include/svdx.h: svdx_gather)."""
+    mode: int
+    n_img: int = 0
+    hi: int = 0
+    wi: int = 0
+    ho: int = 0
+    wo: int = 0
+    cin: int = 0
+    stride: int = 1
+    ups: int = 0
+    t: int = 0
+    hw: int = 0
+    lda: int = 0
+
+    def to_c(self) -> _GatherC:
+        return _GatherC(self.mode, self.n_img, self.hi, self.wi, self.ho, self.wo, self.cin, self.stride,
+                        self.ups, self.t, self.hw, self.lda)
+
+
+# signature table: p void*, i int, f float, l int64, z size_t
+_SIGS = {
+    "svdx_gemm": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifii" "ip",
+    "svdx_small_linear": "pppp" "iiii" "iii" "ip",
+    "svdx_outer_acc": "ppp" "iii" "f" "p",
+    "svdx_timestep_embed": "pp" "ii" "p",
+    "svdx_gn_stats": "pp" "iiii" "ip",
+    "svdx_gn_apply": "ppppp" "iiii" "fi" "ip",
+    "svdx_gn_bwd_stats": "pppppp" "iiii" "fi" "ip",
+    "svdx_gn_bwd_apply": "pppppppp" "iiii" "fi" "ip",
+    "svdx_ln_fwd": "ppppp" "ii" "f" "ip",
+    "svdx_ln_bwd": "pppppppp" "ii" "ip",
+    "svdx_head_transpose": "pi" "p" "iiii" "ip",
+    "svdx_attn_fwd": "ppppp" "iii" "iii" "f" "ip",
+    "svdx_attn_bwd_prep": "ppp" "iii" "i" "ip",
+    "svdx_attn_bwd_dkv": "pppppppppp" "iii" "iiii" "f" "ip",
+    "svdx_attn_bwd_dq": "pppppppp" "iii" "iiii" "f" "ip",
+    "svdx_tattn_fwd": "pppp" "iiii" "ii" "f" "ip",
+    "svdx_tattn_bwd": "ppppppp" "iiii" "iii" "f" "ip",
+    "svdx_geglu_fwd": "pp" "ii" "ip",
+    "svdx_geglu_bwd": "ppp" "ii" "ip",
+    "svdx_add": "ppp" "l" "ip",
+    "svdx_blend": "pppp" "l" "ip",
+    "svdx_blend_bwd": "pppp" "l" "ip",
+    "svdx_add_rowvec": "ppp" "iiiii" "ip",
+    "svdx_colsum": "pp" "iiiiiii" "ip",
+    "svdx_transpose": "pi" "pi" "ii" "ip",
+    "svdx_concat2": "pi" "pi" "p" "i" "ip",
+    "svdx_split2": "p" "pi" "pi" "i" "ip",
+    "svdx_sum2x2": "pp" "iiii" "ip",
+    "svdx_cast_from_f32": "pp" "l" "ip",
+    "svdx_cast_transpose_from_f32": "pp" "ii" "ip",
+    "svdx_nchw_to_rows": "pp" "iiiii" "f" "ip",
+    "svdx_rows_to_nchw": "pp" "iiiii" "ip",
+    "svdx_zero": "pzp",
+    "svdx_edm_loss": "pi" "ppppp" "iiii" "p" "ip",
+    "svdx_check_finite": "plpp",
+    "svdx_optim_prep": "p" "ffff" "ii" "p",
+    "svdx_adamw": "pppp" "l" "ffffff" "pp" "ip",
+}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "l": ctypes.c_int64, "z": ctypes.c_size_t}
+
+EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_version", "svdx_last_error", "svdx_device_ok")
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    """dlopen libsvdx.so and type every entry point.  Raises SvdxError when the library is absent."""
+    if not os.path.exists(path):
+        raise SvdxError(f"{path} not found: build it with `python __graft_entry__.py` "
+                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = ctypes.CDLL(path)
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [_CT[c] for c in sig]
+        fn.restype = ctypes.c_int
+    lib.svdx_version.restype = ctypes.c_int
+    lib.svdx_device_ok.restype = ctypes.c_int
+    lib.svdx_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    lib.svdx_last_error.restype = ctypes.c_int
+    return lib
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float16:
+        return F16
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise SvdxError(f"activation dtype must be float16/bfloat16, got {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t: Optional[torch.Tensor]):
+    if t is not None and t.dtype != torch.float32:
+        raise SvdxError(f"expected float32 tensor, got {t.dtype}")
+    return _p(t)
+
+
+class HipBackend:
+    """Calls into libsvdx.so on the current torch stream."""
+
+    def __init__(self):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise SvdxError("no HIP device visible: svd_xtend_amd runs on MI355X only (no CPU fallback)")
+        if not self.lib.svdx_device_ok():
+            raise SvdxError("libsvdx.so reports no usable gfx950 device: " + self.last_error())
+        self._zero_page = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+
+    def last_error(self) -> str:
+        buf = ctypes.create_string_buffer(512)
+        self.lib.svdx_last_error(buf, 512)
+        return buf.value.decode(errors="replace")
+
+    def _call(self, name, *args):
+        rc = getattr(self.lib, name)(*args)
+        if rc != 0:
+            raise SvdxError(f"{name} failed ({rc}): {self.last_error()}")
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    # ---- GEMM family ------------------------------------------------------------------------------
+    def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
+             res=None, ldres=0, gather: Optional[Gather] = None, out_mode=OUT_ACT, alpha=1.0, split_k=1,
+             variant=0):
+        g = gather.to_c() if gather is not None else None
+        self._call("svdx_gemm", _p(A), _p(B), _p(C), M, N, K, lda, ldb, ldc, _f32(bias),
+                   _f32(rowvec), rv_ld, rv_rpg, rv_mod, _p(res), ldres,
+                   ctypes.cast(ctypes.pointer(g), ctypes.c_void_p) if g is not None else None,
+                   _p(self._zero_page), out_mode, float(alpha), split_k, variant, _dt(A), self._stream())
+
+    def small_linear(self, X, W, bias, Y, M, N, K, ldw, trans=0, silu_in=0, accumulate=0):
+        self._call("svdx_small_linear", _f32(X), _p(W), _f32(bias), _f32(Y), M, N, K, ldw, trans, silu_in,
+                   accumulate, _dt(W), self._stream())
+
+    def outer_acc(self, dY, X, dW, M, N, K, scale=1.0):
+        self._call("svdx_outer_acc", _f32(dY), _f32(X), _f32(dW), M, N, K, float(scale), self._stream())
+
+    def timestep_embed(self, t, out, n, dim):
+        self._call("svdx_timestep_embed", _f32(t), _f32(out), n, dim, self._stream())
+
+    # ---- norms ------------------------------------------------------------------------------------
+    def gn_stats(self, x, stats, n_s, rows, C, G):
+        self._call("svdx_gn_stats", _p(x), _f32(stats), n_s, rows, C, G, _dt(x), self._stream())
+
+    def gn_apply(self, x, stats, gamma, beta, y, n_s, rows, C, G, eps, silu):
+        self._call("svdx_gn_apply", _p(x), _f32(stats), _f32(gamma), _f32(beta), _p(y), n_s, rows, C, G,
+                   float(eps), int(silu), _dt(x), self._stream())
+
+    def gn_bwd_stats(self, dy, x, stats, gamma, beta, bstats, n_s, rows, C, G, eps, silu):
+        self._call("svdx_gn_bwd_stats", _p(dy), _p(x), _f32(stats), _f32(gamma), _f32(beta), _f32(bstats),
+                   n_s, rows, C, G, float(eps), int(silu), _dt(x), self._stream())
+
+    def gn_bwd_apply(self, dy, x, stats, bstats, gamma, beta, add, dx, n_s, rows, C, G, eps, silu):
+        self._call("svdx_gn_bwd_apply", _p(dy), _p(x), _f32(stats), _f32(bstats), _f32(gamma), _f32(beta),
+                   _p(add), _p(dx), n_s, rows, C, G, float(eps), int(silu), _dt(x), self._stream())
+
+    def ln_fwd(self, x, gamma, beta, y, stats, rows, C, eps):
+        self._call("svdx_ln_fwd", _p(x), _f32(gamma), _f32(beta), _p(y), _f32(stats), rows, C, float(eps),
+                   _dt(x), self._stream())
+
+    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C):
+        self._call("svdx_ln_bwd", _p(dy), _p(x), _f32(stats), _f32(gamma), _p(add), _p(dx), _f32(dgamma),
+                   _f32(dbeta), rows, C, _dt(x), self._stream())
+
+    # ---- attention --------------------------------------------------------------------------------
+    def head_transpose(self, inp, ld, out, nb, heads, S, s_pad):
+        self._call("svdx_head_transpose", _p(inp), ld, _p(out), nb, heads, S, s_pad, _dt(inp), self._stream())
+
+    def attn_fwd(self, q, k, vt, o, lse, nb, heads, S, ld, ld_o, s_pad, scale):
+        self._call("svdx_attn_fwd", _p(q), _p(k), _p(vt), _p(o), _f32(lse), nb, heads, S, ld, ld_o, s_pad,
+                   float(scale), _dt(q), self._stream())
+
+    def attn_bwd_prep(self, o, d_o, D, nb, heads, S, ld_o):
+        self._call("svdx_attn_bwd_prep", _p(o), _p(d_o), _f32(D), nb, heads, S, ld_o, _dt(o), self._stream())
+
+    def attn_bwd_dkv(self, q, k, v, d_o, qt, dot, lse, D, dk, dv, nb, heads, S, ld, ld_o, ld_d, s_pad, scale):
+        self._call("svdx_attn_bwd_dkv", _p(q), _p(k), _p(v), _p(d_o), _p(qt), _p(dot), _f32(lse), _f32(D),
+                   _p(dk), _p(dv), nb, heads, S, ld, ld_o, ld_d, s_pad, float(scale), _dt(q), self._stream())
+
+    def attn_bwd_dq(self, q, k, v, kt, d_o, lse, D, dq, nb, heads, S, ld, ld_o, ld_d, s_pad, scale):
+        self._call("svdx_attn_bwd_dq", _p(q), _p(k), _p(v), _p(kt), _p(d_o), _f32(lse), _f32(D), _p(dq),
+                   nb, heads, S, ld, ld_o, ld_d, s_pad, float(scale), _dt(q), self._stream())
+
+    def tattn_fwd(self, q, k, v, o, B, T, HW, heads, ld, ld_o, scale):
+        self._call("svdx_tattn_fwd", _p(q), _p(k), _p(v), _p(o), B, T, HW, heads, ld, ld_o, float(scale),
+                   _dt(q), self._stream())
+
+    def tattn_bwd(self, q, k, v, d_o, dq, dk, dv, B, T, HW, heads, ld, ld_o, ld_d, scale):
+        self._call("svdx_tattn_bwd", _p(q), _p(k), _p(v), _p(d_o), _p(dq), _p(dk), _p(dv), B, T, HW, heads,
+                   ld, ld_o, ld_d, float(scale), _dt(q), self._stream())
+
+    # ---- elementwise ------------------------------------------------------------------------------
+    def geglu_fwd(self, pre, out, M, F):
+        self._call("svdx_geglu_fwd", _p(pre), _p(out), M, F, _dt(pre), self._stream())
+
+    def geglu_bwd(self, dout, pre, dpre, M, F):
+        self._call("svdx_geglu_bwd", _p(dout), _p(pre), _p(dpre), M, F, _dt(pre), self._stream())
+
+    def add(self, a, b, out, n):
+        self._call("svdx_add", _p(a), _p(b), _p(out), n, _dt(a), self._stream())
+
+    def blend(self, a, b, mix, out, n):
+        self._call("svdx_blend", _p(a), _p(b), _f32(mix), _p(out), n, _dt(a), self._stream())
+
+    def blend_bwd(self, dy, mix, da, db, n):
+        self._call("svdx_blend_bwd", _p(dy), _f32(mix), _p(da), _p(db), n, _dt(dy), self._stream())
+
+    def add_rowvec(self, x, vec, out, rows, C, rv_ld, rpg, mod):
+        self._call("svdx_add_rowvec", _p(x), _f32(vec), _p(out), rows, C, rv_ld, rpg, mod, _dt(x), self._stream())
+
+    def colsum(self, x, out, rows, C, ldx, n_groups, rpg, mod, accumulate=0):
+        self._call("svdx_colsum", _p(x), _f32(out), rows, C, ldx, n_groups, rpg, mod, int(accumulate), _dt(x),
+                   self._stream())
+
+    def transpose(self, inp, ld_in, out, ld_out, rows, cols):
+        self._call("svdx_transpose", _p(inp), ld_in, _p(out), ld_out, rows, cols, _dt(inp), self._stream())
+
+    def concat2(self, a, Ca, b, Cb, out, rows):
+        self._call("svdx_concat2", _p(a), Ca, _p(b), Cb, _p(out), rows, _dt(a), self._stream())
+
+    def split2(self, inp, a, Ca, b, Cb, rows):
+        self._call("svdx_split2", _p(inp), _p(a), Ca, _p(b), Cb, rows, _dt(inp), self._stream())
+
+    def sum2x2(self, inp, out, n_img, h, w, C):
+        self._call("svdx_sum2x2", _p(inp), _p(out), n_img, h, w, C, _dt(inp), self._stream())
+
+    def cast_from_f32(self, inp, out, n):
+        self._call("svdx_cast_from_f32", _f32(inp), _p(out), n, _dt(out), self._stream())
+
+    def cast_transpose_from_f32(self, inp, out, R, Ccols):
+        self._call("svdx_cast_transpose_from_f32", _f32(inp), _p(out), R, Ccols, _dt(out), self._stream())
+
+    def nchw_to_rows(self, inp, out, n_img, C, H, W, ld, mul=1.0):
+        self._call("svdx_nchw_to_rows", _f32(inp), _p(out), n_img, C, H, W, ld, float(mul), _dt(out), self._stream())
+
+    def rows_to_nchw(self, inp, out, n_img, C, H, W, ld):
+        self._call("svdx_rows_to_nchw", _p(inp), _f32(out), n_img, C, H, W, ld, _dt(inp), self._stream())
+
+    def zero(self, t):
+        self._call("svdx_zero", _p(t), t.numel() * t.element_size(), self._stream())
+
+    # ---- loss / optimizer -------------------------------------------------------------------------
+    def edm_loss(self, pred, ld, noisy, target, sigma, loss, dpred, B, T, C, HW, opt_state):
+        self._call("svdx_edm_loss", _p(pred), ld, _f32(noisy), _f32(target), _f32(sigma), _f32(loss),
+                   _p(dpred), B, T, C, HW, _f32(opt_state), _dt(pred), self._stream())
+
+    def check_finite(self, g, n, opt_state):
+        self._call("svdx_check_finite", _f32(g), n, _f32(opt_state), self._stream())
+
+    def optim_prep(self, opt_state, beta1, beta2, growth, backoff, growth_interval, dynamic):
+        self._call("svdx_optim_prep", _f32(opt_state), float(beta1), float(beta2), float(growth),
+                   float(backoff), int(growth_interval), int(dynamic), self._stream())
+
+    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, grad_mul, opt_state, p_act):
+        self._call("svdx_adamw", _f32(p), _f32(g), _f32(m), _f32(v), n, float(lr), float(beta1), float(beta2),
+                   float(eps), float(wd), float(grad_mul), _f32(opt_state), _p(p_act),
+                   _dt(p_act) if p_act is not None else F16, self._stream())
+
+
+_backend = None
+
+
+def backend():
+    """The HIP backend (created on first use).  Raises SvdxError when the extension or GPU is missing."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def _set_backend_for_tests(obj) -> None:
+    """tests/ only: install an emulation of this interface so host logic can run without a GPU."""
+    global _backend
+    _backend = obj

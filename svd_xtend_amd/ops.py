@@ -1,0 +1,350 @@
+"""Host-side operators of the SVD UNet hot path: each op owns its packed weights and has an explicit
+`fwd` / `bwd` made of libsvdx kernel launches (svd_xtend_amd.kernels).  No torch.autograd, no ATen math:
+torch is used for allocation, views and one-off weight re-layout at load time only.
+
+Layout: activations are [rows, C] row-major with rows = (b, t, y, x) -- the "(B*T, HW, C)" layout of
+SURVEY.md section 7 -- so transformer linears need no permute, 2-D convs are implicit GEMMs over rows and
+temporal ops address rows with stride HW.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+
+GN_GROUPS = 32
+
+
+def rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class Runtime:
+    """Per-model execution context: backend, activation dtype, device, scratch allocation."""
+
+    def __init__(self, dtype: torch.dtype, device: torch.device):
+        self.dt = dtype
+        self.dev = device
+        self.k = K.backend()
+        self.gemm_variant = 0
+        self.profile = None     # optional callable(kind, flops, bytes) -> context manager (bench instrumentation)
+
+    def empty(self, *shape, dtype=None) -> torch.Tensor:
+        return torch.empty(*shape, dtype=dtype or self.dt, device=self.dev)
+
+    def f32(self, *shape) -> torch.Tensor:
+        return torch.empty(*shape, dtype=torch.float32, device=self.dev)
+
+    def zeros_f32(self, *shape) -> torch.Tensor:
+        t = self.f32(*shape)
+        self.k.zero(t)
+        return t
+
+
+def _choose_split_k(M: int, N: int, Kdim: int) -> int:
+    """Split the reduction when the output grid cannot fill 256 CUs (weight-grad GEMMs: tiny [N,K] outputs,
+    reduction over all rows)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 256 or Kdim < 1024:
+        return 1
+    want = max(1, 512 // tiles)
+    ksteps = Kdim // 64
+    return max(1, min(want, ksteps // 4, 64))
+
+
+# --------------------------------------------------------------------------------------------------
+# Linear
+# --------------------------------------------------------------------------------------------------
+class LinearOp:
+    """y = x W^T (+ b).  `weights` may be several nn.Parameters concatenated along the output dim (fused QKV).
+
+    Replaces nn.Linear inside diffusers Attention / FeedForward / proj_in / proj_out.
+    Packed copies (activation dtype): w [N,K] for fwd, wt [K,N] for the data-grad.  Weight-grad goes to the
+    float .grad of the master parameter(s) through an NT GEMM on transposed operands."""
+
+    def __init__(self, weights: Sequence[nn.Parameter], biases: Optional[Sequence[Optional[nn.Parameter]]] = None):
+        self.weights = list(weights)
+        self.biases = list(biases) if biases is not None else None
+        self.N = sum(w.shape[0] for w in self.weights)
+        self.Kdim = self.weights[0].shape[1]
+        self.trainable = any(w.requires_grad for w in self.weights)
+        self.w = self.wt = self.b = None
+        self.w_grad = self.b_grad = None
+
+    # ---- packing ----
+    def pack(self, rt: Runtime, need_dx: bool = True) -> None:
+        k = rt.k
+        master = self._flat_view([w.data for w in self.weights])
+        if master is None:
+            master = torch.cat([w.data.reshape(w.shape[0], -1) for w in self.weights], 0).contiguous()
+        self.w = rt.empty(self.N, self.Kdim)
+        k.cast_from_f32(master, self.w, self.N * self.Kdim)
+        if need_dx:
+            self.wt = rt.empty(self.Kdim, self.N)
+            k.cast_transpose_from_f32(master, self.wt, self.N, self.Kdim)
+        if self.biases is not None and self.biases[0] is not None:
+            b = self._flat_view([b.data for b in self.biases])
+            self.b = b if b is not None else torch.cat([b.data for b in self.biases]).contiguous()
+        if self.trainable:
+            self.w_grad = self._flat_view([w.grad for w in self.weights])
+            if self.w_grad is None:
+                raise RuntimeError("trainable fused weights must have contiguous .grad views (use Trainer)")
+            if self.b is not None:
+                self.b_grad = self._flat_view([b.grad for b in self.biases])
+
+    @staticmethod
+    def _flat_view(ts: List[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
+        """Return one contiguous tensor covering `ts` when they are adjacent in memory, else None."""
+        if any(t is None for t in ts):
+            return None
+        if len(ts) == 1:
+            return ts[0] if ts[0].is_contiguous() else None
+        ptr = ts[0].data_ptr()
+        total = 0
+        for t in ts:
+            if not t.is_contiguous() or t.data_ptr() != ptr + total * t.element_size() or t.dtype != ts[0].dtype:
+                return None
+            total += t.numel()
+        base = ts[0]
+        return torch.as_strided(base, (total,), (1,), base.storage_offset())
+
+    def refresh(self, rt: Runtime, need_dx: bool = True) -> None:
+        """Re-cast after an optimizer step (trainable weights only)."""
+        master = self._flat_view([w.data for w in self.weights])
+        rt.k.cast_from_f32(master, self.w, self.N * self.Kdim)
+        if self.wt is not None:
+            rt.k.cast_transpose_from_f32(master, self.wt, self.N, self.Kdim)
+
+    # ---- compute ----
+    def fwd(self, rt: Runtime, x: torch.Tensor, M: int, res: Optional[torch.Tensor] = None,
+            rowvec: Optional[torch.Tensor] = None, rv_ld: int = 0, rv_rpg: int = 0, rv_mod: int = 0,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        y = out if out is not None else rt.empty(M, self.N)
+        rt.k.gemm(x, self.w, y, M, self.N, self.Kdim, self.Kdim, self.Kdim, self.N, bias=self.b,
+                  rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod, res=res,
+                  ldres=self.N if res is not None else 0, variant=rt.gemm_variant)
+        return y
+
+    def bwd_dx(self, rt: Runtime, dy: torch.Tensor, M: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        dx = out if out is not None else rt.empty(M, self.Kdim)
+        rt.k.gemm(dy, self.wt, dx, M, self.Kdim, self.N, self.N, self.N, self.Kdim, variant=rt.gemm_variant)
+        return dx
+
+    def bwd_dw(self, rt: Runtime, dy: torch.Tensor, xt: torch.Tensor, M: int) -> None:
+        """w.grad += dy^T x ; b.grad += colsum(dy).   xt = transpose(x) [K, Mpad] (shared by the caller)."""
+        if not self.trainable:
+            return
+        k = rt.k
+        Mp = xt.shape[1]
+        dyt = rt.empty(self.N, Mp)
+        k.transpose(dy, self.N, dyt, Mp, M, self.N)
+        sk = _choose_split_k(self.N, self.Kdim, Mp)
+        k.gemm(dyt, xt, self.w_grad, self.N, self.Kdim, Mp, Mp, Mp, self.Kdim, out_mode=K.OUT_F32_ATOMIC,
+               split_k=sk, variant=rt.gemm_variant)
+        if self.b_grad is not None:
+            k.colsum(dy, self.b_grad, M, self.N, self.N, 1, M, 0, accumulate=1)
+
+
+def transpose_pad(rt: Runtime, x: torch.Tensor, M: int, C: int) -> torch.Tensor:
+    """[M, C] -> [C, rup(M,64)] zero-padded (operand of the weight-grad GEMM)."""
+    Mp = rup(M, 64)
+    xt = rt.empty(C, Mp)
+    rt.k.transpose(x, C, xt, Mp, M, C)
+    return xt
+
+
+_ONES = {}
+
+
+def _ones(rt: Runtime) -> torch.Tensor:
+    key = str(rt.dev)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(1, 1, dtype=torch.float32, device=rt.dev)
+    return _ONES[key]
+
+
+# --------------------------------------------------------------------------------------------------
+# skinny linear (float activations): embedding MLPs and the KV-length-1 cross-attention
+# --------------------------------------------------------------------------------------------------
+class SmallLinearOp:
+    def __init__(self, weight: nn.Parameter, bias: Optional[nn.Parameter]):
+        self.weight, self.bias = weight, bias
+        self.N, self.Kdim = weight.shape
+        self.trainable = weight.requires_grad
+        self.w = None
+
+    def pack(self, rt: Runtime) -> None:
+        self.w = rt.empty(self.N, self.Kdim)
+        rt.k.cast_from_f32(self.weight.data.contiguous(), self.w, self.N * self.Kdim)
+
+    refresh = pack
+
+    def fwd(self, rt: Runtime, x: torch.Tensor, M: int, silu_in: bool = False, out: Optional[torch.Tensor] = None,
+            accumulate: bool = False) -> torch.Tensor:
+        y = out if out is not None else rt.f32(M, self.N)
+        rt.k.small_linear(x, self.w, None if self.bias is None else self.bias.data, y, M, self.N, self.Kdim,
+                          self.Kdim, 0, int(silu_in), int(accumulate))
+        return y
+
+    def bwd(self, rt: Runtime, dy: torch.Tensor, x: torch.Tensor, M: int, need_dx: bool) -> Optional[torch.Tensor]:
+        k = rt.k
+        if self.trainable:
+            k.outer_acc(dy, x, self.weight.grad, M, self.N, self.Kdim, 1.0)
+            if self.bias is not None:
+                k.outer_acc(dy, _ones(rt).expand(M, 1).contiguous(), self.bias.grad.view(self.N, 1), M, self.N, 1, 1.0)
+        if not need_dx:
+            return None
+        dx = rt.f32(M, self.Kdim)
+        k.small_linear(dy, self.w, None, dx, M, self.N, self.Kdim, self.Kdim, 1, 0, 0)
+        return dx
+
+
+# --------------------------------------------------------------------------------------------------
+# convolutions as implicit GEMM
+# --------------------------------------------------------------------------------------------------
+class ConvOp:
+    """3x3 conv2d (stride 1/2, optional nearest-x2 source), 1x1 conv2d, or Conv3d (3,1,1), all as NT GEMMs
+    whose A operand is gathered on the fly (K1-K4 of SURVEY.md 2.3).  Weights are frozen on this path
+    (train_svd.py:761-766 trains only temporal transformer blocks), so only fwd + data-grad exist."""
+
+    def __init__(self, weight: nn.Parameter, bias: Optional[nn.Parameter], kind: str, stride: int = 1,
+                 ups: bool = False, cin_pad: Optional[int] = None, cout_pad: Optional[int] = None):
+        assert kind in ("3x3", "1x1", "t3")
+        self.weight, self.bias, self.kind, self.stride, self.ups = weight, bias, kind, stride, ups
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.cin_p = cin_pad or self.cin
+        self.cout_p = cout_pad or self.cout     # padded channel count of the *incoming gradient* rows
+        self.taps = {"3x3": 9, "1x1": 1, "t3": 3}[kind]
+        self.w = self.wd = None
+        if weight.requires_grad:
+            raise NotImplementedError("conv weight-grad is outside this round's trainable set")
+
+    def pack(self, rt: Runtime, need_dx: bool = True) -> None:
+        W = self.weight.data
+        co, ci, tp = self.cout, self.cin, self.taps
+        w4 = W.reshape(co, ci, tp)                                   # taps flattened dy*3+dx / dt
+        wp = torch.zeros(co, tp, self.cin_p, dtype=torch.float32, device=W.device)
+        wp[:, :, :ci] = w4.permute(0, 2, 1)
+        self.w = rt.empty(co, tp * self.cin_p)
+        rt.k.cast_from_f32(wp.reshape(-1), self.w, wp.numel())
+        if need_dx:
+            flip = self.kind in ("3x3", "t3") and self.stride == 1
+            src = w4.flip(2) if flip else w4
+            wd = torch.zeros(ci, tp, self.cout_p, dtype=torch.float32, device=W.device)
+            wd[:, :, :co] = src.permute(1, 2, 0)
+            self.wd = rt.empty(ci, tp * self.cout_p)
+            rt.k.cast_from_f32(wd.reshape(-1), self.wd, wd.numel())
+        self.b = None if self.bias is None else self.bias.data
+
+    def _gather(self, n_img, hi, wi, ho, wo, cin, lda, T=0, hw=0, dgrad=False) -> Optional[K.Gather]:
+        if self.kind == "1x1":
+            return None
+        if self.kind == "t3":
+            return K.Gather(K.GATHER_TEMPORAL3, n_img=n_img, cin=cin, t=T, hw=hw, lda=lda)
+        if dgrad and self.stride == 2:
+            return K.Gather(K.GATHER_CONV3X3_DGRAD2, n_img=n_img, hi=hi, wi=wi, ho=ho, wo=wo, cin=cin, lda=lda)
+        return K.Gather(K.GATHER_CONV3X3, n_img=n_img, hi=hi, wi=wi, ho=ho, wo=wo, cin=cin,
+                        stride=1 if dgrad else self.stride, ups=int(self.ups and not dgrad), lda=lda)
+
+    def out_hw(self, h: int, w: int):
+        if self.ups:
+            return 2 * h, 2 * w
+        if self.stride == 2:
+            return (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        return h, w
+
+    def fwd(self, rt: Runtime, x: torch.Tensor, n_img: int, h: int, w: int, T: int = 0,
+            res: Optional[torch.Tensor] = None, rowvec=None, rv_ld=0, rv_rpg=0, ldc: Optional[int] = None):
+        """x: [n_img*h*w, cin_p] (t3: n_img = B, rows = B*T*h*w).  Returns ([M, cout], ho, wo)."""
+        ho, wo = self.out_hw(h, w)
+        if self.kind == "t3":
+            M = n_img * T * h * w
+            g = self._gather(n_img, 0, 0, 0, 0, self.cin_p, self.cin_p, T=T, hw=h * w)
+        else:
+            M = n_img * ho * wo
+            g = self._gather(n_img, ho if self.ups else h, wo if self.ups else w, ho, wo, self.cin_p, self.cin_p)
+        ldc = ldc or self.cout
+        y = rt.empty(M, ldc)
+        Kd = self.taps * self.cin_p
+        rt.k.gemm(x, self.w, y, M, self.cout, Kd, self.cin_p, Kd, ldc, bias=self.b, rowvec=rowvec, rv_ld=rv_ld,
+                  rv_rpg=rv_rpg, res=res, ldres=self.cout if res is not None else 0, gather=g,
+                  variant=rt.gemm_variant)
+        return y, ho, wo
+
+    def bwd_dx(self, rt: Runtime, dy: torch.Tensor, n_img: int, h: int, w: int, T: int = 0) -> torch.Tensor:
+        """dy: [M_out, cout_p] -> dx [n_img*h*w, cin] where (h, w) are the conv INPUT dims (pre-upsample)."""
+        k = rt.k
+        ho, wo = self.out_hw(h, w)
+        Kd = self.taps * self.cout_p
+        if self.kind == "t3":
+            M = n_img * T * h * w
+            g = self._gather(n_img, 0, 0, 0, 0, self.cout_p, self.cout_p, T=T, hw=h * w, dgrad=True)
+            dx = rt.empty(M, self.cin)
+            k.gemm(dy, self.wd, dx, M, self.cin, Kd, self.cout_p, Kd, self.cin, gather=g, variant=rt.gemm_variant)
+            return dx
+        if self.ups:
+            Mh = n_img * ho * wo
+            g = self._gather(n_img, ho, wo, ho, wo, self.cout_p, self.cout_p, dgrad=True)
+            dxh = rt.empty(Mh, self.cin)
+            k.gemm(dy, self.wd, dxh, Mh, self.cin, Kd, self.cout_p, Kd, self.cin, gather=g, variant=rt.gemm_variant)
+            dx = rt.empty(n_img * h * w, self.cin)
+            k.sum2x2(dxh, dx, n_img, h, w, self.cin)
+            return dx
+        M = n_img * h * w
+        g = self._gather(n_img, ho, wo, h, w, self.cout_p, self.cout_p, dgrad=True)
+        dx = rt.empty(M, self.cin)
+        k.gemm(dy, self.wd, dx, M, self.cin, Kd, self.cout_p, Kd, self.cin, gather=g, variant=rt.gemm_variant)
+        return dx
+
+
+# --------------------------------------------------------------------------------------------------
+# norms
+# --------------------------------------------------------------------------------------------------
+class GroupNormOp:
+    """GroupNorm(32, C) (+ fused SiLU).  n_s samples of `rows` rows: 2-D norm -> sample = frame,
+    3-D (TemporalResnetBlock) -> sample = clip with rows = T*HW (the group spans all frames)."""
+
+    def __init__(self, mod: nn.GroupNorm, silu: bool):
+        self.mod, self.silu = mod, silu
+        self.C, self.eps = mod.num_channels, mod.eps
+        if mod.weight.requires_grad:
+            raise NotImplementedError("GroupNorm affine grads are outside this round's trainable set")
+
+    def fwd(self, rt: Runtime, x: torch.Tensor, n_s: int, rows: int):
+        stats = rt.f32(n_s, GN_GROUPS, 2)
+        y = rt.empty(n_s * rows, self.C)
+        rt.k.gn_stats(x, stats, n_s, rows, self.C, GN_GROUPS)
+        rt.k.gn_apply(x, stats, self.mod.weight.data, self.mod.bias.data, y, n_s, rows, self.C, GN_GROUPS,
+                      self.eps, self.silu)
+        return y, stats
+
+    def bwd(self, rt: Runtime, dy, x, stats, n_s: int, rows: int, add: Optional[torch.Tensor] = None):
+        bst = rt.f32(n_s, GN_GROUPS, 2)
+        dx = rt.empty(n_s * rows, self.C)
+        g, b = self.mod.weight.data, self.mod.bias.data
+        rt.k.gn_bwd_stats(dy, x, stats, g, b, bst, n_s, rows, self.C, GN_GROUPS, self.eps, self.silu)
+        rt.k.gn_bwd_apply(dy, x, stats, bst, g, b, add, dx, n_s, rows, self.C, GN_GROUPS, self.eps, self.silu)
+        return dx
+
+
+class LayerNormOp:
+    def __init__(self, mod: nn.LayerNorm):
+        self.mod = mod
+        self.C, self.eps = mod.normalized_shape[0], mod.eps
+        self.trainable = mod.weight.requires_grad
+
+    def fwd(self, rt: Runtime, x: torch.Tensor, M: int):
+        y = rt.empty(M, self.C)
+        stats = rt.f32(M, 2)
+        rt.k.ln_fwd(x, self.mod.weight.data, self.mod.bias.data, y, stats, M, self.C, self.eps)
+        return y, stats
+
+    def bwd(self, rt: Runtime, dy, x, stats, M: int, add: Optional[torch.Tensor] = None):
+        dx = rt.empty(M, self.C)
+        dg = self.mod.weight.grad if self.trainable else None
+        db = self.mod.bias.grad if self.trainable else None
+        rt.k.ln_bwd(dy, x, stats, self.mod.weight.data, add, dx, dg, db, M, self.C)
+        return dx

@@ -1,0 +1,133 @@
+"""The training step of /root/reference/train_svd.py:941-1049 on the MI355X-native UNet.
+
+`Trainer` owns what accelerate + torch.optim own in the reference: the trainable-set selection
+(train_svd.py:761-766), one flat float master/grad/Adam buffer, the fp16 loss-scale state machine
+(GradScaler semantics, on device), AdamW (train_svd.py:767-773) and the data-parallel gradient mean
+(intended DDP semantics) as ONE all-reduce of the flat gradient buffer over RCCL.
+Everything on the timed path is libsvdx kernels; torch supplies memory, streams and torch.distributed.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .ops import rup
+from .unet import UNetSpatioTemporalConditionModel
+
+ALIGN = 64  # floats
+
+
+def select_trainable(model: torch.nn.Module, substr: str = "temporal_transformer_block") -> List[str]:
+    """train_svd.py:761-766."""
+    names = []
+    for name, p in model.named_parameters():
+        p.requires_grad = substr in name
+        if p.requires_grad:
+            names.append(name)
+    return names
+
+
+class Trainer:
+    def __init__(self, model: UNetSpatioTemporalConditionModel, dtype: torch.dtype = torch.float16,
+                 lr: float = 1e-5, betas=(0.9, 0.999), weight_decay: float = 1e-2, eps: float = 1e-8,
+                 init_scale: float = 65536.0, growth_interval: int = 2000, process_group=None,
+                 grad_accum: int = 1):
+        self.model, self.dtype = model, dtype
+        self.lr, self.betas, self.wd, self.eps = lr, betas, weight_decay, eps
+        self.growth_interval = growth_interval
+        self.grad_accum = grad_accum
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        dev = next(model.parameters()).device
+        self.dev = dev
+
+        self.names = select_trainable(model)
+        params = dict(model.named_parameters())
+        self.params = [params[n] for n in self.names]
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off = rup(off + p.numel(), ALIGN)
+        self.offsets, self.n_flat = offs, off
+        # one extra aligned slot at the tail carries the loss through the gradient all-reduce (replaces the
+        # separate accelerator.gather of train_svd.py:1039-1040)
+        self.n_total = off + ALIGN
+        self.p_flat = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.g_flat = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.m_flat = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.v_flat = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, offs):
+            n = p.numel()
+            self.p_flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.p_flat[o:o + n].view(p.shape)
+            p.grad = self.g_flat[o:o + n].view(p.shape)
+        self.loss_slot = self.g_flat[off:off + 1]
+        # opt_state: 0 step, 1 loss_scale, 2 growth_tracker, 3 found_inf, 4 inv_scale, 5 bc1, 6 bc2, 7 skip
+        self.dynamic = dtype == torch.float16
+        st = [0.0, init_scale if self.dynamic else 1.0, 0.0, 0.0, 1.0, 1.0, 1.0, 0.0]
+        self.opt_state = torch.tensor(st, dtype=torch.float32, device=dev)
+        model.prepare(dtype)
+        self.rt = model.rt
+        self.micro = 0
+        self.comm_stream = None
+
+    # ---- one micro-step: fwd + loss + bwd, grads accumulate into g_flat ---------------------------------
+    def forward_backward(self, unet_in, timesteps, ehs, added_time_ids, noisy_latents, target, sigmas):
+        """unet_in [B,T,8,h,w]; noisy_latents/target float [B,T,4,h,w]; sigmas float [B].
+        Adds this micro-batch's loss into the loss slot and its grads into the flat buffer."""
+        m, k = self.model, self.rt.k
+        pred = m.forward_rows(unet_in, timesteps, ehs, added_time_ids)
+        B, T, _, h, w = unet_in.shape
+        dpred = self.rt.empty(B * T * h * w, m.cout_pad)
+        k.zero(dpred)
+        k.edm_loss(pred, m.out_channels, noisy_latents.contiguous(), target.contiguous(), sigmas.contiguous(),
+                   self.loss_slot, dpred, B, T, m.out_channels, h * w, self.opt_state)
+        m.backward_rows(dpred)
+        self.micro += 1
+
+    def zero_grad(self):
+        self.rt.k.zero(self.g_flat)
+
+    # ---- gradient mean over ranks: ONE collective on the flat buffer -----------------------------------
+    def allreduce_grads(self, async_op: bool = False):
+        if self.world == 1:
+            return None
+        return dist.all_reduce(self.g_flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+
+    # ---- optimizer step (unscale + inf check + AdamW + re-pack), no host sync -----------------------------
+    def optimizer_step(self):
+        k = self.rt.k
+        n = self.n_flat
+        k.check_finite(self.g_flat, n, self.opt_state)
+        k.optim_prep(self.opt_state, self.betas[0], self.betas[1], 2.0, 0.5, self.growth_interval, int(self.dynamic))
+        grad_mul = 1.0 / (self.world * self.grad_accum)
+        k.adamw(self.p_flat, self.g_flat, self.m_flat, self.v_flat, n, self.lr, self.betas[0], self.betas[1],
+                self.eps, self.wd, grad_mul, self.opt_state, None)
+        self.model.refresh_trainable()
+        self.micro = 0
+
+    def step(self, batch: Dict[str, torch.Tensor]) -> None:
+        """Whole optimizer step for one micro-batch (grad_accum == 1): zero, fwd/bwd, all-reduce, AdamW."""
+        self.zero_grad()
+        self.forward_backward(**batch)
+        self.allreduce_grads()
+        self.optimizer_step()
+
+    def last_loss(self) -> torch.Tensor:
+        """Mean (unscaled) loss over ranks/micro-batches of the last reduced step (device scalar; read it
+        before the next zero_grad)."""
+        return self.loss_slot / (self.world * self.grad_accum)
+
+
+def edm_prepare(latents, noise, cond_latents, sigmas):
+    """UNet inputs of train_svd.py:964-972, 1014-1017 from latents (host-side data prep of the train script).
+    Returns unet_in [B,T,8,h,w], timesteps [B], noisy_latents."""
+    T = latents.shape[1]
+    s = sigmas.to(latents)[:, None, None, None, None]
+    noisy = latents + noise * s
+    timesteps = 0.25 * sigmas.to(torch.float32).log()
+    inp = noisy / ((s ** 2 + 1) ** 0.5)
+    cond = cond_latents.unsqueeze(1).repeat(1, T, 1, 1, 1)
+    return torch.cat([inp, cond], dim=2), timesteps, noisy

@@ -1,0 +1,960 @@
+"""MI355X-native `UNetSpatioTemporalConditionModel`: drop-in for the class the reference trains
+(/root/reference/src/unet_spatio_temporal_condition.py:32-490, used at /root/reference/train_svd.py:1021).
+
+Same constructor arguments, `forward(sample, timestep, encoder_hidden_states, added_time_ids, return_dict)`
+contract and diffusers state-dict key names.  The arithmetic is NOT torch: every block below
+holds its parameters under the diffusers names and runs an explicit, hand-written forward and backward made
+of libsvdx (HIP, gfx950) kernel launches -- see svd_xtend_amd/ops.py and include/svdx.h.  Block internals
+follow diffusers' unet_3d_blocks / transformer_temporal / attention / resnet modules as restated in
+SURVEY.md 8(a) rows a3-a10.
+
+Internal layout is rows = (b, t, y, x), channels last; temporal ops address frames by stride (no
+(B*T,HW,C) <-> (B*HW,T,C) transposes); cross-attention has KV length 1 so it reduces to a per-clip row
+vector `to_out(to_v(ctx))`.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .ops import (ConvOp, GroupNormOp, LayerNormOp, LinearOp, Runtime, SmallLinearOp, rup, transpose_pad)
+
+HEAD_DIM = 64
+
+
+class Geom:
+    """Shape of the activation rows at one resolution level."""
+
+    def __init__(self, B: int, T: int, h: int, w: int):
+        self.B, self.T, self.h, self.w = B, T, h, w
+        self.N = B * T
+        self.HW = h * w
+        self.M = self.N * self.HW
+
+
+# ==================================================================================================
+# holders for diffusers sub-module names
+# ==================================================================================================
+class _TimestepEmbedding(nn.Module):
+    def __init__(self, cin, dim, out_dim=None):
+        super().__init__()
+        self.linear_1 = nn.Linear(cin, dim)
+        self.linear_2 = nn.Linear(dim, out_dim or dim)
+
+    def build(self):
+        self.l1 = SmallLinearOp(self.linear_1.weight, self.linear_1.bias)
+        self.l2 = SmallLinearOp(self.linear_2.weight, self.linear_2.bias)
+
+    def pack(self, rt):
+        self.l1.pack(rt)
+        self.l2.pack(rt)
+
+    def fwd(self, rt, x, M, out=None, accumulate=False):
+        h = self.l1.fwd(rt, x, M)
+        return self.l2.fwd(rt, h, M, silu_in=True, out=out, accumulate=accumulate)
+
+
+class _AlphaBlender(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.mix_factor = nn.Parameter(torch.tensor([0.5], dtype=torch.float32))
+
+
+class _GEGLU(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = nn.Linear(dim, inner * 2)
+
+
+class _FeedForward(nn.Module):
+    """net.0.proj (GEGLU) / net.2; fwd saves (pre, g) for the backward."""
+
+    def __init__(self, dim, dim_out=None):
+        super().__init__()
+        self.dim, self.inner = dim, dim * 4
+        self.net = nn.ModuleList([_GEGLU(dim, self.inner), nn.Dropout(0.0), nn.Linear(self.inner, dim_out or dim)])
+
+    def build(self):
+        self.p1 = LinearOp([self.net[0].proj.weight], [self.net[0].proj.bias])
+        self.p2 = LinearOp([self.net[2].weight], [self.net[2].bias])
+
+    def pack(self, rt):
+        self.p1.pack(rt)
+        self.p2.pack(rt)
+
+    def refresh(self, rt):
+        self.p1.refresh(rt)
+        self.p2.refresh(rt)
+
+    def fwd(self, rt, x, M, res):
+        pre = self.p1.fwd(rt, x, M)
+        g = rt.empty(M, self.inner)
+        rt.k.geglu_fwd(pre, g, M, self.inner)
+        y = self.p2.fwd(rt, g, M, res=res)
+        return y, pre, g
+
+    def bwd(self, rt, dy, x_saved, pre, g, M):
+        """returns d(input of p1); accumulates weight grads when trainable."""
+        k = rt.k
+        dg = self.p2.bwd_dx(rt, dy, M)
+        if self.p2.trainable:
+            self.p2.bwd_dw(rt, dy, transpose_pad(rt, g, M, self.inner), M)
+        dpre = rt.empty(M, 2 * self.inner)
+        k.geglu_bwd(dg, pre, dpre, M, self.inner)
+        del dg
+        dx = self.p1.bwd_dx(rt, dpre, M)
+        if self.p1.trainable:
+            self.p1.bwd_dw(rt, dpre, transpose_pad(rt, x_saved, M, self.dim), M)
+        return dx
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, heads, cross_dim=None):
+        super().__init__()
+        inner = heads * HEAD_DIM
+        kv = cross_dim if cross_dim is not None else dim
+        self.heads, self.dim, self.cross = heads, dim, cross_dim is not None
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_k = nn.Linear(kv, inner, bias=False)
+        self.to_v = nn.Linear(kv, inner, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(inner, dim, bias=True), nn.Dropout(0.0)])
+
+    def build(self):
+        if self.cross:
+            self.v = SmallLinearOp(self.to_v.weight, None)
+            self.o = SmallLinearOp(self.to_out[0].weight, self.to_out[0].bias)
+        else:
+            self.qkv = LinearOp([self.to_q.weight, self.to_k.weight, self.to_v.weight])
+            self.o = LinearOp([self.to_out[0].weight], [self.to_out[0].bias])
+
+    def pack(self, rt):
+        if self.cross:
+            self.v.pack(rt)
+            self.o.pack(rt)
+        else:
+            self.qkv.pack(rt)
+            self.o.pack(rt)
+
+    refresh = pack
+
+    # KV-length-1 cross attention: softmax over one key == 1, so attn2(x, ctx) = to_out(to_v(ctx)) for every
+    # query row; to_q / to_k (and the LayerNorm feeding to_q) receive exactly zero gradient.
+    def cross_vec(self, rt, ctx, Bn):
+        v = self.v.fwd(rt, ctx, Bn)
+        return self.o.fwd(rt, v, Bn), v
+
+    def cross_vec_bwd(self, rt, dvec, v, ctx, Bn):
+        dv = self.o.bwd(rt, dvec, v, Bn, need_dx=self.v.trainable)
+        if self.v.trainable:
+            self.v.bwd(rt, dv, ctx, Bn, need_dx=False)
+
+
+# ==================================================================================================
+# transformer blocks
+# ==================================================================================================
+class BasicTransformerBlock(nn.Module):
+    """Spatial block (diffusers attention.BasicTransformerBlock): self-attn over HW, KV-1 cross-attn, GEGLU FF."""
+
+    def __init__(self, dim, heads, cross_dim):
+        super().__init__()
+        self.dim, self.heads = dim, heads
+        self.norm1 = nn.LayerNorm(dim, eps=1e-5)
+        self.attn1 = _Attention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-5)
+        self.attn2 = _Attention(dim, heads, cross_dim)
+        self.norm3 = nn.LayerNorm(dim, eps=1e-5)
+        self.ff = _FeedForward(dim)
+
+    def build(self):
+        for m in (self.attn1, self.attn2, self.ff):
+            m.build()
+        self.ln1, self.ln3 = LayerNormOp(self.norm1), LayerNormOp(self.norm3)
+        if any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("spatial transformer blocks are frozen on this path (train_svd.py:761-766)")
+
+    def pack(self, rt):
+        for m in (self.attn1, self.attn2, self.ff):
+            m.pack(rt)
+
+    def fwd(self, rt: Runtime, h, g: Geom, ctx):
+        k, C, M, S = rt.k, self.dim, g.M, g.HW
+        n1, st1 = self.ln1.fwd(rt, h, M)
+        qkv = self.attn1.qkv.fwd(rt, n1, M)
+        del n1
+        s_pad = rup(S, 64)
+        vt = rt.empty(g.N * self.heads * HEAD_DIM * s_pad)
+        k.head_transpose(qkv[:, 2 * C:], 3 * C, vt, g.N, self.heads, S, s_pad)
+        o = rt.empty(M, C)
+        lse = rt.f32(g.N * self.heads * S)
+        k.attn_fwd(qkv, qkv[:, C:], vt, o, lse, g.N, self.heads, S, 3 * C, C, s_pad, HEAD_DIM ** -0.5)
+        del vt
+        cvec, _ = self.attn2.cross_vec(rt, ctx, g.B)
+        h2 = self.attn1.o.fwd(rt, o, M, res=h, rowvec=cvec, rv_ld=C, rv_rpg=g.T * g.HW)
+        n3, st3 = self.ln3.fwd(rt, h2, M)
+        h3, pre, _ = self.ff.fwd(rt, n3, M, res=h2)
+        self.sv = (h, st1, qkv, o, lse, h2, st3, pre)
+        return h3
+
+    def bwd(self, rt: Runtime, dh3, g: Geom):
+        k, C, M, S = rt.k, self.dim, g.M, g.HW
+        h, st1, qkv, o, lse, h2, st3, pre = self.sv
+        self.sv = None
+        dn3 = self.ff.bwd(rt, dh3, None, pre, None, M)
+        dh2 = self.ln3.bwd(rt, dn3, h2, st3, M, add=dh3)
+        del dn3, pre, h2
+        d_o = self.attn1.o.bwd_dx(rt, dh2, M)
+        s_pad = rup(S, 64)
+        nhs = g.N * self.heads * HEAD_DIM * s_pad
+        D = rt.f32(g.N * self.heads * S)
+        k.attn_bwd_prep(o, d_o, D, g.N, self.heads, S, C)
+        qt, kt, dot = rt.empty(nhs), rt.empty(nhs), rt.empty(nhs)
+        k.head_transpose(qkv, 3 * C, qt, g.N, self.heads, S, s_pad)
+        k.head_transpose(qkv[:, C:], 3 * C, kt, g.N, self.heads, S, s_pad)
+        k.head_transpose(d_o, C, dot, g.N, self.heads, S, s_pad)
+        dqkv = rt.empty(M, 3 * C)
+        q_, k_, v_ = qkv, qkv[:, C:], qkv[:, 2 * C:]
+        scale = HEAD_DIM ** -0.5
+        k.attn_bwd_dkv(q_, k_, v_, d_o, qt, dot, lse, D, dqkv[:, C:], dqkv[:, 2 * C:], g.N, self.heads, S,
+                       3 * C, C, 3 * C, s_pad, scale)
+        k.attn_bwd_dq(q_, k_, v_, kt, d_o, lse, D, dqkv, g.N, self.heads, S, 3 * C, C, 3 * C, s_pad, scale)
+        del qt, kt, dot, d_o
+        dn1 = self.attn1.qkv.bwd_dx(rt, dqkv, M)
+        del dqkv
+        return self.ln1.bwd(rt, dn1, h, st1, M, add=dh2)
+
+
+class TemporalBasicTransformerBlock(nn.Module):
+    """diffusers attention.TemporalBasicTransformerBlock -- the trainable set of train_svd.py:761-766.
+    Rows stay in (b,t,p) order; only the frame-axis attention looks across rows (strided)."""
+
+    def __init__(self, dim, heads, cross_dim):
+        super().__init__()
+        self.dim, self.heads = dim, heads
+        self.norm_in = nn.LayerNorm(dim)
+        self.ff_in = _FeedForward(dim, dim_out=dim)
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = _Attention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = _Attention(dim, heads, cross_dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = _FeedForward(dim)
+
+    def build(self):
+        for m in (self.ff_in, self.attn1, self.attn2, self.ff):
+            m.build()
+        self.ln0, self.ln1, self.ln3 = LayerNormOp(self.norm_in), LayerNormOp(self.norm1), LayerNormOp(self.norm3)
+        self.trainable = any(p.requires_grad for p in self.parameters())
+
+    def pack(self, rt):
+        for m in (self.ff_in, self.attn1, self.attn2, self.ff):
+            m.pack(rt)
+
+    def refresh(self, rt):
+        for m in (self.ff_in, self.attn1, self.attn2, self.ff):
+            m.refresh(rt)
+
+    @staticmethod
+    def _rv(g: Geom):
+        # diffusers builds time_context in (HW, B) order but the block flattens (B, HW): row r of the block
+        # sees the context of clip r % B (identical to the intended clip only at B == 1).  Reproduced as is.
+        if g.B == 1:
+            return dict(rv_rpg=g.M, rv_mod=0)
+        assert g.HW % g.B == 0, "time_context ordering quirk needs HW % B == 0"
+        return dict(rv_rpg=0, rv_mod=g.B)
+
+    def fwd(self, rt: Runtime, x, g: Geom, tctx):
+        k, C, M = rt.k, self.dim, g.M
+        n0, st0 = self.ln0.fwd(rt, x, M)
+        h, pre0, g0 = self.ff_in.fwd(rt, n0, M, res=x)
+        n1, st1 = self.ln1.fwd(rt, h, M)
+        qkv = self.attn1.qkv.fwd(rt, n1, M)
+        o = rt.empty(M, C)
+        k.tattn_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], o, g.B, g.T, g.HW, self.heads, 3 * C, C, HEAD_DIM ** -0.5)
+        cvec, cv = self.attn2.cross_vec(rt, tctx, g.B)
+        h1 = self.attn1.o.fwd(rt, o, M, res=h, rowvec=cvec, rv_ld=C, **self._rv(g))
+        n3, st3 = self.ln3.fwd(rt, h1, M)
+        out, pre, gg = self.ff.fwd(rt, n3, M, res=h1)
+        if not self.trainable:
+            n0 = g0 = n1 = n3 = gg = None
+        self.sv = (x, st0, n0, pre0, g0, h, st1, n1, qkv, o, cv, tctx, h1, st3, n3, pre, gg)
+        return out
+
+    def bwd(self, rt: Runtime, dout, g: Geom, need_dx: bool = True, add: Optional[torch.Tensor] = None):
+        k, C, M = rt.k, self.dim, g.M
+        x, st0, n0, pre0, g0, h, st1, n1, qkv, o, cv, tctx, h1, st3, n3, pre, gg = self.sv
+        self.sv = None
+        dn3 = self.ff.bwd(rt, dout, n3, pre, gg, M)
+        dh1 = self.ln3.bwd(rt, dn3, h1, st3, M, add=dout)
+        del dn3, pre, gg, n3, h1
+        if self.attn2.o.trainable or self.attn2.v.trainable:
+            rv = self._rv(g)
+            dvec = rt.f32(g.B, C)
+            k.colsum(dh1, dvec, M, C, C, g.B, rv["rv_rpg"], rv["rv_mod"])
+            self.attn2.cross_vec_bwd(rt, dvec, cv, tctx, g.B)
+        d_o = self.attn1.o.bwd_dx(rt, dh1, M)
+        if self.attn1.o.trainable:
+            self.attn1.o.bwd_dw(rt, dh1, transpose_pad(rt, o, M, C), M)
+        dqkv = rt.empty(M, 3 * C)
+        k.tattn_bwd(qkv, qkv[:, C:], qkv[:, 2 * C:], d_o, dqkv, dqkv[:, C:], dqkv[:, 2 * C:], g.B, g.T, g.HW,
+                    self.heads, 3 * C, C, 3 * C, HEAD_DIM ** -0.5)
+        del d_o, qkv, o
+        dn1 = self.attn1.qkv.bwd_dx(rt, dqkv, M)
+        if self.attn1.qkv.trainable:
+            self.attn1.qkv.bwd_dw(rt, dqkv, transpose_pad(rt, n1, M, C), M)
+        del dqkv, n1
+        dh = self.ln1.bwd(rt, dn1, h, st1, M, add=dh1)
+        del dn1, dh1, h
+        dn0 = self.ff_in.bwd(rt, dh, n0, pre0, g0, M)
+        if add is not None:
+            dh2 = rt.empty(M, C)
+            k.add(dh, add, dh2, M * C)
+            dh = dh2
+        if not need_dx and not self.ln0.trainable:
+            return None
+        return self.ln0.bwd(rt, dn0, x, st0, M, add=dh)
+
+
+class TransformerSpatioTemporalModel(nn.Module):
+    """diffusers transformer_temporal.TransformerSpatioTemporalModel."""
+
+    def __init__(self, heads, in_channels, num_layers, cross_dim):
+        super().__init__()
+        assert in_channels == heads * HEAD_DIM, "SVD uses head_dim 64 everywhere"
+        self.C, self.heads = in_channels, heads
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6)
+        self.proj_in = nn.Linear(in_channels, in_channels)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(in_channels, heads, cross_dim) for _ in range(num_layers)])
+        self.temporal_transformer_blocks = nn.ModuleList(
+            [TemporalBasicTransformerBlock(in_channels, heads, cross_dim) for _ in range(num_layers)])
+        self.time_pos_embed = _TimestepEmbedding(in_channels, in_channels * 4, out_dim=in_channels)
+        self.time_mixer = _AlphaBlender()
+        self.proj_out = nn.Linear(in_channels, in_channels)
+        self.need_dx = True
+
+    def build(self):
+        self.gn = GroupNormOp(self.norm, silu=False)
+        self.pin = LinearOp([self.proj_in.weight], [self.proj_in.bias])
+        self.pout = LinearOp([self.proj_out.weight], [self.proj_out.bias])
+        self.time_pos_embed.build()
+        for b in list(self.transformer_blocks) + list(self.temporal_transformer_blocks):
+            b.build()
+        for n, p in self.named_parameters():
+            if p.requires_grad and "temporal_transformer_blocks" not in n:
+                raise NotImplementedError(f"{n}: only temporal_transformer_blocks.* may be trainable this round")
+
+    def has_trainable(self):
+        return any(p.requires_grad for p in self.parameters())
+
+    def pack(self, rt):
+        self.pin.pack(rt)
+        self.pout.pack(rt)
+        self.time_pos_embed.pack(rt)
+        for b in list(self.transformer_blocks) + list(self.temporal_transformer_blocks):
+            b.pack(rt)
+
+    def refresh(self, rt):
+        for b in self.temporal_transformer_blocks:
+            if b.trainable:
+                b.refresh(rt)
+
+    def fwd(self, rt: Runtime, x, g: Geom, ctx):
+        """x [M, C]; ctx float [B, cross_dim] (the CLIP embed of each clip; identical for all its frames, so
+        the first-frame `time_context` of the temporal blocks is the same tensor)."""
+        k, C, M = rt.k, self.C, g.M
+        xn, st = self.gn.fwd(rt, x, g.N, g.HW)
+        h = self.pin.fwd(rt, xn, M)
+        del xn
+        # frame position embedding e[t] = time_pos_embed(Timesteps(C)(arange(T))), one row vector per frame
+        tpos = torch.arange(g.T, dtype=torch.float32, device=rt.dev).repeat(g.B)
+        fe = rt.f32(g.N, C)
+        k.timestep_embed(tpos, fe, g.N, C)
+        e = self.time_pos_embed.fwd(rt, fe, g.N)
+        for blk, tblk in zip(self.transformer_blocks, self.temporal_transformer_blocks):
+            h = blk.fwd(rt, h, g, ctx)
+            hm = rt.empty(M, C)
+            k.add_rowvec(h, e, hm, M, C, C, g.HW, 0)
+            hm = tblk.fwd(rt, hm, g, ctx)
+            h2 = rt.empty(M, C)
+            k.blend(h, hm, self.time_mixer.mix_factor.data, h2, M * C)
+            h = h2
+        out = self.pout.fwd(rt, h, M, res=x)
+        self.sv = (x, st)
+        return out
+
+    def bwd(self, rt: Runtime, dout, g: Geom):
+        k, C, M = rt.k, self.C, g.M
+        x, st = self.sv
+        self.sv = None
+        dh = self.pout.bwd_dx(rt, dout, M)
+        nl = len(self.transformer_blocks)
+        for i in reversed(range(nl)):
+            blk, tblk = self.transformer_blocks[i], self.temporal_transformer_blocks[i]
+            last = (i == 0) and not self.need_dx
+            dh_s, dhm = rt.empty(M, C), rt.empty(M, C)
+            k.blend_bwd(dh, self.time_mixer.mix_factor.data, dh_s, dhm, M * C)
+            del dh
+            # d(h + e) = dhm_in ; the spatial output h feeds both the blend and the temporal block
+            dh = tblk.bwd(rt, dhm, g, need_dx=not last, add=None if last else dh_s)
+            del dhm, dh_s
+            if last:
+                blk.sv = None
+                return None
+            dh = blk.bwd(rt, dh, g)
+        dxn = self.pin.bwd_dx(rt, dh, M)
+        return self.gn.bwd(rt, dxn, x, st, g.N, g.HW, add=dout)
+
+
+# ==================================================================================================
+# resnet blocks
+# ==================================================================================================
+class _ResnetHalf(nn.Module):
+    """ResnetBlock2D (temporal=False) or TemporalResnetBlock (temporal=True) of diffusers resnet.py."""
+
+    def __init__(self, cin, cout, temb_channels, eps, temporal):
+        super().__init__()
+        self.cin, self.cout, self.temporal = cin, cout, temporal
+        self.norm1 = nn.GroupNorm(32, cin, eps=eps)
+        if temporal:
+            self.conv1 = nn.Conv3d(cin, cout, (3, 1, 1), padding=(1, 0, 0))
+        else:
+            self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_channels, cout)
+        self.norm2 = nn.GroupNorm(32, cout, eps=eps)
+        if temporal:
+            self.conv2 = nn.Conv3d(cout, cout, (3, 1, 1), padding=(1, 0, 0))
+        else:
+            self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = None
+        if cin != cout:
+            self.conv_shortcut = nn.Conv3d(cin, cout, 1) if temporal else nn.Conv2d(cin, cout, 1)
+        self.temb_slice = (0, 0)    # (offset, ld) into the batched time_emb_proj output
+
+    def build(self):
+        kind = "t3" if self.temporal else "3x3"
+        self.gn1, self.gn2 = GroupNormOp(self.norm1, True), GroupNormOp(self.norm2, True)
+        self.c1 = ConvOp(self.conv1.weight, self.conv1.bias, kind)
+        self.c2 = ConvOp(self.conv2.weight, self.conv2.bias, kind)
+        self.sc = ConvOp(self.conv_shortcut.weight, self.conv_shortcut.bias, "1x1") if self.conv_shortcut is not None else None
+        if self.time_emb_proj.weight.requires_grad:
+            raise NotImplementedError("time_emb_proj is frozen on this path")
+
+    def pack(self, rt, need_dx):
+        self.c1.pack(rt, need_dx)
+        self.c2.pack(rt, need_dx)
+        if self.sc is not None:
+            self.sc.pack(rt, need_dx)
+
+    def _ns(self, g: Geom):
+        # GroupNorm sample: a frame for the 2-D block, the whole clip (all frames) for the 3-D block
+        return (g.B, g.T * g.HW) if self.temporal else (g.N, g.HW)
+
+    def fwd(self, rt: Runtime, x, g: Geom, temb_all):
+        n_s, rows = self._ns(g)
+        a1, st1 = self.gn1.fwd(rt, x, n_s, rows)
+        off, ld = self.temb_slice
+        ni = g.B if self.temporal else g.N
+        h1, _, _ = self.c1.fwd(rt, a1, ni, g.h, g.w, T=g.T, rowvec=temb_all[:, off:], rv_ld=ld, rv_rpg=g.T * g.HW)
+        del a1
+        a2, st2 = self.gn2.fwd(rt, h1, n_s, rows)
+        sc = x if self.sc is None else self.sc.fwd(rt, x, ni, g.h, g.w, T=g.T)[0]
+        out, _, _ = self.c2.fwd(rt, a2, ni, g.h, g.w, T=g.T, res=sc)
+        self.sv = (x, st1, h1, st2)
+        return out
+
+    def bwd(self, rt: Runtime, dout, g: Geom, add=None):
+        """returns dx (+ add).  The identity/1x1 shortcut gradient is folded into the last GroupNorm backward."""
+        x, st1, h1, st2 = self.sv
+        self.sv = None
+        n_s, rows = self._ns(g)
+        ni = g.B if self.temporal else g.N
+        da2 = self.c2.bwd_dx(rt, dout, ni, g.h, g.w, T=g.T)
+        dh1 = self.gn2.bwd(rt, da2, h1, st2, n_s, rows)
+        del da2, h1
+        da1 = self.c1.bwd_dx(rt, dh1, ni, g.h, g.w, T=g.T)
+        del dh1
+        if self.sc is None:
+            dsc = dout
+        else:
+            dsc = self.sc.bwd_dx(rt, dout, ni, g.h, g.w, T=g.T)
+        if add is not None:
+            tmp = rt.empty(g.M, self.cin)
+            rt.k.add(dsc, add, tmp, g.M * self.cin)
+            dsc = tmp
+        return self.gn1.bwd(rt, da1, x, st1, n_s, rows, add=dsc)
+
+
+class SpatioTemporalResBlock(nn.Module):
+    def __init__(self, cin, cout, temb_channels, eps):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.spatial_res_block = _ResnetHalf(cin, cout, temb_channels, eps, temporal=False)
+        self.temporal_res_block = _ResnetHalf(cout, cout, temb_channels, eps, temporal=True)
+        self.time_mixer = _AlphaBlender()
+        self.need_dx = True
+
+    def build(self):
+        self.spatial_res_block.build()
+        self.temporal_res_block.build()
+        if self.time_mixer.mix_factor.requires_grad:
+            raise NotImplementedError("mix_factor is frozen on this path")
+
+    def has_trainable(self):
+        return False
+
+    def pack(self, rt):
+        self.spatial_res_block.pack(rt, self.need_dx)
+        self.temporal_res_block.pack(rt, self.need_dx)
+
+    def fwd(self, rt: Runtime, x, g: Geom, temb_all):
+        s = self.spatial_res_block.fwd(rt, x, g, temb_all)
+        t = self.temporal_res_block.fwd(rt, s, g, temb_all)
+        out = rt.empty(g.M, self.cout)
+        rt.k.blend(s, t, self.time_mixer.mix_factor.data, out, g.M * self.cout)
+        return out
+
+    def bwd(self, rt: Runtime, dout, g: Geom):
+        if not self.need_dx:
+            self.spatial_res_block.sv = self.temporal_res_block.sv = None
+            return None
+        k = rt.k
+        ds, dt_ = rt.empty(g.M, self.cout), rt.empty(g.M, self.cout)
+        k.blend_bwd(dout, self.time_mixer.mix_factor.data, ds, dt_, g.M * self.cout)
+        # s receives alpha*dout from the blend and the temporal block's input gradient
+        ds_total = self.temporal_res_block.bwd(rt, dt_, g, add=ds)
+        del ds, dt_
+        return self.spatial_res_block.bwd(rt, ds_total, g)
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=1)
+        self.need_dx = True
+
+    def build(self):
+        self.op = ConvOp(self.conv.weight, self.conv.bias, "3x3", stride=2)
+
+    def pack(self, rt):
+        self.op.pack(rt, self.need_dx)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, padding=1)
+        self.need_dx = True
+
+    def build(self):
+        self.op = ConvOp(self.conv.weight, self.conv.bias, "3x3", ups=True)
+
+    def pack(self, rt):
+        self.op.pack(rt, self.need_dx)
+
+
+# ==================================================================================================
+# block containers (diffusers unet_3d_blocks); they only hold names -- the UNet drives a flat step list
+# ==================================================================================================
+class _Block(nn.Module):
+    def __init__(self, resnets, attentions=None, downsample=None, upsample=None):
+        super().__init__()
+        if attentions is not None:
+            self.attentions = nn.ModuleList(attentions)
+        self.resnets = nn.ModuleList(resnets)
+        if downsample is not None:
+            self.downsamplers = nn.ModuleList([downsample])
+        if upsample is not None:
+            self.upsamplers = nn.ModuleList([upsample])
+        self.has_cross_attention = attentions is not None
+
+
+class UNetSpatioTemporalConditionOutput(SimpleNamespace):
+    pass
+
+
+class _UNetFn(torch.autograd.Function):
+    """Thin autograd boundary so `loss.backward()` in a host script reaches the hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, model, sample, timestep, ehs, added_time_ids, _anchor):
+        ctx.model = model
+        return model._forward_impl(sample, timestep, ehs, added_time_ids)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        ctx.model._backward_impl(d_out.contiguous())
+        return None, None, None, None, None, None
+
+
+class UNetSpatioTemporalConditionModel(nn.Module):
+    """Constructor signature of src/unet_spatio_temporal_condition.py:71-96."""
+
+    _supports_gradient_checkpointing = True
+
+    def __init__(self, sample_size=None, in_channels: int = 8, out_channels: int = 4,
+                 down_block_types=("CrossAttnDownBlockSpatioTemporal",) * 3 + ("DownBlockSpatioTemporal",),
+                 up_block_types=("UpBlockSpatioTemporal",) + ("CrossAttnUpBlockSpatioTemporal",) * 3,
+                 block_out_channels=(320, 640, 1280, 1280), addition_time_embed_dim: int = 256,
+                 projection_class_embeddings_input_dim: int = 768, layers_per_block=2, cross_attention_dim=1024,
+                 transformer_layers_per_block=1, num_attention_heads=(5, 10, 20, 20), num_frames: int = 25):
+        super().__init__()
+        n = len(down_block_types)
+        if len(up_block_types) != n or len(block_out_channels) != n:
+            raise ValueError("down_block_types, up_block_types and block_out_channels must have the same length")
+        self.config = SimpleNamespace(
+            sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
+            down_block_types=tuple(down_block_types), up_block_types=tuple(up_block_types),
+            block_out_channels=tuple(block_out_channels), addition_time_embed_dim=addition_time_embed_dim,
+            projection_class_embeddings_input_dim=projection_class_embeddings_input_dim,
+            layers_per_block=layers_per_block, cross_attention_dim=cross_attention_dim,
+            transformer_layers_per_block=transformer_layers_per_block, num_attention_heads=num_attention_heads,
+            num_frames=num_frames)
+        heads = (num_attention_heads,) * n if isinstance(num_attention_heads, int) else tuple(num_attention_heads)
+        cross = (cross_attention_dim,) * n if isinstance(cross_attention_dim, int) else tuple(cross_attention_dim)
+        layers = [layers_per_block] * n if isinstance(layers_per_block, int) else list(layers_per_block)
+        tl = [transformer_layers_per_block] * n if isinstance(transformer_layers_per_block, int) \
+            else list(transformer_layers_per_block)
+        if len(set(cross)) != 1:
+            raise NotImplementedError("a single cross_attention_dim is assumed")
+        ch = block_out_channels
+        temb = ch[0] * 4
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.cin_pad = rup(in_channels, 32)
+        self.cout_pad = rup(out_channels, 32)
+
+        self.conv_in = nn.Conv2d(in_channels, ch[0], 3, padding=1)
+        self.time_embedding = _TimestepEmbedding(ch[0], temb)
+        self.add_embedding = _TimestepEmbedding(projection_class_embeddings_input_dim, temb)
+
+        self.down_blocks = nn.ModuleList()
+        out_c = ch[0]
+        for i, t in enumerate(down_block_types):
+            in_c, out_c = out_c, ch[i]
+            final = i == n - 1
+            if t == "CrossAttnDownBlockSpatioTemporal":
+                res = [SpatioTemporalResBlock(in_c if j == 0 else out_c, out_c, temb, 1e-6) for j in range(layers[i])]
+                att = [TransformerSpatioTemporalModel(heads[i], out_c, tl[i], cross[i]) for _ in range(layers[i])]
+            elif t == "DownBlockSpatioTemporal":
+                res = [SpatioTemporalResBlock(in_c if j == 0 else out_c, out_c, temb, 1e-5) for j in range(layers[i])]
+                att = None
+            else:
+                raise ValueError(f"{t} does not exist.")
+            self.down_blocks.append(_Block(res, att, downsample=None if final else Downsample2D(out_c)))
+
+        mid_c = ch[-1]
+        self.mid_block = _Block([SpatioTemporalResBlock(mid_c, mid_c, temb, 1e-5) for _ in range(2)],
+                                [TransformerSpatioTemporalModel(heads[-1], mid_c, tl[-1], cross[-1])])
+
+        self.up_blocks = nn.ModuleList()
+        rch, rheads, rlayers, rcross, rtl = (list(reversed(v)) for v in (ch, heads, layers, cross, tl))
+        out_c = rch[0]
+        for i, t in enumerate(up_block_types):
+            final = i == n - 1
+            prev_c, out_c = out_c, rch[i]
+            in_c = rch[min(i + 1, n - 1)]
+            nl = rlayers[i] + 1
+            res = []
+            for j in range(nl):
+                skip = in_c if j == nl - 1 else out_c
+                rin = prev_c if j == 0 else out_c
+                res.append(SpatioTemporalResBlock(rin + skip, out_c, temb, 1e-6))
+            if t == "CrossAttnUpBlockSpatioTemporal":
+                att = [TransformerSpatioTemporalModel(rheads[i], out_c, rtl[i], rcross[i]) for _ in range(nl)]
+            elif t == "UpBlockSpatioTemporal":
+                att = None
+            else:
+                raise ValueError(f"{t} does not exist.")
+            self.up_blocks.append(_Block(res, att, upsample=None if final else Upsample2D(out_c)))
+
+        self.conv_norm_out = nn.GroupNorm(num_channels=ch[0], num_groups=32, eps=1e-5)
+        self.conv_out = nn.Conv2d(ch[0], out_channels, 3, padding=1)
+
+        self.add_embedding_in = projection_class_embeddings_input_dim
+        self.rt: Optional[Runtime] = None
+        self._anchor = None
+        self.gradient_checkpointing = False
+
+    # ---- reference-script surface ------------------------------------------------------
+    def enable_gradient_checkpointing(self):      # train_svd.py:732 -- 288 GB HBM: not needed, accepted as no-op
+        self.gradient_checkpointing = False
+
+    def enable_xformers_memory_efficient_attention(self, *a, **k):   # train_svd.py:690 -- own attention kernels
+        return None
+
+    # ---- build / pack ---------------------------------------------------------------------------------
+    def _steps(self):
+        """Flat forward schedule: (kind, module, level_delta)."""
+        steps = []
+        for blk in self.down_blocks:
+            for j, r in enumerate(blk.resnets):
+                steps.append(("res", r))
+                if blk.has_cross_attention:
+                    steps.append(("attn", blk.attentions[j]))
+                steps.append(("push", None))
+            if hasattr(blk, "downsamplers"):
+                steps.append(("down", blk.downsamplers[0]))
+                steps.append(("push", None))
+        steps.append(("res", self.mid_block.resnets[0]))
+        steps.append(("attn", self.mid_block.attentions[0]))
+        steps.append(("res", self.mid_block.resnets[1]))
+        for blk in self.up_blocks:
+            for j, r in enumerate(blk.resnets):
+                steps.append(("pop_cat", r))
+                steps.append(("res", r))
+                if blk.has_cross_attention:
+                    steps.append(("attn", blk.attentions[j]))
+            if hasattr(blk, "upsamplers"):
+                steps.append(("up", blk.upsamplers[0]))
+        return steps
+
+    def prepare(self, dtype: torch.dtype = torch.float16) -> "UNetSpatioTemporalConditionModel":
+        """Build operator objects and pack weights into kernel layouts.  Call after weights are loaded, after
+        `requires_grad` flags are final and (for training) after the Trainer has installed flat grads."""
+        dev = next(self.parameters()).device
+        self.rt = rt = Runtime(dtype, dev)
+        self.steps = self._steps()
+        # which modules need an input gradient: only those executed after the first trainable parameter
+        seen = False
+        skip_flags = [seen]                       # conv_in output
+        for kind, m in self.steps:
+            if kind in ("res", "attn", "down", "up"):
+                m.need_dx = seen
+                if kind == "attn" and m.has_trainable():
+                    seen = True
+            elif kind == "push":
+                skip_flags.append(seen)
+        self._skip_needs_grad = skip_flags
+        self._any_trainable = seen
+        for p_name, p in self.named_parameters():
+            if p.requires_grad and "temporal_transformer_blocks" not in p_name:
+                raise NotImplementedError(f"{p_name}: only temporal_transformer_blocks.* may be trainable this round")
+
+        self.time_embedding.build()
+        self.add_embedding.build()
+        self.time_embedding.pack(rt)
+        self.add_embedding.pack(rt)
+        self.cin_op = ConvOp(self.conv_in.weight, self.conv_in.bias, "3x3", cin_pad=self.cin_pad)
+        self.cin_op.pack(rt, need_dx=False)
+        self.gn_out = GroupNormOp(self.conv_norm_out, silu=True)
+        self.cout_op = ConvOp(self.conv_out.weight, self.conv_out.bias, "3x3", cout_pad=self.cout_pad)
+        self.cout_op.pack(rt, need_dx=True)
+        halves = []
+        for kind, m in self.steps:
+            if kind in ("res", "attn", "down", "up"):
+                m.build()
+                m.pack(rt)
+            if kind == "res":
+                halves += [m.spatial_res_block, m.temporal_res_block]
+        # one batched time_emb_proj for all resnet halves: [sum(Cout), temb] (the input silu(emb) is shared)
+        off = 0
+        for hf in halves:
+            hf.temb_slice = (off, None)
+            off += hf.cout
+        for hf in halves:
+            hf.temb_slice = (hf.temb_slice[0], off)
+        self._temb_total = off
+        wcat = torch.cat([hf.time_emb_proj.weight.data for hf in halves], 0).contiguous()
+        self._temb_b = torch.cat([hf.time_emb_proj.bias.data for hf in halves], 0).contiguous()
+        self._temb_w = rt.empty(off, wcat.shape[1])
+        rt.k.cast_from_f32(wcat, self._temb_w, wcat.numel())
+        self._anchor = torch.zeros((), device=dev, requires_grad=True)
+        return self
+
+    def refresh_trainable(self) -> None:
+        """Re-pack the low-precision copies of trainable weights after an optimizer step."""
+        for kind, m in self.steps:
+            if kind == "attn":
+                m.refresh(self.rt)
+
+    # ---- forward / backward ---------------------------------------------------------------------------
+    def forward(self, sample, timestep, encoder_hidden_states, added_time_ids, return_dict: bool = True):
+        if self.rt is None:
+            self.prepare()
+        if torch.is_grad_enabled() and self._any_trainable:
+            out = _UNetFn.apply(self, sample, timestep, encoder_hidden_states, added_time_ids, self._anchor)
+        else:
+            out = self._forward_impl(sample, timestep, encoder_hidden_states, added_time_ids)
+            self._drop_saved()
+        if not return_dict:
+            return (out,)
+        return UNetSpatioTemporalConditionOutput(sample=out)
+
+    def _drop_saved(self):
+        for kind, m in self.steps:
+            if kind == "res":
+                m.spatial_res_block.sv = m.temporal_res_block.sv = None
+            elif kind == "attn":
+                m.sv = None
+                for b in list(m.transformer_blocks) + list(m.temporal_transformer_blocks):
+                    b.sv = None
+        self._fwd_state = None
+
+    def _forward_impl(self, sample, timestep, ehs, added_time_ids):
+        out_rows = self.forward_rows(sample, timestep, ehs, added_time_ids)
+        B, T = sample.shape[:2]
+        g = self._fwd_state["g0"]
+        out = torch.empty(B, T, self.out_channels, g.h, g.w, dtype=torch.float32, device=self.rt.dev)
+        self.rt.k.rows_to_nchw(out_rows, out, g.N, self.out_channels, g.h, g.w, self.out_channels)
+        return out
+
+    def forward_rows(self, sample, timestep, ehs, added_time_ids):
+        """Forward up to the channels-last prediction rows [B*T*h*w, out_channels] (activation dtype)."""
+        rt = self.rt
+        k = rt.k
+        B, T, Cin, h, w = sample.shape
+        if h % 8 or w % 8:
+            raise ValueError("latent height/width must be multiples of 8 (3 stride-2 levels; SURVEY.md 0.8)")
+        g = Geom(B, T, h, w)
+        dev = rt.dev
+        # 1. time + added-id embeddings (float, skinny path)  src/unet_spatio_temporal_condition.py:386-416
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([float(timestep)], dtype=torch.float32, device=dev)
+        ts = timestep.to(device=dev, dtype=torch.float32).reshape(-1).expand(B).contiguous()
+        C0 = self.config.block_out_channels[0]
+        t_emb = rt.f32(B, C0)
+        k.timestep_embed(ts, t_emb, B, C0)
+        emb = self.time_embedding.fwd(rt, t_emb, B)
+        ids = added_time_ids.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        ad = self.config.addition_time_embed_dim
+        id_emb = rt.f32(ids.numel(), ad)
+        k.timestep_embed(ids, id_emb, ids.numel(), ad)
+        if id_emb.numel() != B * self.add_embedding_in:
+            raise ValueError(f"Model expects an added time embedding vector of length {self.add_embedding_in}, "
+                             f"but a vector of {id_emb.numel() // B} was created.")
+        self.add_embedding.fwd(rt, id_emb.view(B, -1), B, out=emb, accumulate=True)
+        # all 44 time_emb_proj(silu(emb)) at once; emb is identical for every frame of a clip (:423)
+        temb_all = rt.f32(B, self._temb_total)
+        k.small_linear(emb, self._temb_w, self._temb_b, temb_all, B, self._temb_total, emb.shape[1], emb.shape[1],
+                       0, 1, 0)
+        ctx = ehs.to(device=dev, dtype=torch.float32).reshape(B, -1).contiguous()     # [B, 1, D] -> [B, D]
+
+        # 2. conv_in on channels-last rows (input channels zero-padded to a multiple of 32)
+        x0 = rt.empty(g.M, self.cin_pad)
+        k.nchw_to_rows(sample.reshape(g.N, Cin, h, w).to(torch.float32).contiguous(), x0, g.N, Cin, h, w,
+                       self.cin_pad, 1.0)
+        x, _, _ = self.cin_op.fwd(rt, x0, g.N, h, w)
+        del x0
+
+        skips: List[Tuple[torch.Tensor, Geom]] = [(x, g)]
+        geoms = [g]
+        cur = g
+        cat_info = []
+        for kind, m in self.steps:
+            if kind == "res":
+                x = m.fwd(rt, x, cur, temb_all)
+            elif kind == "attn":
+                x = m.fwd(rt, x, cur, ctx)
+            elif kind == "push":
+                skips.append((x, cur))
+            elif kind == "down":
+                x, ho, wo = m.op.fwd(rt, x, cur.N, cur.h, cur.w)
+                cur = Geom(B, T, ho, wo)
+                geoms.append(cur)
+            elif kind == "up":
+                x, ho, wo = m.op.fwd(rt, x, cur.N, cur.h, cur.w)
+                cur = Geom(B, T, ho, wo)
+            elif kind == "pop_cat":
+                s, sg = skips.pop()
+                assert sg.h == cur.h and sg.w == cur.w
+                Ca, Cb = x.shape[1], s.shape[1]
+                cat = rt.empty(cur.M, Ca + Cb)
+                k.concat2(x, Ca, s, Cb, cat, cur.M)
+                cat_info.append((Ca, Cb))
+                x = cat
+        assert not skips
+        # 3. out: GroupNorm + SiLU + conv_out
+        a, st = self.gn_out.fwd(rt, x, cur.N, cur.HW)
+        y, _, _ = self.cout_op.fwd(rt, a, cur.N, cur.h, cur.w)
+        self._fwd_state = dict(g0=g, x_last=x, st_last=st, cat_info=cat_info)
+        return y
+
+    def _backward_impl(self, d_out):
+        """d_out: float [B,T,out_channels,h,w] (gradient of `.sample`)."""
+        rt = self.rt
+        g = self._fwd_state["g0"]
+        dy = rt.empty(g.M, self.cout_pad)
+        rt.k.nchw_to_rows(d_out.reshape(g.N, self.out_channels, g.h, g.w), dy, g.N, self.out_channels, g.h, g.w,
+                          self.cout_pad, 1.0)
+        self.backward_rows(dy)
+
+    def backward_rows(self, dy):
+        """dy: [B*T*h*w, rup(out_channels,32)] channels-last gradient of the prediction rows (zero padded)."""
+        rt = self.rt
+        k = rt.k
+        fs = self._fwd_state
+        self._fwd_state = None
+        g0 = fs["g0"]
+        B, T = g0.B, g0.T
+        cur = g0
+        da = self.cout_op.bwd_dx(rt, dy, cur.N, cur.h, cur.w)
+        dx = self.gn_out.bwd(rt, da, fs["x_last"], fs["st_last"], cur.N, cur.HW)
+        del da
+        cat_info = list(fs["cat_info"])
+        # geometry per resolution level, replayed from the forward schedule
+        level_geoms = [g0]
+        gg = g0
+        for kind, m in self.steps:
+            if kind == "down":
+                ho, wo = m.op.out_hw(gg.h, gg.w)
+                gg = Geom(B, T, ho, wo)
+                level_geoms.append(gg)
+        lvl = 0
+        n_skips = 1 + sum(1 for kind, _ in self.steps if kind == "push")
+        # forward pops skips LIFO: the i-th pop_cat (forward order) consumed skip n_skips-1-i.  Walking the
+        # schedule backwards meets pop_cats with i descending, i.e. skip indices ascending from 0, and then the
+        # pushes with skip indices descending -- so a plain stack pairs them up.
+        pops_left = sum(1 for kind, _ in self.steps if kind == "pop_cat")
+        skip_grads: List[Optional[torch.Tensor]] = []
+        for kind, m in reversed(self.steps):
+            if kind == "push":
+                sg = skip_grads.pop()
+                if sg is not None:
+                    if dx is None:
+                        dx = sg
+                    else:
+                        tmp = rt.empty(*dx.shape)
+                        k.add(dx, sg, tmp, dx.numel())
+                        dx = tmp
+                continue
+            if kind == "up":
+                lvl += 1
+            elif kind == "down":
+                lvl -= 1
+            if dx is None:
+                cur = level_geoms[lvl]
+                if kind == "res":
+                    m.spatial_res_block.sv = m.temporal_res_block.sv = None
+                elif kind == "attn":
+                    m.sv = None
+                    for b in list(m.transformer_blocks) + list(m.temporal_transformer_blocks):
+                        b.sv = None
+                continue
+            if kind == "res" or kind == "attn":
+                dx = m.bwd(rt, dx, cur)
+            elif kind == "up":
+                low = level_geoms[lvl]
+                dx = m.op.bwd_dx(rt, dx, low.N, low.h, low.w) if m.need_dx else None
+            elif kind == "down":
+                hi = level_geoms[lvl]
+                dx = m.op.bwd_dx(rt, dx, hi.N, hi.h, hi.w) if m.need_dx else None
+            elif kind == "pop_cat":
+                Ca, Cb = cat_info.pop()
+                skip_no = n_skips - pops_left
+                pops_left -= 1
+                da_ = rt.empty(cur.M, Ca)
+                db_ = rt.empty(cur.M, Cb)
+                k.split2(dx, da_, Ca, db_, Cb, cur.M)
+                dx = da_
+                skip_grads.append(db_ if self._skip_needs_grad[skip_no] else None)
+            cur = level_geoms[lvl]
+        # the conv_in skip (index 0) and conv_in itself carry no trainable parameters upstream
+        return None
+
+    # ---- convenience for tests / weight exchange ------------------------------------------------------
+    @property
+    def add_embedding_linear_1_in_features(self):
+        return self.add_embedding.linear_1.in_features

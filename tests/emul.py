@@ -1,0 +1,410 @@
+"""Plain-PyTorch emulation of every libsvdx entry point (svd_xtend_amd/kernels.py interface).
+
+TEST INFRASTRUCTURE: (1) the fp32 reference each HIP kernel is compared against in the `-m gpu` tests,
+(2) a CPU stand-in so the host-side orchestration (explicit forward/backward schedules, packing, flat
+buffers, DP) can be checked against the oracle without a GPU.  Pointer semantics are reproduced with
+as_strided on the tensor's storage, so views with offsets behave exactly like `base + offset` pointers.
+"""
+import math
+
+import torch
+
+from svd_xtend_amd import kernels as K
+
+
+def V(t, rows, cols, ld):
+    return torch.as_strided(t, (rows, cols), (ld, 1), t.storage_offset())
+
+
+def V1(t, n):
+    return torch.as_strided(t, (n,), (1,), t.storage_offset())
+
+
+def gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x * 0.7071067811865476))
+
+
+def gelu_grad(x):
+    return 0.5 * (1.0 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327
+
+
+def silu(x):
+    return x * torch.sigmoid(x)
+
+
+def silu_grad(x):
+    s = torch.sigmoid(x)
+    return s * (1 + x * (1 - s))
+
+
+def gather_rows(A, g: K.Gather, M):
+    """Effective [M, taps*cin] A operand of the implicit GEMM (float)."""
+    dev = A.device
+    m = torch.arange(M, device=dev)
+    cols = []
+    if g.mode in (K.GATHER_CONV3X3, K.GATHER_CONV3X3_DGRAD2):
+        x = m % g.wo
+        y = (m // g.wo) % g.ho
+        n = m // (g.wo * g.ho)
+        for dy in range(3):
+            for dx in range(3):
+                if g.mode == K.GATHER_CONV3X3:
+                    ys, xs = y * g.stride + dy - 1, x * g.stride + dx - 1
+                    valid = (ys >= 0) & (ys < g.hi) & (xs >= 0) & (xs < g.wi)
+                    if g.ups:
+                        row = (n * (g.hi // 2) + ys.clamp(min=0) // 2) * (g.wi // 2) + xs.clamp(min=0) // 2
+                    else:
+                        row = (n * g.hi + ys) * g.wi + xs
+                else:
+                    y2, x2 = y + 1 - dy, x + 1 - dx
+                    valid = (y2 >= 0) & (y2 % 2 == 0) & (y2 // 2 < g.hi) & (x2 >= 0) & (x2 % 2 == 0) & (x2 // 2 < g.wi)
+                    row = (n * g.hi + y2 // 2) * g.wi + x2 // 2
+                cols.append((row, valid))
+        nsrc = g.n_img * (g.hi // 2 if g.ups else g.hi) * (g.wi // 2 if g.ups else g.wi)
+    elif g.mode == K.GATHER_TEMPORAL3:
+        p = m % g.hw
+        t = (m // g.hw) % g.t
+        b = m // (g.hw * g.t)
+        for dt in range(3):
+            ts = t + dt - 1
+            valid = (ts >= 0) & (ts < g.t)
+            cols.append(((b * g.t + ts) * g.hw + p, valid))
+        nsrc = g.n_img * g.t * g.hw
+    else:
+        raise ValueError(g.mode)
+    src = V(A, nsrc, g.cin, g.lda).float()
+    out = []
+    for row, valid in cols:
+        r = src[row.clamp(0, nsrc - 1)]
+        out.append(torch.where(valid[:, None], r, torch.zeros_like(r)))
+    return torch.cat(out, 1)
+
+
+class EmuBackend:
+    # ---- GEMM family ----
+    def gemm(self, A, B, C, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
+             res=None, ldres=0, gather=None, out_mode=K.OUT_ACT, alpha=1.0, split_k=1, variant=0):
+        assert Kd % 32 == 0, "GEMM K must be a multiple of 32"
+        if gather is None or gather.mode == K.GATHER_PLAIN:
+            a = V(A, M, Kd, lda).float()
+        else:
+            a = gather_rows(A, gather, M)
+            assert a.shape[1] == Kd
+        b = V(B, N, Kd, ldb).float()
+        v = alpha * (a @ b.t())
+        if bias is not None:
+            v = v + V1(bias, N)[None]
+        if rowvec is not None:
+            m = torch.arange(M, device=A.device)
+            gi = (m % rv_mod) if rv_mod else (m // rv_rpg)
+            ng = int(gi.max()) + 1
+            v = v + V(rowvec, ng, N, rv_ld)[gi]
+        if res is not None:
+            v = v + V(res, M, N, ldres).float()
+        c = V(C, M, N, ldc)
+        if out_mode == K.OUT_F32_ATOMIC:
+            assert C.dtype == torch.float32
+            c += v
+        else:
+            assert C.dtype == torch.float32 or out_mode == K.OUT_ACT
+            c.copy_(v.to(C.dtype))
+
+    def small_linear(self, X, W, bias, Y, M, N, Kd, ldw, trans=0, silu_in=0, accumulate=0):
+        w = V(W, N, Kd, ldw).float()
+        if trans == 0:
+            x = V(X, M, Kd, Kd)
+            if silu_in:
+                x = silu(x)
+            y = x @ w.t()
+            if bias is not None:
+                y = y + V1(bias, N)[None]
+            out = V(Y, M, N, N)
+        else:
+            y = V(X, M, N, N) @ w
+            out = V(Y, M, Kd, Kd)
+        if accumulate:
+            out += y
+        else:
+            out.copy_(y)
+
+    def outer_acc(self, dY, X, dW, M, N, Kd, scale=1.0):
+        V(dW, N, Kd, Kd).add_(scale * (V(dY, M, N, N).t() @ V(X, M, Kd, Kd)))
+
+    def timestep_embed(self, t, out, n, dim):
+        half = dim // 2
+        f = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+        e = V1(t, n)[:, None] * f[None]
+        V(out, n, dim, dim).copy_(torch.cat([torch.cos(e), torch.sin(e)], 1))
+
+    # ---- GroupNorm ----
+    @staticmethod
+    def _gn_parts(x, stats, n_s, rows, C, G, eps):
+        xf = V(x, n_s * rows, C, C).float().view(n_s, rows, G, C // G)
+        cnt = rows * (C // G)
+        st = V(stats, n_s * G, 2, 2).view(n_s, G, 2)
+        mean = st[..., 0] / cnt
+        var = (st[..., 1] / cnt - mean * mean).clamp(min=0)
+        rstd = torch.rsqrt(var + eps)
+        return xf, mean[:, None, :, None], rstd[:, None, :, None], cnt
+
+    def gn_stats(self, x, stats, n_s, rows, C, G):
+        xf = V(x, n_s * rows, C, C).float().view(n_s, rows, G, C // G)
+        st = V(stats, n_s * G, 2, 2).view(n_s, G, 2)
+        st[..., 0] = xf.sum((1, 3))
+        st[..., 1] = (xf * xf).sum((1, 3))
+
+    def gn_apply(self, x, stats, gamma, beta, y, n_s, rows, C, G, eps, silu_):
+        xf, mean, rstd, _ = self._gn_parts(x, stats, n_s, rows, C, G, eps)
+        z = ((xf - mean) * rstd).reshape(n_s, rows, C) * V1(gamma, C) + V1(beta, C)
+        if silu_:
+            z = silu(z)
+        V(y, n_s * rows, C, C).copy_(z.reshape(n_s * rows, C).to(y.dtype))
+
+    def _gn_dz(self, dy, x, stats, gamma, beta, n_s, rows, C, G, eps, silu_):
+        xf, mean, rstd, cnt = self._gn_parts(x, stats, n_s, rows, C, G, eps)
+        xhat = (xf - mean) * rstd
+        dz = V(dy, n_s * rows, C, C).float().view(n_s, rows, C)
+        if silu_:
+            z = xhat.reshape(n_s, rows, C) * V1(gamma, C) + V1(beta, C)
+            dz = dz * silu_grad(z)
+        dzg = (dz * V1(gamma, C)).view(n_s, rows, G, C // G)
+        return xhat, dzg, rstd, cnt
+
+    def gn_bwd_stats(self, dy, x, stats, gamma, beta, bstats, n_s, rows, C, G, eps, silu_):
+        xhat, dzg, _, _ = self._gn_dz(dy, x, stats, gamma, beta, n_s, rows, C, G, eps, silu_)
+        bs = V(bstats, n_s * G, 2, 2).view(n_s, G, 2)
+        bs[..., 0] = dzg.sum((1, 3))
+        bs[..., 1] = (dzg * xhat).sum((1, 3))
+
+    def gn_bwd_apply(self, dy, x, stats, bstats, gamma, beta, add, dx, n_s, rows, C, G, eps, silu_):
+        xhat, dzg, rstd, cnt = self._gn_dz(dy, x, stats, gamma, beta, n_s, rows, C, G, eps, silu_)
+        bs = V(bstats, n_s * G, 2, 2).view(n_s, G, 2)
+        s1 = bs[..., 0][:, None, :, None]
+        s2 = bs[..., 1][:, None, :, None]
+        d = rstd * (dzg - (s1 + xhat * s2) / cnt)
+        d = d.reshape(n_s * rows, C)
+        if add is not None:
+            d = d + V(add, n_s * rows, C, C).float()
+        V(dx, n_s * rows, C, C).copy_(d.to(dx.dtype))
+
+    # ---- LayerNorm ----
+    def ln_fwd(self, x, gamma, beta, y, stats, rows, C, eps):
+        xf = V(x, rows, C, C).float()
+        mean = xf.mean(1, keepdim=True)
+        var = xf.var(1, unbiased=False, keepdim=True)
+        rstd = torch.rsqrt(var + eps)
+        st = V(stats, rows, 2, 2)
+        st[:, 0:1] = mean
+        st[:, 1:2] = rstd
+        V(y, rows, C, C).copy_((((xf - mean) * rstd) * V1(gamma, C) + V1(beta, C)).to(y.dtype))
+
+    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C):
+        xf = V(x, rows, C, C).float()
+        st = V(stats, rows, 2, 2)
+        xhat = (xf - st[:, 0:1]) * st[:, 1:2]
+        d = V(dy, rows, C, C).float()
+        dg = d * V1(gamma, C)
+        out = st[:, 1:2] * (dg - dg.mean(1, keepdim=True) - xhat * (dg * xhat).mean(1, keepdim=True))
+        if add is not None:
+            out = out + V(add, rows, C, C).float()
+        V(dx, rows, C, C).copy_(out.to(dx.dtype))
+        if dgamma is not None:
+            V1(dgamma, C).add_((d * xhat).sum(0))
+        if dbeta is not None:
+            V1(dbeta, C).add_(d.sum(0))
+
+    # ---- spatial attention ----
+    @staticmethod
+    def _hv(t, nb, S, heads, ld):
+        return torch.as_strided(t, (nb, heads, S, 64), (S * ld, 64, ld, 1), t.storage_offset())
+
+    def head_transpose(self, inp, ld, out, nb, heads, S, s_pad):
+        o = V1(out, nb * heads * 64 * s_pad).view(nb, heads, 64, s_pad)
+        o.zero_()
+        o[..., :S] = self._hv(inp, nb, S, heads, ld).transpose(2, 3)
+
+    def attn_fwd(self, q, k, vt, o, lse, nb, heads, S, ld, ld_o, s_pad, scale):
+        qf, kf = self._hv(q, nb, S, heads, ld).float(), self._hv(k, nb, S, heads, ld).float()
+        vf = V1(vt, nb * heads * 64 * s_pad).view(nb, heads, 64, s_pad)[..., :S].transpose(2, 3).float()
+        s = (qf @ kf.transpose(2, 3)) * scale
+        l = torch.logsumexp(s, -1)
+        p = torch.exp(s - l[..., None])
+        V1(lse, nb * heads * S).view(nb, heads, S).copy_(l)
+        self._hv(o, nb, S, heads, ld_o).copy_((p @ vf).to(o.dtype))
+
+    def attn_bwd_prep(self, o, d_o, D, nb, heads, S, ld_o):
+        V1(D, nb * heads * S).view(nb, heads, S).copy_(
+            (self._hv(o, nb, S, heads, ld_o).float() * self._hv(d_o, nb, S, heads, ld_o).float()).sum(-1))
+
+    def _attn_bwd_common(self, q, k, v, d_o, lse, D, nb, heads, S, ld, ld_o, scale):
+        qf, kf, vf = (self._hv(t, nb, S, heads, ld).float() for t in (q, k, v))
+        dof = self._hv(d_o, nb, S, heads, ld_o).float()
+        l = V1(lse, nb * heads * S).view(nb, heads, S)
+        Dv = V1(D, nb * heads * S).view(nb, heads, S)
+        p = torch.exp((qf @ kf.transpose(2, 3)) * scale - l[..., None])
+        dp = dof @ vf.transpose(2, 3)
+        ds = p * (dp - Dv[..., None])
+        return qf, kf, vf, dof, p, ds
+
+    def attn_bwd_dkv(self, q, k, v, d_o, qt, dot, lse, D, dk, dv, nb, heads, S, ld, ld_o, ld_d, s_pad, scale):
+        qf, kf, vf, dof, p, ds = self._attn_bwd_common(q, k, v, d_o, lse, D, nb, heads, S, ld, ld_o, scale)
+        qt_ = V1(qt, nb * heads * 64 * s_pad).view(nb, heads, 64, s_pad)[..., :S].transpose(2, 3).float()
+        dot_ = V1(dot, nb * heads * 64 * s_pad).view(nb, heads, 64, s_pad)[..., :S].transpose(2, 3).float()
+        assert torch.equal(qt_, qf) and torch.equal(dot_, dof), "transposed operands do not match"
+        self._hv(dv, nb, S, heads, ld_d).copy_((p.transpose(2, 3) @ dof).to(dv.dtype))
+        self._hv(dk, nb, S, heads, ld_d).copy_(((ds.transpose(2, 3) @ qf) * scale).to(dk.dtype))
+
+    def attn_bwd_dq(self, q, k, v, kt, d_o, lse, D, dq, nb, heads, S, ld, ld_o, ld_d, s_pad, scale):
+        qf, kf, vf, dof, p, ds = self._attn_bwd_common(q, k, v, d_o, lse, D, nb, heads, S, ld, ld_o, scale)
+        kt_ = V1(kt, nb * heads * 64 * s_pad).view(nb, heads, 64, s_pad)[..., :S].transpose(2, 3).float()
+        assert torch.equal(kt_, kf), "transposed K does not match"
+        self._hv(dq, nb, S, heads, ld_d).copy_(((ds @ kf) * scale).to(dq.dtype))
+
+    # ---- temporal attention ----
+    @staticmethod
+    def _tv(t, B, T, HW, heads, ld):
+        # -> [B, HW, heads, T, 64]
+        return torch.as_strided(t, (B, HW, heads, T, 64), (T * HW * ld, ld, 64, HW * ld, 1), t.storage_offset())
+
+    def tattn_fwd(self, q, k, v, o, B, T, HW, heads, ld, ld_o, scale):
+        qf, kf, vf = (self._tv(t, B, T, HW, heads, ld).float() for t in (q, k, v))
+        p = torch.softmax((qf @ kf.transpose(-1, -2)) * scale, -1)
+        self._tv(o, B, T, HW, heads, ld_o).copy_((p @ vf).to(o.dtype))
+
+    def tattn_bwd(self, q, k, v, d_o, dq, dk, dv, B, T, HW, heads, ld, ld_o, ld_d, scale):
+        qf, kf, vf = (self._tv(t, B, T, HW, heads, ld).float() for t in (q, k, v))
+        dof = self._tv(d_o, B, T, HW, heads, ld_o).float()
+        p = torch.softmax((qf @ kf.transpose(-1, -2)) * scale, -1)
+        dp = dof @ vf.transpose(-1, -2)
+        ds = p * (dp - (dp * p).sum(-1, keepdim=True))
+        self._tv(dv, B, T, HW, heads, ld_d).copy_((p.transpose(-1, -2) @ dof).to(dv.dtype))
+        self._tv(dq, B, T, HW, heads, ld_d).copy_(((ds @ kf) * scale).to(dq.dtype))
+        self._tv(dk, B, T, HW, heads, ld_d).copy_(((ds.transpose(-1, -2) @ qf) * scale).to(dk.dtype))
+
+    # ---- elementwise ----
+    def geglu_fwd(self, pre, out, M, F):
+        p = V(pre, M, 2 * F, 2 * F).float()
+        V(out, M, F, F).copy_((p[:, :F] * gelu(p[:, F:])).to(out.dtype))
+
+    def geglu_bwd(self, dout, pre, dpre, M, F):
+        p = V(pre, M, 2 * F, 2 * F).float()
+        d = V(dout, M, F, F).float()
+        o = V(dpre, M, 2 * F, 2 * F)
+        o[:, :F] = (d * gelu(p[:, F:])).to(o.dtype)
+        o[:, F:] = (d * p[:, :F] * gelu_grad(p[:, F:])).to(o.dtype)
+
+    def add(self, a, b, out, n):
+        V1(out, n).copy_((V1(a, n).float() + V1(b, n).float()).to(out.dtype))
+
+    def blend(self, a, b, mix, out, n):
+        al = torch.sigmoid(V1(mix, 1))
+        V1(out, n).copy_((al * V1(a, n).float() + (1 - al) * V1(b, n).float()).to(out.dtype))
+
+    def blend_bwd(self, dy, mix, da, db, n):
+        al = torch.sigmoid(V1(mix, 1))
+        d = V1(dy, n).float()
+        V1(da, n).copy_((al * d).to(da.dtype))
+        V1(db, n).copy_(((1 - al) * d).to(db.dtype))
+
+    @staticmethod
+    def _gidx(rows, rpg, mod, dev):
+        m = torch.arange(rows, device=dev)
+        return (m % mod) if mod else (m // rpg)
+
+    def add_rowvec(self, x, vec, out, rows, C, rv_ld, rpg, mod):
+        gi = self._gidx(rows, rpg, mod, x.device)
+        v = V(vec, int(gi.max()) + 1, C, rv_ld)
+        V(out, rows, C, C).copy_((V(x, rows, C, C).float() + v[gi]).to(out.dtype))
+
+    def colsum(self, x, out, rows, C, ldx, n_groups, rpg, mod, accumulate=0):
+        gi = self._gidx(rows, rpg, mod, x.device)
+        o = V(out, n_groups, C, C)
+        if not accumulate:
+            o.zero_()
+        o.index_add_(0, gi, V(x, rows, C, ldx).float())
+
+    def transpose(self, inp, ld_in, out, ld_out, rows, cols):
+        o = V(out, cols, ld_out, ld_out)
+        o.zero_()
+        o[:, :rows] = V(inp, rows, cols, ld_in).t()
+
+    def concat2(self, a, Ca, b, Cb, out, rows):
+        o = V(out, rows, Ca + Cb, Ca + Cb)
+        o[:, :Ca] = V(a, rows, Ca, Ca)
+        o[:, Ca:] = V(b, rows, Cb, Cb)
+
+    def split2(self, inp, a, Ca, b, Cb, rows):
+        i = V(inp, rows, Ca + Cb, Ca + Cb)
+        V(a, rows, Ca, Ca).copy_(i[:, :Ca])
+        V(b, rows, Cb, Cb).copy_(i[:, Ca:])
+
+    def sum2x2(self, inp, out, n_img, h, w, C):
+        i = V(inp, n_img * 4 * h * w, C, C).float().view(n_img, h, 2, w, 2, C)
+        V(out, n_img * h * w, C, C).copy_(i.sum((2, 4)).reshape(-1, C).to(out.dtype))
+
+    def cast_from_f32(self, inp, out, n):
+        V1(out, n).copy_(V1(inp, n).to(out.dtype))
+
+    def cast_transpose_from_f32(self, inp, out, R, Cc):
+        V(out, Cc, R, R).copy_(V(inp, R, Cc, Cc).t().to(out.dtype))
+
+    def nchw_to_rows(self, inp, out, n_img, C, H, W, ld, mul=1.0):
+        o = V(out, n_img * H * W, ld, ld)
+        o.zero_()
+        i = V1(inp, n_img * C * H * W).view(n_img, C, H * W)
+        o[:, :C] = (i * mul).permute(0, 2, 1).reshape(-1, C).to(out.dtype)
+
+    def rows_to_nchw(self, inp, out, n_img, C, H, W, ld):
+        i = V(inp, n_img * H * W, C, ld).float().view(n_img, H * W, C)
+        V1(out, n_img * C * H * W).view(n_img, C, H * W).copy_(i.permute(0, 2, 1))
+
+    def zero(self, t):
+        t.zero_()
+
+    # ---- loss / optimizer ----
+    def edm_loss(self, pred, ld, noisy, target, sigma, loss, dpred, B, T, C, HW, opt_state):
+        p = V(pred, B * T * HW, C, ld).float().view(B, T, HW, C).permute(0, 1, 3, 2)
+        nz = V1(noisy, B * T * C * HW).view(B, T, C, HW)
+        tg = V1(target, B * T * C * HW).view(B, T, C, HW)
+        s = V1(sigma, B)[:, None, None, None]
+        c_out = -s / torch.sqrt(s * s + 1)
+        c_skip = 1 / (s * s + 1)
+        wgt = (1 + s * s) / (s * s)
+        diff = c_out * p + c_skip * nz - tg
+        norm = 1.0 / (B * T * C * HW)
+        V1(loss, 1).add_((wgt * diff * diff).sum() * norm)
+        d = opt_state[1] * 2 * wgt * diff * c_out * norm
+        V(dpred, B * T * HW, C, dpred.shape[1]).copy_(d.permute(0, 1, 3, 2).reshape(-1, C).to(dpred.dtype))
+
+    def check_finite(self, g, n, opt_state):
+        if not torch.isfinite(V1(g, n)).all():
+            opt_state[3] = 1.0
+
+    def optim_prep(self, st, beta1, beta2, growth, backoff, interval, dynamic):
+        found = bool(st[3] > 0)
+        inv = 1.0 / float(st[1])
+        scale, tracker, step = float(st[1]), float(st[2]), float(st[0])
+        if dynamic:
+            if found:
+                scale, tracker = scale * backoff, 0.0
+            else:
+                tracker += 1
+                if tracker >= interval:
+                    scale, tracker = scale * growth, 0.0
+        if not found:
+            step += 1
+        st.copy_(torch.tensor([step, scale, tracker, 0.0, inv, 1 - beta1 ** step, 1 - beta2 ** step,
+                               1.0 if found else 0.0], dtype=torch.float32))
+
+    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, grad_mul, st, p_act):
+        if float(st[7]) > 0:
+            return
+        P, G, Mm, Vv = V1(p, n), V1(g, n), V1(m, n), V1(v, n)
+        gg = G * (float(st[4]) * grad_mul)
+        P.mul_(1 - lr * wd)
+        Mm.mul_(beta1).add_(gg, alpha=1 - beta1)
+        Vv.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+        denom = Vv.sqrt() / math.sqrt(float(st[6])) + eps
+        P.addcdiv_(Mm, denom, value=-lr / float(st[5]))
+        if p_act is not None:
+            V1(p_act, n).copy_(P.to(p_act.dtype))
