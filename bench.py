@@ -1,0 +1,261 @@
+"""bench.py -- train-step samples/sec of the MI355X-native SVD UNet (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one synthetic clip per rank: zero grads -> UNet forward -> EDM loss
+-> hand-written backward -> [gradient all-reduce over RCCL when N > 1] -> inf-check + AdamW + re-pack of the
+trainable weights (the 397.6 M `temporal_transformer_block` parameters of train_svd.py:761-766).  Workload at
+N=1: BASELINE.json configs[1] -- SVD UNet (1,524,623,082 params), 14 frames, 512x320 (latent 64x40), fp16,
+batch 1, random-init weights, synthetic latents already resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
+  roofline     -- the dominant kernel (the MFMA GEMM / implicit-conv kernel): algorithmic FLOPs of all its launches
+                  in one step / their summed duration (HIP events on the launch stream, one instrumented step)
+  cpu_baseline -- the CPU oracle train step timed on the host cores on a bounded sample (c1': 8 frames 256x192)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
+STEP_TFLOP_C2 = 24.80          # 2x fwd (10.707 T) + dW of the trainable set, 14x512x320, B=1
+
+
+def init_weights_(model: torch.nn.Module, seed: int) -> None:
+    """Random init with O(1) activations (same law as oracle.unet.scaled_init_, drawn on device)."""
+    g = torch.Generator(device=next(model.parameters()).device).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("mix_factor"):
+                p.fill_(0.5)
+            elif p.ndim == 1:
+                if "norm" in name and name.endswith("weight"):
+                    p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device=p.device))
+                elif "norm" in name:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g, device=p.device))
+                else:
+                    p.copy_(0.02 * torch.randn(p.shape, generator=g, device=p.device))
+            else:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g, device=p.device) * math.sqrt(1.0 / fan_in))
+
+
+def make_batch(B, T, h, w, cross_dim, seed, dev):
+    from svd_xtend_amd.train import edm_prepare
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    latents = 0.7 * torch.randn(B, T, 4, h, w, generator=g)
+    noise = torch.randn(B, T, 4, h, w, generator=g)
+    cond = torch.randn(B, 4, h, w, generator=g)
+    ehs = torch.randn(B, 1, cross_dim, generator=g)
+    u = torch.rand(B, generator=g) * (1 - 2e-7) + 1e-7
+    cond_sigma = torch.distributions.Normal(-3.0, 0.5).icdf(u).exp()          # train_svd.py:954
+    u = torch.rand(B, generator=g) * (1 - 2e-7) + 1e-7
+    sigmas = torch.distributions.Normal(0.7, 1.6).icdf(u).exp()               # train_svd.py:964
+    unet_in, ts, noisy = edm_prepare(latents, noise, cond, sigmas)
+    ids = torch.tensor([[7.0, 127.0, float(cond_sigma[0])]]).repeat(B, 1)     # train_svd.py:981-988
+    return dict(unet_in=unet_in.to(dev), timesteps=ts.to(dev), ehs=ehs.to(dev), added_time_ids=ids.to(dev),
+                noisy_latents=noisy.to(dev), target=latents.to(dev), sigmas=sigmas.to(dev))
+
+
+def cpu_baseline(max_seconds: float = 60.0):
+    """The oracle (kind 'port': pure-PyTorch restatement; diffusers is not installed) on the host cores.
+    Sample: c1' = one 8-frame 256x192 clip, fp32, full SVD UNet, fwd + loss + bwd + AdamW, 1 step."""
+    from oracle.step import make_optimizer, make_synthetic_batch, train_step
+    from oracle.unet import SVD_CONFIG, UNetSpatioTemporalConditionOracle
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    orc = UNetSpatioTemporalConditionOracle(**SVD_CONFIG)
+    opt = make_optimizer(orc, lr=1e-5)
+    batch = make_synthetic_batch(1, 8, 24, 32, 1)
+    t_build = time.time() - t0
+    t1 = time.time()
+    loss, _ = train_step(orc, batch, opt)
+    dt = time.time() - t1
+    return {"value": 1.0 / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "c1': 1 step of the full SVD UNet on one 8-frame 256x192 clip (latent 24x32), fp32, "
+                      f"fwd+loss+bwd+AdamW, {dt:.1f}s (+{t_build:.1f}s model build); 4.1 TFLOP/step",
+            "seconds": dt, "loss": float(loss)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=14)
+    ap.add_argument("--height", type=int, default=320)     # pixels; README.md:40-53 trains 512x320
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("SVDX_GEMM_VARIANT", "0")))
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="debug: tiny topology instead of the SVD config")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from svd_xtend_amd.train import Trainer
+    from svd_xtend_amd.unet import UNetSpatioTemporalConditionModel
+    dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    cfg = {}
+    if args.tiny:
+        cfg = dict(block_out_channels=(64, 128, 128, 128), addition_time_embed_dim=32,
+                   projection_class_embeddings_input_dim=96, cross_attention_dim=64, num_attention_heads=(1, 2, 2, 2))
+    with torch.device(dev):
+        model = UNetSpatioTemporalConditionModel(**cfg)
+    init_weights_(model, seed=1234)            # identical on every rank (DDP's init broadcast)
+    trainer = Trainer(model, dtype=dt, lr=1e-5)
+    trainer.rt.gemm_variant = args.gemm_variant
+    n_params = sum(p.numel() for p in model.parameters())
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    B, T, h, w = 1, args.frames, args.height // 8, args.width // 8
+    cross = model.config.cross_attention_dim
+    batch = make_batch(B, T, h, w, cross, seed=123 + rank, dev=dev)       # rank-distinct data
+
+    def fwd_bwd():
+        trainer.zero_grad()
+        trainer.forward_backward(**batch)
+
+    def opt_step():
+        trainer.optimizer_step()
+
+    def step_eager():
+        fwd_bwd()
+        trainer.allreduce_grads()
+        opt_step()
+
+    # ---- warmup (eager), then try to capture the two halves of the step into hipGraphs ---------------------
+    for _ in range(max(1, args.warmup)):
+        step_eager()
+    torch.cuda.synchronize()
+    exec_mode = "eager"
+    step = step_eager
+    if not args.no_graph:
+        try:
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                fwd_bwd()
+                opt_step()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g1):
+                fwd_bwd()
+            with torch.cuda.graph(g2):
+                opt_step()
+
+            def step_graph():
+                g1.replay()
+                trainer.allreduce_grads()
+                g2.replay()
+            step_graph()
+            torch.cuda.synchronize()
+            step = step_graph
+            exec_mode = "hipgraph"
+        except Exception as e:  # noqa: BLE001 - fall back to eager launches, say so in the JSON line
+            print(f"[bench] graph capture failed ({e!r}); running eager", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            step = step_eager
+
+    # ---- timed region ------------------------------------------------------------------------------------
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te)
+    loss = float(trainer.last_loss())
+    state = trainer.opt_state.cpu().tolist()
+    ms = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (one instrumented eager step; events on the launch stream) ---------
+    roof = None
+    if not args.no_roofline and rank == 0:
+        k = trainer.rt.k
+        orig = k.gemm
+        recs = []
+
+        def timed_gemm(A, Bm, C, M, N, Kd, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(A, Bm, C, M, N, Kd, *a, **kw)
+            e1.record()
+            recs.append((e0, e1, 2.0 * M * N * Kd))
+        k.gemm = timed_gemm
+        try:
+            fwd_bwd()
+            torch.cuda.synchronize()
+        finally:
+            k.gemm = orig
+        opt_step()
+        torch.cuda.synchronize()
+        t_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+        fl = sum(f for _, _, f in recs)
+        ach = fl / (t_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_kernel (NT GEMM + implicit conv)", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None, "launches": len(recs),
+                "flops_per_step": fl, "kernel_ms_per_step": t_ms}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline()
+        except Exception as e:  # noqa: BLE001
+            cpu = {"error": repr(e)[:200]}
+
+    if rank == 0:
+        full = (not args.tiny) and (T, h, w) == (14, 40, 64)
+        line = {
+            "metric": "train-step samples/sec (14-frame 512x320 fp16 SVD UNet)",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic latents/CLIP embed, random-init weights (no checkpoints offline)",
+            "config": {"workload": f"SVD UNet train step, {T} frames {args.width}x{args.height}, batch 1/GPU, "
+                                   f"{n_params} params ({n_train} trainable: temporal_transformer_block*), "
+                                   "fwd + EDM loss + bwd + grad all-reduce + AdamW",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "exec": exec_mode,
+                       "gemm_variant": args.gemm_variant, "loss": loss, "loss_scale": state[1], "opt_steps": state[0],
+                       "step_tflops_per_gpu": (STEP_TFLOP_C2 / (ms * 1e-3) if full else None),
+                       "step_frac_of_mfma_peak": (STEP_TFLOP_C2 / (ms * 1e-3) / MFMA_PEAK_TFLOPS if full else None)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

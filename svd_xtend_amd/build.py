@@ -1,0 +1,51 @@
+"""Builds svd_xtend_amd/csrc/libsvdx.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["common.cpp", "gemm.hip", "norm.hip", "elementwise.hip", "attention.hip", "optim.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+LIB = os.path.join(CSRC, "libsvdx.so")
+
+
+def _stale(out: str, deps) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "svdx.h")]
+    objs = []
+
+    def compile_one(src):
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+        return o
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

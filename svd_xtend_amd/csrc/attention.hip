@@ -1,0 +1,785 @@
+// attention.hip -- self-attention kernels of the SVD UNet for gfx950 (head_dim 64).
+//
+// Spatial attention (sequence = HW): flash-style, MFMA 16x16x32, fp32 online softmax.
+//   The score tile is computed TRANSPOSED (S^T = K Q^T) so that every lane owns one query column: row max /
+//   sum are in-lane reductions plus two shuffles, the O rescale is a per-lane scalar, and the probabilities
+//   feed the second MFMA (O^T = V^T P^T) straight from their accumulator registers -- no LDS round trip.
+//   The k-slot <-> key mapping of that MFMA is arbitrary as long as both operands agree, so the V^T operand
+//   is read from a head-transposed copy of V ([d][key], made by svdx_head_transpose) with two 8-byte LDS
+//   reads per fragment.  The backward uses the same trick in both orientations (dQ kernel: lanes own
+//   queries; dK/dV kernel: lanes own keys), with head-transposed K, Q, dO as the strided operands.
+//   Row-major LDS tiles (128-byte rows) are XOR-swizzled on the 16-byte chunk index; transposed tiles use a
+//   136-byte row pitch; both make the fragment reads bank-conflict free.
+//
+// Temporal attention (sequence = frames): T <= 32, so each (clip, pixel, head) problem is one
+//   wave of plain VALU work on data addressed in place with stride HW*ld -- the (B*T,HW,C)<->(B*HW,T,C)
+//   transposes of the reference never happen.  The op is HBM-bound (AI = T/2 flop/B).
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr int TP = 136;   // byte pitch of transposed LDS tiles ([64 d][64 keys] halfs + 8 B pad)
+
+// ---- LDS tile staging -------------------------------------------------------------------------------------------
+// 64 rows x 64 halfs, row r taken from base + row_index(r)*ld (rows clamped to s_max-1), chunk-swizzled.
+template <typename T>
+__device__ __forceinline__ void stage_rows(char* lds, const T* base, size_t ld, int row0, int s_max, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = i * 256 + tid;
+        const int r = id >> 3, pc = id & 7, lc = pc ^ (r & 7);
+        const int row = min(row0 + r, s_max - 1);
+        const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + lc * 8);
+        *reinterpret_cast<uint4*>(lds + r * 128 + pc * 16) = v;
+    }
+}
+// 64 rows (d) x 64 halfs (positions col0..col0+63) from a head-transposed tensor [64][s_pad]
+template <typename T>
+__device__ __forceinline__ void stage_trans(char* lds, const T* base, int s_pad, int col0, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = i * 256 + tid;
+        const int r = id >> 3, c = id & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)r * s_pad + col0 + c * 8);
+        *reinterpret_cast<uint2*>(lds + r * TP + c * 16) = make_uint2(v.x, v.y);
+        *reinterpret_cast<uint2*>(lds + r * TP + c * 16 + 8) = make_uint2(v.z, v.w);
+    }
+}
+// row-major fragment: row (blk*16 + fr), logical 16-byte chunk (ks*4 + fg)
+template <typename T>
+__device__ __forceinline__ typename TT<T>::v8 frag_rows(const char* lds, int blk, int ks, int fr, int fg) {
+    return *reinterpret_cast<const typename TT<T>::v8*>(lds + (blk * 16 + fr) * 128 + (((ks * 4 + fg) ^ (fr & 7)) * 16));
+}
+// transposed fragment: row d = db*16 + fr; k-slots 0..3 <-> positions pb0*16 + fg*4 + e, slots 4..7 <-> pb1*16 + fg*4 + e
+template <typename T>
+__device__ __forceinline__ typename TT<T>::v8 frag_trans(const char* lds, int db, int pb0, int pb1, int fr, int fg) {
+    typedef typename TT<T>::v4 v4;
+    const char* row = lds + (db * 16 + fr) * TP;
+    const v4 lo = *reinterpret_cast<const v4*>(row + (pb0 * 16 + fg * 4) * 2);
+    const v4 hi = *reinterpret_cast<const v4*>(row + (pb1 * 16 + fg * 4) * 2);
+    typename TT<T>::v8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ typename TT<T>::v8 pack8(const f32x4& a, const f32x4& b) {
+    typename TT<T>::v8 r;
+    r[0] = from_f<T>(a[0]); r[1] = from_f<T>(a[1]); r[2] = from_f<T>(a[2]); r[3] = from_f<T>(a[3]);
+    r[4] = from_f<T>(b[0]); r[5] = from_f<T>(b[1]); r[6] = from_f<T>(b[2]); r[7] = from_f<T>(b[3]);
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const f32x4& v, float mul) {
+    Vec4<T> o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(v[e] * mul);
+    *reinterpret_cast<Vec4<T>*>(p) = o;
+}
+
+// ================================================================================================================
+// forward: block = (128 queries, head, frame); 4 waves x 32 queries; KV tiles of 64 keys
+// ================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                       const T* __restrict__ vt, T* __restrict__ o, float* __restrict__ lse,
+                                                       int heads, int S, int ld, int ld_o, int s_pad, float sl2) {
+    typedef typename TT<T>::v8 v8;
+    __shared__ __attribute__((aligned(16))) char smem[64 * 128 + 64 * TP];
+    char* Ks = smem;
+    char* Vs = smem + 64 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const T* qb_ = q + (size_t)n * S * ld + h * 64;
+    const T* kb_ = k + (size_t)n * S * ld + h * 64;
+    const T* vtb = vt + (size_t)(n * heads + h) * 64 * s_pad;
+
+    v8 qf[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int qi = min(q0 + qb * 16 + fr, S - 1);
+            qf[qb][ks] = *reinterpret_cast<const v8*>(qb_ + (size_t)qi * ld + ks * 32 + fg * 8);
+        }
+    f32x4 oacc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrow[2] = {-1e30f, -1e30f}, lrow[2] = {0.f, 0.f};
+
+    const int ntiles = (S + 63) / 64;
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        stage_rows<T>(Ks, kb_, ld, t * 64, S, tid);
+        stage_trans<T>(Vs, vtb, s_pad, t * 64, tid);
+        __syncthreads();
+        f32x4 s[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const v8 kf = frag_rows<T>(Ks, kb, ks, fr, fg);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) s[kb][qb] = TT<T>::mfma(kf, qf[qb][ks], s[kb][qb]);
+            }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * 64 + kb * 16 + fg * 4 + r;
+                    const float v = key < S ? s[kb][qb][r] * sl2 : -1e30f;
+                    s[kb][qb][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(mrow[qb], mx);
+            const float alpha = exp2f(mrow[qb] - mn);
+            mrow[qb] = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp2f(s[kb][qb][r] - mn);
+                    s[kb][qb][r] = p;
+                    ps += p;
+                }
+            lrow[qb] = lrow[qb] * alpha + ps;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) oacc[db][qb] *= alpha;
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            v8 pf[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) pf[qb] = pack8<T>(s[2 * k2][qb], s[2 * k2 + 1][qb]);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const v8 vf = frag_trans<T>(Vs, db, 2 * k2, 2 * k2 + 1, fr, fg);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) oacc[db][qb] = TT<T>::mfma(vf, pf[qb], oacc[db][qb]);
+            }
+        }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float lt = lrow[qb];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        const int qi = q0 + qb * 16 + fr;
+        if (qi < S) {
+            const float inv = 1.f / lt;
+            T* op = o + (size_t)(n * S + qi) * ld_o + h * 64 + fg * 4;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) store4<T>(op + db * 16, oacc[db][qb], inv);
+            if (fg == 0) lse[(size_t)(n * heads + h) * S + qi] = (mrow[qb] + log2f(lt)) * LN2;
+        }
+    }
+}
+
+template <typename T>
+__global__ void attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restrict__ d_o, float* __restrict__ D, int nb,
+                                     int heads, int S, int ld_o) {
+    const long n = (long)nb * S * heads;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int h = (int)(i % heads);
+        const long row = i / heads;
+        const T* op = o + row * ld_o + h * 64;
+        const T* dp = d_o + row * ld_o + h * 64;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float a[8], b[8];
+            load8<T>(op + c * 8, a);
+            load8<T>(dp + c * 8, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += a[e] * b[e];
+        }
+        const long nn = row / S;
+        const int s = (int)(row - nn * S);
+        D[(nn * heads + h) * S + s] = acc;
+    }
+}
+
+// ================================================================================================================
+// backward dQ: same orientation as the forward (lanes own queries), loops over KV tiles
+// ================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                          const T* __restrict__ kt, const T* __restrict__ d_o,
+                                                          const float* __restrict__ lse, const float* __restrict__ Dv,
+                                                          T* __restrict__ dq, int heads, int S, int ld, int ld_o, int ld_d,
+                                                          int s_pad, float scale) {
+    typedef typename TT<T>::v8 v8;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128 + 64 * TP];
+    char* Ks = smem;
+    char* Vs = smem + 64 * 128;
+    char* Kts = smem + 2 * 64 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const float sl2 = scale * LOG2E;
+    const T* qb_ = q + (size_t)n * S * ld + h * 64;
+    const T* kb_ = k + (size_t)n * S * ld + h * 64;
+    const T* vb_ = v + (size_t)n * S * ld + h * 64;
+    const T* dob = d_o + (size_t)n * S * ld_o + h * 64;
+    const T* ktb = kt + (size_t)(n * heads + h) * 64 * s_pad;
+
+    v8 qf[2][2], dof[2][2];
+    float lse2[2], dd[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = min(q0 + qb * 16 + fr, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[qb][ks] = *reinterpret_cast<const v8*>(qb_ + (size_t)qi * ld + ks * 32 + fg * 8);
+            dof[qb][ks] = *reinterpret_cast<const v8*>(dob + (size_t)qi * ld_o + ks * 32 + fg * 8);
+        }
+        lse2[qb] = lse[(size_t)(n * heads + h) * S + qi] * LOG2E;
+        dd[qb] = Dv[(size_t)(n * heads + h) * S + qi];
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (S + 63) / 64;
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        stage_rows<T>(Ks, kb_, ld, t * 64, S, tid);
+        stage_rows<T>(Vs, vb_, ld, t * 64, S, tid);
+        stage_trans<T>(Kts, ktb, s_pad, t * 64, tid);
+        __syncthreads();
+        f32x4 s[4][2], dp[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const v8 kf = frag_rows<T>(Ks, kb, ks, fr, fg);
+                const v8 vf = frag_rows<T>(Vs, kb, ks, fr, fg);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    s[kb][qb] = TT<T>::mfma(kf, qf[qb][ks], s[kb][qb]);
+                    dp[kb][qb] = TT<T>::mfma(vf, dof[qb][ks], dp[kb][qb]);
+                }
+            }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * 64 + kb * 16 + fg * 4 + r;
+                    const float p = key < S ? exp2f(s[kb][qb][r] * sl2 - lse2[qb]) : 0.f;
+                    s[kb][qb][r] = p * (dp[kb][qb][r] - dd[qb]);      // dS^T
+                }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            v8 df[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) df[qb] = pack8<T>(s[2 * k2][qb], s[2 * k2 + 1][qb]);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const v8 ktf = frag_trans<T>(Kts, db, 2 * k2, 2 * k2 + 1, fr, fg);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) acc[db][qb] = TT<T>::mfma(ktf, df[qb], acc[db][qb]);
+            }
+        }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = q0 + qb * 16 + fr;
+        if (qi < S) {
+            T* op = dq + (size_t)(n * S + qi) * ld_d + h * 64 + fg * 4;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) store4<T>(op + db * 16, acc[db][qb], scale);
+        }
+    }
+}
+
+// ================================================================================================================
+// backward dK/dV: lanes own keys (block = 128 keys, 4 waves x 32 keys), loops over query tiles of 64
+// ================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                           const T* __restrict__ d_o, const T* __restrict__ qt,
+                                                           const T* __restrict__ dot, const float* __restrict__ lse,
+                                                           const float* __restrict__ Dv, T* __restrict__ dk, T* __restrict__ dv,
+                                                           int heads, int S, int ld, int ld_o, int ld_d, int s_pad, float scale) {
+    typedef typename TT<T>::v8 v8;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128 + 2 * 64 * TP + 512];
+    char* Qs = smem;
+    char* dOs = smem + 64 * 128;
+    char* Qts = smem + 2 * 64 * 128;
+    char* dOts = Qts + 64 * TP;
+    float* Ls = reinterpret_cast<float*>(dOts + 64 * TP);   // [64] lse*log2e, then [64] D
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const int k0 = blockIdx.x * 128 + wave * 32;
+    const float sl2 = scale * LOG2E;
+    const T* qb_ = q + (size_t)n * S * ld + h * 64;
+    const T* kb_ = k + (size_t)n * S * ld + h * 64;
+    const T* vb_ = v + (size_t)n * S * ld + h * 64;
+    const T* dob = d_o + (size_t)n * S * ld_o + h * 64;
+    const T* qtb = qt + (size_t)(n * heads + h) * 64 * s_pad;
+    const T* dotb = dot + (size_t)(n * heads + h) * 64 * s_pad;
+    const float* lsb = lse + (size_t)(n * heads + h) * S;
+    const float* dvb = Dv + (size_t)(n * heads + h) * S;
+
+    v8 kf[2][2], vf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int ki = min(k0 + kb * 16 + fr, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[kb][ks] = *reinterpret_cast<const v8*>(kb_ + (size_t)ki * ld + ks * 32 + fg * 8);
+            vf[kb][ks] = *reinterpret_cast<const v8*>(vb_ + (size_t)ki * ld + ks * 32 + fg * 8);
+        }
+    }
+    f32x4 dka[4][2], dva[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { dka[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dva[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int ntiles = (S + 63) / 64;
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        stage_rows<T>(Qs, qb_, ld, t * 64, S, tid);
+        stage_rows<T>(dOs, dob, ld_o, t * 64, S, tid);
+        stage_trans<T>(Qts, qtb, s_pad, t * 64, tid);
+        stage_trans<T>(dOts, dotb, s_pad, t * 64, tid);
+        if (tid < 64) {
+            const int qi = min(t * 64 + tid, S - 1);
+            Ls[tid] = lsb[qi] * LOG2E;
+        } else if (tid < 128) {
+            const int qi = min(t * 64 + tid - 64, S - 1);
+            Ls[tid] = dvb[qi];
+        }
+        __syncthreads();
+        // S[q,key] and dP[q,key]: rows = queries (A from LDS), cols = this lane's key (B resident)
+        f32x4 s[4][2], dp[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) {
+                const v8 qf = frag_rows<T>(Qs, qb, ks, fr, fg);
+                const v8 df = frag_rows<T>(dOs, qb, ks, fr, fg);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    s[qb][kb] = TT<T>::mfma(qf, kf[kb][ks], s[qb][kb]);
+                    dp[qb][kb] = TT<T>::mfma(df, vf[kb][ks], dp[qb][kb]);
+                }
+            }
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qb * 16 + fg * 4);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ls + 64 + qb * 16 + fg * 4);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qi = t * 64 + qb * 16 + fg * 4 + r;
+                    const float p = qi < S ? exp2f(s[qb][kb][r] * sl2 - l4[r]) : 0.f;
+                    s[qb][kb][r] = p;
+                    dp[qb][kb][r] = p * (dp[qb][kb][r] - d4[r]);   // dS
+                }
+        }
+        // dV^T[d,key] += dO^T[d,q] P[q,key] ;  dK^T[d,key] += Q^T[d,q] dS[q,key]
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            v8 pf[2], sf[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                pf[kb] = pack8<T>(s[2 * k2][kb], s[2 * k2 + 1][kb]);
+                sf[kb] = pack8<T>(dp[2 * k2][kb], dp[2 * k2 + 1][kb]);
+            }
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const v8 dotf = frag_trans<T>(dOts, db, 2 * k2, 2 * k2 + 1, fr, fg);
+                const v8 qtf = frag_trans<T>(Qts, db, 2 * k2, 2 * k2 + 1, fr, fg);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    dva[db][kb] = TT<T>::mfma(dotf, pf[kb], dva[db][kb]);
+                    dka[db][kb] = TT<T>::mfma(qtf, sf[kb], dka[db][kb]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int ki = k0 + kb * 16 + fr;
+        if (ki < S) {
+            T* kp = dk + (size_t)(n * S + ki) * ld_d + h * 64 + fg * 4;
+            T* vp = dv + (size_t)(n * S + ki) * ld_d + h * 64 + fg * 4;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                store4<T>(kp + db * 16, dka[db][kb], scale);
+                store4<T>(vp + db * 16, dva[db][kb], 1.f);
+            }
+        }
+    }
+}
+
+// ================================================================================================================
+// temporal attention: one wave per (clip, pixel, head); TP_ = padded frame count (16 or 32)
+// ================================================================================================================
+template <typename T, int TPAD>
+struct TemporalCfg {
+    static constexpr int LPQ = 64 / TPAD;       // lanes per query
+    static constexpr int DCH = 64 / LPQ;        // head-dim slice per lane
+};
+
+template <typename T>
+__device__ __forceinline__ void tload_rows(char* dst, const T* base, size_t tstride, int Tn, int lane) {
+    for (int id = lane; id < Tn * 8; id += 64) {
+        const int t = id >> 3, c = id & 7;
+        *reinterpret_cast<uint4*>(dst + t * 128 + c * 16) = *reinterpret_cast<const uint4*>(base + (size_t)t * tstride + c * 8);
+    }
+}
+
+template <typename T, int TPAD>
+__global__ __launch_bounds__(256) void tattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                        T* __restrict__ o, int B, int Tn, int HW, int heads, int ld, int ld_o,
+                                                        float sl2, long nprob) {
+    typedef TemporalCfg<T, TPAD> Cfg;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* Kl = smem + wave * (2 * TPAD * 128);
+    char* Vl = Kl + TPAD * 128;
+    const long prob = (long)blockIdx.x * 4 + wave;
+    if (prob >= nprob) return;
+    const int h = (int)(prob % heads);
+    const long bp = prob / heads;
+    const int p = (int)(bp % HW), b = (int)(bp / HW);
+    const size_t row0 = (size_t)b * Tn * HW + p;
+    const size_t ts = (size_t)HW * ld;
+    tload_rows<T>(Kl, k + row0 * ld + h * 64, ts, Tn, lane);
+    tload_rows<T>(Vl, v + row0 * ld + h * 64, ts, Tn, lane);
+    const int tq = lane / Cfg::LPQ, part = lane % Cfg::LPQ;
+    const int tqc = min(tq, Tn - 1);
+    float qv[Cfg::DCH];
+    {
+        const T* qp = q + (row0 + (size_t)tqc * HW) * ld + h * 64 + part * Cfg::DCH;
+#pragma unroll
+        for (int c = 0; c < Cfg::DCH / 8; ++c) {
+            float t8[8];
+            load8<T>(qp + c * 8, t8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[c * 8 + e] = t8[e];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // LDS writes of this wave are visible to its own later reads after the wait
+    __builtin_amdgcn_wave_barrier();
+    float sc[TPAD];
+    float mx = -1e30f;
+#pragma unroll
+    for (int tk = 0; tk < TPAD; ++tk) {
+        float a = 0.f;
+        if (tk < Tn) {
+#pragma unroll
+            for (int c = 0; c < Cfg::DCH / 8; ++c) {
+                float k8[8];
+                load8<T>(reinterpret_cast<const T*>(Kl + tk * 128) + part * Cfg::DCH + c * 8, k8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a += qv[c * 8 + e] * k8[e];
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < Cfg::LPQ; off <<= 1) a += __shfl_xor(a, off, 64);
+        a = tk < Tn ? a * sl2 : -1e30f;
+        sc[tk] = a;
+        mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int tk = 0; tk < TPAD; ++tk) { sc[tk] = exp2f(sc[tk] - mx); sum += sc[tk]; }
+    const float inv = 1.f / sum;
+    float ov[Cfg::DCH];
+#pragma unroll
+    for (int e = 0; e < Cfg::DCH; ++e) ov[e] = 0.f;
+#pragma unroll
+    for (int tk = 0; tk < TPAD; ++tk) {
+        if (tk < Tn) {
+            const float pw = sc[tk] * inv;
+#pragma unroll
+            for (int c = 0; c < Cfg::DCH / 8; ++c) {
+                float v8_[8];
+                load8<T>(reinterpret_cast<const T*>(Vl + tk * 128) + part * Cfg::DCH + c * 8, v8_);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[c * 8 + e] += pw * v8_[e];
+            }
+        }
+    }
+    if (tq < Tn) {
+        T* op = o + (row0 + (size_t)tq * HW) * ld_o + h * 64 + part * Cfg::DCH;
+#pragma unroll
+        for (int c = 0; c < Cfg::DCH / 8; ++c) {
+            float t8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t8[e] = ov[c * 8 + e];
+            store8<T>(op + c * 8, t8);
+        }
+    }
+}
+
+template <typename T, int TPAD>
+__global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                        const T* __restrict__ d_o, T* __restrict__ dq, T* __restrict__ dk,
+                                                        T* __restrict__ dv, int B, int Tn, int HW, int heads, int ld, int ld_o,
+                                                        int ld_d, float scale, long nprob) {
+    typedef TemporalCfg<T, TPAD> Cfg;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WAVE_BYTES = 4 * TPAD * 128 + 2 * TPAD * (TPAD + 1) * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* Ql = smem + wave * WAVE_BYTES;
+    char* Kl = Ql + TPAD * 128;
+    char* Vl = Kl + TPAD * 128;
+    char* Dl = Vl + TPAD * 128;
+    float* Pm = reinterpret_cast<float*>(Dl + TPAD * 128);   // [TPAD][TPAD+1] probabilities
+    float* Sm = Pm + TPAD * (TPAD + 1);                      // [TPAD][TPAD+1] dS
+    const long prob = (long)blockIdx.x * 4 + wave;
+    if (prob >= nprob) return;
+    const int h = (int)(prob % heads);
+    const long bp = prob / heads;
+    const int p = (int)(bp % HW), b = (int)(bp / HW);
+    const size_t row0 = (size_t)b * Tn * HW + p;
+    const float sl2 = scale * LOG2E;
+    tload_rows<T>(Ql, q + row0 * ld + h * 64, (size_t)HW * ld, Tn, lane);
+    tload_rows<T>(Kl, k + row0 * ld + h * 64, (size_t)HW * ld, Tn, lane);
+    tload_rows<T>(Vl, v + row0 * ld + h * 64, (size_t)HW * ld, Tn, lane);
+    tload_rows<T>(Dl, d_o + row0 * ld_o + h * 64, (size_t)HW * ld_o, Tn, lane);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const int tq = lane / Cfg::LPQ, part = lane % Cfg::LPQ;
+    const int tqc = min(tq, Tn - 1);
+    float qv[Cfg::DCH], dov[Cfg::DCH];
+#pragma unroll
+    for (int c = 0; c < Cfg::DCH / 8; ++c) {
+        float a8[8], b8[8];
+        load8<T>(reinterpret_cast<const T*>(Ql + tqc * 128) + part * Cfg::DCH + c * 8, a8);
+        load8<T>(reinterpret_cast<const T*>(Dl + tqc * 128) + part * Cfg::DCH + c * 8, b8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qv[c * 8 + e] = a8[e]; dov[c * 8 + e] = b8[e]; }
+    }
+    float sc[TPAD], dp[TPAD];
+    float mx = -1e30f;
+#pragma unroll
+    for (int tk = 0; tk < TPAD; ++tk) {
+        float a = 0.f, d = 0.f;
+        if (tk < Tn) {
+#pragma unroll
+            for (int c = 0; c < Cfg::DCH / 8; ++c) {
+                float k8[8], v8_[8];
+                load8<T>(reinterpret_cast<const T*>(Kl + tk * 128) + part * Cfg::DCH + c * 8, k8);
+                load8<T>(reinterpret_cast<const T*>(Vl + tk * 128) + part * Cfg::DCH + c * 8, v8_);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a += qv[c * 8 + e] * k8[e]; d += dov[c * 8 + e] * v8_[e]; }
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < Cfg::LPQ; off <<= 1) { a += __shfl_xor(a, off, 64); d += __shfl_xor(d, off, 64); }
+        a = tk < Tn ? a * sl2 : -1e30f;
+        sc[tk] = a;
+        dp[tk] = d;
+        mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int tk = 0; tk < TPAD; ++tk) { sc[tk] = exp2f(sc[tk] - mx); sum += sc[tk]; }
+    const float inv = 1.f / sum;
+    float dsum = 0.f;
+#pragma unroll
+    for (int tk = 0; tk < TPAD; ++tk) { sc[tk] *= inv; dsum += sc[tk] * dp[tk]; }
+    // dS = P * (dP - sum_k P dP); dQ[tq] = scale * sum_k dS[tq,k] K[k]
+    float dqv[Cfg::DCH];
+#pragma unroll
+    for (int e = 0; e < Cfg::DCH; ++e) dqv[e] = 0.f;
+    const bool qvalid = tq < Tn;
+#pragma unroll
+    for (int tk = 0; tk < TPAD; ++tk) {
+        const float ds = qvalid && tk < Tn ? sc[tk] * (dp[tk] - dsum) : 0.f;
+        if (part == 0 && tq < TPAD) {
+            Pm[tq * (TPAD + 1) + tk] = qvalid ? sc[tk] : 0.f;
+            Sm[tq * (TPAD + 1) + tk] = ds;
+        }
+        if (tk < Tn) {
+#pragma unroll
+            for (int c = 0; c < Cfg::DCH / 8; ++c) {
+                float k8[8];
+                load8<T>(reinterpret_cast<const T*>(Kl + tk * 128) + part * Cfg::DCH + c * 8, k8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dqv[c * 8 + e] += ds * k8[e];
+            }
+        }
+    }
+    if (qvalid) {
+        T* op = dq + (row0 + (size_t)tq * HW) * ld_d + h * 64 + part * Cfg::DCH;
+#pragma unroll
+        for (int c = 0; c < Cfg::DCH / 8; ++c) {
+            float t8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t8[e] = dqv[c * 8 + e] * scale;
+            store8<T>(op + c * 8, t8);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // now the lane owns key tk = tq: dV[tk] = sum_q P[q,tk] dO[q] ; dK[tk] = scale * sum_q dS[q,tk] Q[q]
+    float dkv_[Cfg::DCH], dvv[Cfg::DCH];
+#pragma unroll
+    for (int e = 0; e < Cfg::DCH; ++e) { dkv_[e] = 0.f; dvv[e] = 0.f; }
+    const int tkc = min(tq, TPAD - 1);
+#pragma unroll
+    for (int t2 = 0; t2 < TPAD; ++t2) {
+        if (t2 < Tn) {
+            const float pw = Pm[t2 * (TPAD + 1) + tkc];
+            const float dsw = Sm[t2 * (TPAD + 1) + tkc];
+#pragma unroll
+            for (int c = 0; c < Cfg::DCH / 8; ++c) {
+                float q8[8], d8[8];
+                load8<T>(reinterpret_cast<const T*>(Ql + t2 * 128) + part * Cfg::DCH + c * 8, q8);
+                load8<T>(reinterpret_cast<const T*>(Dl + t2 * 128) + part * Cfg::DCH + c * 8, d8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { dvv[c * 8 + e] += pw * d8[e]; dkv_[c * 8 + e] += dsw * q8[e]; }
+            }
+        }
+    }
+    if (qvalid) {
+        T* kp = dk + (row0 + (size_t)tq * HW) * ld_d + h * 64 + part * Cfg::DCH;
+        T* vp = dv + (row0 + (size_t)tq * HW) * ld_d + h * 64 + part * Cfg::DCH;
+#pragma unroll
+        for (int c = 0; c < Cfg::DCH / 8; ++c) {
+            float a8[8], b8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a8[e] = dkv_[c * 8 + e] * scale; b8[e] = dvv[c * 8 + e]; }
+            store8<T>(kp + c * 8, a8);
+            store8<T>(vp + c * 8, b8);
+        }
+    }
+}
+
+}  // namespace
+
+#define ATTN_ARGS_OK(ld_, ptr_) ((ld_) % 8 == 0 && (((uintptr_t)(ptr_)) & 15) == 0)
+
+extern "C" int svdx_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int nb, int heads, int S, int ld,
+                             int ld_o, int s_pad, float scale, int dtype, void* stream) {
+    SVDX_CHECK_ARG(q && k && vt && o && lse && nb > 0 && heads > 0 && S > 0, "svdx_attn_fwd: bad args");
+    SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(s_pad, vt) && ld_o % 4 == 0 && s_pad % 64 == 0 &&
+                       s_pad >= S && (((uintptr_t)o) & 7) == 0, "svdx_attn_fwd: alignment (ld=%d ld_o=%d s_pad=%d)", ld, ld_o, s_pad);
+    dim3 grid(cdiv(S, 128), heads, nb);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_fwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q, (const T*)k,
+                                             (const T*)vt, (T*)o, lse, heads, S, ld, ld_o, s_pad, scale * LOG2E));
+    SVDX_LAUNCH_CHECK("svdx_attn_fwd");
+    return 0;
+}
+
+extern "C" int svdx_attn_bwd_prep(const void* o, const void* d_o, float* D, int nb, int heads, int S, int ld_o, int dtype, void* stream) {
+    SVDX_CHECK_ARG(o && d_o && D && ATTN_ARGS_OK(ld_o, o) && ATTN_ARGS_OK(ld_o, d_o), "svdx_attn_bwd_prep: bad args");
+    const long n = (long)nb * S * heads;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_bwd_prep_kernel<T>), dim3((int)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0,
+                                             (hipStream_t)stream, (const T*)o, (const T*)d_o, D, nb, heads, S, ld_o));
+    SVDX_LAUNCH_CHECK("svdx_attn_bwd_prep");
+    return 0;
+}
+
+extern "C" int svdx_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* d_o, const void* qt, const void* dot,
+                                 const float* lse, const float* D, void* dk, void* dv, int nb, int heads, int S, int ld, int ld_o,
+                                 int ld_d, int s_pad, float scale, int dtype, void* stream) {
+    SVDX_CHECK_ARG(q && k && v && d_o && qt && dot && lse && D && dk && dv, "svdx_attn_bwd_dkv: null argument");
+    SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ATTN_ARGS_OK(ld_o, d_o) &&
+                       ATTN_ARGS_OK(s_pad, qt) && ATTN_ARGS_OK(s_pad, dot) && ld_d % 4 == 0 && s_pad % 64 == 0 && s_pad >= S,
+                   "svdx_attn_bwd_dkv: alignment");
+    dim3 grid(cdiv(S, 128), heads, nb);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q,
+                                             (const T*)k, (const T*)v, (const T*)d_o, (const T*)qt, (const T*)dot, lse, D, (T*)dk,
+                                             (T*)dv, heads, S, ld, ld_o, ld_d, s_pad, scale));
+    SVDX_LAUNCH_CHECK("svdx_attn_bwd_dkv");
+    return 0;
+}
+
+extern "C" int svdx_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse,
+                                const float* D, void* dq, int nb, int heads, int S, int ld, int ld_o, int ld_d, int s_pad,
+                                float scale, int dtype, void* stream) {
+    SVDX_CHECK_ARG(q && k && v && kt && d_o && lse && D && dq, "svdx_attn_bwd_dq: null argument");
+    SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ATTN_ARGS_OK(ld_o, d_o) &&
+                       ATTN_ARGS_OK(s_pad, kt) && ld_d % 4 == 0 && s_pad % 64 == 0 && s_pad >= S, "svdx_attn_bwd_dq: alignment");
+    dim3 grid(cdiv(S, 128), heads, nb);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q,
+                                             (const T*)k, (const T*)v, (const T*)kt, (const T*)d_o, lse, D, (T*)dq, heads, S, ld,
+                                             ld_o, ld_d, s_pad, scale));
+    SVDX_LAUNCH_CHECK("svdx_attn_bwd_dq");
+    return 0;
+}
+
+extern "C" int svdx_tattn_fwd(const void* q, const void* k, const void* v, void* o, int B, int Tn, int HW, int heads, int ld,
+                              int ld_o, float scale, int dtype, void* stream) {
+    SVDX_CHECK_ARG(q && k && v && o && B > 0 && Tn > 0 && Tn <= 32 && HW > 0 && heads > 0, "svdx_tattn_fwd: bad args (T<=32)");
+    SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ATTN_ARGS_OK(ld_o, o), "svdx_tattn_fwd: alignment");
+    const long nprob = (long)B * HW * heads;
+    const int blocks = cdiv(nprob, 4);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        if (Tn <= 16)
+            hipLaunchKernelGGL((tattn_fwd_kernel<T, 16>), dim3(blocks), dim3(256), 4 * 2 * 16 * 128, st, (const T*)q, (const T*)k,
+                               (const T*)v, (T*)o, B, Tn, HW, heads, ld, ld_o, scale * LOG2E, nprob);
+        else
+            hipLaunchKernelGGL((tattn_fwd_kernel<T, 32>), dim3(blocks), dim3(256), 4 * 2 * 32 * 128, st, (const T*)q, (const T*)k,
+                               (const T*)v, (T*)o, B, Tn, HW, heads, ld, ld_o, scale * LOG2E, nprob);
+    });
+    SVDX_LAUNCH_CHECK("svdx_tattn_fwd");
+    return 0;
+}
+
+template <typename T, int TPAD>
+static int launch_tattn_bwd(const void* q, const void* k, const void* v, const void* d_o, void* dq, void* dk, void* dv, int B, int Tn,
+                            int HW, int heads, int ld, int ld_o, int ld_d, float scale, long nprob, hipStream_t st) {
+    constexpr int WAVE_BYTES = 4 * TPAD * 128 + 2 * TPAD * (TPAD + 1) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_bwd_kernel<T, TPAD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  4 * WAVE_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((tattn_bwd_kernel<T, TPAD>), dim3(cdiv(nprob, 4)), dim3(256), 4 * WAVE_BYTES, st, (const T*)q, (const T*)k,
+                       (const T*)v, (const T*)d_o, (T*)dq, (T*)dk, (T*)dv, B, Tn, HW, heads, ld, ld_o, ld_d, scale, nprob);
+    return 0;
+}
+
+extern "C" int svdx_tattn_bwd(const void* q, const void* k, const void* v, const void* d_o, void* dq, void* dk, void* dv, int B,
+                              int Tn, int HW, int heads, int ld, int ld_o, int ld_d, float scale, int dtype, void* stream) {
+    SVDX_CHECK_ARG(q && k && v && d_o && dq && dk && dv && B > 0 && Tn > 0 && Tn <= 32, "svdx_tattn_bwd: bad args (T<=32)");
+    SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ATTN_ARGS_OK(ld_o, d_o) &&
+                       ATTN_ARGS_OK(ld_d, dq) && ATTN_ARGS_OK(ld_d, dk) && ATTN_ARGS_OK(ld_d, dv), "svdx_tattn_bwd: alignment");
+    const long nprob = (long)B * HW * heads;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        if (Tn <= 16) launch_tattn_bwd<T, 16>(q, k, v, d_o, dq, dk, dv, B, Tn, HW, heads, ld, ld_o, ld_d, scale, nprob, st);
+        else launch_tattn_bwd<T, 32>(q, k, v, d_o, dq, dk, dv, B, Tn, HW, heads, ld, ld_o, ld_d, scale, nprob, st);
+    });
+    SVDX_LAUNCH_CHECK("svdx_tattn_bwd");
+    return 0;
+}

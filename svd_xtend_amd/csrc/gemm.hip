@@ -1,0 +1,488 @@
+// gemm.hip -- NT GEMM on MFMA for gfx950 with an implicit-convolution A operand.
+//
+//   acc[m,n] = sum_k Aeff[m,k] * B[n,k]      (f16/bf16 in, f32 accumulate, v_mfma_f32_16x16x32_*)
+//
+// One kernel serves every matmul-shaped op of the SVD UNet step: nn.Linear fwd /
+// data-grad / weight-grad, conv2d 3x3 (stride 1/2, nearest-x2 source) and its data-grads, Conv3d (3,1,1).
+// Convolutions never materialise im2col: each K-tile of 64 channels belongs to one filter tap, and the A
+// rows of that tile are fetched from the tap's shifted pixel (or from a zero page outside the image).
+//
+// Tile: 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16 fragments.
+// LDS: two stages x (A 16 KiB + B 16 KiB); rows are 128 B and the 16-byte chunk index is XOR-swizzled with
+// (row & 7) so that the ds_read_b128 fragment reads are bank-conflict free.  Two staging paths:
+//   variant 0: global -> VGPR -> ds_write_b128, loads issued before the MFMA phase (latency hidden)
+//   variant 1: global_load_lds_dwordx4 (LDS-DMA), swizzle applied on the per-lane SOURCE address
+// Epilogue: accumulators are staged through LDS (f32, padded rows) so that bias / per-clip row vector /
+// residual are applied and stored with 16-byte coalesced accesses.
+// Block -> tile mapping is XCD-aware (consecutive tiles of one A row-panel stay on one XCD's L2).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
+constexpr int CS_LD = 132;                          // padded f32 row of the epilogue staging tile
+
+struct GemmParams {
+    const void* A; const void* B; void* C;
+    int M, N, K, lda, ldb, ldc;
+    const float* bias; const float* rowvec; int rv_ld, rv_rpg, rv_mod;
+    const void* res; int ldres;
+    svdx_gather g; const void* zero_page;
+    int out_mode; float alpha; int split_k; int tiles_m, tiles_n; int vec_ok;
+};
+
+struct RowInfo { int a, b, base; };   // per gathered A row (meaning depends on gather mode)
+
+template <typename T>
+__device__ __forceinline__ const T* a_row_ptr(const GemmParams& p, const RowInfo& ri, int m_clamped, int k0,
+                                              int tap, int ci0, bool& valid) {
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const svdx_gather& g = p.g;
+    valid = true;
+    if (g.mode == SVDX_GATHER_PLAIN) return A + (size_t)m_clamped * p.lda + k0;
+    int src;
+    if (g.mode == SVDX_GATHER_CONV3X3) {
+        int dy = tap / 3, dx = tap - dy * 3;
+        int ys = ri.a + dy, xs = ri.b + dx;
+        valid = (ys >= 0) & (ys < g.hi) & (xs >= 0) & (xs < g.wi);
+        int wsrc = g.wi >> g.ups;
+        src = ri.base + (ys >> g.ups) * wsrc + (xs >> g.ups);
+    } else if (g.mode == SVDX_GATHER_CONV3X3_DGRAD2) {
+        int dy = tap / 3, dx = tap - dy * 3;
+        int y2 = ri.a - dy, x2 = ri.b - dx;
+        valid = (y2 >= 0) & ((y2 & 1) == 0) & ((y2 >> 1) < g.hi) & (x2 >= 0) & ((x2 & 1) == 0) & ((x2 >> 1) < g.wi);
+        src = ri.base + (y2 >> 1) * g.wi + (x2 >> 1);
+    } else {   // TEMPORAL3
+        int ts = ri.a + tap - 1;
+        valid = (ts >= 0) & (ts < g.t);
+        src = ri.base + ts * g.hw;
+    }
+    return A + (size_t)(valid ? src : 0) * g.lda + ci0;
+}
+
+__device__ __forceinline__ RowInfo decode_row(const svdx_gather& g, int m) {
+    RowInfo ri{0, 0, 0};
+    if (g.mode == SVDX_GATHER_CONV3X3) {
+        int x = m % g.wo, t = m / g.wo;
+        int y = t % g.ho, n = t / g.ho;
+        ri.a = y * g.stride - 1;
+        ri.b = x * g.stride - 1;
+        ri.base = n * (g.hi >> g.ups) * (g.wi >> g.ups);
+    } else if (g.mode == SVDX_GATHER_CONV3X3_DGRAD2) {
+        int x = m % g.wo, t = m / g.wo;
+        int y = t % g.ho, n = t / g.ho;
+        ri.a = y + 1;
+        ri.b = x + 1;
+        ri.base = n * g.hi * g.wi;
+    } else if (g.mode == SVDX_GATHER_TEMPORAL3) {
+        int pp = m % g.hw, t = m / g.hw;
+        int tt = t % g.t, b = t / g.t;
+        ri.a = tt;
+        ri.base = b * g.t * g.hw + pp;
+    }
+    return ri;
+}
+
+template <typename T, bool GLDS>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename TT<T>::v8 v8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware tile mapping (block b runs on XCD b % 8; give each XCD a contiguous run of tiles) ----
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int pid_m = swz / p.tiles_n, pid_n = swz - pid_m * p.tiles_n;
+    const int m0 = pid_m * BM, n0 = pid_n * BN;
+
+    // ---- split-K range ----
+    const int kt_total = p.K / BK;
+    const int z = blockIdx.y;
+    const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
+    const int kt_begin = z * kt_per;
+    const int kt_end = min(kt_total, kt_begin + kt_per);
+    if (kt_begin >= kt_end) return;
+
+    // ---- per-thread staging assignment: 4 A rows + 4 B rows, one 16-byte chunk each ----
+    const int ld_row = tid >> 3;                 // 0..31
+    const int pc = tid & 7;                      // physical chunk inside the 128-byte LDS row
+    const int lc = pc ^ (ld_row & 7);            // logical chunk (k offset lc*8) that lives there
+    int a_m[4];
+    RowInfo a_ri[4];
+    const T* b_ptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = min(m0 + i * 32 + ld_row, p.M - 1);
+        a_m[i] = m;
+        a_ri[i] = decode_row(p.g, m);
+        int n = min(n0 + i * 32 + ld_row, p.N - 1);
+        b_ptr[i] = reinterpret_cast<const T*>(p.B) + (size_t)n * p.ldb + lc * 8;
+    }
+    const int cin = p.g.mode == SVDX_GATHER_PLAIN ? p.K : p.g.cin;
+    const T* zero = reinterpret_cast<const T*>(p.zero_page);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto stage_ptrs = [&](int kt, const T* (&pa)[4], const T* (&pb)[4]) __attribute__((always_inline)) {
+        const int k0 = kt * BK;
+        int tap = 0, ci0 = k0;
+        if (p.g.mode != SVDX_GATHER_PLAIN) { tap = k0 / cin; ci0 = k0 - tap * cin; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bool valid;
+            const T* ptr = a_row_ptr<T>(p, a_ri[i], a_m[i], k0, tap, ci0, valid);
+            pa[i] = valid ? ptr + lc * 8 : zero;
+            pb[i] = b_ptr[i] + k0;
+        }
+    };
+#define SVDX_LOAD_REGS(kt_)                                                               \
+    uint4 ra[4], rb[4];                                                                   \
+    {                                                                                     \
+        const T* pa[4]; const T* pb[4];                                                   \
+        stage_ptrs((kt_), pa, pb);                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(pa[i]); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const uint4*>(pb[i]); \
+    }
+#define SVDX_WRITE_LDS(stage_)                                                            \
+    {                                                                                     \
+        char* As_ = smem + (stage_) * STAGE_BYTES;                                        \
+        char* Bs_ = As_ + BM * BK * 2;                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                   \
+            const int off = (i * 32 + ld_row) * 128 + pc * 16;                            \
+            *reinterpret_cast<uint4*>(As_ + off) = ra[i];                                 \
+            *reinterpret_cast<uint4*>(Bs_ + off) = rb[i];                                 \
+        }                                                                                 \
+    }
+    auto issue_glds = [&](int kt, int stage) __attribute__((always_inline)) {
+        const T* pa[4]; const T* pb[4];
+        stage_ptrs(kt, pa, pb);
+        char* As = smem + stage * STAGE_BYTES;
+        char* Bs = As + BM * BK * 2;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // LDS destination = wave-uniform base + lane*16 (chunk id = i*256 + tid)
+            const int base = (i * 256 + wave_u * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[i],
+                                             (__attribute__((address_space(3))) void*)(As + base), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[i],
+                                             (__attribute__((address_space(3))) void*)(Bs + base), 16, 0, 0);
+        }
+    };
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        const char* As = smem + stage * STAGE_BYTES;
+        const char* Bs = As + BM * BK * 2;
+        const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+            v8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const v8*>(As + (wm * 64 + i * 16 + fr) * 128 + chunk);
+                bf[i] = *reinterpret_cast<const v8*>(Bs + (wn * 64 + i * 16 + fr) * 128 + chunk);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = TT<T>::mfma(af[i], bf[j], acc[i][j]);
+        }
+    };
+
+    if (GLDS) {
+        issue_glds(kt_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
+            issue_glds(kt + 1, cur ^ 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+        compute(cur);
+        __syncthreads();
+    } else {
+        {
+            SVDX_LOAD_REGS(kt_begin);
+            SVDX_WRITE_LDS(0);
+        }
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
+            SVDX_LOAD_REGS(kt + 1);     // global loads in flight during the MFMA phase
+            compute(cur);
+            SVDX_WRITE_LDS(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+        compute(cur);
+        __syncthreads();
+    }
+#undef SVDX_LOAD_REGS
+#undef SVDX_WRITE_LDS
+
+    // ---- epilogue: stage 64 rows at a time through LDS as f32, then vectorised fused store ----
+    float* Cs = reinterpret_cast<float*>(smem);
+    const bool lead = (z == 0);
+    T* Ct = reinterpret_cast<T*>(p.C);
+    float* Cf = reinterpret_cast<float*>(p.C);
+    const T* R = reinterpret_cast<const T*>(p.res);
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wm == pass) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Cs[(i * 16 + (lane >> 4) * 4 + r) * CS_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const int id = i * 256 + tid;
+            const int row = id >> 4, c8 = id & 15;
+            const int m = m0 + pass * 64 + row, nc = n0 + c8 * 8;
+            if (m >= p.M || nc >= p.N) continue;
+            float v[8];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + row * CS_LD + c8 * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + row * CS_LD + c8 * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = lo[j] * p.alpha; v[4 + j] = hi[j] * p.alpha; }
+            const bool full = p.vec_ok && (nc + 8 <= p.N);
+            const int nvalid = min(8, p.N - nc);
+            if (lead) {
+                if (p.bias) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += p.bias[nc + j];
+                }
+                if (p.rowvec) {
+                    const int gi = p.rv_mod ? (m % p.rv_mod) : (m / p.rv_rpg);
+                    const float* rv = p.rowvec + (size_t)gi * p.rv_ld + nc;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += rv[j];
+                }
+                if (R) {
+                    const T* rp = R + (size_t)m * p.ldres + nc;
+                    if (full) {
+                        float rr[8];
+                        load8<T>(rp, rr);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += rr[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += to_f<T>(rp[j]);
+                    }
+                }
+            }
+            const size_t co = (size_t)m * p.ldc + nc;
+            if (p.out_mode == SVDX_OUT_ACT) {
+                if (full) {
+                    store8<T>(Ct + co, v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (j < nvalid) Ct[co + j] = from_f<T>(v[j]);
+                }
+            } else if (p.out_mode == SVDX_OUT_F32) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < nvalid) Cf[co + j] = v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < nvalid) atomicAdd(Cf + co + j, v[j]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- skinny linear: one wave per output column, lanes split K (trans = 0) --------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void small_linear_nt(const float* X, const T* W, const float* bias, float* Y,
+                                                       int M, int N, int K, int ldw, int silu_in, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const T* w = W + (size_t)n * ldw;
+    for (int mb = 0; mb < M; mb += 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k8 = lane; k8 * 8 < K; k8 += 64) {
+            float wv[8];
+            load8<T>(w + k8 * 8, wv);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                if (mb + mi < M) {
+                    const float* x = X + (size_t)(mb + mi) * K + k8 * 8;
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float xv = x[j];
+                        if (silu_in) xv = siluf_(xv);
+                        s += xv * wv[j];
+                    }
+                    acc[mi] += s;
+                }
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            float s = wave_sum(acc[mi]);
+            if (lane == 0 && mb + mi < M) {
+                if (bias) s += bias[n];
+                float* y = Y + (size_t)(mb + mi) * N + n;
+                *y = accumulate ? *y + s : s;
+            }
+        }
+    }
+}
+
+// trans = 1: Y[m,k] (+)= sum_n X[m,n] W[n,k]; thread per 8 consecutive k, block row per m
+template <typename T>
+__global__ __launch_bounds__(256) void small_linear_nn(const float* X, const T* W, float* Y, int M, int N, int K,
+                                                       int ldw, int accumulate) {
+    const int k8 = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y;
+    if (k8 * 8 >= K) return;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* x = X + (size_t)m * N;
+    for (int n = 0; n < N; ++n) {
+        float wv[8];
+        load8<T>(W + (size_t)n * ldw + k8 * 8, wv);
+        const float xv = x[n];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += xv * wv[j];
+    }
+    float* y = Y + (size_t)m * K + k8 * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = accumulate ? y[j] + acc[j] : acc[j];
+}
+
+__global__ void outer_acc_kernel(const float* dY, const float* X, float* dW, int M, int N, int K, float scale) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * K) return;
+    const int n = (int)(idx / K), k = (int)(idx - (size_t)n * K);
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += dY[(size_t)m * N + n] * X[(size_t)m * K + k];
+    dW[idx] += scale * s;
+}
+
+__global__ void timestep_embed_kernel(const float* t, float* out, int n, int dim) {
+    const int half = dim / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * half) return;
+    const int i = idx / half, j = idx - i * half;
+    const float f = expf(-9.210340371976184f * (float)j / (float)half);   // ln(10000)
+    const float a = t[i] * f;
+    out[(size_t)i * dim + j] = cosf(a);
+    out[(size_t)i * dim + half + j] = sinf(a);
+}
+
+template <typename T, bool GLDS>
+int launch_gemm(const GemmParams& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, GLDS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
+    hipLaunchKernelGGL((gemm_kernel<T, GLDS>), grid, dim3(NTHREADS), 2 * STAGE_BYTES, st, p);
+    SVDX_LAUNCH_CHECK("svdx_gemm");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                         const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
+                         const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
+                         int out_mode, float alpha, int split_k, int variant, int dtype, void* stream) {
+    SVDX_CHECK_ARG(A && B && C, "svdx_gemm: null operand");
+    SVDX_CHECK_ARG(M > 0 && N > 0 && K > 0, "svdx_gemm: bad sizes M=%d N=%d K=%d", M, N, K);
+    SVDX_CHECK_ARG(K % BK == 0, "svdx_gemm: K=%d must be a multiple of %d", K, BK);
+    SVDX_CHECK_ARG(ldb % 8 == 0 && ((uintptr_t)B & 15) == 0, "svdx_gemm: B must be 16-byte aligned (ldb=%d)", ldb);
+    SVDX_CHECK_ARG(split_k >= 1 && (split_k == 1 || out_mode == SVDX_OUT_F32_ATOMIC),
+                   "svdx_gemm: split_k=%d needs atomic output", split_k);
+    SVDX_CHECK_ARG(!rowvec || rv_mod > 0 || rv_rows_per_group > 0, "svdx_gemm: rowvec needs a grouping");
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.bias = bias; p.rowvec = rowvec; p.rv_ld = rv_ld; p.rv_rpg = rv_rows_per_group; p.rv_mod = rv_mod;
+    p.res = res; p.ldres = ldres; p.zero_page = zero_page;
+    p.out_mode = out_mode; p.alpha = alpha; p.split_k = split_k;
+    if (gather && gather->mode != SVDX_GATHER_PLAIN) {
+        p.g = *gather;
+        SVDX_CHECK_ARG(p.g.cin % BK == 0, "svdx_gemm: gather cin=%d must be a multiple of %d", p.g.cin, BK);
+        SVDX_CHECK_ARG(p.g.lda % 8 == 0 && ((uintptr_t)A & 15) == 0, "svdx_gemm: gather source misaligned");
+        SVDX_CHECK_ARG(zero_page && ((uintptr_t)zero_page & 15) == 0, "svdx_gemm: gather needs an aligned zero page");
+        const int taps = p.g.mode == SVDX_GATHER_TEMPORAL3 ? 3 : 9;
+        SVDX_CHECK_ARG(K == taps * p.g.cin, "svdx_gemm: K=%d != taps*cin=%d", K, taps * p.g.cin);
+        if (p.g.mode == SVDX_GATHER_CONV3X3) {
+            SVDX_CHECK_ARG(M == p.g.n_img * p.g.ho * p.g.wo, "svdx_gemm: conv rows mismatch");
+            SVDX_CHECK_ARG(p.g.stride == 1 || p.g.stride == 2, "svdx_gemm: conv stride");
+            SVDX_CHECK_ARG(!p.g.ups || (p.g.hi % 2 == 0 && p.g.wi % 2 == 0), "svdx_gemm: upsampled dims must be even");
+        } else if (p.g.mode == SVDX_GATHER_CONV3X3_DGRAD2) {
+            SVDX_CHECK_ARG(M == p.g.n_img * p.g.ho * p.g.wo, "svdx_gemm: dgrad rows mismatch");
+        } else if (p.g.mode == SVDX_GATHER_TEMPORAL3) {
+            SVDX_CHECK_ARG(M == p.g.n_img * p.g.t * p.g.hw, "svdx_gemm: temporal rows mismatch");
+        } else {
+            svdx_set_error("svdx_gemm: unknown gather mode %d", p.g.mode);
+            return -2;
+        }
+    } else {
+        p.g = svdx_gather{};
+        p.g.mode = SVDX_GATHER_PLAIN;
+        SVDX_CHECK_ARG(lda % 8 == 0 && ((uintptr_t)A & 15) == 0, "svdx_gemm: A must be 16-byte aligned (lda=%d)", lda);
+    }
+    p.tiles_m = cdiv(M, BM);
+    p.tiles_n = cdiv(N, BN);
+    const int esz = out_mode == SVDX_OUT_ACT ? 2 : 4;
+    p.vec_ok = (ldc % 8 == 0) && (((uintptr_t)C % (esz == 2 ? 16 : 4)) == 0) &&
+               (!res || (ldres % 8 == 0 && ((uintptr_t)res & 15) == 0));
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, return variant == 1 ? launch_gemm<T, true>(p, st) : launch_gemm<T, false>(p, st));
+}
+
+extern "C" int svdx_small_linear(const float* X, const void* W, const float* bias, float* Y, int M, int N, int K,
+                                 int ldw, int trans, int silu_in, int accumulate, int dtype, void* stream) {
+    SVDX_CHECK_ARG(X && W && Y && M > 0 && N > 0 && K > 0, "svdx_small_linear: bad args");
+    SVDX_CHECK_ARG(K % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)W & 15) == 0, "svdx_small_linear: K/ldw must be multiples of 8");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, {
+        if (trans == 0) {
+            hipLaunchKernelGGL((small_linear_nt<T>), dim3(cdiv(N, 4)), dim3(256), 0, st, X, (const T*)W, bias, Y, M, N, K,
+                               ldw, silu_in, accumulate);
+        } else {
+            SVDX_CHECK_ARG(!bias && !silu_in, "svdx_small_linear: trans=1 takes no bias/activation");
+            hipLaunchKernelGGL((small_linear_nn<T>), dim3(cdiv(K / 8, 256), M), dim3(256), 0, st, X, (const T*)W, Y, M, N,
+                               K, ldw, accumulate);
+        }
+    });
+    SVDX_LAUNCH_CHECK("svdx_small_linear");
+    return 0;
+}
+
+extern "C" int svdx_outer_acc(const float* dY, const float* X, float* dW, int M, int N, int K, float scale, void* stream) {
+    SVDX_CHECK_ARG(dY && X && dW && M > 0 && N > 0 && K > 0, "svdx_outer_acc: bad args");
+    const size_t n = (size_t)N * K;
+    hipLaunchKernelGGL(outer_acc_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dY, X, dW, M, N, K, scale);
+    SVDX_LAUNCH_CHECK("svdx_outer_acc");
+    return 0;
+}
+
+extern "C" int svdx_timestep_embed(const float* t, float* out, int n, int dim, void* stream) {
+    SVDX_CHECK_ARG(t && out && n > 0 && dim > 0 && dim % 2 == 0, "svdx_timestep_embed: bad args");
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3(cdiv((long)n * dim / 2, 256)), dim3(256), 0, (hipStream_t)stream, t, out,
+                       n, dim);
+    SVDX_LAUNCH_CHECK("svdx_timestep_embed");
+    return 0;
+}

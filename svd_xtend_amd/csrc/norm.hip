@@ -1,0 +1,365 @@
+// norm.hip -- GroupNorm(32)(+SiLU) and LayerNorm, forward and backward, for channels-last rows (gfx950).
+//
+// HBM-bound kernels.  Every thread owns one fixed 16-byte column chunk (8 channels)
+// and walks rows, so per-channel scale/shift (or partial sums) live in registers; loads/stores are 16 B per
+// lane, coalesced across the row.  Group statistics are reduced thread -> LDS -> one atomicAdd per group per
+// block.  GroupNorm "sample" = `rows` consecutive rows (a frame for the 2-D norms, a whole clip for the
+// TemporalResnetBlock norms whose groups span all frames).
+#include "common.h"
+
+namespace {
+
+constexpr int GN_SLAB = 64;    // rows per block
+
+struct GnGeom {
+    int n_s, rows, C, G, cg, cc, rpi;   // cg channels/group, cc 16-byte chunks per row, rpi rows per iteration
+};
+
+__device__ __forceinline__ void group_mean_rstd(const float* stats, int n, int G, int g, float cnt, float eps,
+                                                float& mean, float& rstd) {
+    const float s = stats[((size_t)n * G + g) * 2], ss = stats[((size_t)n * G + g) * 2 + 1];
+    mean = s / cnt;
+    const float var = fmaxf(ss / cnt - mean * mean, 0.f);
+    rstd = rsqrtf(var + eps);
+}
+
+// MODE 0: stats of x.  MODE 1: backward stats (sum dz*gamma, sum dz*gamma*xhat).
+template <typename T, int MODE>
+__global__ void gn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ stats,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta, float* out,
+                                 GnGeom q, float eps, int silu) {
+    __shared__ float gacc[64];
+    const int t = threadIdx.x;
+    if (t < 64) gacc[t] = 0.f;
+    __syncthreads();
+    const int n = blockIdx.x, slab = blockIdx.y;
+    const int j = t % q.cc, ry = t / q.cc;
+    const int r0 = slab * GN_SLAB, r1 = min(q.rows, r0 + GN_SLAB);
+    float a0[8], a1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
+    float sc[8], sh[8], gm[8], mu[8], rs[8];
+    if (MODE == 1) {
+        const float cnt = (float)q.rows * q.cg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = j * 8 + e;
+            float mean, rstd;
+            group_mean_rstd(stats, n, q.G, c / q.cg, cnt, eps, mean, rstd);
+            mu[e] = mean; rs[e] = rstd; gm[e] = gamma[c];
+            sc[e] = rstd * gm[e];
+            sh[e] = beta[c] - mean * sc[e];
+        }
+    }
+    if (ry < q.rpi) {
+        for (int r = r0 + ry; r < r1; r += q.rpi) {
+            const size_t off = ((size_t)n * q.rows + r) * q.C + j * 8;
+            float xv[8];
+            load8<T>(x + off, xv);
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a0[e] += xv[e]; a1[e] += xv[e] * xv[e]; }
+            } else {
+                float dv[8];
+                load8<T>(dy + off, dv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float dz = dv[e];
+                    if (silu) dz *= silu_gradf_(xv[e] * sc[e] + sh[e]);
+                    const float dzg = dz * gm[e];
+                    a0[e] += dzg;
+                    a1[e] += dzg * (xv[e] - mu[e]) * rs[e];
+                }
+            }
+        }
+        // merge the 8 channels into their groups (runs of equal group id), then one LDS atomic per run
+        int cur = (j * 8) / q.cg;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (j * 8 + e) / q.cg;
+            if (g != cur) {
+                atomicAdd(&gacc[cur * 2], s0);
+                atomicAdd(&gacc[cur * 2 + 1], s1);
+                cur = g; s0 = 0.f; s1 = 0.f;
+            }
+            s0 += a0[e]; s1 += a1[e];
+        }
+        atomicAdd(&gacc[cur * 2], s0);
+        atomicAdd(&gacc[cur * 2 + 1], s1);
+    }
+    __syncthreads();
+    if (t < 2 * q.G) atomicAdd(out + (size_t)n * q.G * 2 + t, gacc[t]);
+}
+
+// MODE 0: y = act(xhat*gamma+beta).  MODE 1: dx = rstd*(dz*gamma - (s1 + xhat*s2)/cnt) (+ add).
+template <typename T, int MODE>
+__global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ stats,
+                                const float* __restrict__ bstats, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const T* __restrict__ add, T* __restrict__ out,
+                                GnGeom q, float eps, int silu) {
+    const int t = threadIdx.x;
+    const int n = blockIdx.x, slab = blockIdx.y;
+    const int j = t % q.cc, ry = t / q.cc;
+    if (ry >= q.rpi) return;
+    const int r0 = slab * GN_SLAB, r1 = min(q.rows, r0 + GN_SLAB);
+    const float cnt = (float)q.rows * q.cg;
+    float sc[8], sh[8], gm[8], mu[8], rs[8], b1[8], b2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = j * 8 + e, g = c / q.cg;
+        float mean, rstd;
+        group_mean_rstd(stats, n, q.G, g, cnt, eps, mean, rstd);
+        mu[e] = mean; rs[e] = rstd; gm[e] = gamma[c];
+        sc[e] = rstd * gm[e];
+        sh[e] = beta[c] - mean * sc[e];
+        if (MODE == 1) {
+            b1[e] = bstats[((size_t)n * q.G + g) * 2] / cnt;
+            b2[e] = bstats[((size_t)n * q.G + g) * 2 + 1] / cnt;
+        }
+    }
+    for (int r = r0 + ry; r < r1; r += q.rpi) {
+        const size_t off = ((size_t)n * q.rows + r) * q.C + j * 8;
+        float xv[8], o[8];
+        load8<T>(x + off, xv);
+        if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float z = xv[e] * sc[e] + sh[e];
+                o[e] = silu ? siluf_(z) : z;
+            }
+        } else {
+            float dv[8];
+            load8<T>(dy + off, dv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float dz = dv[e];
+                if (silu) dz *= silu_gradf_(xv[e] * sc[e] + sh[e]);
+                const float xhat = (xv[e] - mu[e]) * rs[e];
+                o[e] = rs[e] * (dz * gm[e] - (b1[e] + xhat * b2[e]));
+            }
+            if (add) {
+                float av[8];
+                load8<T>(add + off, av);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += av[e];
+            }
+        }
+        store8<T>(out + off, o);
+    }
+}
+
+int gn_geom(GnGeom& q, int n_s, int rows, int C, int G, int& threads) {
+    SVDX_CHECK_ARG(n_s > 0 && rows > 0 && C > 0 && G > 0 && G <= 32, "groupnorm: bad sizes");
+    SVDX_CHECK_ARG(C % G == 0 && C % 8 == 0 && C / 8 <= 1024, "groupnorm: C=%d must be a multiple of 8 and of G", C);
+    q.n_s = n_s; q.rows = rows; q.C = C; q.G = G; q.cg = C / G; q.cc = C / 8;
+    q.rpi = q.cc >= 256 ? 1 : 256 / q.cc;
+    threads = q.cc * q.rpi;
+    return 0;
+}
+
+// ---- LayerNorm: one wave per row, whole row in registers (C <= 2048) ------------------------------------------
+constexpr int LN_MAXCH = 4;
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ stats, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int cc = C / 8;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    for (int row = wid; row < rows; row += nw) {
+        float v[LN_MAXCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; ++i) {
+            const int j = lane + i * 64;
+            if (j < cc) {
+                load8<T>(x + (size_t)row * C + j * 8, v[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[i][e];
+            }
+        }
+        const float mean = wave_sum(s) / C;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; ++i) {
+            if (lane + i * 64 < cc) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(ss) / C + eps);
+        if (lane == 0) { stats[(size_t)row * 2] = mean; stats[(size_t)row * 2 + 1] = rstd; }
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; ++i) {
+            const int j = lane + i * 64;
+            if (j < cc) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * gamma[j * 8 + e] + beta[j * 8 + e];
+                store8<T>(y + (size_t)row * C + j * 8, o);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     const T* __restrict__ add, T* __restrict__ dx, float* dgamma,
+                                                     float* dbeta, int rows, int C) {
+    extern __shared__ float red[];   // [2][C] when affine grads are requested
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cc = C / 8;
+    const bool affine = dgamma != nullptr;
+    if (affine) {
+        for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+        __syncthreads();
+    }
+    float gmv[LN_MAXCH][8], pg[LN_MAXCH][8], pb[LN_MAXCH][8];
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = lane + i * 64;
+            gmv[i][e] = j < cc ? gamma[j * 8 + e] : 0.f;
+            pg[i][e] = pb[i][e] = 0.f;
+        }
+    const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    for (int row = wid; row < rows; row += nw) {
+        const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
+        float xh[LN_MAXCH][8], dg[LN_MAXCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; ++i) {
+            const int j = lane + i * 64;
+            if (j < cc) {
+                float xv[8], dv[8];
+                load8<T>(x + (size_t)row * C + j * 8, xv);
+                load8<T>(dy + (size_t)row * C + j * 8, dv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[i][e] = (xv[e] - mean) * rstd;
+                    dg[i][e] = dv[e] * gmv[i][e];
+                    s1 += dg[i][e];
+                    s2 += dg[i][e] * xh[i][e];
+                    pg[i][e] += dv[e] * xh[i][e];
+                    pb[i][e] += dv[e];
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; ++i) {
+            const int j = lane + i * 64;
+            if (j < cc) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (dg[i][e] - m1 - xh[i][e] * m2);
+                if (add) {
+                    float av[8];
+                    load8<T>(add + (size_t)row * C + j * 8, av);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += av[e];
+                }
+                store8<T>(dx + (size_t)row * C + j * 8, o);
+            }
+        }
+    }
+    if (affine) {
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; ++i) {
+            const int j = lane + i * 64;
+            if (j < cc) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    atomicAdd(&red[j * 8 + e], pg[i][e]);
+                    atomicAdd(&red[C + j * 8 + e], pb[i][e]);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < C; i += 256) {
+            atomicAdd(dgamma + i, red[i]);
+            atomicAdd(dbeta + i, red[C + i]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int C, int G, int dtype, void* stream) {
+    GnGeom q; int threads;
+    if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * n_s * G, st);
+    dim3 grid(n_s, cdiv(rows, GN_SLAB));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_reduce_kernel<T, 0>), grid, dim3(threads), 0, st, (const T*)x,
+                                             (const T*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                                             (const float*)nullptr, stats, q, 0.f, 0));
+    SVDX_LAUNCH_CHECK("svdx_gn_stats");
+    return 0;
+}
+
+extern "C" int svdx_gn_apply(const void* x, const float* stats, const float* gamma, const float* beta, void* y,
+                             int n_s, int rows, int C, int G, float eps, int silu, int dtype, void* stream) {
+    GnGeom q; int threads;
+    if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
+    dim3 grid(n_s, cdiv(rows, GN_SLAB));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_apply_kernel<T, 0>), grid, dim3(threads), 0, (hipStream_t)stream,
+                                             (const T*)x, (const T*)nullptr, stats, (const float*)nullptr, gamma, beta,
+                                             (const T*)nullptr, (T*)y, q, eps, silu));
+    SVDX_LAUNCH_CHECK("svdx_gn_apply");
+    return 0;
+}
+
+extern "C" int svdx_gn_bwd_stats(const void* dy, const void* x, const float* stats, const float* gamma,
+                                 const float* beta, float* bstats, int n_s, int rows, int C, int G, float eps,
+                                 int silu, int dtype, void* stream) {
+    GnGeom q; int threads;
+    if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * n_s * G, st);
+    dim3 grid(n_s, cdiv(rows, GN_SLAB));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_reduce_kernel<T, 1>), grid, dim3(threads), 0, st, (const T*)x,
+                                             (const T*)dy, stats, gamma, beta, bstats, q, eps, silu));
+    SVDX_LAUNCH_CHECK("svdx_gn_bwd_stats");
+    return 0;
+}
+
+extern "C" int svdx_gn_bwd_apply(const void* dy, const void* x, const float* stats, const float* bstats,
+                                 const float* gamma, const float* beta, const void* add, void* dx, int n_s, int rows,
+                                 int C, int G, float eps, int silu, int dtype, void* stream) {
+    GnGeom q; int threads;
+    if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
+    dim3 grid(n_s, cdiv(rows, GN_SLAB));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_apply_kernel<T, 1>), grid, dim3(threads), 0, (hipStream_t)stream,
+                                             (const T*)x, (const T*)dy, stats, bstats, gamma, beta, (const T*)add,
+                                             (T*)dx, q, eps, silu));
+    SVDX_LAUNCH_CHECK("svdx_gn_bwd_apply");
+    return 0;
+}
+
+extern "C" int svdx_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows,
+                           int C, float eps, int dtype, void* stream) {
+    SVDX_CHECK_ARG(rows > 0 && C % 8 == 0 && C / 8 <= 64 * LN_MAXCH, "svdx_ln_fwd: C=%d unsupported", C);
+    const int blocks = min(cdiv(rows, 4), 2048);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)x, gamma, beta, (T*)y, stats, rows, C, eps));
+    SVDX_LAUNCH_CHECK("svdx_ln_fwd");
+    return 0;
+}
+
+extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* add,
+                           void* dx, float* dgamma, float* dbeta, int rows, int C, int dtype, void* stream) {
+    SVDX_CHECK_ARG(rows > 0 && C % 8 == 0 && C / 8 <= 64 * LN_MAXCH, "svdx_ln_bwd: C=%d unsupported", C);
+    SVDX_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "svdx_ln_bwd: dgamma/dbeta must come together");
+    const int blocks = min(cdiv(rows, 4), 512);
+    const size_t sh = dgamma ? sizeof(float) * 2 * C : 0;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), sh, (hipStream_t)stream,
+                                             (const T*)dy, (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma,
+                                             dbeta, rows, C));
+    SVDX_LAUNCH_CHECK("svdx_ln_bwd");
+    return 0;
+}

@@ -1,0 +1,152 @@
+// optim.hip -- EDM loss (+gradient), gradient finiteness check, loss-scale state machine and fused AdamW (gfx950).
+//
+// Replaces, on device and without host synchronisation: the loss arithmetic of train_svd.py:1025-1036,
+// torch.optim.AdamW (train_svd.py:767-773) and accelerate's GradScaler (scale / unscale / inf-skip / growth).
+// opt_state float[8]: 0 step, 1 loss_scale, 2 growth_tracker, 3 found_inf, 4 inv_scale, 5 bc1, 6 bc2, 7 skip.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void edm_loss_kernel(const T* __restrict__ pred, int ld, const float* __restrict__ noisy,
+                                                       const float* __restrict__ target, const float* __restrict__ sigma,
+                                                       float* loss, T* __restrict__ dpred, int ld_d, int B, int T_, int C,
+                                                       int HW, const float* __restrict__ opt_state) {
+    __shared__ float red[4];
+    const long n = (long)B * T_ * C * HW;
+    const float norm = 1.f / (float)n;
+    const float lscale = opt_state[1];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        // i indexes the NCHW-per-frame float tensors: ((b*T + t)*C + c)*HW + p
+        const int p = (int)(i % HW);
+        const long t1 = i / HW;
+        const int c = (int)(t1 % C);
+        const long bt = t1 / C;
+        const int b = (int)(bt / T_);
+        const float s = sigma[b];
+        const float s2 = s * s;
+        const float c_out = -s / sqrtf(s2 + 1.f);
+        const float c_skip = 1.f / (s2 + 1.f);
+        const float w = (1.f + s2) / s2;
+        const size_t ro = ((size_t)bt * HW + p);
+        const float pr = to_f<T>(pred[ro * ld + c]);
+        const float diff = c_out * pr + c_skip * noisy[i] - target[i];
+        acc += w * diff * diff;
+        dpred[ro * ld_d + c] = from_f<T>(lscale * 2.f * w * diff * c_out * norm);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * norm);
+}
+
+__global__ void check_finite_kernel(const float* __restrict__ g, long n, float* opt_state) {
+    bool bad = false;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bad |= !isfinite(v[e]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) bad |= !isfinite(g[n4 * 4 + threadIdx.x]);
+    if (__any(bad)) {
+        if ((threadIdx.x & 63) == 0) opt_state[3] = 1.f;
+    }
+}
+
+__global__ void optim_prep_kernel(float* st, float beta1, float beta2, float growth, float backoff, int interval, int dynamic) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool found = st[3] > 0.f;
+    float step = st[0], scale = st[1], tracker = st[2];
+    const float inv = 1.f / scale;
+    if (dynamic) {
+        if (found) { scale *= backoff; tracker = 0.f; }
+        else {
+            tracker += 1.f;
+            if (tracker >= (float)interval) { scale *= growth; tracker = 0.f; }
+        }
+    }
+    if (!found) step += 1.f;
+    st[0] = step; st[1] = scale; st[2] = tracker; st[3] = 0.f; st[4] = inv;
+    st[5] = 1.f - powf(beta1, step);
+    st[6] = 1.f - powf(beta2, step);
+    st[7] = found ? 1.f : 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
+                                                    float wd, float grad_mul, const float* __restrict__ st, T* __restrict__ p_act) {
+    if (st[7] > 0.f) return;     // inf/nan in the gradients: skip the step (GradScaler semantics)
+    const float gmul = st[4] * grad_mul;
+    const float step_size = lr / st[5];
+    const float inv_bc2_sqrt = rsqrtf(st[6]);
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pv = *reinterpret_cast<const f32x4*>(p + i * 4);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+        f32x4 mv = *reinterpret_cast<const f32x4*>(m + i * 4);
+        f32x4 vv = *reinterpret_cast<const f32x4*>(v + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = gv[e] * gmul;
+            pv[e] *= (1.f - lr * wd);
+            mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
+            vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
+            const float denom = sqrtf(vv[e]) * inv_bc2_sqrt + eps;
+            pv[e] -= step_size * mv[e] / denom;
+        }
+        *reinterpret_cast<f32x4*>(p + i * 4) = pv;
+        *reinterpret_cast<f32x4*>(m + i * 4) = mv;
+        *reinterpret_cast<f32x4*>(v + i * 4) = vv;
+        if (p_act) {
+            Vec4<T> o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(pv[e]);
+            *reinterpret_cast<Vec4<T>*>(p_act + i * 4) = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int svdx_edm_loss(const void* pred, int ld, const float* noisy, const float* target, const float* sigma,
+                             float* loss, void* dpred, int B, int T_, int C, int HW, const float* opt_state, int dtype,
+                             void* stream) {
+    SVDX_CHECK_ARG(pred && noisy && target && sigma && loss && dpred && opt_state, "svdx_edm_loss: null argument");
+    const long n = (long)B * T_ * C * HW;
+    const int ld_d = ((C + 63) / 64) * 64;
+    const int blocks = (int)std::min<long>((n + 255) / 256, 1024);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((edm_loss_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)pred,
+                                             ld, noisy, target, sigma, loss, (T*)dpred, ld_d, B, T_, C, HW, opt_state));
+    SVDX_LAUNCH_CHECK("svdx_edm_loss");
+    return 0;
+}
+
+extern "C" int svdx_check_finite(const float* g, int64_t n, float* opt_state, void* stream) {
+    SVDX_CHECK_ARG(g && opt_state && n > 0 && ((uintptr_t)g & 15) == 0, "svdx_check_finite: bad args");
+    const int blocks = (int)std::min<long>((n / 4 + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(check_finite_kernel, dim3(std::max(1, blocks)), dim3(256), 0, (hipStream_t)stream, g, (long)n, opt_state);
+    SVDX_LAUNCH_CHECK("svdx_check_finite");
+    return 0;
+}
+
+extern "C" int svdx_optim_prep(float* opt_state, float beta1, float beta2, float growth, float backoff, int growth_interval,
+                               int dynamic, void* stream) {
+    SVDX_CHECK_ARG(opt_state, "svdx_optim_prep: null state");
+    hipLaunchKernelGGL(optim_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, opt_state, beta1, beta2, growth, backoff,
+                       growth_interval, dynamic);
+    SVDX_LAUNCH_CHECK("svdx_optim_prep");
+    return 0;
+}
+
+extern "C" int svdx_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                          float wd, float grad_mul, const float* opt_state, void* p_act, int dtype, void* stream) {
+    SVDX_CHECK_ARG(p && g && m && v && opt_state && n > 0 && n % 4 == 0, "svdx_adamw: bad args (n must be a multiple of 4)");
+    const int blocks = (int)std::min<long>((n / 4 + 255) / 256, 256 * 8);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((adamw_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                                             (long)n, lr, beta1, beta2, eps, wd, grad_mul, opt_state, (T*)p_act));
+    SVDX_LAUNCH_CHECK("svdx_adamw");
+    return 0;
+}

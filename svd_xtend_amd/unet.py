@@ -623,8 +623,8 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         ch = block_out_channels
         temb = ch[0] * 4
         self.in_channels, self.out_channels = in_channels, out_channels
-        self.cin_pad = rup(in_channels, 32)
-        self.cout_pad = rup(out_channels, 32)
+        self.cin_pad = rup(in_channels, 64)
+        self.cout_pad = rup(out_channels, 64)
 
         self.conv_in = nn.Conv2d(in_channels, ch[0], 3, padding=1)
         self.time_embedding = _TimestepEmbedding(ch[0], temb)
@@ -832,7 +832,7 @@ class UNetSpatioTemporalConditionModel(nn.Module):
                        0, 1, 0)
         ctx = ehs.to(device=dev, dtype=torch.float32).reshape(B, -1).contiguous()     # [B, 1, D] -> [B, D]
 
-        # 2. conv_in on channels-last rows (input channels zero-padded to a multiple of 32)
+        # 2. conv_in on channels-last rows (input channels zero-padded to a multiple of 64)
         x0 = rt.empty(g.M, self.cin_pad)
         k.nchw_to_rows(sample.reshape(g.N, Cin, h, w).to(torch.float32).contiguous(), x0, g.N, Cin, h, w,
                        self.cin_pad, 1.0)
@@ -882,7 +882,7 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         self.backward_rows(dy)
 
     def backward_rows(self, dy):
-        """dy: [B*T*h*w, rup(out_channels,32)] channels-last gradient of the prediction rows (zero padded)."""
+        """dy: [B*T*h*w, rup(out_channels,64)] channels-last gradient of the prediction rows (zero padded)."""
         rt = self.rt
         k = rt.k
         fs = self._fwd_state

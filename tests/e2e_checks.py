@@ -1,0 +1,84 @@
+"""End-to-end parity: MI355X-native UNet train step (HIP kernels) vs the CPU oracle on identical seeded
+weights / latents / sigmas.  Metric (BASELINE.json north_star): |loss_gpu - loss_cpu| / loss_cpu <= 1e-3 (fp16)."""
+import copy
+import time
+
+import torch
+
+from oracle.step import edm_inputs, edm_loss, make_optimizer, make_synthetic_batch
+from oracle.unet import TINY_CONFIG, UNetSpatioTemporalConditionOracle, scaled_init_
+from svd_xtend_amd.train import Trainer
+from svd_xtend_amd.unet import UNetSpatioTemporalConditionModel
+
+
+def cosine(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def oracle_step(cfg, B, T, h, w, seed, lr, cross_dim):
+    orc = UNetSpatioTemporalConditionOracle(**cfg)
+    scaled_init_(orc, seed)
+    batch = make_synthetic_batch(B, T, h, w, seed + 1, cross_dim=cross_dim)
+    opt = make_optimizer(orc, lr=lr)
+    sd0 = copy.deepcopy(orc.state_dict())
+    unet_in, ts, ehs, ids, noisy, sig = edm_inputs(batch)
+    pred = orc(unet_in, ts, ehs, added_time_ids=ids).sample
+    loss = edm_loss(pred, noisy, batch["latents"], sig)
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in orc.named_parameters() if p.grad is not None}
+    opt.step()
+    return dict(sd0=sd0, batch=batch, inputs=(unet_in, ts, ehs, ids, noisy), loss=float(loss), pred=pred.detach(),
+                grads=grads, params_after={n: p.detach().clone() for n, p in orc.named_parameters() if p.requires_grad})
+
+
+def product_step(ref, cfg, dtype, dev, lr):
+    m = UNetSpatioTemporalConditionModel(**cfg)
+    m.load_state_dict(ref["sd0"], strict=True)
+    m.to(dev)
+    tr = Trainer(m, dtype=dtype, lr=lr)
+    unet_in, ts, ehs, ids, noisy = (t.to(dev) for t in ref["inputs"])
+    b = ref["batch"]
+    tr.zero_grad()
+    tr.forward_backward(unet_in, ts, ehs, ids, noisy, b["latents"].to(dev), b["sigmas"].to(dev))
+    loss = float(tr.last_loss())
+    scale = float(tr.opt_state[1])
+    grads = {n: (p.grad.detach().float().cpu() / scale) for n, p in m.named_parameters() if p.requires_grad}
+    tr.optimizer_step()
+    params = {n: p.detach().float().cpu() for n, p in m.named_parameters() if p.requires_grad}
+    with torch.no_grad():
+        pred = m(unet_in, ts, ehs, ids).sample.float().cpu()
+    return dict(loss=loss, grads=grads, params_after=params, pred_after=pred, state=tr.opt_state.cpu().tolist())
+
+
+def compare(ref, got):
+    out = dict(loss_ref=ref["loss"], loss=got["loss"], loss_rel=abs(got["loss"] - ref["loss"]) / abs(ref["loss"]))
+    cos = {n: cosine(got["grads"][n], g) for n, g in ref["grads"].items() if n in got["grads"] and float(g.abs().max()) > 0}
+    out["grad_cos_min"] = min(cos.values())
+    out["grad_cos_worst"] = min(cos, key=cos.get)
+    gn_ref = sum(float(g.double().pow(2).sum()) for g in ref["grads"].values()) ** 0.5
+    gn = sum(float(g.double().pow(2).sum()) for g in got["grads"].values()) ** 0.5
+    out["grad_norm_rel"] = abs(gn - gn_ref) / gn_ref
+    out["param_max_diff"] = max(float((got["params_after"][n] - p).abs().max()) for n, p in ref["params_after"].items())
+    out["opt_state"] = got["state"]
+    return out
+
+
+def run_all(verbose=False, dev=None):
+    dev = dev or torch.device("cuda")
+    cfg = TINY_CONFIG
+    res = {}
+    for (B, T, h, w) in [(1, 4, 16, 16), (2, 3, 16, 24)]:
+        t0 = time.time()
+        ref = oracle_step(cfg, B, T, h, w, seed=3, lr=1e-4, cross_dim=cfg["cross_attention_dim"])
+        for dt in (torch.float16, torch.bfloat16):
+            key = f"tiny B={B} T={T} {h}x{w} {str(dt).split('.')[-1]}"
+            try:
+                res[key] = compare(ref, product_step(ref, cfg, dt, dev, 1e-4))
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                res[key] = {"error": repr(e)[:400]}
+            if verbose:
+                print(key, res[key], f"{time.time() - t0:.1f}s", flush=True)
+    return res

@@ -84,7 +84,7 @@ class EmuBackend:
     # ---- GEMM family ----
     def gemm(self, A, B, C, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
              res=None, ldres=0, gather=None, out_mode=K.OUT_ACT, alpha=1.0, split_k=1, variant=0):
-        assert Kd % 32 == 0, "GEMM K must be a multiple of 32"
+        assert Kd % 64 == 0, "GEMM K must be a multiple of 64"
         if gather is None or gather.mode == K.GATHER_PLAIN:
             a = V(A, M, Kd, lda).float()
         else:

@@ -1,0 +1,374 @@
+"""Per-kernel parity checks: libsvdx (HIP) vs the fp32 torch emulation (tests/emul.py) on identical seeded inputs.
+
+Each check returns a list of (label, err, tol) triples; `run_all` executes everything without stopping so one GPU
+run reports every kernel.  Used by tests/test_kernels_gpu.py (pytest -m gpu) and tools/gpu_report.py.
+"""
+import math
+
+import torch
+
+import emul
+from svd_xtend_amd import kernels as K
+
+DTYPES = (torch.float16, torch.bfloat16)
+
+
+def tol_for(dt, scale=1.0):
+    return (2e-3 if dt == torch.float16 else 1.6e-2) * scale
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    if not torch.isfinite(a).all():
+        return float("inf")
+    return float((a - b).abs().max() / (b.abs().max() + 1e-6))
+
+
+def rnd(shape, dt, dev, g, scale=1.0):
+    return (torch.randn(shape, generator=g, device="cpu") * scale).to(dt).to(dev)
+
+
+def rndf(shape, dev, g, scale=1.0):
+    return (torch.randn(shape, generator=g, device="cpu") * scale).to(dev)
+
+
+class Pair:
+    """Runs the same call on the implementation under test and on the emulation, on cloned outputs."""
+
+    def __init__(self, impl, dev):
+        self.impl, self.ref, self.dev = impl, emul.EmuBackend(), dev
+
+    def run(self, name, args_fn, outs):
+        """args_fn(outs_dict) -> (args, kwargs).  `outs` maps name -> initial tensor.  Returns (impl_outs, ref_outs)."""
+        o1 = {k: v.clone() for k, v in outs.items()}
+        o2 = {k: v.clone() for k, v in outs.items()}
+        a, kw = args_fn(o1)
+        getattr(self.impl, name)(*a, **kw)
+        a, kw = args_fn(o2)
+        getattr(self.ref, name)(*a, **kw)
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
+        return o1, o2
+
+
+def check_gemm_plain(P, dt, variant):
+    g = torch.Generator().manual_seed(1)
+    res = []
+    shapes = [(128, 128, 64), (200, 320, 320), (1000, 4, 576), (130, 2560, 128), (64, 640, 1280), (3, 320, 64)]
+    for (M, N, Kd) in shapes:
+        A, B = rnd((M, Kd), dt, P.dev, g), rnd((N, Kd), dt, P.dev, g, Kd ** -0.5)
+        bias, R = rndf((N,), P.dev, g), rnd((M, N), dt, P.dev, g)
+        rv = rndf((4, N), P.dev, g)
+        rpg = (M + 3) // 4
+        for mode in ("plain", "bias_res", "rowvec", "rowvec_mod", "f32", "atomic_split"):
+            kw = dict(variant=variant)
+            out = torch.zeros(M, N, dtype=dt, device=P.dev)
+            if mode == "bias_res":
+                kw.update(bias=bias, res=R, ldres=N)
+            elif mode == "rowvec":
+                kw.update(bias=bias, rowvec=rv, rv_ld=N, rv_rpg=rpg)
+            elif mode == "rowvec_mod":
+                kw.update(rowvec=rv, rv_ld=N, rv_mod=4)
+            elif mode == "f32":
+                kw.update(out_mode=K.OUT_F32, alpha=0.5)
+                out = torch.zeros(M, N, dtype=torch.float32, device=P.dev)
+            elif mode == "atomic_split":
+                sk = 2 if Kd >= 128 else 1
+                kw.update(out_mode=K.OUT_F32_ATOMIC, split_k=sk, bias=bias)
+                out = torch.ones(M, N, dtype=torch.float32, device=P.dev)
+            o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, N, Kd, Kd, Kd, N), kw), dict(C=out))
+            res.append((f"gemm v{variant} {M}x{N}x{Kd} {mode}", relerr(o1["C"], o2["C"]), tol_for(dt)))
+    # strided operands / output views (fused qkv buffers)
+    M, N, Kd = 256, 128, 128
+    big = rnd((M, 3 * Kd), dt, P.dev, g)
+    B = rnd((N, Kd), dt, P.dev, g, Kd ** -0.5)
+    outb = torch.zeros(M, 3 * N, dtype=dt, device=P.dev)
+    o1, o2 = P.run("gemm", lambda o: ((big[:, Kd:], B, o["C"][:, N:], M, N, Kd, 3 * Kd, Kd, 3 * N), dict(variant=variant)),
+                   dict(C=outb))
+    res.append((f"gemm v{variant} strided views", relerr(o1["C"], o2["C"]), tol_for(dt)))
+    return res
+
+
+def check_gemm_gather(P, dt, variant):
+    g = torch.Generator().manual_seed(2)
+    res = []
+    cases = []
+    # (label, Gather, M, cin, cout, nsrc_rows)
+    n, h, w, ci, co = 3, 10, 12, 64, 96
+    cases.append(("conv3x3 s1", K.Gather(K.GATHER_CONV3X3, n_img=n, hi=h, wi=w, ho=h, wo=w, cin=ci, stride=1, lda=ci),
+                  n * h * w, ci, co, n * h * w, 9))
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    cases.append(("conv3x3 s2", K.Gather(K.GATHER_CONV3X3, n_img=n, hi=h, wi=w, ho=ho, wo=wo, cin=ci, stride=2, lda=ci),
+                  n * ho * wo, ci, co, n * h * w, 9))
+    cases.append(("conv3x3 ups", K.Gather(K.GATHER_CONV3X3, n_img=n, hi=2 * h, wi=2 * w, ho=2 * h, wo=2 * w, cin=ci, stride=1,
+                                          ups=1, lda=ci), n * 4 * h * w, ci, co, n * h * w, 9))
+    cases.append(("conv3x3 dgrad2", K.Gather(K.GATHER_CONV3X3_DGRAD2, n_img=n, hi=ho, wi=wo, ho=h, wo=w, cin=ci, lda=ci),
+                  n * h * w, ci, co, n * ho * wo, 9))
+    Bc, T, hw = 2, 5, 37
+    cases.append(("temporal3", K.Gather(K.GATHER_TEMPORAL3, n_img=Bc, cin=ci, t=T, hw=hw, lda=ci), Bc * T * hw, ci, co,
+                  Bc * T * hw, 3))
+    cases.append(("temporal3 T=1", K.Gather(K.GATHER_TEMPORAL3, n_img=3, cin=ci, t=1, hw=hw, lda=ci), 3 * hw, ci, co, 3 * hw, 3))
+    for label, ga, M, ci_, co_, nsrc, taps in cases:
+        A = rnd((nsrc, ci_), dt, P.dev, g)
+        B = rnd((co_, taps * ci_), dt, P.dev, g, (taps * ci_) ** -0.5)
+        bias = rndf((co_,), P.dev, g)
+        out = torch.zeros(M, co_, dtype=dt, device=P.dev)
+        o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, co_, taps * ci_, ci_, taps * ci_, co_),
+                                          dict(bias=bias, gather=ga, variant=variant)), dict(C=out))
+        res.append((f"gemm v{variant} {label}", relerr(o1["C"], o2["C"]), tol_for(dt)))
+    return res
+
+
+def check_small(P, dt):
+    g = torch.Generator().manual_seed(3)
+    res = []
+    for (M, N, Kd) in [(1, 1280, 320), (2, 96, 64), (14, 320, 1280), (25, 640, 96)]:
+        X, W, b = rndf((M, Kd), P.dev, g), rnd((N, Kd), dt, P.dev, g, Kd ** -0.5), rndf((N,), P.dev, g)
+        for silu_in, acc in ((0, 0), (1, 1)):
+            o1, o2 = P.run("small_linear", lambda o: ((X, W, b, o["Y"], M, N, Kd, Kd), dict(trans=0, silu_in=silu_in, accumulate=acc)),
+                           dict(Y=torch.ones(M, N, device=P.dev)))
+            res.append((f"small_linear nt {M}x{N}x{Kd} silu={silu_in} acc={acc}", relerr(o1["Y"], o2["Y"]), 1e-4))
+        dY = rndf((M, N), P.dev, g)
+        o1, o2 = P.run("small_linear", lambda o: ((dY, W, None, o["Y"], M, N, Kd, Kd), dict(trans=1)),
+                       dict(Y=torch.zeros(M, Kd, device=P.dev)))
+        res.append((f"small_linear nn {M}x{N}x{Kd}", relerr(o1["Y"], o2["Y"]), 1e-4))
+        o1, o2 = P.run("outer_acc", lambda o: ((dY, X, o["W"], M, N, Kd), dict(scale=0.5)), dict(W=torch.ones(N, Kd, device=P.dev)))
+        res.append((f"outer_acc {M}x{N}x{Kd}", relerr(o1["W"], o2["W"]), 1e-4))
+    t = torch.tensor([0.0, 0.31, -1.7, 127.0, 7.0, 24.0], device=P.dev)
+    for dim in (320, 256, 64):
+        o1, o2 = P.run("timestep_embed", lambda o: ((t, o["E"], 6, dim), {}), dict(E=torch.zeros(6, dim, device=P.dev)))
+        res.append((f"timestep_embed dim={dim}", float((o1["E"] - o2["E"]).abs().max()), 2e-4))
+    return res
+
+
+def check_groupnorm(P, dt):
+    g = torch.Generator().manual_seed(4)
+    res = []
+    for (n_s, rows, C) in [(3, 70, 64), (2, 200, 320), (1, 333, 960), (2, 64, 2560), (5, 16, 192)]:
+        x = (rnd((n_s * rows, C), dt, P.dev, g) * 1.5 + 0.3).to(dt)
+        dy = rnd((n_s * rows, C), dt, P.dev, g)
+        add = rnd((n_s * rows, C), dt, P.dev, g)
+        gamma, beta = 1 + 0.1 * rndf((C,), P.dev, g), 0.1 * rndf((C,), P.dev, g)
+        st = torch.zeros(n_s, 32, 2, device=P.dev)
+        o1, o2 = P.run("gn_stats", lambda o: ((x, o["st"], n_s, rows, C, 32), {}), dict(st=st))
+        res.append((f"gn_stats {n_s}x{rows}x{C}", relerr(o1["st"], o2["st"]), 1e-4))
+        stats = o2["st"]
+        for silu in (0, 1):
+            o1, o2 = P.run("gn_apply", lambda o: ((x, stats, gamma, beta, o["y"], n_s, rows, C, 32, 1e-5, silu), {}),
+                           dict(y=torch.zeros_like(x)))
+            res.append((f"gn_apply {n_s}x{rows}x{C} silu={silu}", relerr(o1["y"], o2["y"]), tol_for(dt)))
+            o1, o2 = P.run("gn_bwd_stats", lambda o: ((dy, x, stats, gamma, beta, o["b"], n_s, rows, C, 32, 1e-5, silu), {}),
+                           dict(b=torch.zeros(n_s, 32, 2, device=P.dev)))
+            res.append((f"gn_bwd_stats {n_s}x{rows}x{C} silu={silu}", relerr(o1["b"], o2["b"]), 2e-3))
+            bst = o2["b"]
+            for ad in (None, add):
+                o1, o2 = P.run("gn_bwd_apply", lambda o: ((dy, x, stats, bst, gamma, beta, ad, o["dx"], n_s, rows, C, 32, 1e-5, silu), {}),
+                               dict(dx=torch.zeros_like(x)))
+                res.append((f"gn_bwd_apply {n_s}x{rows}x{C} silu={silu} add={ad is not None}", relerr(o1["dx"], o2["dx"]), tol_for(dt)))
+    return res
+
+
+def check_layernorm(P, dt):
+    g = torch.Generator().manual_seed(5)
+    res = []
+    for (rows, C) in [(100, 64), (777, 320), (130, 640), (50, 1280), (9, 128)]:
+        x = (rnd((rows, C), dt, P.dev, g) * 2 + 0.5).to(dt)
+        dy, add = rnd((rows, C), dt, P.dev, g), rnd((rows, C), dt, P.dev, g)
+        gamma, beta = 1 + 0.1 * rndf((C,), P.dev, g), 0.1 * rndf((C,), P.dev, g)
+        o1, o2 = P.run("ln_fwd", lambda o: ((x, gamma, beta, o["y"], o["st"], rows, C, 1e-5), {}),
+                       dict(y=torch.zeros_like(x), st=torch.zeros(rows, 2, device=P.dev)))
+        res.append((f"ln_fwd {rows}x{C} y", relerr(o1["y"], o2["y"]), tol_for(dt)))
+        res.append((f"ln_fwd {rows}x{C} stats", relerr(o1["st"], o2["st"]), 1e-4))
+        st = o2["st"]
+        for affine in (False, True):
+            outs = dict(dx=torch.zeros_like(x), dg=torch.ones(C, device=P.dev), db=torch.ones(C, device=P.dev))
+            o1, o2 = P.run("ln_bwd", lambda o: ((dy, x, st, gamma, add if affine else None, o["dx"],
+                                                 o["dg"] if affine else None, o["db"] if affine else None, rows, C), {}), outs)
+            res.append((f"ln_bwd {rows}x{C} affine={affine} dx", relerr(o1["dx"], o2["dx"]), tol_for(dt)))
+            if affine:
+                res.append((f"ln_bwd {rows}x{C} dgamma", relerr(o1["dg"], o2["dg"]), 2e-3))
+                res.append((f"ln_bwd {rows}x{C} dbeta", relerr(o1["db"], o2["db"]), 2e-3))
+    return res
+
+
+def check_attention(P, dt):
+    g = torch.Generator().manual_seed(6)
+    res = []
+    for (nb, heads, S) in [(2, 2, 40), (1, 5, 160), (3, 1, 200), (1, 2, 640), (1, 1, 16)]:
+        C = heads * 64
+        s_pad = (S + 63) // 64 * 64
+        qkv = rnd((nb * S, 3 * C), dt, P.dev, g, 1.0)
+        d_o = rnd((nb * S, C), dt, P.dev, g)
+        q, k, v = qkv, qkv[:, C:], qkv[:, 2 * C:]
+        nhs = nb * heads * 64 * s_pad
+        tr = {}
+        for name, src, ld in (("vt", v, 3 * C), ("kt", k, 3 * C), ("qt", q, 3 * C), ("dot", d_o, C)):
+            o1, o2 = P.run("head_transpose", lambda o: ((src, ld, o["t"], nb, heads, S, s_pad), {}),
+                           dict(t=torch.full((nhs,), 7.0, dtype=dt, device=P.dev)))
+            res.append((f"head_transpose {name} nb={nb} h={heads} S={S}", relerr(o1["t"], o2["t"]), 0.0))
+            tr[name] = o2["t"]
+        scale = 0.125
+        o1, o2 = P.run("attn_fwd", lambda o: ((q, k, tr["vt"], o["o"], o["lse"], nb, heads, S, 3 * C, C, s_pad, scale), {}),
+                       dict(o=torch.zeros(nb * S, C, dtype=dt, device=P.dev), lse=torch.zeros(nb * heads * S, device=P.dev)))
+        res.append((f"attn_fwd nb={nb} h={heads} S={S} o", relerr(o1["o"], o2["o"]), tol_for(dt, 2)))
+        res.append((f"attn_fwd nb={nb} h={heads} S={S} lse", float((o1["lse"] - o2["lse"]).abs().max()), 2e-2))
+        o_ref, lse = o2["o"], o2["lse"]
+        o1, o2 = P.run("attn_bwd_prep", lambda o: ((o_ref, d_o, o["D"], nb, heads, S, C), {}), dict(D=torch.zeros(nb * heads * S, device=P.dev)))
+        res.append((f"attn_bwd_prep nb={nb} h={heads} S={S}", relerr(o1["D"], o2["D"]), 1e-3))
+        D = o2["D"]
+        dqkv = torch.zeros(nb * S, 3 * C, dtype=dt, device=P.dev)
+        o1, o2 = P.run("attn_bwd_dkv", lambda o: ((q, k, v, d_o, tr["qt"], tr["dot"], lse, D, o["d"][:, C:], o["d"][:, 2 * C:],
+                                                   nb, heads, S, 3 * C, C, 3 * C, s_pad, scale), {}), dict(d=dqkv))
+        res.append((f"attn_bwd_dkv nb={nb} h={heads} S={S} dk", relerr(o1["d"][:, C:2 * C], o2["d"][:, C:2 * C]), tol_for(dt, 4)))
+        res.append((f"attn_bwd_dkv nb={nb} h={heads} S={S} dv", relerr(o1["d"][:, 2 * C:], o2["d"][:, 2 * C:]), tol_for(dt, 4)))
+        o1, o2 = P.run("attn_bwd_dq", lambda o: ((q, k, v, tr["kt"], d_o, lse, D, o["d"], nb, heads, S, 3 * C, C, 3 * C, s_pad, scale), {}),
+                       dict(d=dqkv))
+        res.append((f"attn_bwd_dq nb={nb} h={heads} S={S}", relerr(o1["d"][:, :C], o2["d"][:, :C]), tol_for(dt, 4)))
+    return res
+
+
+def check_temporal_attention(P, dt):
+    g = torch.Generator().manual_seed(7)
+    res = []
+    for (B, T, HW, heads) in [(1, 14, 9, 2), (2, 25, 5, 1), (1, 3, 16, 5), (1, 16, 4, 1), (1, 1, 4, 1)]:
+        C = heads * 64
+        M = B * T * HW
+        qkv = rnd((M, 3 * C), dt, P.dev, g)
+        d_o = rnd((M, C), dt, P.dev, g)
+        q, k, v = qkv, qkv[:, C:], qkv[:, 2 * C:]
+        o1, o2 = P.run("tattn_fwd", lambda o: ((q, k, v, o["o"], B, T, HW, heads, 3 * C, C, 0.125), {}),
+                       dict(o=torch.zeros(M, C, dtype=dt, device=P.dev)))
+        res.append((f"tattn_fwd B={B} T={T} HW={HW} h={heads}", relerr(o1["o"], o2["o"]), tol_for(dt)))
+        o1, o2 = P.run("tattn_bwd", lambda o: ((q, k, v, d_o, o["d"], o["d"][:, C:], o["d"][:, 2 * C:], B, T, HW, heads, 3 * C, C,
+                                                3 * C, 0.125), {}), dict(d=torch.zeros(M, 3 * C, dtype=dt, device=P.dev)))
+        for i, nm in enumerate(("dq", "dk", "dv")):
+            res.append((f"tattn_bwd B={B} T={T} HW={HW} h={heads} {nm}",
+                        relerr(o1["d"][:, i * C:(i + 1) * C], o2["d"][:, i * C:(i + 1) * C]), tol_for(dt, 2)))
+    return res
+
+
+def check_elementwise(P, dt):
+    g = torch.Generator().manual_seed(8)
+    res = []
+    M, F = 77, 256
+    pre, dout = rnd((M, 2 * F), dt, P.dev, g, 1.5), rnd((M, F), dt, P.dev, g)
+    o1, o2 = P.run("geglu_fwd", lambda o: ((pre, o["y"], M, F), {}), dict(y=torch.zeros(M, F, dtype=dt, device=P.dev)))
+    res.append(("geglu_fwd", relerr(o1["y"], o2["y"]), tol_for(dt)))
+    o1, o2 = P.run("geglu_bwd", lambda o: ((dout, pre, o["d"], M, F), {}), dict(d=torch.zeros(M, 2 * F, dtype=dt, device=P.dev)))
+    res.append(("geglu_bwd", relerr(o1["d"], o2["d"]), tol_for(dt)))
+    n = 8 * 1237
+    a, b = rnd((n,), dt, P.dev, g), rnd((n,), dt, P.dev, g)
+    mix = torch.tensor([0.37], device=P.dev)
+    o1, o2 = P.run("add", lambda o: ((a, b, o["y"], n), {}), dict(y=torch.zeros(n, dtype=dt, device=P.dev)))
+    res.append(("add", relerr(o1["y"], o2["y"]), tol_for(dt)))
+    o1, o2 = P.run("blend", lambda o: ((a, b, mix, o["y"], n), {}), dict(y=torch.zeros(n, dtype=dt, device=P.dev)))
+    res.append(("blend", relerr(o1["y"], o2["y"]), tol_for(dt)))
+    o1, o2 = P.run("blend_bwd", lambda o: ((a, mix, o["da"], o["db"], n), {}),
+                   dict(da=torch.zeros(n, dtype=dt, device=P.dev), db=torch.zeros(n, dtype=dt, device=P.dev)))
+    res.append(("blend_bwd da", relerr(o1["da"], o2["da"]), tol_for(dt)))
+    res.append(("blend_bwd db", relerr(o1["db"], o2["db"]), tol_for(dt)))
+    rows, C = 150, 192
+    x = rnd((rows, C), dt, P.dev, g)
+    vec = rndf((5, 2 * C), P.dev, g)
+    for rpg, mod in ((30, 0), (0, 5)):
+        o1, o2 = P.run("add_rowvec", lambda o: ((x, vec[:, C:], o["y"], rows, C, 2 * C, rpg, mod), {}), dict(y=torch.zeros_like(x)))
+        res.append((f"add_rowvec rpg={rpg} mod={mod}", relerr(o1["y"], o2["y"]), tol_for(dt)))
+        for acc in (0, 1):
+            o1, o2 = P.run("colsum", lambda o: ((x, o["s"], rows, C, C, 5, rpg, mod), dict(accumulate=acc)),
+                           dict(s=torch.ones(5, C, device=P.dev)))
+            res.append((f"colsum rpg={rpg} mod={mod} acc={acc}", relerr(o1["s"], o2["s"]), 1e-3))
+    big = rnd((700, 3 * 320), dt, P.dev, g)
+    o1, o2 = P.run("colsum", lambda o: ((big[:, 320:], o["s"], 700, 320, 960, 1, 700, 0), {}), dict(s=torch.zeros(1, 320, device=P.dev)))
+    res.append(("colsum strided 1 group", relerr(o1["s"], o2["s"]), 1e-3))
+    for (r, c) in [(100, 64), (333, 200), (64, 1000)]:
+        xx = rnd((r, c + 8), dt, P.dev, g)
+        ldo = (r + 63) // 64 * 64
+        o1, o2 = P.run("transpose", lambda o: ((xx, c + 8, o["t"], ldo, r, c), {}), dict(t=torch.full((c, ldo), 3.0, dtype=dt, device=P.dev)))
+        res.append((f"transpose {r}x{c}", relerr(o1["t"], o2["t"]), 0.0))
+        wf = rndf((r, c), P.dev, g)
+        o1, o2 = P.run("cast_transpose_from_f32", lambda o: ((wf, o["t"], r, c), {}), dict(t=torch.zeros(c, r, dtype=dt, device=P.dev)))
+        res.append((f"cast_transpose {r}x{c}", relerr(o1["t"], o2["t"]), 0.0))
+    a2, b2 = rnd((90, 64), dt, P.dev, g), rnd((90, 128), dt, P.dev, g)
+    o1, o2 = P.run("concat2", lambda o: ((a2, 64, b2, 128, o["c"], 90), {}), dict(c=torch.zeros(90, 192, dtype=dt, device=P.dev)))
+    res.append(("concat2", relerr(o1["c"], o2["c"]), 0.0))
+    cat = o2["c"]
+    o1, o2 = P.run("split2", lambda o: ((cat, o["a"], 64, o["b"], 128, 90), {}),
+                   dict(a=torch.zeros(90, 64, dtype=dt, device=P.dev), b=torch.zeros(90, 128, dtype=dt, device=P.dev)))
+    res.append(("split2", max(relerr(o1["a"], o2["a"]), relerr(o1["b"], o2["b"])), 0.0))
+    xin = rnd((2 * 6 * 10, 64), dt, P.dev, g)
+    o1, o2 = P.run("sum2x2", lambda o: ((xin, o["y"], 2, 3, 5, 64), {}), dict(y=torch.zeros(2 * 3 * 5, 64, dtype=dt, device=P.dev)))
+    res.append(("sum2x2", relerr(o1["y"], o2["y"]), tol_for(dt)))
+    wf = rndf((1000 * 8 + 3,), P.dev, g)
+    o1, o2 = P.run("cast_from_f32", lambda o: ((wf, o["y"], wf.numel()), {}), dict(y=torch.zeros(wf.numel(), dtype=dt, device=P.dev)))
+    res.append(("cast_from_f32", relerr(o1["y"], o2["y"]), 0.0))
+    img = rndf((3, 8, 6, 10), P.dev, g)
+    o1, o2 = P.run("nchw_to_rows", lambda o: ((img, o["y"], 3, 8, 6, 10, 64), dict(mul=2.0)), dict(y=torch.ones(180, 64, dtype=dt, device=P.dev)))
+    res.append(("nchw_to_rows", relerr(o1["y"], o2["y"]), tol_for(dt)))
+    rows_t = rnd((180, 4), dt, P.dev, g)
+    o1, o2 = P.run("rows_to_nchw", lambda o: ((rows_t, o["y"], 3, 4, 6, 10, 4), {}), dict(y=torch.zeros(3, 4, 6, 10, device=P.dev)))
+    res.append(("rows_to_nchw", relerr(o1["y"], o2["y"]), 0.0))
+    return res
+
+
+def check_optim(P, dt):
+    g = torch.Generator().manual_seed(9)
+    res = []
+    B, T, C, HW = 2, 3, 4, 48
+    pred = rnd((B * T * HW, C), dt, P.dev, g)
+    noisy, target = rndf((B, T, C, HW), P.dev, g), rndf((B, T, C, HW), P.dev, g)
+    sigma = torch.tensor([0.7, 3.1], device=P.dev)
+    st = torch.tensor([0, 1024.0, 0, 0, 1, 1, 1, 0], dtype=torch.float32, device=P.dev)
+    o1, o2 = P.run("edm_loss", lambda o: ((pred, C, noisy, target, sigma, o["loss"], o["d"], B, T, C, HW, st), {}),
+                   dict(loss=torch.zeros(1, device=P.dev), d=torch.zeros(B * T * HW, 64, dtype=dt, device=P.dev)))
+    res.append(("edm_loss loss", relerr(o1["loss"], o2["loss"]), 1e-4))
+    res.append(("edm_loss dpred", relerr(o1["d"], o2["d"]), tol_for(dt)))
+    n = 4 * 5000
+    p, gr = rndf((n,), P.dev, g), rndf((n,), P.dev, g, 100.0)
+    m, v = rndf((n,), P.dev, g, 0.1), rndf((n,), P.dev, g).abs()
+    for found in (False, True):
+        gg = gr.clone()
+        if found:
+            gg[1234] = float("inf")
+        st0 = torch.tensor([3, 1024.0, 5, 0, 1, 1, 1, 0], dtype=torch.float32, device=P.dev)
+        outs = dict(st=st0, p=p.clone(), m=m.clone(), v=v.clone(), pa=torch.zeros(n, dtype=dt, device=P.dev))
+
+        def seq(be, o):
+            be.check_finite(gg, n, o["st"])
+            be.optim_prep(o["st"], 0.9, 0.999, 2.0, 0.5, 7, 1)
+            be.adamw(o["p"], gg, o["m"], o["v"], n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0.5, o["st"], o["pa"])
+        o1 = {k_: t.clone() for k_, t in outs.items()}
+        o2 = {k_: t.clone() for k_, t in outs.items()}
+        seq(P.impl, o1)
+        seq(P.ref, o2)
+        if P.dev.type == "cuda":
+            torch.cuda.synchronize()
+        res.append((f"optim found_inf={found} state", relerr(o1["st"], o2["st"]), 1e-5))
+        for nm in ("p", "m", "v"):
+            res.append((f"adamw found_inf={found} {nm}", relerr(o1[nm], o2[nm]), 1e-5))
+        res.append((f"adamw found_inf={found} p_act", relerr(o1["pa"], o2["pa"]), tol_for(dt)))
+    return res
+
+
+def run_all(impl, dev, dtypes=DTYPES, verbose=True):
+    P = Pair(impl, dev)
+    out = []
+    for dt in dtypes:
+        checks = [("gemm_plain_v0", lambda: check_gemm_plain(P, dt, 0)), ("gemm_plain_v1", lambda: check_gemm_plain(P, dt, 1)),
+                  ("gemm_gather_v0", lambda: check_gemm_gather(P, dt, 0)), ("gemm_gather_v1", lambda: check_gemm_gather(P, dt, 1)),
+                  ("small", lambda: check_small(P, dt)), ("groupnorm", lambda: check_groupnorm(P, dt)),
+                  ("layernorm", lambda: check_layernorm(P, dt)), ("attention", lambda: check_attention(P, dt)),
+                  ("temporal_attention", lambda: check_temporal_attention(P, dt)), ("elementwise", lambda: check_elementwise(P, dt)),
+                  ("optim", lambda: check_optim(P, dt))]
+        for name, fn in checks:
+            try:
+                for label, err, tol in fn():
+                    ok = err <= tol and math.isfinite(err)
+                    out.append(dict(group=name, dtype=str(dt), label=label, err=err, tol=tol, ok=ok))
+                    if verbose and not ok:
+                        print(f"FAIL [{dt}] {label}: err={err:.3e} tol={tol:.1e}", flush=True)
+            except Exception as e:  # noqa: BLE001 - report and continue with the other kernels
+                out.append(dict(group=name, dtype=str(dt), label=f"{name} raised", err=float("inf"), tol=0.0, ok=False,
+                                exc=repr(e)[:500]))
+                if verbose:
+                    print(f"EXC  [{dt}] {name}: {e!r}", flush=True)
+    return out
