@@ -103,9 +103,12 @@ class LinearOp:
         if len(ts) == 1:
             return ts[0] if ts[0].is_contiguous() else None
         ptr = ts[0].data_ptr()
+        store = ts[0].untyped_storage().data_ptr()
         total = 0
         for t in ts:
-            if not t.is_contiguous() or t.data_ptr() != ptr + total * t.element_size() or t.dtype != ts[0].dtype:
+            # adjacent addresses are not enough: the caching allocator often places separate tensors back to back
+            if (not t.is_contiguous() or t.data_ptr() != ptr + total * t.element_size() or t.dtype != ts[0].dtype
+                    or t.untyped_storage().data_ptr() != store):
                 return None
             total += t.numel()
         base = ts[0]

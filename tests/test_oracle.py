@@ -1,0 +1,80 @@
+"""Self-pinning checks of the CPU oracle: the reference holds no golden vectors, so the
+restatement is pinned structurally -- parameter inventory, trainable set, LoRA delta, key layout."""
+import pytest
+import torch
+
+from oracle.step import edm_inputs, edm_loss, make_synthetic_batch, rand_log_normal
+from oracle.unet import SVD_CONFIG, TINY_CONFIG, UNetSpatioTemporalConditionOracle, scaled_init_
+
+
+@pytest.fixture(scope="module")
+def meta_model():
+    with torch.device("meta"):
+        return UNetSpatioTemporalConditionOracle(**SVD_CONFIG)
+
+
+def test_param_count_matches_published_svd_unet(meta_model):
+    assert sum(p.numel() for p in meta_model.parameters()) == 1_524_623_082
+
+
+def test_trainable_set_train_svd_761(meta_model):
+    n = sum(p.numel() for k, p in meta_model.named_parameters() if "temporal_transformer_block" in k)
+    assert n == 397_620_480
+
+
+def test_lora_rank64_delta(meta_model):
+    r, tot = 64, 0
+    for name, mod in meta_model.named_modules():
+        if isinstance(mod, torch.nn.Linear) and name.endswith(("to_q", "to_k", "to_v", "to_out.0")):
+            tot += r * (mod.in_features + mod.out_features)
+    assert tot == 26_558_464
+
+
+def test_state_dict_key_layout(meta_model):
+    keys = set(meta_model.state_dict().keys())
+    for k in ["conv_in.weight", "time_embedding.linear_1.weight", "add_embedding.linear_2.bias",
+              "down_blocks.0.resnets.0.spatial_res_block.norm1.weight",
+              "down_blocks.0.resnets.1.temporal_res_block.conv1.weight",
+              "down_blocks.0.resnets.0.time_mixer.mix_factor",
+              "down_blocks.1.resnets.0.spatial_res_block.conv_shortcut.weight",
+              "down_blocks.0.attentions.0.time_pos_embed.linear_1.weight",
+              "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out.0.bias",
+              "down_blocks.0.attentions.0.temporal_transformer_blocks.0.ff_in.net.0.proj.weight",
+              "down_blocks.0.attentions.0.temporal_transformer_blocks.0.ff.net.2.bias",
+              "down_blocks.2.downsamplers.0.conv.weight", "mid_block.attentions.0.proj_out.weight",
+              "mid_block.resnets.1.temporal_res_block.time_emb_proj.bias", "up_blocks.0.upsamplers.0.conv.weight",
+              "up_blocks.3.attentions.2.time_mixer.mix_factor", "conv_norm_out.weight", "conv_out.bias"]:
+        assert k in keys, k
+    assert "down_blocks.3.downsamplers.0.conv.weight" not in keys and "up_blocks.3.upsamplers.0.conv.weight" not in keys
+    sd = meta_model.state_dict()
+    assert sd["down_blocks.0.resnets.0.temporal_res_block.conv1.weight"].shape == (320, 320, 3, 1, 1)
+    assert sd["up_blocks.1.resnets.2.spatial_res_block.conv1.weight"].shape == (1280, 1920, 3, 3)
+    assert sd["down_blocks.0.attentions.0.temporal_transformer_blocks.0.attn2.to_k.weight"].shape == (320, 1024)
+    assert sum(1 for k in keys if k.endswith("mix_factor")) == 38
+
+
+def test_tiny_forward_shape_and_loss_finite():
+    torch.manual_seed(0)
+    m = UNetSpatioTemporalConditionOracle(**TINY_CONFIG)
+    scaled_init_(m, 0)
+    b = make_synthetic_batch(2, 3, 16, 24, 1, cross_dim=64)
+    unet_in, ts, ehs, ids, noisy, sig = edm_inputs(b)
+    assert unet_in.shape == (2, 3, 8, 16, 24) and ts.shape == (2,) and ids.shape == (2, 3)
+    out = m(unet_in, ts, ehs, added_time_ids=ids).sample
+    assert out.shape == (2, 3, 4, 16, 24)
+    assert torch.isfinite(edm_loss(out, noisy, b["latents"], sig))
+
+
+def test_config1_as_written_is_infeasible():
+    """BASELINE.json config 1 (256x160 -> latent 20x32): 20 -> 10 -> 5 -> 3, upsample gives 6 != 5."""
+    m = UNetSpatioTemporalConditionOracle(**TINY_CONFIG)
+    b = make_synthetic_batch(1, 2, 20, 32, 1, cross_dim=64)
+    unet_in, ts, ehs, ids, _, _ = edm_inputs(b)
+    with pytest.raises(RuntimeError):
+        m(unet_in, ts, ehs, added_time_ids=ids)
+
+
+def test_rand_log_normal_matches_reference_formula():
+    g = torch.Generator().manual_seed(5)
+    s = rand_log_normal([1000], loc=0.7, scale=1.6, generator=g)
+    assert (s > 0).all() and abs(float(s.log().mean()) - 0.7) < 0.2
