@@ -66,6 +66,11 @@ int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int ld
               const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
               int out_mode, float alpha, int split_k, int variant, int dtype, void* stream);
 
+/* Epilogue of a split-K GEMM whose partial sums were accumulated (SVDX_OUT_F32_ATOMIC) into the float buffer
+ * `acc` [M,N]: C[m*ldc+n] = (dtype)(acc + bias + rowvec + res), same operand meaning as svdx_gemm. */
+int svdx_gemm_finalize(const float* acc, void* C, int M, int N, int ldc, const float* bias, const float* rowvec,
+                       int rv_ld, int rv_rows_per_group, int rv_mod, const void* res, int ldres, int dtype, void* stream);
+
 /* Skinny linears (M <= 64): time/added-id embedding MLPs, time_emb_proj, time_pos_embed, the KV-length-1
  * cross-attention.  X, Y float; W in dtype.
  * trans=0: Y[m,n] (+)= sum_k act(X[m,k]) W[n*ldw+k] + bias[n];  trans=1: Y[m,k] (+)= sum_n X[m,n] W[n*ldw+k]. */

@@ -90,27 +90,38 @@ __global__ void add_rowvec_kernel(const T* __restrict__ x, const float* __restri
     }
 }
 
-constexpr int CS_SLAB = 256;
+constexpr int CS_SLAB = 64;
+// grid (groups, row slabs of 64, column blocks); a block covers cpb = min(C/8, 256) 16-byte column chunks x (256/cpb) rows at
+// a time, two independent row loads in flight per thread; partial sums go out with one atomicAdd per element per thread.
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, float* out, int rows, int C, int ldx, int rpg, int mod) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* out, int rows, int C, int ldx, int rpg, int mod,
+                                                     int cpb) {
     const int g = blockIdx.x, slab = blockIdx.y;
     const int cnt = mod ? (rows - g + mod - 1) / mod : min(rpg, rows - g * rpg);
     const int i0 = slab * CS_SLAB, i1 = min(cnt, i0 + CS_SLAB);
-    const int c8n = C / 8;
-    for (int j = threadIdx.x; j < c8n; j += blockDim.x) {
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = i0; i < i1; ++i) {
-            const int m = mod ? g + i * mod : g * rpg + i;
-            float v[8];
-            load8<T>(x + (size_t)m * ldx + j * 8, v);
+    const int rsub = 256 / cpb;
+    const int jj = threadIdx.x % cpb, rs = threadIdx.x / cpb;
+    const int j = blockIdx.z * cpb + jj;
+    if (rs >= rsub || j * 8 >= C || i0 >= i1) return;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t rstride = (size_t)(mod ? mod : 1) * ldx;
+    const T* base = x + (size_t)(mod ? g : g * rpg) * ldx + j * 8;
+    int i = i0 + rs;
+    for (; i + rsub < i1; i += 2 * rsub) {
+        float v0[8], v1[8];
+        load8<T>(base + (size_t)i * rstride, v0);
+        load8<T>(base + (size_t)(i + rsub) * rstride, v1);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += v[e];
-        }
-        if (i1 > i0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(out + (size_t)g * C + j * 8 + e, acc[e]);
-        }
+        for (int e = 0; e < 8; ++e) acc[e] += v0[e] + v1[e];
     }
+    if (i < i1) {
+        float v[8];
+        load8<T>(base + (size_t)i * rstride, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(out + (size_t)g * C + j * 8 + e, acc[e]);
 }
 
 // batched tiled transpose: out[b][c*ld_out + r] = in[b][r*ld_in + c], r in [0, ld_out) zero-filled beyond rows.
@@ -287,9 +298,10 @@ extern "C" int svdx_colsum(const void* x, float* out, int rows, int C, int ldx, 
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * n_groups * C, st);
     const int maxcnt = mod ? cdiv(rows, mod) : std::min(rows_per_group, rows);
-    dim3 grid(n_groups, cdiv(maxcnt, CS_SLAB));
+    const int cpb = std::min(C / 8, 256);
+    dim3 grid(n_groups, cdiv(maxcnt, CS_SLAB), cdiv(C / 8, cpb));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, out, rows, C, ldx,
-                                             rows_per_group, mod));
+                                             rows_per_group, mod, cpb));
     SVDX_LAUNCH_CHECK("svdx_colsum");
     return 0;
 }

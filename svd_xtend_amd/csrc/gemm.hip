@@ -346,16 +346,19 @@ __global__ __launch_bounds__(256) void small_linear_nt(const float* X, const T* 
     }
 }
 
-// trans = 1: Y[m,k] (+)= sum_n X[m,n] W[n,k]; thread per 8 consecutive k, block row per m
+// trans = 1: Y[m,k] += sum_n X[m,n] W[n,k]; thread = (8 consecutive k, slice of 32 n), partial sums by atomicAdd
+constexpr int NN_SLICE = 32;
 template <typename T>
-__global__ __launch_bounds__(256) void small_linear_nn(const float* X, const T* W, float* Y, int M, int N, int K,
-                                                       int ldw, int accumulate) {
-    const int k8 = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void small_linear_nn(const float* X, const T* W, float* Y, int M, int N, int K, int ldw) {
+    const int k8n = K / 8;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int k8 = idx % k8n, ns = idx / k8n;
     const int m = blockIdx.y;
-    if (k8 * 8 >= K) return;
+    const int n0 = ns * NN_SLICE, n1 = min(N, n0 + NN_SLICE);
+    if (n0 >= N) return;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const float* x = X + (size_t)m * N;
-    for (int n = 0; n < N; ++n) {
+    for (int n = n0; n < n1; ++n) {
         float wv[8];
         load8<T>(W + (size_t)n * ldw + k8 * 8, wv);
         const float xv = x[n];
@@ -364,7 +367,23 @@ __global__ __launch_bounds__(256) void small_linear_nn(const float* X, const T* 
     }
     float* y = Y + (size_t)m * K + k8 * 8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) y[j] = accumulate ? y[j] + acc[j] : acc[j];
+    for (int j = 0; j < 8; ++j) atomicAdd(y + j, acc[j]);
+}
+
+// split-K epilogue: C = (dtype)(acc + bias + rowvec + res) from the float accumulation buffer
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_finalize_kernel(const float* __restrict__ acc, T* __restrict__ C, int M, int N, int ldc,
+                                                            const float* __restrict__ bias, const float* __restrict__ rowvec,
+                                                            int rv_ld, int rv_rpg, int rv_mod, const T* __restrict__ res, int ldres) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i - (long)m * N);
+        float v = acc[i];
+        if (bias) v += bias[n];
+        if (rowvec) v += rowvec[(size_t)(rv_mod ? m % rv_mod : m / rv_rpg) * rv_ld + n];
+        if (res) v += to_f<T>(res[(size_t)m * ldres + n]);
+        C[(size_t)m * ldc + n] = from_f<T>(v);
+    }
 }
 
 __global__ void outer_acc_kernel(const float* dY, const float* X, float* dW, int M, int N, int K, float scale) {
@@ -463,11 +482,23 @@ extern "C" int svdx_small_linear(const float* X, const void* W, const float* bia
                                ldw, silu_in, accumulate);
         } else {
             SVDX_CHECK_ARG(!bias && !silu_in, "svdx_small_linear: trans=1 takes no bias/activation");
-            hipLaunchKernelGGL((small_linear_nn<T>), dim3(cdiv(K / 8, 256), M), dim3(256), 0, st, X, (const T*)W, Y, M, N,
-                               K, ldw, accumulate);
+            if (!accumulate) (void)hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * K, st);
+            hipLaunchKernelGGL((small_linear_nn<T>), dim3(cdiv((long)(K / 8) * cdiv(N, NN_SLICE), 256), M), dim3(256), 0, st, X,
+                               (const T*)W, Y, M, N, K, ldw);
         }
     });
     SVDX_LAUNCH_CHECK("svdx_small_linear");
+    return 0;
+}
+
+extern "C" int svdx_gemm_finalize(const float* acc, void* C, int M, int N, int ldc, const float* bias, const float* rowvec,
+                                  int rv_ld, int rv_rows_per_group, int rv_mod, const void* res, int ldres, int dtype, void* stream) {
+    SVDX_CHECK_ARG(acc && C && M > 0 && N > 0, "svdx_gemm_finalize: bad args");
+    SVDX_CHECK_ARG(!rowvec || rv_mod > 0 || rv_rows_per_group > 0, "svdx_gemm_finalize: rowvec needs a grouping");
+    const int blocks = (int)std::min<long>(((long)M * N + 255) / 256, 4096);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_finalize_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, (T*)C,
+                                             M, N, ldc, bias, rowvec, rv_ld, rv_rows_per_group, rv_mod, (const T*)res, ldres));
+    SVDX_LAUNCH_CHECK("svdx_gemm_finalize");
     return 0;
 }
 

@@ -57,6 +57,7 @@ class Gather:
 # signature table: p void*, i int, f float, l int64, z size_t
 _SIGS = {
     "svdx_gemm": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifii" "ip",
+    "svdx_gemm_finalize": "pp" "iii" "pp" "iii" "pi" "ip",
     "svdx_small_linear": "pppp" "iiii" "iii" "ip",
     "svdx_outer_acc": "ppp" "iii" "f" "p",
     "svdx_timestep_embed": "pp" "ii" "p",
@@ -168,6 +169,10 @@ class HipBackend:
                    _f32(rowvec), rv_ld, rv_rpg, rv_mod, _p(res), ldres,
                    ctypes.cast(ctypes.pointer(g), ctypes.c_void_p) if g is not None else None,
                    _p(self._zero_page), out_mode, float(alpha), split_k, variant, _dt(A), self._stream())
+
+    def gemm_finalize(self, acc, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0, res=None, ldres=0):
+        self._call("svdx_gemm_finalize", _f32(acc), _p(C), M, N, ldc, _f32(bias), _f32(rowvec), rv_ld, rv_rpg, rv_mod,
+                   _p(res), ldres, _dt(C), self._stream())
 
     def small_linear(self, X, W, bias, Y, M, N, K, ldw, trans=0, silu_in=0, accumulate=0):
         self._call("svdx_small_linear", _f32(X), _p(W), _f32(bias), _f32(Y), M, N, K, ldw, trans, silu_in,

@@ -29,7 +29,8 @@ class Runtime:
         self.dt = dtype
         self.dev = device
         self.k = K.backend()
-        self.gemm_variant = 0
+        self.gemm_variant = 1      # 0: register-staged tiles, 1: global_load_lds (LDS-DMA) staging
+        self.split_k = True
         self.profile = None     # optional callable(kind, flops, bytes) -> context manager (bench instrumentation)
 
     def empty(self, *shape, dtype=None) -> torch.Tensor:
@@ -42,6 +43,28 @@ class Runtime:
         t = self.f32(*shape)
         self.k.zero(t)
         return t
+
+
+def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
+             res=None, ldres=0, gather=None) -> None:
+    """Activation-dtype GEMM.  When the 128x128 output grid cannot fill the 256 CUs and K is long (the 10x16 / 5x8
+    latent levels: M = 2240 / 560 rows against K up to 23040) the reduction is split across blocks: partial sums are
+    accumulated with float atomics into a scratch buffer and a small epilogue kernel applies bias/row-vector/residual."""
+    k = rt.k
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    kt = Kd // 64
+    split = 1
+    if rt.split_k and tiles <= 192 and kt >= 16:
+        split = max(1, min(384 // tiles, kt // 8, 16))
+    if split == 1:
+        k.gemm(A, B, out, M, N, Kd, lda, ldb, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod,
+               res=res, ldres=ldres, gather=gather, variant=rt.gemm_variant)
+        return
+    acc = rt.zeros_f32(M, N)
+    k.gemm(A, B, acc, M, N, Kd, lda, ldb, N, gather=gather, out_mode=K.OUT_F32_ATOMIC, split_k=split,
+           variant=rt.gemm_variant)
+    k.gemm_finalize(acc, out, M, N, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod, res=res,
+                    ldres=ldres)
 
 
 def _choose_split_k(M: int, N: int, Kdim: int) -> int:
@@ -126,14 +149,14 @@ class LinearOp:
             rowvec: Optional[torch.Tensor] = None, rv_ld: int = 0, rv_rpg: int = 0, rv_mod: int = 0,
             out: Optional[torch.Tensor] = None) -> torch.Tensor:
         y = out if out is not None else rt.empty(M, self.N)
-        rt.k.gemm(x, self.w, y, M, self.N, self.Kdim, self.Kdim, self.Kdim, self.N, bias=self.b,
-                  rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod, res=res,
-                  ldres=self.N if res is not None else 0, variant=rt.gemm_variant)
+        gemm_act(rt, x, self.w, y, M, self.N, self.Kdim, self.Kdim, self.Kdim, self.N, bias=self.b,
+                 rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod, res=res,
+                 ldres=self.N if res is not None else 0)
         return y
 
     def bwd_dx(self, rt: Runtime, dy: torch.Tensor, M: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         dx = out if out is not None else rt.empty(M, self.Kdim)
-        rt.k.gemm(dy, self.wt, dx, M, self.Kdim, self.N, self.N, self.N, self.Kdim, variant=rt.gemm_variant)
+        gemm_act(rt, dy, self.wt, dx, M, self.Kdim, self.N, self.N, self.N, self.Kdim)
         return dx
 
     def bwd_dw(self, rt: Runtime, dy: torch.Tensor, xt: torch.Tensor, M: int) -> None:
@@ -272,9 +295,8 @@ class ConvOp:
         ldc = ldc or self.cout
         y = rt.empty(M, ldc)
         Kd = self.taps * self.cin_p
-        rt.k.gemm(x, self.w, y, M, self.cout, Kd, self.cin_p, Kd, ldc, bias=self.b, rowvec=rowvec, rv_ld=rv_ld,
-                  rv_rpg=rv_rpg, res=res, ldres=self.cout if res is not None else 0, gather=g,
-                  variant=rt.gemm_variant)
+        gemm_act(rt, x, self.w, y, M, self.cout, Kd, self.cin_p, Kd, ldc, bias=self.b, rowvec=rowvec, rv_ld=rv_ld,
+                 rv_rpg=rv_rpg, res=res, ldres=self.cout if res is not None else 0, gather=g)
         return y, ho, wo
 
     def bwd_dx(self, rt: Runtime, dy: torch.Tensor, n_img: int, h: int, w: int, T: int = 0) -> torch.Tensor:
@@ -286,20 +308,20 @@ class ConvOp:
             M = n_img * T * h * w
             g = self._gather(n_img, 0, 0, 0, 0, self.cout_p, self.cout_p, T=T, hw=h * w, dgrad=True)
             dx = rt.empty(M, self.cin)
-            k.gemm(dy, self.wd, dx, M, self.cin, Kd, self.cout_p, Kd, self.cin, gather=g, variant=rt.gemm_variant)
+            gemm_act(rt, dy, self.wd, dx, M, self.cin, Kd, self.cout_p, Kd, self.cin, gather=g)
             return dx
         if self.ups:
             Mh = n_img * ho * wo
             g = self._gather(n_img, ho, wo, ho, wo, self.cout_p, self.cout_p, dgrad=True)
             dxh = rt.empty(Mh, self.cin)
-            k.gemm(dy, self.wd, dxh, Mh, self.cin, Kd, self.cout_p, Kd, self.cin, gather=g, variant=rt.gemm_variant)
+            gemm_act(rt, dy, self.wd, dxh, Mh, self.cin, Kd, self.cout_p, Kd, self.cin, gather=g)
             dx = rt.empty(n_img * h * w, self.cin)
             k.sum2x2(dxh, dx, n_img, h, w, self.cin)
             return dx
         M = n_img * h * w
         g = self._gather(n_img, ho, wo, h, w, self.cout_p, self.cout_p, dgrad=True)
         dx = rt.empty(M, self.cin)
-        k.gemm(dy, self.wd, dx, M, self.cin, Kd, self.cout_p, Kd, self.cin, gather=g, variant=rt.gemm_variant)
+        gemm_act(rt, dy, self.wd, dx, M, self.cin, Kd, self.cout_p, Kd, self.cin, gather=g)
         return dx
 
 

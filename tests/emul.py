@@ -109,6 +109,18 @@ class EmuBackend:
             assert C.dtype == torch.float32 or out_mode == K.OUT_ACT
             c.copy_(v.to(C.dtype))
 
+    def gemm_finalize(self, acc, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0, res=None, ldres=0):
+        v = V(acc, M, N, N).clone()
+        if bias is not None:
+            v = v + V1(bias, N)[None]
+        if rowvec is not None:
+            m = torch.arange(M, device=acc.device)
+            gi = (m % rv_mod) if rv_mod else (m // rv_rpg)
+            v = v + V(rowvec, int(gi.max()) + 1, N, rv_ld)[gi]
+        if res is not None:
+            v = v + V(res, M, N, ldres).float()
+        V(C, M, N, ldc).copy_(v.to(C.dtype))
+
     def small_linear(self, X, W, bias, Y, M, N, Kd, ldw, trans=0, silu_in=0, accumulate=0):
         w = V(W, N, Kd, ldw).float()
         if trans == 0:

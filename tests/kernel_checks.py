@@ -78,6 +78,19 @@ def check_gemm_plain(P, dt, variant):
                 out = torch.ones(M, N, dtype=torch.float32, device=P.dev)
             o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, N, Kd, Kd, Kd, N), kw), dict(C=out))
             res.append((f"gemm v{variant} {M}x{N}x{Kd} {mode}", relerr(o1["C"], o2["C"]), tol_for(dt)))
+    # split-K into a float scratch + finalize epilogue
+    M, N, Kd = 200, 320, 1280
+    A, B = rnd((M, Kd), dt, P.dev, g), rnd((N, Kd), dt, P.dev, g, Kd ** -0.5)
+    bias, R, rv = rndf((N,), P.dev, g), rnd((M, N), dt, P.dev, g), rndf((4, N), P.dev, g)
+
+    def splitk(be, o):
+        acc = torch.zeros(M, N, device=P.dev)
+        be.gemm(A, B, acc, M, N, Kd, Kd, Kd, N, out_mode=K.OUT_F32_ATOMIC, split_k=4, variant=variant)
+        be.gemm_finalize(acc, o, M, N, N, bias=bias, rowvec=rv, rv_ld=N, rv_rpg=50, res=R, ldres=N)
+    c1, c2 = torch.zeros(M, N, dtype=dt, device=P.dev), torch.zeros(M, N, dtype=dt, device=P.dev)
+    splitk(P.impl, c1)
+    splitk(P.ref, c2)
+    res.append((f"gemm v{variant} split-k + finalize", relerr(c1, c2), tol_for(dt)))
     # strided operands / output views (fused qkv buffers)
     M, N, Kd = 256, 128, 128
     big = rnd((M, 3 * Kd), dt, P.dev, g)
