@@ -31,6 +31,7 @@ extern "C" {
 #define SVDX_OUT_ACT 0      /* store in activation dtype            */
 #define SVDX_OUT_F32 1      /* store float                          */
 #define SVDX_OUT_F32_ATOMIC 2 /* atomicAdd float (grad accumulation, split-K) */
+#define SVDX_OUT_F32_SLAB 3   /* split-K: split z stores its partial sums (float) to C + z*M*ldc; no bias/res here */
 
 #define SVDX_GATHER_PLAIN 0
 #define SVDX_GATHER_CONV3X3 1     /* 3x3, pad 1, stride 1|2, optional nearest x2 upsampled source */
@@ -66,10 +67,11 @@ int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int ld
               const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
               int out_mode, float alpha, int split_k, int variant, int dtype, void* stream);
 
-/* Epilogue of a split-K GEMM whose partial sums were accumulated (SVDX_OUT_F32_ATOMIC) into the float buffer
- * `acc` [M,N]: C[m*ldc+n] = (dtype)(acc + bias + rowvec + res), same operand meaning as svdx_gemm. */
-int svdx_gemm_finalize(const float* acc, void* C, int M, int N, int ldc, const float* bias, const float* rowvec,
-                       int rv_ld, int rv_rows_per_group, int rv_mod, const void* res, int ldres, int dtype, void* stream);
+/* Epilogue of a split-K GEMM run with SVDX_OUT_F32_SLAB: v = sum_z acc[z*slab_stride + m*N + n] + bias + rowvec + res (same operand
+ * meaning as svdx_gemm); c_is_f32_accumulate ? ((float*)C)[m*ldc+n] += v : C[m*ldc+n] = (dtype)v. */
+int svdx_gemm_finalize(const float* acc, int nsplit, int64_t slab_stride, void* C, int c_is_f32_accumulate, int M, int N, int ldc,
+                       const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
+                       const void* res, int ldres, int dtype, void* stream);
 
 /* Skinny linears (M <= 64): time/added-id embedding MLPs, time_emb_proj, time_pos_embed, the KV-length-1
  * cross-attention.  X, Y float; W in dtype.

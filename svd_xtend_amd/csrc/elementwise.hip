@@ -90,38 +90,49 @@ __global__ void add_rowvec_kernel(const T* __restrict__ x, const float* __restri
     }
 }
 
-constexpr int CS_SLAB = 64;
-// grid (groups, row slabs of 64, column blocks); a block covers cpb = min(C/8, 256) 16-byte column chunks x (256/cpb) rows at
-// a time, two independent row loads in flight per thread; partial sums go out with one atomicAdd per element per thread.
+constexpr int CS_SLAB = 512;
+// grid (groups, row slabs of 512, column blocks of 256 channels).  A block = 32 column chunks (16 B) x 8 row lanes; every
+// thread streams 64 rows with 4 loads in flight, the 8 row lanes are reduced through LDS and one atomicAdd per column per
+// block goes out (float atomics are the scarce resource: ~15/ns chip-wide).
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* out, int rows, int C, int ldx, int rpg, int mod,
-                                                     int cpb) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* out, int rows, int C, int ldx, int rpg, int mod) {
+    __shared__ float red[8][32 * 8 + 8];
     const int g = blockIdx.x, slab = blockIdx.y;
     const int cnt = mod ? (rows - g + mod - 1) / mod : min(rpg, rows - g * rpg);
     const int i0 = slab * CS_SLAB, i1 = min(cnt, i0 + CS_SLAB);
-    const int rsub = 256 / cpb;
-    const int jj = threadIdx.x % cpb, rs = threadIdx.x / cpb;
-    const int j = blockIdx.z * cpb + jj;
-    if (rs >= rsub || j * 8 >= C || i0 >= i1) return;
+    const int jj = threadIdx.x & 31, rs = threadIdx.x >> 5;
+    const int j = blockIdx.z * 32 + jj;
+    const bool active = j * 8 < C;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const size_t rstride = (size_t)(mod ? mod : 1) * ldx;
-    const T* base = x + (size_t)(mod ? g : g * rpg) * ldx + j * 8;
-    int i = i0 + rs;
-    for (; i + rsub < i1; i += 2 * rsub) {
-        float v0[8], v1[8];
-        load8<T>(base + (size_t)i * rstride, v0);
-        load8<T>(base + (size_t)(i + rsub) * rstride, v1);
+    if (active) {
+        const size_t rstride = (size_t)(mod ? mod : 1) * ldx;
+        const T* base = x + (size_t)(mod ? g : g * rpg) * ldx + j * 8;
+        int i = i0 + rs;
+        for (; i + 24 < i1; i += 32) {
+            float v0[8], v1[8], v2[8], v3[8];
+            load8<T>(base + (size_t)i * rstride, v0);
+            load8<T>(base + (size_t)(i + 8) * rstride, v1);
+            load8<T>(base + (size_t)(i + 16) * rstride, v2);
+            load8<T>(base + (size_t)(i + 24) * rstride, v3);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += v0[e] + v1[e];
+            for (int e = 0; e < 8; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+        }
+        for (; i < i1; i += 8) {
+            float v[8];
+            load8<T>(base + (size_t)i * rstride, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
     }
-    if (i < i1) {
-        float v[8];
-        load8<T>(base + (size_t)i * rstride, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += v[e];
-    }
+    for (int e = 0; e < 8; ++e) red[rs][jj * 8 + e] = acc[e];
+    __syncthreads();
+    const int c = threadIdx.x;          // 256 columns of this block
+    float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + (size_t)g * C + j * 8 + e, acc[e]);
+    for (int r = 0; r < 8; ++r) s += red[r][c];
+    const int col = blockIdx.z * 256 + c;
+    if (col < C && i0 < i1) atomicAdd(out + (size_t)g * C + col, s);
 }
 
 // batched tiled transpose: out[b][c*ld_out + r] = in[b][r*ld_in + c], r in [0, ld_out) zero-filled beyond rows.
@@ -298,10 +309,9 @@ extern "C" int svdx_colsum(const void* x, float* out, int rows, int C, int ldx, 
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * n_groups * C, st);
     const int maxcnt = mod ? cdiv(rows, mod) : std::min(rows_per_group, rows);
-    const int cpb = std::min(C / 8, 256);
-    dim3 grid(n_groups, cdiv(maxcnt, CS_SLAB), cdiv(C / 8, cpb));
+    dim3 grid(n_groups, cdiv(maxcnt, CS_SLAB), cdiv(C, 256));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, out, rows, C, ldx,
-                                             rows_per_group, mod, cpb));
+                                             rows_per_group, mod));
     SVDX_LAUNCH_CHECK("svdx_colsum");
     return 0;
 }

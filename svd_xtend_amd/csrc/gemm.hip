@@ -29,7 +29,7 @@ struct GemmParams {
     const float* bias; const float* rowvec; int rv_ld, rv_rpg, rv_mod;
     const void* res; int ldres;
     svdx_gather g; const void* zero_page;
-    int out_mode; float alpha; int split_k; int tiles_m, tiles_n; int vec_ok;
+    int out_mode; float alpha; int split_k; int tiles_m, tiles_n; int vec_ok; long slab_stride;
 };
 
 struct RowInfo { int a, b, base; };   // per gathered A row (meaning depends on gather mode)
@@ -233,9 +233,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
 
     // ---- epilogue: stage 64 rows at a time through LDS as f32, then vectorised fused store ----
     float* Cs = reinterpret_cast<float*>(smem);
-    const bool lead = (z == 0);
+    const bool lead = (z == 0) && p.out_mode != SVDX_OUT_F32_SLAB;
     T* Ct = reinterpret_cast<T*>(p.C);
-    float* Cf = reinterpret_cast<float*>(p.C);
+    float* Cf = reinterpret_cast<float*>(p.C) + (p.out_mode == SVDX_OUT_F32_SLAB ? (size_t)z * p.slab_stride : 0);
     const T* R = reinterpret_cast<const T*>(p.res);
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
@@ -294,9 +294,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) if (j < nvalid) Ct[co + j] = from_f<T>(v[j]);
                 }
-            } else if (p.out_mode == SVDX_OUT_F32) {
+            } else if (p.out_mode == SVDX_OUT_F32 || p.out_mode == SVDX_OUT_F32_SLAB) {
+                if (full) {
+                    *reinterpret_cast<f32x4*>(Cf + co) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(Cf + co + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (j < nvalid) Cf[co + j] = v[j];
+                    for (int j = 0; j < 8; ++j) if (j < nvalid) Cf[co + j] = v[j];
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (j < nvalid) atomicAdd(Cf + co + j, v[j]);
@@ -370,19 +375,41 @@ __global__ __launch_bounds__(256) void small_linear_nn(const float* X, const T* 
     for (int j = 0; j < 8; ++j) atomicAdd(y + j, acc[j]);
 }
 
-// split-K epilogue: C = (dtype)(acc + bias + rowvec + res) from the float accumulation buffer
+// split-K epilogue: v = sum over `nsplit` float slabs (+ bias + rowvec + res);  C = (dtype)v, or Cf += v (weight grads)
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_finalize_kernel(const float* __restrict__ acc, T* __restrict__ C, int M, int N, int ldc,
+__global__ __launch_bounds__(256) void gemm_finalize_kernel(const float* __restrict__ acc, int nsplit, long slab_stride, T* __restrict__ C,
+                                                            float* __restrict__ Cf, int M, int N, int ldc,
                                                             const float* __restrict__ bias, const float* __restrict__ rowvec,
                                                             int rv_ld, int rv_rpg, int rv_mod, const T* __restrict__ res, int ldres) {
-    const long total = (long)M * N;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long total4 = (long)M * N / 4;       // N % 4 == 0
+    for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
+        const long i = i4 * 4;
         const int m = (int)(i / N), n = (int)(i - (long)m * N);
-        float v = acc[i];
-        if (bias) v += bias[n];
-        if (rowvec) v += rowvec[(size_t)(rv_mod ? m % rv_mod : m / rv_rpg) * rv_ld + n];
-        if (res) v += to_f<T>(res[(size_t)m * ldres + n]);
-        C[(size_t)m * ldc + n] = from_f<T>(v);
+        f32x4 v = *reinterpret_cast<const f32x4*>(acc + i);
+        for (int z = 1; z < nsplit; ++z) v += *reinterpret_cast<const f32x4*>(acc + (size_t)z * slab_stride + i);
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bias[n + e];
+        }
+        if (rowvec) {
+            const float* rv = rowvec + (size_t)(rv_mod ? m % rv_mod : m / rv_rpg) * rv_ld + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rv[e];
+        }
+        if (res) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += to_f<T>(res[(size_t)m * ldres + n + e]);
+        }
+        if (Cf) {
+            float* o = Cf + (size_t)m * ldc + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += v[e];
+        } else {
+            Vec4<T> o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(v[e]);
+            *reinterpret_cast<Vec4<T>*>(C + (size_t)m * ldc + n) = o;
+        }
     }
 }
 
@@ -430,14 +457,14 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
     SVDX_CHECK_ARG(M > 0 && N > 0 && K > 0, "svdx_gemm: bad sizes M=%d N=%d K=%d", M, N, K);
     SVDX_CHECK_ARG(K % BK == 0, "svdx_gemm: K=%d must be a multiple of %d", K, BK);
     SVDX_CHECK_ARG(ldb % 8 == 0 && ((uintptr_t)B & 15) == 0, "svdx_gemm: B must be 16-byte aligned (ldb=%d)", ldb);
-    SVDX_CHECK_ARG(split_k >= 1 && (split_k == 1 || out_mode == SVDX_OUT_F32_ATOMIC),
-                   "svdx_gemm: split_k=%d needs atomic output", split_k);
+    SVDX_CHECK_ARG(split_k >= 1 && (split_k == 1 || out_mode == SVDX_OUT_F32_ATOMIC || out_mode == SVDX_OUT_F32_SLAB),
+                   "svdx_gemm: split_k=%d needs atomic or slab output", split_k);
     SVDX_CHECK_ARG(!rowvec || rv_mod > 0 || rv_rows_per_group > 0, "svdx_gemm: rowvec needs a grouping");
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.rowvec = rowvec; p.rv_ld = rv_ld; p.rv_rpg = rv_rows_per_group; p.rv_mod = rv_mod;
     p.res = res; p.ldres = ldres; p.zero_page = zero_page;
-    p.out_mode = out_mode; p.alpha = alpha; p.split_k = split_k;
+    p.out_mode = out_mode; p.alpha = alpha; p.split_k = split_k; p.slab_stride = (long)M * ldc;
     if (gather && gather->mode != SVDX_GATHER_PLAIN) {
         p.g = *gather;
         SVDX_CHECK_ARG(p.g.cin % BK == 0, "svdx_gemm: gather cin=%d must be a multiple of %d", p.g.cin, BK);
@@ -491,13 +518,18 @@ extern "C" int svdx_small_linear(const float* X, const void* W, const float* bia
     return 0;
 }
 
-extern "C" int svdx_gemm_finalize(const float* acc, void* C, int M, int N, int ldc, const float* bias, const float* rowvec,
-                                  int rv_ld, int rv_rows_per_group, int rv_mod, const void* res, int ldres, int dtype, void* stream) {
-    SVDX_CHECK_ARG(acc && C && M > 0 && N > 0, "svdx_gemm_finalize: bad args");
+extern "C" int svdx_gemm_finalize(const float* acc, int nsplit, int64_t slab_stride, void* C, int c_is_f32_accumulate, int M, int N,
+                                  int ldc, const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
+                                  const void* res, int ldres, int dtype, void* stream) {
+    SVDX_CHECK_ARG(acc && C && M > 0 && N > 0 && nsplit >= 1, "svdx_gemm_finalize: bad args");
+    SVDX_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && slab_stride % 4 == 0 && (!res || ldres % 4 == 0) && (!rowvec || rv_ld % 4 == 0),
+                   "svdx_gemm_finalize: N/ld must be multiples of 4");
     SVDX_CHECK_ARG(!rowvec || rv_mod > 0 || rv_rows_per_group > 0, "svdx_gemm_finalize: rowvec needs a grouping");
-    const int blocks = (int)std::min<long>(((long)M * N + 255) / 256, 4096);
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_finalize_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, (T*)C,
-                                             M, N, ldc, bias, rowvec, rv_ld, rv_rows_per_group, rv_mod, (const T*)res, ldres));
+    const int blocks = (int)std::min<long>(((long)M * N / 4 + 255) / 256, 4096);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_finalize_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, nsplit,
+                                             (long)slab_stride, c_is_f32_accumulate ? (T*)nullptr : (T*)C,
+                                             c_is_f32_accumulate ? (float*)C : (float*)nullptr, M, N, ldc, bias, rowvec, rv_ld,
+                                             rv_rows_per_group, rv_mod, (const T*)res, ldres));
     SVDX_LAUNCH_CHECK("svdx_gemm_finalize");
     return 0;
 }

@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int GN_SLAB = 64;    // rows per block
+constexpr int GN_SLAB = 32;    // rows per block (small slabs -> enough waves per SIMD to hide HBM latency)
 
 struct GnGeom {
     int n_s, rows, C, G, cg, cc, rpi;   // cg channels/group, cc 16-byte chunks per row, rpi rows per iteration
@@ -52,16 +52,11 @@ __global__ void gn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ 
         }
     }
     if (ry < q.rpi) {
-        for (int r = r0 + ry; r < r1; r += q.rpi) {
-            const size_t off = ((size_t)n * q.rows + r) * q.C + j * 8;
-            float xv[8];
-            load8<T>(x + off, xv);
+        auto accum = [&](const float (&xv)[8], const float (&dv)[8]) __attribute__((always_inline)) {
             if (MODE == 0) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { a0[e] += xv[e]; a1[e] += xv[e] * xv[e]; }
             } else {
-                float dv[8];
-                load8<T>(dy + off, dv);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float dz = dv[e];
@@ -71,6 +66,25 @@ __global__ void gn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ 
                     a1[e] += dzg * (xv[e] - mu[e]) * rs[e];
                 }
             }
+        };
+        const size_t base = (size_t)n * q.rows * q.C + j * 8;
+        int r = r0 + ry;
+        for (; r + q.rpi < r1; r += 2 * q.rpi) {          // two independent rows in flight
+            float x0[8], x1[8], d0[8], d1[8];
+            load8<T>(x + base + (size_t)r * q.C, x0);
+            load8<T>(x + base + (size_t)(r + q.rpi) * q.C, x1);
+            if (MODE == 1) {
+                load8<T>(dy + base + (size_t)r * q.C, d0);
+                load8<T>(dy + base + (size_t)(r + q.rpi) * q.C, d1);
+            }
+            accum(x0, d0);
+            accum(x1, d1);
+        }
+        if (r < r1) {
+            float x0[8], d0[8];
+            load8<T>(x + base + (size_t)r * q.C, x0);
+            if (MODE == 1) load8<T>(dy + base + (size_t)r * q.C, d0);
+            accum(x0, d0);
         }
         // merge the 8 channels into their groups (runs of equal group id), then one LDS atomic per run
         int cur = (j * 8) / q.cg;
@@ -118,6 +132,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ d
             b2[e] = bstats[((size_t)n * q.G + g) * 2 + 1] / cnt;
         }
     }
+#pragma unroll 2
     for (int r = r0 + ry; r < r1; r += q.rpi) {
         const size_t off = ((size_t)n * q.rows + r) * q.C + j * 8;
         float xv[8], o[8];
@@ -159,9 +174,9 @@ int gn_geom(GnGeom& q, int n_s, int rows, int C, int G, int& threads) {
 }
 
 // ---- LayerNorm: one wave per row, whole row in registers (C <= 2048) ------------------------------------------
-constexpr int LN_MAXCH = 4;
+constexpr int LN_MAXCH_LIMIT = 4;
 
-template <typename T>
+template <typename T, int LN_MAXCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ stats, int rows, int C, float eps) {
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
 }
 
-template <typename T>
+template <typename T, int LN_MAXCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const T* __restrict__ add, T* __restrict__ dx, float* dgamma,
@@ -343,23 +358,28 @@ extern "C" int svdx_gn_bwd_apply(const void* dy, const void* x, const float* sta
 
 extern "C" int svdx_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows,
                            int C, float eps, int dtype, void* stream) {
-    SVDX_CHECK_ARG(rows > 0 && C % 8 == 0 && C / 8 <= 64 * LN_MAXCH, "svdx_ln_fwd: C=%d unsupported", C);
+    SVDX_CHECK_ARG(rows > 0 && C % 8 == 0 && C / 8 <= 64 * LN_MAXCH_LIMIT, "svdx_ln_fwd: C=%d unsupported", C);
     const int blocks = min(cdiv(rows, 4), 2048);
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                                             (const T*)x, gamma, beta, (T*)y, stats, rows, C, eps));
+    const int nch = (C / 8 + 63) / 64;
+#define LN_FWD(NCH) hipLaunchKernelGGL((ln_fwd_kernel<T, NCH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, gamma, \
+                                       beta, (T*)y, stats, rows, C, eps)
+    DISPATCH_DTYPE(dtype, { if (nch == 1) LN_FWD(1); else if (nch == 2) LN_FWD(2); else if (nch == 3) LN_FWD(3); else LN_FWD(4); });
+#undef LN_FWD
     SVDX_LAUNCH_CHECK("svdx_ln_fwd");
     return 0;
 }
 
 extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* add,
                            void* dx, float* dgamma, float* dbeta, int rows, int C, int dtype, void* stream) {
-    SVDX_CHECK_ARG(rows > 0 && C % 8 == 0 && C / 8 <= 64 * LN_MAXCH, "svdx_ln_bwd: C=%d unsupported", C);
+    SVDX_CHECK_ARG(rows > 0 && C % 8 == 0 && C / 8 <= 64 * LN_MAXCH_LIMIT, "svdx_ln_bwd: C=%d unsupported", C);
     SVDX_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "svdx_ln_bwd: dgamma/dbeta must come together");
-    const int blocks = min(cdiv(rows, 4), 512);
+    const int blocks = min(cdiv(rows, 4), 1024);
     const size_t sh = dgamma ? sizeof(float) * 2 * C : 0;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), sh, (hipStream_t)stream,
-                                             (const T*)dy, (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma,
-                                             dbeta, rows, C));
+    const int nch = (C / 8 + 63) / 64;
+#define LN_BWD(NCH) hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(blocks), dim3(256), sh, (hipStream_t)stream, (const T*)dy, \
+                                       (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, rows, C)
+    DISPATCH_DTYPE(dtype, { if (nch == 1) LN_BWD(1); else if (nch == 2) LN_BWD(2); else if (nch == 3) LN_BWD(3); else LN_BWD(4); });
+#undef LN_BWD
     SVDX_LAUNCH_CHECK("svdx_ln_bwd");
     return 0;
 }

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsvdx.so")
 
 F16, BF16 = 0, 1
-OUT_ACT, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
+OUT_ACT, OUT_F32, OUT_F32_ATOMIC, OUT_F32_SLAB = 0, 1, 2, 3
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3 = 0, 1, 2, 3
 
 
@@ -57,7 +57,7 @@ class Gather:
 # signature table: p void*, i int, f float, l int64, z size_t
 _SIGS = {
     "svdx_gemm": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifii" "ip",
-    "svdx_gemm_finalize": "pp" "iii" "pp" "iii" "pi" "ip",
+    "svdx_gemm_finalize": "pil" "pi" "iii" "pp" "iii" "pi" "ip",
     "svdx_small_linear": "pppp" "iiii" "iii" "ip",
     "svdx_outer_acc": "ppp" "iii" "f" "p",
     "svdx_timestep_embed": "pp" "ii" "p",
@@ -170,9 +170,11 @@ class HipBackend:
                    ctypes.cast(ctypes.pointer(g), ctypes.c_void_p) if g is not None else None,
                    _p(self._zero_page), out_mode, float(alpha), split_k, variant, _dt(A), self._stream())
 
-    def gemm_finalize(self, acc, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0, res=None, ldres=0):
-        self._call("svdx_gemm_finalize", _f32(acc), _p(C), M, N, ldc, _f32(bias), _f32(rowvec), rv_ld, rv_rpg, rv_mod,
-                   _p(res), ldres, _dt(C), self._stream())
+    def gemm_finalize(self, acc, nsplit, slab_stride, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
+                      res=None, ldres=0, accumulate_f32=False, dtype=None):
+        dt = F16 if dtype == torch.float16 else BF16 if dtype == torch.bfloat16 else _dt(C)
+        self._call("svdx_gemm_finalize", _f32(acc), nsplit, slab_stride, _p(C), int(accumulate_f32), M, N, ldc, _f32(bias),
+                   _f32(rowvec), rv_ld, rv_rpg, rv_mod, _p(res), ldres, dt, self._stream())
 
     def small_linear(self, X, W, bias, Y, M, N, K, ldw, trans=0, silu_in=0, accumulate=0):
         self._call("svdx_small_linear", _f32(X), _p(W), _f32(bias), _f32(Y), M, N, K, ldw, trans, silu_in,

@@ -54,17 +54,19 @@ def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowve
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     kt = Kd // 64
     split = 1
-    if rt.split_k and tiles <= 192 and kt >= 16:
-        split = max(1, min(384 // tiles, kt // 8, 16))
+    if rt.split_k and tiles <= 192 and kt >= 16 and N % 4 == 0 and ldc % 4 == 0:
+        split = max(1, min(512 // tiles, kt // 8, 16))
+        while split > 1 and (kt + split - 1) // split * (split - 1) >= kt:     # every split must own >= 1 K-tile
+            split -= 1
     if split == 1:
         k.gemm(A, B, out, M, N, Kd, lda, ldb, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod,
                res=res, ldres=ldres, gather=gather, variant=rt.gemm_variant)
         return
-    acc = rt.zeros_f32(M, N)
-    k.gemm(A, B, acc, M, N, Kd, lda, ldb, N, gather=gather, out_mode=K.OUT_F32_ATOMIC, split_k=split,
+    acc = rt.f32(split, M, N)
+    k.gemm(A, B, acc, M, N, Kd, lda, ldb, N, gather=gather, out_mode=K.OUT_F32_SLAB, split_k=split,
            variant=rt.gemm_variant)
-    k.gemm_finalize(acc, out, M, N, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod, res=res,
-                    ldres=ldres)
+    k.gemm_finalize(acc, split, M * N, out, M, N, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod,
+                    res=res, ldres=ldres)
 
 
 def _choose_split_k(M: int, N: int, Kdim: int) -> int:
@@ -75,7 +77,10 @@ def _choose_split_k(M: int, N: int, Kdim: int) -> int:
         return 1
     want = max(1, 512 // tiles)
     ksteps = Kdim // 64
-    return max(1, min(want, ksteps // 4, 64))
+    split = max(1, min(want, ksteps // 4, 32))
+    while split > 1 and (ksteps + split - 1) // split * (split - 1) >= ksteps:
+        split -= 1
+    return split
 
 
 # --------------------------------------------------------------------------------------------------
@@ -168,8 +173,15 @@ class LinearOp:
         dyt = rt.empty(self.N, Mp)
         k.transpose(dy, self.N, dyt, Mp, M, self.N)
         sk = _choose_split_k(self.N, self.Kdim, Mp)
-        k.gemm(dyt, xt, self.w_grad, self.N, self.Kdim, Mp, Mp, Mp, self.Kdim, out_mode=K.OUT_F32_ATOMIC,
-               split_k=sk, variant=rt.gemm_variant)
+        if sk == 1:
+            k.gemm(dyt, xt, self.w_grad, self.N, self.Kdim, Mp, Mp, Mp, self.Kdim, out_mode=K.OUT_F32_ATOMIC,
+                   variant=rt.gemm_variant)
+        else:
+            slabs = rt.f32(sk, self.N, self.Kdim)
+            k.gemm(dyt, xt, slabs, self.N, self.Kdim, Mp, Mp, Mp, self.Kdim, out_mode=K.OUT_F32_SLAB, split_k=sk,
+                   variant=rt.gemm_variant)
+            k.gemm_finalize(slabs, sk, self.N * self.Kdim, self.w_grad, self.N, self.Kdim, self.Kdim, accumulate_f32=True,
+                            dtype=rt.dt)
         if self.b_grad is not None:
             k.colsum(dy, self.b_grad, M, self.N, self.N, 1, M, 0, accumulate=1)
 

@@ -101,6 +101,13 @@ class EmuBackend:
             v = v + V(rowvec, ng, N, rv_ld)[gi]
         if res is not None:
             v = v + V(res, M, N, ldres).float()
+        if out_mode == K.OUT_F32_SLAB:
+            assert bias is None and rowvec is None and res is None and C.dtype == torch.float32 and ldc == N
+            ksz = (Kd // 64 + split_k - 1) // split_k * 64
+            for z in range(split_k):
+                sl = torch.as_strided(C, (M, N), (N, 1), C.storage_offset() + z * M * N)
+                sl.copy_(alpha * (a[:, z * ksz:(z + 1) * ksz] @ b[:, z * ksz:(z + 1) * ksz].t()))
+            return
         c = V(C, M, N, ldc)
         if out_mode == K.OUT_F32_ATOMIC:
             assert C.dtype == torch.float32
@@ -109,8 +116,11 @@ class EmuBackend:
             assert C.dtype == torch.float32 or out_mode == K.OUT_ACT
             c.copy_(v.to(C.dtype))
 
-    def gemm_finalize(self, acc, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0, res=None, ldres=0):
-        v = V(acc, M, N, N).clone()
+    def gemm_finalize(self, acc, nsplit, slab_stride, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
+                      res=None, ldres=0, accumulate_f32=False, dtype=None):
+        v = torch.zeros(M, N, device=acc.device)
+        for z in range(nsplit):
+            v = v + torch.as_strided(acc, (M, N), (N, 1), acc.storage_offset() + z * slab_stride)
         if bias is not None:
             v = v + V1(bias, N)[None]
         if rowvec is not None:
@@ -119,7 +129,10 @@ class EmuBackend:
             v = v + V(rowvec, int(gi.max()) + 1, N, rv_ld)[gi]
         if res is not None:
             v = v + V(res, M, N, ldres).float()
-        V(C, M, N, ldc).copy_(v.to(C.dtype))
+        if accumulate_f32:
+            V(C, M, N, ldc).add_(v)
+        else:
+            V(C, M, N, ldc).copy_(v.to(C.dtype))
 
     def small_linear(self, X, W, bias, Y, M, N, Kd, ldw, trans=0, silu_in=0, accumulate=0):
         w = V(W, N, Kd, ldw).float()

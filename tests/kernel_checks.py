@@ -84,13 +84,21 @@ def check_gemm_plain(P, dt, variant):
     bias, R, rv = rndf((N,), P.dev, g), rnd((M, N), dt, P.dev, g), rndf((4, N), P.dev, g)
 
     def splitk(be, o):
-        acc = torch.zeros(M, N, device=P.dev)
-        be.gemm(A, B, acc, M, N, Kd, Kd, Kd, N, out_mode=K.OUT_F32_ATOMIC, split_k=4, variant=variant)
-        be.gemm_finalize(acc, o, M, N, N, bias=bias, rowvec=rv, rv_ld=N, rv_rpg=50, res=R, ldres=N)
+        acc = torch.zeros(3, M, N, device=P.dev)
+        be.gemm(A, B, acc, M, N, Kd, Kd, Kd, N, out_mode=K.OUT_F32_SLAB, split_k=3, variant=variant)
+        if o.dtype != torch.float32:
+            be.gemm_finalize(acc, 3, M * N, o, M, N, N, bias=bias, rowvec=rv, rv_ld=N, rv_rpg=50, res=R, ldres=N)
+        else:
+            o.fill_(1.0)
+            be.gemm_finalize(acc, 3, M * N, o, M, N, N, accumulate_f32=True, dtype=dt)
     c1, c2 = torch.zeros(M, N, dtype=dt, device=P.dev), torch.zeros(M, N, dtype=dt, device=P.dev)
     splitk(P.impl, c1)
     splitk(P.ref, c2)
     res.append((f"gemm v{variant} split-k + finalize", relerr(c1, c2), tol_for(dt)))
+    f1, f2 = torch.zeros(M, N, device=P.dev), torch.zeros(M, N, device=P.dev)
+    splitk(P.impl, f1)
+    splitk(P.ref, f2)
+    res.append((f"gemm v{variant} split-k + f32 accumulate finalize", relerr(f1, f2), tol_for(dt)))
     # strided operands / output views (fused qkv buffers)
     M, N, Kd = 256, 128, 128
     big = rnd((M, 3 * Kd), dt, P.dev, g)
