@@ -31,6 +31,7 @@ extern "C" {
 #define SVDX_OUT_ACT 0      /* store in activation dtype            */
 #define SVDX_OUT_F32 1      /* store float                          */
 #define SVDX_OUT_F32_ATOMIC 2 /* atomicAdd float (grad accumulation, split-K) */
+#define SVDX_OUT_F32_ADD 4    /* float read-modify-write without atomics (each element has one owner block) */
 #define SVDX_OUT_F32_SLAB 3   /* split-K: split z stores its partial sums (float) to C + z*M*ldc; no bias/res here */
 
 #define SVDX_GATHER_PLAIN 0
@@ -66,6 +67,12 @@ int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int ld
               const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
               const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
               int out_mode, float alpha, int split_k, int variant, int dtype, void* stream);
+
+/* Weight-gradient GEMM in TN form: C[n*ldc + k] (+)= sum_r A[r*lda + n] * B[r*ldb + k]  (A = dY [R,N], B = X [R,K], float C).
+ * Replaces the dW part of autograd's Linear backward (train_svd.py:1044) without materialising transposes.
+ * out_mode: F32 (store), F32_ADD (+=), F32_SLAB (split z -> C + z*N*ldc), F32_ATOMIC. */
+int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
+                 const void* zero_page, int out_mode, int split_k, int dtype, void* stream);
 
 /* Epilogue of a split-K GEMM run with SVDX_OUT_F32_SLAB: v = sum_z acc[z*slab_stride + m*N + n] + bias + rowvec + res (same operand
  * meaning as svdx_gemm); c_is_f32_accumulate ? ((float*)C)[m*ldc+n] += v : C[m*ldc+n] = (dtype)v. */

@@ -84,6 +84,100 @@ __device__ __forceinline__ RowInfo decode_row(const svdx_gather& g, int m) {
     return ri;
 }
 
+template <typename T>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], char* smem, int m0, int n0, int z, int tid,
+                                              int lane, int wm, int wn) {
+    // ---- epilogue: stage 64 rows at a time through LDS as f32, then vectorised fused store ----
+    float* Cs = reinterpret_cast<float*>(smem);
+    const bool lead = (z == 0) && p.out_mode != SVDX_OUT_F32_SLAB;
+    T* Ct = reinterpret_cast<T*>(p.C);
+    float* Cf = reinterpret_cast<float*>(p.C) + (p.out_mode == SVDX_OUT_F32_SLAB ? (size_t)z * p.slab_stride : 0);
+    const T* R = reinterpret_cast<const T*>(p.res);
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wm == pass) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Cs[(i * 16 + (lane >> 4) * 4 + r) * CS_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const int id = i * 256 + tid;
+            const int row = id >> 4, c8 = id & 15;
+            const int m = m0 + pass * 64 + row, nc = n0 + c8 * 8;
+            if (m >= p.M || nc >= p.N) continue;
+            float v[8];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + row * CS_LD + c8 * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + row * CS_LD + c8 * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = lo[j] * p.alpha; v[4 + j] = hi[j] * p.alpha; }
+            const bool full = p.vec_ok && (nc + 8 <= p.N);
+            const int nvalid = min(8, p.N - nc);
+            if (lead) {
+                if (p.bias) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += p.bias[nc + j];
+                }
+                if (p.rowvec) {
+                    const int gi = p.rv_mod ? (m % p.rv_mod) : (m / p.rv_rpg);
+                    const float* rv = p.rowvec + (size_t)gi * p.rv_ld + nc;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += rv[j];
+                }
+                if (R) {
+                    const T* rp = R + (size_t)m * p.ldres + nc;
+                    if (full) {
+                        float rr[8];
+                        load8<T>(rp, rr);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += rr[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += to_f<T>(rp[j]);
+                    }
+                }
+            }
+            const size_t co = (size_t)m * p.ldc + nc;
+            if (p.out_mode == SVDX_OUT_ACT) {
+                if (full) {
+                    store8<T>(Ct + co, v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (j < nvalid) Ct[co + j] = from_f<T>(v[j]);
+                }
+            } else if (p.out_mode == SVDX_OUT_F32 || p.out_mode == SVDX_OUT_F32_SLAB) {
+                if (full) {
+                    *reinterpret_cast<f32x4*>(Cf + co) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(Cf + co + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (j < nvalid) Cf[co + j] = v[j];
+                }
+            } else if (p.out_mode == SVDX_OUT_F32_ADD) {      // this block owns the element: plain read-modify-write
+                if (full) {
+                    f32x4 c0 = *reinterpret_cast<const f32x4*>(Cf + co), c1 = *reinterpret_cast<const f32x4*>(Cf + co + 4);
+                    c0 += f32x4{v[0], v[1], v[2], v[3]};
+                    c1 += f32x4{v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<f32x4*>(Cf + co) = c0;
+                    *reinterpret_cast<f32x4*>(Cf + co + 4) = c1;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (j < nvalid) Cf[co + j] += v[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < nvalid) atomicAdd(Cf + co + j, v[j]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T, bool GLDS>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -231,84 +325,117 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
 #undef SVDX_LOAD_REGS
 #undef SVDX_WRITE_LDS
 
-    // ---- epilogue: stage 64 rows at a time through LDS as f32, then vectorised fused store ----
-    float* Cs = reinterpret_cast<float*>(smem);
-    const bool lead = (z == 0) && p.out_mode != SVDX_OUT_F32_SLAB;
-    T* Ct = reinterpret_cast<T*>(p.C);
-    float* Cf = reinterpret_cast<float*>(p.C) + (p.out_mode == SVDX_OUT_F32_SLAB ? (size_t)z * p.slab_stride : 0);
-    const T* R = reinterpret_cast<const T*>(p.res);
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        if (wm == pass) {
+    gemm_epilogue<T>(p, acc, smem, m0, n0, z, tid, lane, wm, wn);
+}
+
+
+// ================================================================================================================
+// TN form for weight gradients:  C[n,k] (+)= sum_r A[r,n] * B[r,k]   (A = dY [R, lda], B = X [R, ldb]; float output)
+// Both operands are stored with the reduction index r as the ROW, so tiles are staged row-major ([64 r][128 cols],
+// 256-byte rows, coalesced 16-byte loads along the columns) and the MFMA fragments -- 8 consecutive r for one column --
+// are fetched with ds_read_b64_tr_b16, gfx950's transposing LDS read: within a 16-lane group lane i supplies the
+// address of row (i>>2), column piece (i&3)*4, and receives column i of the 4x16 block (probed on hardware, see
+// tools/probes/tr_probe.hip).  No transposed copies of dY / X are ever materialised and every output element has
+// one owner, so no atomics either.  8-byte units of a row are XOR-swizzled with a 3-bit row id so the 32 lanes of
+// a half-wave hit 32 distinct bank pairs.
+// ================================================================================================================
+__device__ __forceinline__ int tn_rid(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <typename T>
+__device__ __forceinline__ typename TT<T>::v8 tn_frag(const char* tile, int colblk16, int ks, int fr, int fg) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    const int r0 = ks * 32 + fg * 8 + (fr >> 2);
+    const int unit = colblk16 * 4 + (fr & 3);
+    const int a0 = r0 * 256 + ((unit ^ (tn_rid(r0) << 2)) * 8);
+    const int a1 = (r0 + 4) * 256 + ((unit ^ (tn_rid(r0 + 4) << 2)) * 8);
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(tile + a0));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(tile + a1));
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const v8s r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(typename TT<T>::v8, r);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename TT<T>::v8 v8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int pid_m = swz / p.tiles_n, pid_n = swz - pid_m * p.tiles_n;
+    const int m0 = pid_m * BM, n0 = pid_n * BN;          // m0: first output row (a column of A), n0: first output col (a column of B)
+    const int R = p.K;                                   // reduction length (rows of A and B)
+    const int kt_total = (R + BK - 1) / BK;
+    const int z = blockIdx.y;
+    const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
+    const int kt_begin = z * kt_per;
+    const int kt_end = min(kt_total, kt_begin + kt_per);
+    if (kt_begin >= kt_end) return;
+
+    // staging: tile = 64 rows x 16 chunks (16 B); thread handles 4 rows, one fixed physical chunk
+    const int pc = tid & 15, ld_row = tid >> 4;          // ld_row 0..15; rows ld_row + 16*i
+    const T* zero = reinterpret_cast<const T*>(p.zero_page);
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+        char* As = smem + stage * STAGE_BYTES;
+        char* Bs = As + BM * BK * 2;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 16 + ld_row;
+            const int lc = pc ^ (tn_rid(row) << 1);       // logical 16-byte chunk stored at physical chunk pc
+            const int r = kt * BK + row;
+            const int ca = m0 + lc * 8, cb = n0 + lc * 8;
+            const T* pa = (r < R && ca < p.M) ? A + (size_t)r * p.lda + ca : zero;
+            const T* pb = (r < R && cb < p.N) ? B + (size_t)r * p.ldb + cb : zero;
+            const int base = (i * 256 + wave_u * 64) * 16;      // chunk id = i*256 + tid = row*16 + pc
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa,
+                                             (__attribute__((address_space(3))) void*)(As + base), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb,
+                                             (__attribute__((address_space(3))) void*)(Bs + base), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        const char* As = smem + stage * STAGE_BYTES;
+        const char* Bs = As + BM * BK * 2;
+        const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = tn_frag<T>(As, wm * 4 + i, ks, fr, fg);
+                bf[i] = tn_frag<T>(Bs, wn * 4 + i, ks, fr, fg);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        Cs[(i * 16 + (lane >> 4) * 4 + r) * CS_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+                for (int j = 0; j < 4; ++j) acc[i][j] = TT<T>::mfma(af[i], bf[j], acc[i][j]);
         }
+    };
+    issue(kt_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
+        issue(kt + 1, cur ^ 1);
+        compute(cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-#pragma unroll 1
-        for (int i = 0; i < 4; ++i) {
-            const int id = i * 256 + tid;
-            const int row = id >> 4, c8 = id & 15;
-            const int m = m0 + pass * 64 + row, nc = n0 + c8 * 8;
-            if (m >= p.M || nc >= p.N) continue;
-            float v[8];
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + row * CS_LD + c8 * 8);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + row * CS_LD + c8 * 8 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = lo[j] * p.alpha; v[4 + j] = hi[j] * p.alpha; }
-            const bool full = p.vec_ok && (nc + 8 <= p.N);
-            const int nvalid = min(8, p.N - nc);
-            if (lead) {
-                if (p.bias) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += p.bias[nc + j];
-                }
-                if (p.rowvec) {
-                    const int gi = p.rv_mod ? (m % p.rv_mod) : (m / p.rv_rpg);
-                    const float* rv = p.rowvec + (size_t)gi * p.rv_ld + nc;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += rv[j];
-                }
-                if (R) {
-                    const T* rp = R + (size_t)m * p.ldres + nc;
-                    if (full) {
-                        float rr[8];
-                        load8<T>(rp, rr);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += rr[j];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += to_f<T>(rp[j]);
-                    }
-                }
-            }
-            const size_t co = (size_t)m * p.ldc + nc;
-            if (p.out_mode == SVDX_OUT_ACT) {
-                if (full) {
-                    store8<T>(Ct + co, v);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) if (j < nvalid) Ct[co + j] = from_f<T>(v[j]);
-                }
-            } else if (p.out_mode == SVDX_OUT_F32 || p.out_mode == SVDX_OUT_F32_SLAB) {
-                if (full) {
-                    *reinterpret_cast<f32x4*>(Cf + co) = f32x4{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(Cf + co + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) if (j < nvalid) Cf[co + j] = v[j];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) if (j < nvalid) atomicAdd(Cf + co + j, v[j]);
-            }
-        }
-        __syncthreads();
+        cur ^= 1;
     }
+    compute(cur);
+    __syncthreads();
+    gemm_epilogue<T>(p, acc, smem, m0, n0, z, tid, lane, wm, wn);
 }
 
 // ---- skinny linear: one wave per output column, lanes split K (trans = 0) --------------------------------
@@ -447,7 +574,40 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
     return 0;
 }
 
+template <typename T>
+int launch_gemm_tn(const GemmParams& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * STAGE_BYTES);
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
+    hipLaunchKernelGGL((gemm_tn_kernel<T>), grid, dim3(NTHREADS), 2 * STAGE_BYTES, st, p);
+    SVDX_LAUNCH_CHECK("svdx_gemm_tn");
+    return 0;
+}
+
 }  // namespace
+
+extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
+                            const void* zero_page, int out_mode, int split_k, int dtype, void* stream) {
+    SVDX_CHECK_ARG(A && B && C && zero_page && R > 0 && N > 0 && K > 0, "svdx_gemm_tn: bad args");
+    SVDX_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
+                       ((uintptr_t)zero_page & 15) == 0, "svdx_gemm_tn: operands must be 16-byte aligned, N/K multiples of 8");
+    SVDX_CHECK_ARG(out_mode == SVDX_OUT_F32 || out_mode == SVDX_OUT_F32_ADD || out_mode == SVDX_OUT_F32_SLAB ||
+                       out_mode == SVDX_OUT_F32_ATOMIC, "svdx_gemm_tn: float output modes only");
+    SVDX_CHECK_ARG(split_k >= 1 && (split_k == 1 || out_mode == SVDX_OUT_F32_SLAB || out_mode == SVDX_OUT_F32_ATOMIC),
+                   "svdx_gemm_tn: split_k needs slab or atomic output");
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C; p.M = N; p.N = K; p.K = R; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.bias = nullptr; p.rowvec = nullptr; p.rv_ld = 0; p.rv_rpg = 0; p.rv_mod = 0; p.res = nullptr; p.ldres = 0;
+    p.g = svdx_gather{}; p.zero_page = zero_page; p.out_mode = out_mode; p.alpha = 1.f; p.split_k = split_k;
+    p.tiles_m = cdiv(N, BM); p.tiles_n = cdiv(K, BN);
+    p.vec_ok = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) && (K % 8 == 0);
+    p.slab_stride = (long)N * ldc;
+    DISPATCH_DTYPE(dtype, return launch_gemm_tn<T>(p, (hipStream_t)stream));
+}
 
 extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                          const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsvdx.so")
 
 F16, BF16 = 0, 1
-OUT_ACT, OUT_F32, OUT_F32_ATOMIC, OUT_F32_SLAB = 0, 1, 2, 3
+OUT_ACT, OUT_F32, OUT_F32_ATOMIC, OUT_F32_SLAB, OUT_F32_ADD = 0, 1, 2, 3, 4
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3 = 0, 1, 2, 3
 
 
@@ -57,6 +57,7 @@ class Gather:
 # signature table: p void*, i int, f float, l int64, z size_t
 _SIGS = {
     "svdx_gemm": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifii" "ip",
+    "svdx_gemm_tn": "ppp" "iiiiii" "p" "ii" "ip",
     "svdx_gemm_finalize": "pil" "pi" "iii" "pp" "iii" "pi" "ip",
     "svdx_small_linear": "pppp" "iiii" "iii" "ip",
     "svdx_outer_acc": "ppp" "iii" "f" "p",
@@ -169,6 +170,10 @@ class HipBackend:
                    _f32(rowvec), rv_ld, rv_rpg, rv_mod, _p(res), ldres,
                    ctypes.cast(ctypes.pointer(g), ctypes.c_void_p) if g is not None else None,
                    _p(self._zero_page), out_mode, float(alpha), split_k, variant, _dt(A), self._stream())
+
+    def gemm_tn(self, A, B, C, R, N, K, lda, ldb, ldc, out_mode=OUT_F32_ADD, split_k=1):
+        self._call("svdx_gemm_tn", _p(A), _p(B), _f32(C), R, N, K, lda, ldb, ldc, _p(self._zero_page), out_mode, split_k,
+                   _dt(A), self._stream())
 
     def gemm_finalize(self, acc, nsplit, slab_stride, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
                       res=None, ldres=0, accumulate_f32=False, dtype=None):

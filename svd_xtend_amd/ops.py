@@ -164,22 +164,23 @@ class LinearOp:
         gemm_act(rt, dy, self.wt, dx, M, self.Kdim, self.N, self.N, self.N, self.Kdim)
         return dx
 
-    def bwd_dw(self, rt: Runtime, dy: torch.Tensor, xt: torch.Tensor, M: int) -> None:
-        """w.grad += dy^T x ; b.grad += colsum(dy).   xt = transpose(x) [K, Mpad] (shared by the caller)."""
+    def bwd_dw(self, rt: Runtime, dy: torch.Tensor, x: torch.Tensor, M: int) -> None:
+        """w.grad += dy^T x ; b.grad += colsum(dy).  TN GEMM straight from the row-major dy [M,N] and x [M,K]."""
         if not self.trainable:
             return
         k = rt.k
-        Mp = xt.shape[1]
-        dyt = rt.empty(self.N, Mp)
-        k.transpose(dy, self.N, dyt, Mp, M, self.N)
-        sk = _choose_split_k(self.N, self.Kdim, Mp)
+        tiles = ((self.N + 127) // 128) * ((self.Kdim + 127) // 128)
+        rtiles = (M + 63) // 64
+        sk = 1
+        if tiles < 256 and rtiles >= 16:
+            sk = max(1, min(512 // tiles, rtiles // 4, 32))
+            while sk > 1 and (rtiles + sk - 1) // sk * (sk - 1) >= rtiles:
+                sk -= 1
         if sk == 1:
-            k.gemm(dyt, xt, self.w_grad, self.N, self.Kdim, Mp, Mp, Mp, self.Kdim, out_mode=K.OUT_F32_ATOMIC,
-                   variant=rt.gemm_variant)
+            k.gemm_tn(dy, x, self.w_grad, M, self.N, self.Kdim, self.N, self.Kdim, self.Kdim, out_mode=K.OUT_F32_ADD)
         else:
             slabs = rt.f32(sk, self.N, self.Kdim)
-            k.gemm(dyt, xt, slabs, self.N, self.Kdim, Mp, Mp, Mp, self.Kdim, out_mode=K.OUT_F32_SLAB, split_k=sk,
-                   variant=rt.gemm_variant)
+            k.gemm_tn(dy, x, slabs, M, self.N, self.Kdim, self.N, self.Kdim, self.Kdim, out_mode=K.OUT_F32_SLAB, split_k=sk)
             k.gemm_finalize(slabs, sk, self.N * self.Kdim, self.w_grad, self.N, self.Kdim, self.Kdim, accumulate_f32=True,
                             dtype=rt.dt)
         if self.b_grad is not None:

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .ops import (ConvOp, GroupNormOp, LayerNormOp, LinearOp, Runtime, SmallLinearOp, rup, transpose_pad)
+from .ops import ConvOp, GroupNormOp, LayerNormOp, LinearOp, Runtime, SmallLinearOp, rup
 
 HEAD_DIM = 64
 
@@ -102,13 +102,13 @@ class _FeedForward(nn.Module):
         k = rt.k
         dg = self.p2.bwd_dx(rt, dy, M)
         if self.p2.trainable:
-            self.p2.bwd_dw(rt, dy, transpose_pad(rt, g, M, self.inner), M)
+            self.p2.bwd_dw(rt, dy, g, M)
         dpre = rt.empty(M, 2 * self.inner)
         k.geglu_bwd(dg, pre, dpre, M, self.inner)
         del dg
         dx = self.p1.bwd_dx(rt, dpre, M)
         if self.p1.trainable:
-            self.p1.bwd_dw(rt, dpre, transpose_pad(rt, x_saved, M, self.dim), M)
+            self.p1.bwd_dw(rt, dpre, x_saved, M)
         return dx
 
 
@@ -297,14 +297,14 @@ class TemporalBasicTransformerBlock(nn.Module):
             self.attn2.cross_vec_bwd(rt, dvec, cv, tctx, g.B)
         d_o = self.attn1.o.bwd_dx(rt, dh1, M)
         if self.attn1.o.trainable:
-            self.attn1.o.bwd_dw(rt, dh1, transpose_pad(rt, o, M, C), M)
+            self.attn1.o.bwd_dw(rt, dh1, o, M)
         dqkv = rt.empty(M, 3 * C)
         k.tattn_bwd(qkv, qkv[:, C:], qkv[:, 2 * C:], d_o, dqkv, dqkv[:, C:], dqkv[:, 2 * C:], g.B, g.T, g.HW,
                     self.heads, 3 * C, C, 3 * C, HEAD_DIM ** -0.5)
         del d_o, qkv, o
         dn1 = self.attn1.qkv.bwd_dx(rt, dqkv, M)
         if self.attn1.qkv.trainable:
-            self.attn1.qkv.bwd_dw(rt, dqkv, transpose_pad(rt, n1, M, C), M)
+            self.attn1.qkv.bwd_dw(rt, dqkv, n1, M)
         del dqkv, n1
         dh = self.ln1.bwd(rt, dn1, h, st1, M, add=dh1)
         del dn1, dh1, h

@@ -116,6 +116,23 @@ class EmuBackend:
             assert C.dtype == torch.float32 or out_mode == K.OUT_ACT
             c.copy_(v.to(C.dtype))
 
+    def gemm_tn(self, A, B, C, R, N, Kd, lda, ldb, ldc, out_mode=K.OUT_F32_ADD, split_k=1):
+        a, b = V(A, R, N, lda).float(), V(B, R, Kd, ldb).float()
+        if out_mode == K.OUT_F32_SLAB:
+            assert ldc == Kd
+            rt = (R + 63) // 64
+            per = (rt + split_k - 1) // split_k * 64
+            for z in range(split_k):
+                sl = torch.as_strided(C, (N, Kd), (Kd, 1), C.storage_offset() + z * N * Kd)
+                sl.copy_(a[z * per:(z + 1) * per].t() @ b[z * per:(z + 1) * per])
+            return
+        v = a.t() @ b
+        c = V(C, N, Kd, ldc)
+        if out_mode == K.OUT_F32:
+            c.copy_(v)
+        else:
+            c += v
+
     def gemm_finalize(self, acc, nsplit, slab_stride, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
                       res=None, ldres=0, accumulate_f32=False, dtype=None):
         v = torch.zeros(M, N, device=acc.device)

@@ -110,6 +110,28 @@ def check_gemm_plain(P, dt, variant):
     return res
 
 
+def check_gemm_tn(P, dt):
+    g = torch.Generator().manual_seed(11)
+    res = []
+    for (R, N, Kd) in [(64, 128, 128), (200, 320, 64), (1000, 2560, 320), (77, 8, 1280), (560, 640, 640)]:
+        A, B = rnd((R, N), dt, P.dev, g), rnd((R, Kd), dt, P.dev, g, R ** -0.5)
+        for mode, sk in ((K.OUT_F32, 1), (K.OUT_F32_ADD, 1), (K.OUT_F32_SLAB, 3)):
+            if mode == K.OUT_F32_SLAB:
+                if (R + 63) // 64 < 3:
+                    continue
+                outs = dict(C=torch.zeros(3, N, Kd, device=P.dev))
+            else:
+                outs = dict(C=torch.ones(N, Kd, device=P.dev))
+            o1, o2 = P.run("gemm_tn", lambda o: ((A, B, o["C"], R, N, Kd, N, Kd, Kd), dict(out_mode=mode, split_k=sk)), outs)
+            res.append((f"gemm_tn {R}x{N}x{Kd} mode={mode}", relerr(o1["C"], o2["C"]), tol_for(dt)))
+    big = rnd((300, 3 * 128), dt, P.dev, g)
+    X = rnd((300, 64), dt, P.dev, g)
+    o1, o2 = P.run("gemm_tn", lambda o: ((big[:, 128:], X, o["C"], 300, 128, 64, 384, 64, 64), dict(out_mode=K.OUT_F32)),
+                   dict(C=torch.zeros(128, 64, device=P.dev)))
+    res.append(("gemm_tn strided A", relerr(o1["C"], o2["C"]), tol_for(dt)))
+    return res
+
+
 def check_gemm_gather(P, dt, variant):
     g = torch.Generator().manual_seed(2)
     res = []
@@ -375,7 +397,7 @@ def run_all(impl, dev, dtypes=DTYPES, verbose=True):
     out = []
     for dt in dtypes:
         checks = [("gemm_plain_v0", lambda: check_gemm_plain(P, dt, 0)), ("gemm_plain_v1", lambda: check_gemm_plain(P, dt, 1)),
-                  ("gemm_gather_v0", lambda: check_gemm_gather(P, dt, 0)), ("gemm_gather_v1", lambda: check_gemm_gather(P, dt, 1)),
+                  ("gemm_tn", lambda: check_gemm_tn(P, dt)), ("gemm_gather_v0", lambda: check_gemm_gather(P, dt, 0)), ("gemm_gather_v1", lambda: check_gemm_gather(P, dt, 1)),
                   ("small", lambda: check_small(P, dt)), ("groupnorm", lambda: check_groupnorm(P, dt)),
                   ("layernorm", lambda: check_layernorm(P, dt)), ("attention", lambda: check_attention(P, dt)),
                   ("temporal_attention", lambda: check_temporal_attention(P, dt)), ("elementwise", lambda: check_elementwise(P, dt)),
