@@ -438,6 +438,120 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
     gemm_epilogue<T>(p, acc, smem, m0, n0, z, tid, lane, wm, wn);
 }
 
+
+// ================================================================================================================
+// variant 2: deep LDS ring.  Same 128x128 output tile and wave layout, but K is consumed 32 at a time through a
+// 5-stage ring of 16-KiB stages filled by LDS-DMA (global_load_lds_dwordx4), 4 tiles of prefetch in flight per block
+// and 2 blocks per CU (2 x 80 KiB LDS).  The HBM/L2 latency (~1-2 us under load) is hidden behind 4 MFMA phases
+// instead of one.  Synchronisation is one raw s_barrier per K-step plus a COUNTED s_waitcnt vmcnt(4*tiles_after):
+// a __syncthreads() would drain the whole DMA queue (cdna_hip_programming.md, "Pipelining across barriers").
+// 64-byte LDS rows; the 16-byte chunk index is XORed with 3*((row>>2)&1), which makes the ds_read_b128 fragment
+// reads conflict free for this pitch.
+// ================================================================================================================
+constexpr int PK = 32, PNS = 5, PSTAGE = (BM + BN) * PK * 2;     // 16 KiB per stage
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename TT<T>::v8 v8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int pid_m = swz / p.tiles_n, pid_n = swz - pid_m * p.tiles_n;
+    const int m0 = pid_m * BM, n0 = pid_n * BN;
+    const int kt_total = p.K / PK;
+    const int z = blockIdx.y;
+    int kt_per = (kt_total + p.split_k - 1) / p.split_k;
+    kt_per += kt_per & 1;                                   // keep split boundaries on the 64-deep grid of variant 0/1
+    const int kt_begin = z * kt_per;
+    const int kt_end = min(kt_total, kt_begin + kt_per);
+    if (kt_begin >= kt_end) return;
+    const int nt = kt_end - kt_begin;
+
+    // staging: tile = 128 rows x 4 chunks; thread handles rows (tid>>2) and 64+(tid>>2), one physical chunk
+    const int ld_row = tid >> 2, pc = tid & 3;
+    const int lc = pc ^ (((ld_row >> 2) & 1) * 3);
+    int a_m[2];
+    RowInfo a_ri[2];
+    const T* b_ptr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = min(m0 + i * 64 + ld_row, p.M - 1);
+        a_m[i] = m;
+        a_ri[i] = decode_row(p.g, m);
+        const int n = min(n0 + i * 64 + ld_row, p.N - 1);
+        b_ptr[i] = reinterpret_cast<const T*>(p.B) + (size_t)n * p.ldb + lc * 8;
+    }
+    const int cin = p.g.mode == SVDX_GATHER_PLAIN ? p.K : p.g.cin;
+    const T* zero = reinterpret_cast<const T*>(p.zero_page);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+        const int k0 = kt * PK;
+        int tap = 0, ci0 = k0;
+        if (p.g.mode != SVDX_GATHER_PLAIN) { tap = k0 / cin; ci0 = k0 - tap * cin; }
+        char* As = smem + stage * PSTAGE;
+        char* Bs = As + BM * PK * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bool valid;
+            const T* ptr = a_row_ptr<T>(p, a_ri[i], a_m[i], k0, tap, ci0, valid);
+            const T* pa = valid ? ptr + lc * 8 : zero;
+            const T* pb = b_ptr[i] + k0;
+            const int base = (i * 256 + wave_u * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa,
+                                             (__attribute__((address_space(3))) void*)(As + base), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb,
+                                             (__attribute__((address_space(3))) void*)(Bs + base), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    const int fchunk = (fg ^ (((fr >> 2) & 1) * 3)) * 16;        // (row>>2)&1 == (fr>>2)&1: row offsets are multiples of 16
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        const char* As = smem + stage * PSTAGE;
+        const char* Bs = As + BM * PK * 2;
+        v8 af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = *reinterpret_cast<const v8*>(As + (wm * 64 + i * 16 + fr) * 64 + fchunk);
+            bf[i] = *reinterpret_cast<const v8*>(Bs + (wn * 64 + i * 16 + fr) * 64 + fchunk);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = TT<T>::mfma(af[i], bf[j], acc[i][j]);
+    };
+
+    constexpr int D = PNS - 1;                                   // tiles of prefetch
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nt) issue(kt_begin + s, s);
+    int stage = 0;
+    for (int it = 0; it < nt; ++it) {
+        const int after = min(D - 1, nt - 1 - it);               // tiles issued after tile `it` and still allowed in flight
+        if (after >= 3) wait_vmcnt<12>();
+        else if (after == 2) wait_vmcnt<8>();
+        else if (after == 1) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                            // tile `it` is complete in LDS; stage of tile it-1 is free
+        if (it + D < nt) issue(kt_begin + it + D, stage == 0 ? PNS - 1 : stage - 1);
+        compute(stage);
+        stage = stage + 1 == PNS ? 0 : stage + 1;
+    }
+    __syncthreads();
+    gemm_epilogue<T>(p, acc, smem, m0, n0, z, tid, lane, wm, wn);
+}
+
 // ---- skinny linear: one wave per output column, lanes split K (trans = 0) --------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void small_linear_nt(const float* X, const T* W, const float* bias, float* Y,
@@ -575,6 +689,20 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
 }
 
 template <typename T>
+int launch_gemm_pipe(const GemmParams& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  PNS * PSTAGE);
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
+    hipLaunchKernelGGL((gemm_pipe_kernel<T>), grid, dim3(NTHREADS), PNS * PSTAGE, st, p);
+    SVDX_LAUNCH_CHECK("svdx_gemm");
+    return 0;
+}
+
+template <typename T>
 int launch_gemm_tn(const GemmParams& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -655,7 +783,7 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
     p.vec_ok = (ldc % 8 == 0) && (((uintptr_t)C % (esz == 2 ? 16 : 4)) == 0) &&
                (!res || (ldres % 8 == 0 && ((uintptr_t)res & 15) == 0));
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DTYPE(dtype, return variant == 1 ? launch_gemm<T, true>(p, st) : launch_gemm<T, false>(p, st));
+    DISPATCH_DTYPE(dtype, return variant == 2 ? launch_gemm_pipe<T>(p, st) : variant == 1 ? launch_gemm<T, true>(p, st) : launch_gemm<T, false>(p, st));
 }
 
 extern "C" int svdx_small_linear(const float* X, const void* W, const float* bias, float* Y, int M, int N, int K,
