@@ -552,6 +552,189 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(GemmParams p) {
     gemm_epilogue<T>(p, acc, smem, m0, n0, z, tid, lane, wm, wn);
 }
 
+
+// ================================================================================================================
+// variant 3: 128 x (32*NB) x 64 tile, NB = 4 or 5.  All channel counts of the SVD UNet are multiples of 320, so
+// BN = 160 tiles N exactly (BN = 128 wastes 17 % of the MFMA work at N = 320) and raises the MFMA : ds_read ratio
+// (40 : 18 per wave per K-tile).  The accumulators are kept TRANSPOSED (acc = mfma(B_frag, A_frag)): a lane then owns
+// 4 consecutive output columns of one row, so the epilogue adds bias / row vector / residual and stores straight
+// from registers with 8-byte (activation) or 16-byte (float) accesses -- no LDS staging, no barriers.  Short-K
+// GEMMs (K = 320 at the 40x64 level: 5 K-tiles) spend a third of their time in the epilogue otherwise.
+// ================================================================================================================
+template <typename T, int NB>
+__global__ __launch_bounds__(NTHREADS) void gemm_v3_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename TT<T>::v8 v8;
+    constexpr int BN3 = 32 * NB;                      // 2 waves along N, NB/2... each wave owns NB*16 columns
+    constexpr int WN3 = 16 * NB;                      // columns per wave
+    constexpr int STAGE3 = (BM + BN3) * BK * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int pid_m = swz / p.tiles_n, pid_n = swz - pid_m * p.tiles_n;
+    const int m0 = pid_m * BM, n0 = pid_n * BN3;
+    const int kt_total = p.K / BK;
+    const int z = blockIdx.y;
+    const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
+    const int kt_begin = z * kt_per;
+    const int kt_end = min(kt_total, kt_begin + kt_per);
+    if (kt_begin >= kt_end) return;
+
+    const int ld_row = tid >> 3, pc = tid & 7, lc = pc ^ (ld_row & 7);
+    int a_m[4];
+    RowInfo a_ri[4];
+    const T* b_ptr[NB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = min(m0 + i * 32 + ld_row, p.M - 1);
+        a_m[i] = m;
+        a_ri[i] = decode_row(p.g, m);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = min(n0 + i * 32 + ld_row, p.N - 1);
+        b_ptr[i] = reinterpret_cast<const T*>(p.B) + (size_t)n * p.ldb + lc * 8;
+    }
+    const int cin = p.g.mode == SVDX_GATHER_PLAIN ? p.K : p.g.cin;
+    const T* zero = reinterpret_cast<const T*>(p.zero_page);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+        const int k0 = kt * BK;
+        int tap = 0, ci0 = k0;
+        if (p.g.mode != SVDX_GATHER_PLAIN) { tap = k0 / cin; ci0 = k0 - tap * cin; }
+        char* As = smem + stage * STAGE3;
+        char* Bs = As + BM * BK * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bool valid;
+            const T* ptr = a_row_ptr<T>(p, a_ri[i], a_m[i], k0, tap, ci0, valid);
+            const T* pa = valid ? ptr + lc * 8 : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa,
+                                             (__attribute__((address_space(3))) void*)(As + (i * 256 + wave_u * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(Bs + (i * 256 + wave_u * 64) * 16), 16, 0, 0);
+    };
+    f32x4 acc[NB][4];                                   // [n-block][m-block], transposed: rows = n, cols = m
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        const char* As = smem + stage * STAGE3;
+        const char* Bs = As + BM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+            v8 af[4], bf[NB];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(As + (wm * 64 + i * 16 + fr) * 128 + chunk);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) bf[i] = *reinterpret_cast<const v8*>(Bs + (wn * WN3 + i * 16 + fr) * 128 + chunk);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = TT<T>::mfma(bf[i], af[j], acc[i][j]);
+        }
+    };
+    issue(kt_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
+        issue(kt + 1, cur ^ 1);
+        compute(cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    compute(cur);
+
+    // ---- direct epilogue: lane (fr, fg) owns row m = .. + fr and columns n = .. + fg*4 + {0..3} of every 16x16 block ----
+    const bool lead = (z == 0) && p.out_mode != SVDX_OUT_F32_SLAB;
+    T* Ct = reinterpret_cast<T*>(p.C);
+    float* Cf = reinterpret_cast<float*>(p.C) + (p.out_mode == SVDX_OUT_F32_SLAB ? (size_t)z * p.slab_stride : 0);
+    const T* R = reinterpret_cast<const T*>(p.res);
+    const int nbase = n0 + wn * WN3 + fg * 4;
+    float bv[NB][4];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = nbase + i * 16 + e;
+            bv[i][e] = (lead && p.bias && n < p.N) ? p.bias[n] : 0.f;
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + fr;
+        if (m >= p.M) continue;
+        const float* rv = nullptr;
+        if (lead && p.rowvec) rv = p.rowvec + (size_t)(p.rv_mod ? (m % p.rv_mod) : (m / p.rv_rpg)) * p.rv_ld;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int n = nbase + i * 16;
+            if (n >= p.N) continue;
+            const int nvalid = min(4, p.N - n);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha + bv[i][e];
+            if (rv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += rv[n + e];
+            }
+            const bool full = p.vec_ok && nvalid == 4;
+            if (lead && R) {
+                const T* rp = R + (size_t)m * p.ldres + n;
+                if (full) {
+                    const Vec4<T> r4 = *reinterpret_cast<const Vec4<T>*>(rp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += to_f<T>(r4.v[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += to_f<T>(rp[e]);
+                }
+            }
+            const size_t co = (size_t)m * p.ldc + n;
+            if (p.out_mode == SVDX_OUT_ACT) {
+                if (full) {
+                    Vec4<T> o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(v[e]);
+                    *reinterpret_cast<Vec4<T>*>(Ct + co) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nvalid) Ct[co + e] = from_f<T>(v[e]);
+                }
+            } else if (p.out_mode == SVDX_OUT_F32 || p.out_mode == SVDX_OUT_F32_SLAB) {
+                if (full) *reinterpret_cast<f32x4*>(Cf + co) = f32x4{v[0], v[1], v[2], v[3]};
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nvalid) Cf[co + e] = v[e];
+                }
+            } else if (p.out_mode == SVDX_OUT_F32_ADD) {
+                if (full) {
+                    f32x4 c = *reinterpret_cast<const f32x4*>(Cf + co);
+                    c += f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(Cf + co) = c;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nvalid) Cf[co + e] += v[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nvalid) atomicAdd(Cf + co + e, v[e]);
+            }
+        }
+    }
+}
+
 // ---- skinny linear: one wave per output column, lanes split K (trans = 0) --------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void small_linear_nt(const float* X, const T* W, const float* bias, float* Y,
@@ -688,6 +871,25 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
     return 0;
 }
 
+template <typename T, int NB>
+int launch_gemm_v3(GemmParams p, hipStream_t st) {
+    constexpr int LDS = 2 * (BM + 32 * NB) * BK * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v3_kernel<T, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    p.tiles_n = cdiv(p.N, 32 * NB);
+    // 4-wide vector access needs ldc % 4 and 8-byte (act) / 16-byte (float) aligned bases
+    const int esz = p.out_mode == SVDX_OUT_ACT ? 2 : 4;
+    p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C % (esz == 2 ? 8 : 16)) == 0) &&
+               (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 7) == 0));
+    dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
+    hipLaunchKernelGGL((gemm_v3_kernel<T, NB>), grid, dim3(NTHREADS), LDS, st, p);
+    SVDX_LAUNCH_CHECK("svdx_gemm");
+    return 0;
+}
+
 template <typename T>
 int launch_gemm_pipe(const GemmParams& p, hipStream_t st) {
     static bool attr_set = false;
@@ -783,7 +985,10 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
     p.vec_ok = (ldc % 8 == 0) && (((uintptr_t)C % (esz == 2 ? 16 : 4)) == 0) &&
                (!res || (ldres % 8 == 0 && ((uintptr_t)res & 15) == 0));
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DTYPE(dtype, return variant == 2 ? launch_gemm_pipe<T>(p, st) : variant == 1 ? launch_gemm<T, true>(p, st) : launch_gemm<T, false>(p, st));
+    DISPATCH_DTYPE(dtype, {
+        if (variant == 3) return (N % 160 == 0) ? launch_gemm_v3<T, 5>(p, st) : launch_gemm_v3<T, 4>(p, st);
+        return variant == 2 ? launch_gemm_pipe<T>(p, st) : variant == 1 ? launch_gemm<T, true>(p, st) : launch_gemm<T, false>(p, st);
+    });
 }
 
 extern "C" int svdx_small_linear(const float* X, const void* W, const float* bias, float* Y, int M, int N, int K,

@@ -54,7 +54,7 @@ class Pair:
 def check_gemm_plain(P, dt, variant):
     g = torch.Generator().manual_seed(1)
     res = []
-    shapes = [(128, 128, 64), (200, 320, 320), (1000, 4, 576), (130, 2560, 128), (64, 640, 1280), (3, 320, 64)]
+    shapes = [(128, 128, 64), (200, 320, 320), (1000, 4, 576), (130, 2560, 128), (64, 640, 1280), (3, 320, 64), (300, 960, 192)]
     for (M, N, Kd) in shapes:
         A, B = rnd((M, Kd), dt, P.dev, g), rnd((N, Kd), dt, P.dev, g, Kd ** -0.5)
         bias, R = rndf((N,), P.dev, g), rnd((M, N), dt, P.dev, g)
@@ -398,6 +398,7 @@ def run_all(impl, dev, dtypes=DTYPES, verbose=True):
     for dt in dtypes:
         checks = [("gemm_plain_v0", lambda: check_gemm_plain(P, dt, 0)), ("gemm_plain_v1", lambda: check_gemm_plain(P, dt, 1)),
                   ("gemm_plain_v2", lambda: check_gemm_plain(P, dt, 2)), ("gemm_gather_v2", lambda: check_gemm_gather(P, dt, 2)),
+                  ("gemm_plain_v3", lambda: check_gemm_plain(P, dt, 3)), ("gemm_gather_v3", lambda: check_gemm_gather(P, dt, 3)),
                   ("gemm_tn", lambda: check_gemm_tn(P, dt)), ("gemm_gather_v0", lambda: check_gemm_gather(P, dt, 0)), ("gemm_gather_v1", lambda: check_gemm_gather(P, dt, 1)),
                   ("small", lambda: check_small(P, dt)), ("groupnorm", lambda: check_groupnorm(P, dt)),
                   ("layernorm", lambda: check_layernorm(P, dt)), ("attention", lambda: check_attention(P, dt)),
