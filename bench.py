@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-table", action="store_true", help="dump per-shape GEMM timings of one step")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny topology instead of the SVD config")
     args = ap.parse_args()
 
@@ -205,7 +206,7 @@ def main():
     roof = None
     if not args.no_roofline and rank == 0:
         k = trainer.rt.k
-        orig = k.gemm
+        orig, orig_tn = k.gemm, k.gemm_tn
         recs = []
 
         def timed_gemm(A, Bm, C, M, N, Kd, *a, **kw):
@@ -213,19 +214,39 @@ def main():
             e0.record()
             orig(A, Bm, C, M, N, Kd, *a, **kw)
             e1.record()
-            recs.append((e0, e1, 2.0 * M * N * Kd))
-        k.gemm = timed_gemm
+            g = kw.get("gather")
+            recs.append((e0, e1, 2.0 * M * N * Kd, ("nt", M, N, Kd, g.mode if g is not None else 0, kw.get("split_k", 1))))
+
+        def timed_gemm_tn(A, Bm, C, R, N, Kd, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig_tn(A, Bm, C, R, N, Kd, *a, **kw)
+            e1.record()
+            recs.append((e0, e1, 2.0 * R * N * Kd, ("tn", N, Kd, R, 0, kw.get("split_k", 1))))
+        k.gemm, k.gemm_tn = timed_gemm, timed_gemm_tn
         try:
             fwd_bwd()
             torch.cuda.synchronize()
         finally:
-            k.gemm = orig
+            k.gemm, k.gemm_tn = orig, orig_tn
         opt_step()
         torch.cuda.synchronize()
+        if args.gemm_table:
+            agg = {}
+            for a, b, f, key in recs:
+                e = agg.setdefault(key, [0, 0.0, 0.0])
+                e[0] += 1
+                e[1] += a.elapsed_time(b)
+                e[2] += f
+            rows = sorted(([list(kk) + [v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12] for kk, v in agg.items()]), key=lambda r: -r[7])
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "gemm_table.json"), "w") as f:
+                json.dump(rows, f)
+        recs = [(a, b, f) for a, b, f, _ in recs]
         t_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
         fl = sum(f for _, _, f in recs)
         ach = fl / (t_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_kernel (NT GEMM + implicit conv)", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
+        roof = {"bound": "mfma", "kernel": "MFMA GEMM family (NT + implicit conv, TN weight-grad)", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None, "launches": len(recs),
                 "flops_per_step": fl, "kernel_ms_per_step": t_ms}
 

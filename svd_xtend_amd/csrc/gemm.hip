@@ -29,7 +29,7 @@ struct GemmParams {
     const float* bias; const float* rowvec; int rv_ld, rv_rpg, rv_mod;
     const void* res; int ldres;
     svdx_gather g; const void* zero_page;
-    int out_mode; float alpha; int split_k; int tiles_m, tiles_n; int vec_ok; long slab_stride;
+    int out_mode; float alpha; int split_k; int tiles_m, tiles_n; int vec_ok; long slab_stride; int a_bytes, b_bytes;
 };
 
 struct RowInfo { int a, b, base; };   // per gathered A row (meaning depends on gather mode)
@@ -735,6 +735,192 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v3_kernel(GemmParams p) {
     }
 }
 
+// ================================================================================================================
+// variant 4 = variant 3 with a LEAN K-loop.  PMC counters on variant 3 (profiles/r1_gemm_pmc.txt): 2.4 VALU + 2.9 SALU
+// instructions per MFMA -- 64-bit pointer arithmetic, gather-mode branches and M0 setup -- make the loop issue-bound
+// (MFMA busy ~33 %).  Here the tiles are staged with buffer_load_dwordx4 ... lds: per-lane 32-bit byte offsets are
+// computed once per filter tap, the K position is a single scalar soffset, and zero padding comes from the buffer
+// bounds check (offset >= num_records reads 0) instead of a zero page + select.
+// ================================================================================================================
+template <typename T, int NB>
+__global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename TT<T>::v8 v8;
+    constexpr int BN3 = 32 * NB;                      // 2 waves along N, NB/2... each wave owns NB*16 columns
+    constexpr int WN3 = 16 * NB;                      // columns per wave
+    constexpr int STAGE3 = (BM + BN3) * BK * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int pid_m = swz / p.tiles_n, pid_n = swz - pid_m * p.tiles_n;
+    const int m0 = pid_m * BM, n0 = pid_n * BN3;
+    const int kt_total = p.K / BK;
+    const int z = blockIdx.y;
+    const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
+    const int kt_begin = z * kt_per;
+    const int kt_end = min(kt_total, kt_begin + kt_per);
+    if (kt_begin >= kt_end) return;
+
+    // ---- lean staging: buffer_load ... lds with per-lane byte offsets (fixed per filter tap) + one scalar K offset ----
+    const int ld_row = tid >> 3, pc = tid & 7, lc = pc ^ (ld_row & 7);
+    RowInfo a_ri[4];
+    int a_m[4], voa[4], vob[NB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_m[i] = min(m0 + i * 32 + ld_row, p.M - 1);
+        a_ri[i] = decode_row(p.g, a_m[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) vob[i] = (min(n0 + i * 32 + ld_row, p.N - 1) * p.ldb + lc * 8) * 2;
+    const bool plain = p.g.mode == SVDX_GATHER_PLAIN;
+    const int cin = plain ? p.K : p.g.cin;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int tap = plain ? 0 : (kt_begin * BK) / cin;
+    int ci0 = kt_begin * BK - tap * cin;                // channel offset inside the tap (plain: k offset)
+    auto set_tap = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bool valid;
+            const T* ptr = a_row_ptr<T>(p, a_ri[i], a_m[i], 0, tap, 0, valid);
+            // invalid (zero-padding) rows: an offset beyond num_records makes the buffer load return zeros
+            voa[i] = valid ? (int)((ptr - reinterpret_cast<const T*>(p.A)) + lc * 8) * 2 : (int)0x80000000;
+        }
+    };
+    set_tap();
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        char* As = smem + stage * STAGE3;
+        char* Bs = As + BM * BK * 2;
+        const int soa = ci0 * 2, sob = (tap * cin + ci0) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(As + (i * 256 + wave_u * 64) * 16), 16,
+                                                     voa[i], soa, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(Bs + (i * 256 + wave_u * 64) * 16), 16,
+                                                     vob[i], sob, 0, 0);
+        ci0 += BK;
+        if (!plain && ci0 == cin) { ci0 = 0; ++tap; set_tap(); }
+    };
+    f32x4 acc[NB][4];                                   // [n-block][m-block], transposed: rows = n, cols = m
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        const char* As = smem + stage * STAGE3;
+        const char* Bs = As + BM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+            v8 af[4], bf[NB];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(As + (wm * 64 + i * 16 + fr) * 128 + chunk);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) bf[i] = *reinterpret_cast<const v8*>(Bs + (wn * WN3 + i * 16 + fr) * 128 + chunk);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = TT<T>::mfma(bf[i], af[j], acc[i][j]);
+        }
+    };
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
+        issue(cur ^ 1);
+        compute(cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    compute(cur);
+
+    // ---- direct epilogue: lane (fr, fg) owns row m = .. + fr and columns n = .. + fg*4 + {0..3} of every 16x16 block ----
+    const bool lead = (z == 0) && p.out_mode != SVDX_OUT_F32_SLAB;
+    T* Ct = reinterpret_cast<T*>(p.C);
+    float* Cf = reinterpret_cast<float*>(p.C) + (p.out_mode == SVDX_OUT_F32_SLAB ? (size_t)z * p.slab_stride : 0);
+    const T* R = reinterpret_cast<const T*>(p.res);
+    const int nbase = n0 + wn * WN3 + fg * 4;
+    float bv[NB][4];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = nbase + i * 16 + e;
+            bv[i][e] = (lead && p.bias && n < p.N) ? p.bias[n] : 0.f;
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + fr;
+        if (m >= p.M) continue;
+        const float* rv = nullptr;
+        if (lead && p.rowvec) rv = p.rowvec + (size_t)(p.rv_mod ? (m % p.rv_mod) : (m / p.rv_rpg)) * p.rv_ld;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int n = nbase + i * 16;
+            if (n >= p.N) continue;
+            const int nvalid = min(4, p.N - n);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha + bv[i][e];
+            if (rv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += rv[n + e];
+            }
+            const bool full = p.vec_ok && nvalid == 4;
+            if (lead && R) {
+                const T* rp = R + (size_t)m * p.ldres + n;
+                if (full) {
+                    const Vec4<T> r4 = *reinterpret_cast<const Vec4<T>*>(rp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += to_f<T>(r4.v[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += to_f<T>(rp[e]);
+                }
+            }
+            const size_t co = (size_t)m * p.ldc + n;
+            if (p.out_mode == SVDX_OUT_ACT) {
+                if (full) {
+                    Vec4<T> o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(v[e]);
+                    *reinterpret_cast<Vec4<T>*>(Ct + co) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nvalid) Ct[co + e] = from_f<T>(v[e]);
+                }
+            } else if (p.out_mode == SVDX_OUT_F32 || p.out_mode == SVDX_OUT_F32_SLAB) {
+                if (full) *reinterpret_cast<f32x4*>(Cf + co) = f32x4{v[0], v[1], v[2], v[3]};
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nvalid) Cf[co + e] = v[e];
+                }
+            } else if (p.out_mode == SVDX_OUT_F32_ADD) {
+                if (full) {
+                    f32x4 c = *reinterpret_cast<const f32x4*>(Cf + co);
+                    c += f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(Cf + co) = c;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nvalid) Cf[co + e] += v[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nvalid) atomicAdd(Cf + co + e, v[e]);
+            }
+        }
+    }
+}
+
 // ---- skinny linear: one wave per output column, lanes split K (trans = 0) --------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void small_linear_nt(const float* X, const T* W, const float* bias, float* Y,
@@ -890,6 +1076,24 @@ int launch_gemm_v3(GemmParams p, hipStream_t st) {
     return 0;
 }
 
+template <typename T, int NB>
+int launch_gemm_v4(GemmParams p, hipStream_t st) {
+    constexpr int LDS = 2 * (BM + 32 * NB) * BK * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    p.tiles_n = cdiv(p.N, 32 * NB);
+    const int esz = p.out_mode == SVDX_OUT_ACT ? 2 : 4;
+    p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C % (esz == 2 ? 8 : 16)) == 0) &&
+               (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 7) == 0));
+    dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
+    hipLaunchKernelGGL((gemm_v4_kernel<T, NB>), grid, dim3(NTHREADS), LDS, st, p);
+    SVDX_LAUNCH_CHECK("svdx_gemm");
+    return 0;
+}
+
 template <typename T>
 int launch_gemm_pipe(const GemmParams& p, hipStream_t st) {
     static bool attr_set = false;
@@ -985,8 +1189,21 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
     p.vec_ok = (ldc % 8 == 0) && (((uintptr_t)C % (esz == 2 ? 16 : 4)) == 0) &&
                (!res || (ldres % 8 == 0 && ((uintptr_t)res & 15) == 0));
     hipStream_t st = (hipStream_t)stream;
+    // extents of the A / B buffers for the bounds-checked buffer loads of variant 4 (must stay below 2 GiB)
+    long a_rows = M;
+    if (p.g.mode == SVDX_GATHER_CONV3X3) a_rows = (long)p.g.n_img * (p.g.hi >> p.g.ups) * (p.g.wi >> p.g.ups);
+    else if (p.g.mode == SVDX_GATHER_CONV3X3_DGRAD2) a_rows = (long)p.g.n_img * p.g.hi * p.g.wi;
+    else if (p.g.mode == SVDX_GATHER_TEMPORAL3) a_rows = (long)p.g.n_img * p.g.t * p.g.hw;
+    const int a_ld = p.g.mode == SVDX_GATHER_PLAIN ? lda : p.g.lda;
+    const int a_w = p.g.mode == SVDX_GATHER_PLAIN ? K : p.g.cin;
+    long a_bytes = ((a_rows - 1) * a_ld + a_w) * 2, b_bytes = ((long)(N - 1) * ldb + K) * 2;
+    if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) { a_bytes = 0; b_bytes = 0; if (variant == 4) variant = 3; }
     DISPATCH_DTYPE(dtype, {
         if (variant == 3) return (N % 160 == 0) ? launch_gemm_v3<T, 5>(p, st) : launch_gemm_v3<T, 4>(p, st);
+        if (variant == 4 && a_bytes > 0 && b_bytes > 0) {
+            p.a_bytes = (int)a_bytes; p.b_bytes = (int)b_bytes;
+            return (N % 160 == 0) ? launch_gemm_v4<T, 5>(p, st) : launch_gemm_v4<T, 4>(p, st);
+        }
         return variant == 2 ? launch_gemm_pipe<T>(p, st) : variant == 1 ? launch_gemm<T, true>(p, st) : launch_gemm<T, false>(p, st);
     });
 }
