@@ -744,6 +744,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v3_kernel(GemmParams p) {
 // ================================================================================================================
 template <typename T, int NB>
 __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and LDS-DMA builtin only exist in the device pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
     constexpr int BN3 = 32 * NB;                      // 2 waves along N, NB/2... each wave owns NB*16 columns
@@ -919,6 +920,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
             }
         }
     }
+#endif
 }
 
 // ---- skinny linear: one wave per output column, lanes split K (trans = 0) --------------------------------
