@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--height", type=int, default=320)     # pixels; README.md:40-53 trains 512x320
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
-    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("SVDX_GEMM_VARIANT", "1")))
+    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("SVDX_GEMM_VARIANT", "4")))
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

@@ -29,7 +29,7 @@ class Runtime:
         self.dt = dtype
         self.dev = device
         self.k = K.backend()
-        self.gemm_variant = 1      # 0: register-staged tiles, 1: global_load_lds (LDS-DMA) staging
+        self.gemm_variant = 4      # 0 reg-staged, 1 global_load_lds, 2 deep ring, 3 BN160+direct epilogue, 4 = 3 + lean buffer_load-lds loop
         self.split_k = True
         self.profile = None     # optional callable(kind, flops, bytes) -> context manager (bench instrumentation)
 
