@@ -631,6 +631,7 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         self.add_embedding = _TimestepEmbedding(projection_class_embeddings_input_dim, temb)
 
         self.down_blocks = nn.ModuleList()
+        self.up_blocks = nn.ModuleList()      # registered before mid_block, as in the reference (:146-147): same parameter order
         out_c = ch[0]
         for i, t in enumerate(down_block_types):
             in_c, out_c = out_c, ch[i]
@@ -649,7 +650,6 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         self.mid_block = _Block([SpatioTemporalResBlock(mid_c, mid_c, temb, 1e-5) for _ in range(2)],
                                 [TransformerSpatioTemporalModel(heads[-1], mid_c, tl[-1], cross[-1])])
 
-        self.up_blocks = nn.ModuleList()
         rch, rheads, rlayers, rcross, rtl = (list(reversed(v)) for v in (ch, heads, layers, cross, tl))
         out_c = rch[0]
         for i, t in enumerate(up_block_types):

@@ -1,0 +1,55 @@
+"""C-ABI boundary: libsvdx.so loads, exports every symbol include/svdx.h declares, and the product refuses to run
+without a GPU (no CPU fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "svdx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(svdx_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from svd_xtend_amd import build, kernels
+    path = build.build()
+    return kernels.load_library(path)
+
+
+def test_header_and_binding_agree():
+    from svd_xtend_amd import kernels
+    assert header_symbols() == sorted(kernels.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    assert lib.svdx_version() >= 100
+
+
+def test_error_reporting_without_device(lib):
+    import ctypes
+    # argument validation happens before any launch, so it can be exercised without a GPU
+    rc = lib.svdx_gemm(None, None, None, 0, 0, 0, 0, 0, 0, None, None, 0, 0, 0, None, 0, None, None, 0, 1.0, 1, 0, 0, None)
+    assert rc != 0
+    buf = ctypes.create_string_buffer(256)
+    lib.svdx_last_error(buf, 256)
+    assert b"svdx_gemm" in buf.value
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only box check")
+def test_product_fails_loudly_without_gpu():
+    from svd_xtend_amd import kernels
+    prev = kernels._backend
+    kernels._backend = None
+    try:
+        with pytest.raises(kernels.SvdxError):
+            kernels.backend()
+    finally:
+        kernels._backend = prev
