@@ -22,6 +22,27 @@ def rup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+def flatten_trainables(model: "nn.Module", align: int = 64):
+    """Re-home every trainable parameter (and its .grad) as a view of one flat float buffer, in named_parameters()
+    order -- adjacent q/k/v weights then form one [3C, C] block for the fused weight-grad GEMM, and the whole set is
+    one all-reduce / one AdamW launch.  Returns (params, offsets, n_flat, p_flat, g_flat); the buffers carry one extra
+    aligned slot at the tail (the loss rides there through the gradient all-reduce)."""
+    params = [p for _, p in model.named_parameters() if p.requires_grad]
+    dev = params[0].device if params else next(model.parameters()).device
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off = rup(off + p.numel(), align)
+    p_flat = torch.zeros(off + align, dtype=torch.float32, device=dev)
+    g_flat = torch.zeros(off + align, dtype=torch.float32, device=dev)
+    for p, o in zip(params, offs):
+        n = p.numel()
+        p_flat[o:o + n].copy_(p.data.reshape(-1))
+        p.data = p_flat[o:o + n].view(p.shape)
+        p.grad = g_flat[o:o + n].view(p.shape)
+    return params, offs, off, p_flat, g_flat
+
+
 class Runtime:
     """Per-model execution context: backend, activation dtype, device, scratch allocation."""
 

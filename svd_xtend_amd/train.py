@@ -13,7 +13,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
-from .ops import rup
+from .ops import flatten_trainables
 from .unet import UNetSpatioTemporalConditionModel
 
 ALIGN = 64  # floats
@@ -44,25 +44,13 @@ class Trainer:
         self.dev = dev
 
         self.names = select_trainable(model)
-        params = dict(model.named_parameters())
-        self.params = [params[n] for n in self.names]
-        offs, off = [], 0
-        for p in self.params:
-            offs.append(off)
-            off = rup(off + p.numel(), ALIGN)
-        self.offsets, self.n_flat = offs, off
+        self.params, self.offsets, off, self.p_flat, self.g_flat = flatten_trainables(model, ALIGN)
+        self.n_flat = off
         # one extra aligned slot at the tail carries the loss through the gradient all-reduce (replaces the
         # separate accelerator.gather of train_svd.py:1039-1040)
         self.n_total = off + ALIGN
-        self.p_flat = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
-        self.g_flat = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
         self.m_flat = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
         self.v_flat = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
-        for p, o in zip(self.params, offs):
-            n = p.numel()
-            self.p_flat[o:o + n].copy_(p.data.reshape(-1))
-            p.data = self.p_flat[o:o + n].view(p.shape)
-            p.grad = self.g_flat[o:o + n].view(p.shape)
         self.loss_slot = self.g_flat[off:off + 1]
         # opt_state: 0 step, 1 loss_scale, 2 growth_tracker, 3 found_inf, 4 inv_scale, 5 bc1, 6 bc2, 7 skip
         self.dynamic = dtype == torch.float16

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .ops import ConvOp, GroupNormOp, LayerNormOp, LinearOp, Runtime, SmallLinearOp, rup
+from .ops import ConvOp, GroupNormOp, LayerNormOp, LinearOp, Runtime, SmallLinearOp, flatten_trainables, rup
 
 HEAD_DIM = 64
 
@@ -715,6 +715,9 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         """Build operator objects and pack weights into kernel layouts.  Call after weights are loaded, after
         `requires_grad` flags are final and (for training) after the Trainer has installed flat grads."""
         dev = next(self.parameters()).device
+        if any(p.requires_grad and p.grad is None for p in self.parameters()):
+            # stand-alone use (host script keeps its own optimizer): give the trainables flat, adjacent storage
+            self._flat = flatten_trainables(self)
         self.rt = rt = Runtime(dtype, dev)
         self.steps = self._steps()
         # which modules need an input gradient: only those executed after the first trainable parameter

@@ -78,6 +78,28 @@ def test_drop_in_forward_and_autograd_boundary(emu_backend):
     assert torch.allclose(g, g_ref, atol=1e-5 * float(g_ref.abs().max()) + 1e-8)
 
 
+def test_minimal_change_route_with_torch_optimizer(emu_backend):
+    """INTEGRATION.md section 1, first route: host script keeps loss.backward() and torch.optim.AdamW."""
+    orc, m = build_pair(8)
+    select_trainable(m)
+    m.prepare(torch.float32)
+    opt_ref = make_optimizer(orc, lr=1e-3)
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-2)
+    batch = make_synthetic_batch(1, 2, 16, 16, 9, cross_dim=64)
+    unet_in, ts, ehs, ids, noisy, sig = edm_inputs(batch)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=False)
+        edm_loss(m(unet_in, ts, ehs, added_time_ids=ids).sample, noisy, batch["latents"], sig).backward()
+        opt.step()
+        m.refresh_trainable()
+        edm_loss(orc(unet_in, ts, ehs, added_time_ids=ids).sample, noisy, batch["latents"], sig).backward()
+        opt_ref.step()
+        opt_ref.zero_grad()
+    out = m(unet_in, ts, ehs, ids).sample
+    ref = orc(unet_in, ts, ehs, added_time_ids=ids).sample
+    assert torch.allclose(out, ref, atol=5e-4), float((out - ref).abs().max())
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
 def test_low_precision_storage_meets_loss_tolerance(emu_backend, dt, tol):
     ref = e2e_checks.oracle_step(TINY_CONFIG, 1, 3, 16, 16, seed=3, lr=1e-4, cross_dim=64)
