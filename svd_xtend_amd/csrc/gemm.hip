@@ -844,6 +844,62 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
     }
     compute(cur);
 
+    // ---- epilogue A (activation output): coalesced.  Each lane adds bias / row vector to its 4-column groups, rounds to the
+    //      activation dtype and parks them in LDS (the stage buffers are free now); then every thread moves 16-byte row
+    //      pieces: residual add + store with full-line coalescing (20 lanes cover one 320-byte output row of the tile).
+    if (p.out_mode == SVDX_OUT_ACT && p.vec_ok && (p.ldc % 8 == 0) && (!p.res || p.ldres % 8 == 0) && (n0 + BN3 <= p.N)) {
+        constexpr int PITCH = (BN3 + 8) * 2;              // bytes per staged row (multiple of 16)
+        __syncthreads();
+        {
+            const bool lead0 = (z == 0);
+            const int nb0 = n0 + wn * WN3 + fg * 4;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                float bb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bb[e] = (lead0 && p.bias) ? p.bias[nb0 + i * 16 + e] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ml = wm * 64 + j * 16 + fr;
+                    const int m = min(m0 + ml, p.M - 1);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha + bb[e];
+                    if (lead0 && p.rowvec) {
+                        const float* rv = p.rowvec + (size_t)(p.rv_mod ? (m % p.rv_mod) : (m / p.rv_rpg)) * p.rv_ld + nb0 + i * 16;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+                    Vec4<T> o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(v[e]);
+                    *reinterpret_cast<Vec4<T>*>(smem + ml * PITCH + (wn * WN3 + i * 16 + fg * 4) * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BN3 / 8;                      // 16-byte chunks per row
+        T* Ct2 = reinterpret_cast<T*>(p.C);
+        const T* R2 = (z == 0) ? reinterpret_cast<const T*>(p.res) : nullptr;
+#pragma unroll 2
+        for (int id = tid; id < BM * CPR; id += NTHREADS) {
+            const int row = id / CPR, c = id - row * CPR;
+            const int m = m0 + row;
+            if (m >= p.M) continue;
+            const Vec8<T> t8 = *reinterpret_cast<const Vec8<T>*>(smem + row * PITCH + c * 16);
+            const size_t co = (size_t)m * p.ldc + n0 + c * 8;
+            if (R2) {
+                const Vec8<T> r8 = *reinterpret_cast<const Vec8<T>*>(R2 + (size_t)m * p.ldres + n0 + c * 8);
+                Vec8<T> o8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8.v[e] = from_f<T>(to_f<T>(t8.v[e]) + to_f<T>(r8.v[e]));
+                *reinterpret_cast<Vec8<T>*>(Ct2 + co) = o8;
+            } else {
+                *reinterpret_cast<Vec8<T>*>(Ct2 + co) = t8;
+            }
+        }
+        return;
+    }
     // ---- direct epilogue: lane (fr, fg) owns row m = .. + fr and columns n = .. + fg*4 + {0..3} of every 16x16 block ----
     const bool lead = (z == 0) && p.out_mode != SVDX_OUT_F32_SLAB;
     T* Ct = reinterpret_cast<T*>(p.C);
@@ -1088,8 +1144,8 @@ int launch_gemm_v4(GemmParams p, hipStream_t st) {
     }
     p.tiles_n = cdiv(p.N, 32 * NB);
     const int esz = p.out_mode == SVDX_OUT_ACT ? 2 : 4;
-    p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C % (esz == 2 ? 8 : 16)) == 0) &&
-               (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 7) == 0));
+    p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 15) == 0));
+    (void)esz;
     dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
     hipLaunchKernelGGL((gemm_v4_kernel<T, NB>), grid, dim3(NTHREADS), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm");
