@@ -979,41 +979,41 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
 #endif
 }
 
-// ---- skinny linear: one wave per output column, lanes split K (trans = 0) --------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void small_linear_nt(const float* X, const T* W, const float* bias, float* Y,
-                                                       int M, int N, int K, int ldw, int silu_in, int accumulate) {
+// ---- skinny linear: one wave per output column, lanes split K (trans = 0); MT rows of X per pass ------------------
+template <typename T, int MT>
+__global__ __launch_bounds__(256) void small_linear_nt(const float* __restrict__ X, const T* __restrict__ W, const float* __restrict__ bias,
+                                                       float* Y, int M, int N, int K, int ldw, int silu_in, int accumulate) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const T* w = W + (size_t)n * ldw;
-    for (int mb = 0; mb < M; mb += 8) {
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int mb = 0; mb < M; mb += MT) {
+        float acc[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) acc[mi] = 0.f;
         for (int k8 = lane; k8 * 8 < K; k8 += 64) {
             float wv[8];
             load8<T>(w + k8 * 8, wv);
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
+            for (int mi = 0; mi < MT; ++mi) {
                 if (mb + mi < M) {
-                    const float* x = X + (size_t)(mb + mi) * K + k8 * 8;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(X + (size_t)(mb + mi) * K + k8 * 8);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(X + (size_t)(mb + mi) * K + k8 * 8 + 4);
+                    float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
                     float s = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float xv = x[j];
-                        if (silu_in) xv = siluf_(xv);
-                        s += xv * wv[j];
-                    }
+                    for (int j = 0; j < 8; ++j) s += (silu_in ? siluf_(xv[j]) : xv[j]) * wv[j];
                     acc[mi] += s;
                 }
             }
         }
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            float s = wave_sum(acc[mi]);
+        for (int mi = 0; mi < MT; ++mi) {
+            const float s = wave_sum(acc[mi]);
             if (lane == 0 && mb + mi < M) {
-                if (bias) s += bias[n];
                 float* y = Y + (size_t)(mb + mi) * N + n;
-                *y = accumulate ? *y + s : s;
+                const float r = s + (bias ? bias[n] : 0.f);
+                *y = accumulate ? *y + r : r;
             }
         }
     }
@@ -1273,8 +1273,16 @@ extern "C" int svdx_small_linear(const float* X, const void* W, const float* bia
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, {
         if (trans == 0) {
-            hipLaunchKernelGGL((small_linear_nt<T>), dim3(cdiv(N, 4)), dim3(256), 0, st, X, (const T*)W, bias, Y, M, N, K,
-                               ldw, silu_in, accumulate);
+            SVDX_CHECK_ARG(((uintptr_t)X & 15) == 0 && K % 4 == 0, "svdx_small_linear: X must be 16-byte aligned");
+            if (M == 1)
+                hipLaunchKernelGGL((small_linear_nt<T, 1>), dim3(cdiv(N, 4)), dim3(256), 0, st, X, (const T*)W, bias, Y, M, N, K, ldw,
+                                   silu_in, accumulate);
+            else if (M <= 4)
+                hipLaunchKernelGGL((small_linear_nt<T, 4>), dim3(cdiv(N, 4)), dim3(256), 0, st, X, (const T*)W, bias, Y, M, N, K, ldw,
+                                   silu_in, accumulate);
+            else
+                hipLaunchKernelGGL((small_linear_nt<T, 8>), dim3(cdiv(N, 4)), dim3(256), 0, st, X, (const T*)W, bias, Y, M, N, K, ldw,
+                                   silu_in, accumulate);
         } else {
             SVDX_CHECK_ARG(!bias && !silu_in, "svdx_small_linear: trans=1 takes no bias/activation");
             if (!accumulate) (void)hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * K, st);

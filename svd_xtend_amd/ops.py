@@ -52,6 +52,17 @@ class Runtime:
         self.k = K.backend()
         self.gemm_variant = 4      # 0 reg-staged, 1 global_load_lds, 2 deep ring, 3 BN160+direct epilogue, 4 = 3 + lean buffer_load-lds loop
         self.split_k = True
+        self.p_flat = None          # flat float master buffer of the trainables (ops.flatten_trainables)
+        self.w16_flat = None        # same layout in the activation dtype, written by svdx_adamw / one cast per refresh
+
+    def act_view(self, master: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """The activation-dtype twin of a contiguous float tensor living inside p_flat (None otherwise)."""
+        if master is None or self.p_flat is None:
+            return None
+        off = (master.data_ptr() - self.p_flat.data_ptr()) // 4
+        if master.untyped_storage().data_ptr() != self.p_flat.untyped_storage().data_ptr() or off < 0:
+            return None
+        return self.w16_flat[off:off + master.numel()]
         self.profile = None     # optional callable(kind, flops, bytes) -> context manager (bench instrumentation)
 
     def empty(self, *shape, dtype=None) -> torch.Tensor:
@@ -129,8 +140,13 @@ class LinearOp:
         master = self._flat_view([w.data for w in self.weights])
         if master is None:
             master = torch.cat([w.data.reshape(w.shape[0], -1) for w in self.weights], 0).contiguous()
-        self.w = rt.empty(self.N, self.Kdim)
-        k.cast_from_f32(master, self.w, self.N * self.Kdim)
+        twin = rt.act_view(master) if self.trainable else None
+        self.w_is_view = twin is not None
+        if twin is not None:
+            self.w = twin.view(self.N, self.Kdim)          # kept current by AdamW / refresh_trainable (no per-op cast)
+        else:
+            self.w = rt.empty(self.N, self.Kdim)
+            k.cast_from_f32(master, self.w, self.N * self.Kdim)
         if need_dx:
             self.wt = rt.empty(self.Kdim, self.N)
             k.cast_transpose_from_f32(master, self.wt, self.N, self.Kdim)
@@ -166,7 +182,8 @@ class LinearOp:
     def refresh(self, rt: Runtime, need_dx: bool = True) -> None:
         """Re-cast after an optimizer step (trainable weights only)."""
         master = self._flat_view([w.data for w in self.weights])
-        rt.k.cast_from_f32(master, self.w, self.N * self.Kdim)
+        if not getattr(self, "w_is_view", False):
+            rt.k.cast_from_f32(master, self.w, self.N * self.Kdim)
         if self.wt is not None:
             rt.k.cast_transpose_from_f32(master, self.wt, self.N, self.Kdim)
 
@@ -237,10 +254,17 @@ class SmallLinearOp:
         self.w = None
 
     def pack(self, rt: Runtime) -> None:
+        twin = rt.act_view(self.weight.data) if self.trainable else None
+        self.w_is_view = twin is not None
+        if twin is not None:
+            self.w = twin.view(self.N, self.Kdim)
+            return
         self.w = rt.empty(self.N, self.Kdim)
         rt.k.cast_from_f32(self.weight.data.contiguous(), self.w, self.N * self.Kdim)
 
-    refresh = pack
+    def refresh(self, rt: Runtime) -> None:
+        if not self.w_is_view:
+            rt.k.cast_from_f32(self.weight.data.contiguous(), self.w, self.N * self.Kdim)
 
     def fwd(self, rt: Runtime, x: torch.Tensor, M: int, silu_in: bool = False, out: Optional[torch.Tensor] = None,
             accumulate: bool = False) -> torch.Tensor:

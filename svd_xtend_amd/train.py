@@ -44,7 +44,8 @@ class Trainer:
         self.dev = dev
 
         self.names = select_trainable(model)
-        self.params, self.offsets, off, self.p_flat, self.g_flat = flatten_trainables(model, ALIGN)
+        model._flat = flatten_trainables(model, ALIGN)
+        self.params, self.offsets, off, self.p_flat, self.g_flat = model._flat
         self.n_flat = off
         # one extra aligned slot at the tail carries the loss through the gradient all-reduce (replaces the
         # separate accelerator.gather of train_svd.py:1039-1040)
@@ -92,8 +93,8 @@ class Trainer:
         k.optim_prep(self.opt_state, self.betas[0], self.betas[1], 2.0, 0.5, self.growth_interval, int(self.dynamic))
         grad_mul = 1.0 / (self.world * self.grad_accum)
         k.adamw(self.p_flat, self.g_flat, self.m_flat, self.v_flat, n, self.lr, self.betas[0], self.betas[1],
-                self.eps, self.wd, grad_mul, self.opt_state, None)
-        self.model.refresh_trainable()
+                self.eps, self.wd, grad_mul, self.opt_state, self.rt.w16_flat)
+        self.model.refresh_trainable(masters_changed_on_host=False)
         self.micro = 0
 
     def step(self, batch: Dict[str, torch.Tensor]) -> None:

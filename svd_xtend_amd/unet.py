@@ -335,6 +335,7 @@ class TransformerSpatioTemporalModel(nn.Module):
         self.time_mixer = _AlphaBlender()
         self.proj_out = nn.Linear(in_channels, in_channels)
         self.need_dx = True
+        self._pos_cache = None
 
     def build(self):
         self.gn = GroupNormOp(self.norm, silu=False)
@@ -351,6 +352,7 @@ class TransformerSpatioTemporalModel(nn.Module):
         return any(p.requires_grad for p in self.parameters())
 
     def pack(self, rt):
+        self._pos_cache = None
         self.pin.pack(rt)
         self.pout.pack(rt)
         self.time_pos_embed.pack(rt)
@@ -369,11 +371,15 @@ class TransformerSpatioTemporalModel(nn.Module):
         xn, st = self.gn.fwd(rt, x, g.N, g.HW)
         h = self.pin.fwd(rt, xn, M)
         del xn
-        # frame position embedding e[t] = time_pos_embed(Timesteps(C)(arange(T))), one row vector per frame
-        tpos = torch.arange(g.T, dtype=torch.float32, device=rt.dev).repeat(g.B)
-        fe = rt.f32(g.N, C)
-        k.timestep_embed(tpos, fe, g.N, C)
-        e = self.time_pos_embed.fwd(rt, fe, g.N)
+        # frame position embedding e[t] = time_pos_embed(Timesteps(C)(arange(T))), one row vector per frame.  It depends only on
+        # (frozen) weights and the clip geometry, so it is computed once per (B, T) and reused by every later step.
+        key = (g.B, g.T)
+        if self._pos_cache is None or self._pos_cache[0] != key:
+            tpos = torch.arange(g.T, dtype=torch.float32, device=rt.dev).repeat(g.B)
+            fe = rt.f32(g.N, C)
+            k.timestep_embed(tpos, fe, g.N, C)
+            self._pos_cache = (key, self.time_pos_embed.fwd(rt, fe, g.N))
+        e = self._pos_cache[1]
         for blk, tblk in zip(self.transformer_blocks, self.temporal_transformer_blocks):
             h = blk.fwd(rt, h, g, ctx)
             hm = rt.empty(M, C)
@@ -719,6 +725,10 @@ class UNetSpatioTemporalConditionModel(nn.Module):
             # stand-alone use (host script keeps its own optimizer): give the trainables flat, adjacent storage
             self._flat = flatten_trainables(self)
         self.rt = rt = Runtime(dtype, dev)
+        if getattr(self, "_flat", None) is not None and self._flat[2] > 0:
+            rt.p_flat = self._flat[3]
+            rt.w16_flat = torch.empty(rt.p_flat.numel(), dtype=dtype, device=dev)
+            rt.k.cast_from_f32(rt.p_flat, rt.w16_flat, rt.p_flat.numel())
         self.steps = self._steps()
         # which modules need an input gradient: only those executed after the first trainable parameter
         seen = False
@@ -767,8 +777,11 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         self._anchor = torch.zeros((), device=dev, requires_grad=True)
         return self
 
-    def refresh_trainable(self) -> None:
-        """Re-pack the low-precision copies of trainable weights after an optimizer step."""
+    def refresh_trainable(self, masters_changed_on_host: bool = True) -> None:
+        """Re-pack the low-precision copies of trainable weights after an optimizer step.  `masters_changed_on_host`
+        (torch optimizer route): one cast of the whole flat buffer; the Trainer's AdamW kernel writes it directly."""
+        if masters_changed_on_host and self.rt.p_flat is not None:
+            self.rt.k.cast_from_f32(self.rt.p_flat, self.rt.w16_flat, self.rt.p_flat.numel())
         for kind, m in self.steps:
             if kind == "attn":
                 m.refresh(self.rt)
