@@ -9,10 +9,10 @@
 
 namespace {
 
-constexpr int GN_SLAB = 32;    // rows per block (small slabs -> enough waves per SIMD to hide HBM latency)
 
 struct GnGeom {
     int n_s, rows, C, G, cg, cc, rpi;   // cg channels/group, cc 16-byte chunks per row, rpi rows per iteration
+    int slab;                           // rows per block: sized so that even the 5x8 latent level launches >= ~1000 blocks
 };
 
 __device__ __forceinline__ void group_mean_rstd(const float* stats, int n, int G, int g, float cnt, float eps,
@@ -34,7 +34,7 @@ __global__ void gn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ 
     __syncthreads();
     const int n = blockIdx.x, slab = blockIdx.y;
     const int j = t % q.cc, ry = t / q.cc;
-    const int r0 = slab * GN_SLAB, r1 = min(q.rows, r0 + GN_SLAB);
+    const int r0 = slab * q.slab, r1 = min(q.rows, r0 + q.slab);
     float a0[8], a1[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
@@ -116,7 +116,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ d
     const int n = blockIdx.x, slab = blockIdx.y;
     const int j = t % q.cc, ry = t / q.cc;
     if (ry >= q.rpi) return;
-    const int r0 = slab * GN_SLAB, r1 = min(q.rows, r0 + GN_SLAB);
+    const int r0 = slab * q.slab, r1 = min(q.rows, r0 + q.slab);
     const float cnt = (float)q.rows * q.cg;
     float sc[8], sh[8], gm[8], mu[8], rs[8], b1[8], b2[8];
 #pragma unroll
@@ -170,6 +170,9 @@ int gn_geom(GnGeom& q, int n_s, int rows, int C, int G, int& threads) {
     q.n_s = n_s; q.rows = rows; q.C = C; q.G = G; q.cg = C / G; q.cc = C / 8;
     q.rpi = q.cc >= 256 ? 1 : 256 / q.cc;
     threads = q.cc * q.rpi;
+    int slab = 32;
+    while (slab > 2 * q.rpi && slab > 2 && (long)n_s * ((rows + slab - 1) / slab) < 1024) slab >>= 1;
+    q.slab = slab;
     return 0;
 }
 
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             pg[i][e] = pb[i][e] = 0.f;
         }
     const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+#pragma unroll 2
     for (int row = wid; row < rows; row += nw) {
         const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
         float xh[LN_MAXCH][8], dg[LN_MAXCH][8];
@@ -309,7 +313,7 @@ extern "C" int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int
     if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
     hipStream_t st = (hipStream_t)stream;
     (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * n_s * G, st);
-    dim3 grid(n_s, cdiv(rows, GN_SLAB));
+    dim3 grid(n_s, cdiv(rows, q.slab));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_reduce_kernel<T, 0>), grid, dim3(threads), 0, st, (const T*)x,
                                              (const T*)nullptr, (const float*)nullptr, (const float*)nullptr,
                                              (const float*)nullptr, stats, q, 0.f, 0));
@@ -321,7 +325,7 @@ extern "C" int svdx_gn_apply(const void* x, const float* stats, const float* gam
                              int n_s, int rows, int C, int G, float eps, int silu, int dtype, void* stream) {
     GnGeom q; int threads;
     if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
-    dim3 grid(n_s, cdiv(rows, GN_SLAB));
+    dim3 grid(n_s, cdiv(rows, q.slab));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_apply_kernel<T, 0>), grid, dim3(threads), 0, (hipStream_t)stream,
                                              (const T*)x, (const T*)nullptr, stats, (const float*)nullptr, gamma, beta,
                                              (const T*)nullptr, (T*)y, q, eps, silu));
@@ -336,7 +340,7 @@ extern "C" int svdx_gn_bwd_stats(const void* dy, const void* x, const float* sta
     if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
     hipStream_t st = (hipStream_t)stream;
     (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * n_s * G, st);
-    dim3 grid(n_s, cdiv(rows, GN_SLAB));
+    dim3 grid(n_s, cdiv(rows, q.slab));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_reduce_kernel<T, 1>), grid, dim3(threads), 0, st, (const T*)x,
                                              (const T*)dy, stats, gamma, beta, bstats, q, eps, silu));
     SVDX_LAUNCH_CHECK("svdx_gn_bwd_stats");
@@ -348,7 +352,7 @@ extern "C" int svdx_gn_bwd_apply(const void* dy, const void* x, const float* sta
                                  int C, int G, float eps, int silu, int dtype, void* stream) {
     GnGeom q; int threads;
     if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
-    dim3 grid(n_s, cdiv(rows, GN_SLAB));
+    dim3 grid(n_s, cdiv(rows, q.slab));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_apply_kernel<T, 1>), grid, dim3(threads), 0, (hipStream_t)stream,
                                              (const T*)x, (const T*)dy, stats, bstats, gamma, beta, (const T*)add,
                                              (T*)dx, q, eps, silu));
@@ -373,7 +377,8 @@ extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, co
                            void* dx, float* dgamma, float* dbeta, int rows, int C, int dtype, void* stream) {
     SVDX_CHECK_ARG(rows > 0 && C % 8 == 0 && C / 8 <= 64 * LN_MAXCH_LIMIT, "svdx_ln_bwd: C=%d unsupported", C);
     SVDX_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "svdx_ln_bwd: dgamma/dbeta must come together");
-    const int blocks = min(cdiv(rows, 4), 1024);
+    // with affine grads every block ends with 2*C float atomics: keep one block per CU there
+    const int blocks = min(cdiv(rows, 4), dgamma ? 256 : 2048);
     const size_t sh = dgamma ? sizeof(float) * 2 * C : 0;
     const int nch = (C / 8 + 63) / 64;
 #define LN_BWD(NCH) hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(blocks), dim3(256), sh, (hipStream_t)stream, (const T*)dy, \
