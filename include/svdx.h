@@ -34,6 +34,10 @@ extern "C" {
 #define SVDX_OUT_F32_ADD 4    /* float read-modify-write without atomics (each element has one owner block) */
 #define SVDX_OUT_F32_SLAB 3   /* split-K: split z stores its partial sums (float) to C + z*M*ldc; no bias/res here */
 
+#define SVDX_EPI_NONE 0
+#define SVDX_EPI_GEGLU_FWD 1  /* B = GEGLU proj [2F,K]: C = pre [M,2F] and aux_out = h [M,F] = pre[:, :F] * gelu(pre[:, F:])       */
+#define SVDX_EPI_GEGLU_BWD 2  /* GEMM result = dh [M,F] (not stored); aux_in = pre [M,2F]; C = dpre [M,2F] (GEGLU backward)    */
+
 #define SVDX_GATHER_PLAIN 0
 #define SVDX_GATHER_CONV3X3 1     /* 3x3, pad 1, stride 1|2, optional nearest x2 upsampled source */
 #define SVDX_GATHER_CONV3X3_DGRAD2 2 /* data-gradient of the stride-2 3x3 conv (transposed conv) */
@@ -62,11 +66,13 @@ int         svdx_device_ok(void);
 /* ---- GEMM family: nn.Linear / conv2d / conv3d fwd and data-grad, weight-grad (NT form) ------------
  * acc[m,n] = sum_k Aeff[m,k] * B[n,k];  v = alpha*acc + bias[n] + rowvec[g(m)*rv_ld + n] + res[m*ldres+n]
  * g(m) = rv_mod ? m % rv_mod : m / rv_rows_per_group.   B is [N,K] row-major (ldb).
- * out_mode ACT: C[m*ldc+n] = (dtype)v ; F32: float store ; F32_ATOMIC: atomicAdd (split_k >= 1). */
+ * out_mode ACT: C[m*ldc+n] = (dtype)v ; F32: float store ; F32_ATOMIC: atomicAdd (split_k >= 1).
+ * epilogue (variant 4 only): SVDX_EPI_GEGLU_FWD / _BWD fuse diffusers' GEGLU (attention.py) into the projection GEMMs, aux_dim = F. */
 int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
               const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
               const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
-              int out_mode, float alpha, int split_k, int variant, int dtype, void* stream);
+              int out_mode, float alpha, int split_k, int variant, int epilogue, const void* aux_in, void* aux_out, int aux_dim,
+              int dtype, void* stream);
 
 /* Weight-gradient GEMM in TN form: C[n*ldc + k] (+)= sum_r A[r*lda + n] * B[r*ldb + k]  (A = dY [R,N], B = X [R,K], float C).
  * Replaces the dW part of autograd's Linear backward (train_svd.py:1044) without materialising transposes.
@@ -92,13 +98,15 @@ int svdx_outer_acc(const float* dY, const float* X, float* dW, int M, int N, int
 int svdx_timestep_embed(const float* t, float* out, int n, int dim, void* stream);
 
 /* ---- GroupNorm(32) (+SiLU) over n_s samples of `rows` rows x C channels (2-D: sample = frame;
- *      3-D: sample = clip, rows = T*HW).  stats[n_s, G, 2] = (sum, sumsq). -------------------------- */
-int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int C, int G, int dtype, void* stream);
+ *      3-D: sample = clip, rows = T*HW).  stats[n_s, G, 2] = (sum, sumsq), accumulated with atomics: the kernels zero
+ *      the buffer first unless `prezeroed` (the host zeroes one arena per pass instead of ~200 tiny memsets). -------- */
+int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int C, int G, int prezeroed, int dtype, void* stream);
 int svdx_gn_apply(const void* x, const float* stats, const float* gamma, const float* beta, void* y,
                   int n_s, int rows, int C, int G, float eps, int silu, int dtype, void* stream);
 /* bstats[n_s,G,2] = (sum dz*gamma, sum dz*gamma*xhat), dz = dy * silu'(z) when silu */
 int svdx_gn_bwd_stats(const void* dy, const void* x, const float* stats, const float* gamma, const float* beta,
-                      float* bstats, int n_s, int rows, int C, int G, float eps, int silu, int dtype, void* stream);
+                      float* bstats, int n_s, int rows, int C, int G, float eps, int silu, int prezeroed, int dtype,
+                      void* stream);
 int svdx_gn_bwd_apply(const void* dy, const void* x, const float* stats, const float* bstats,
                       const float* gamma, const float* beta, const void* add, void* dx,
                       int n_s, int rows, int C, int G, float eps, int silu, int dtype, void* stream);

@@ -87,6 +87,11 @@ __device__ __forceinline__ float silu_gradf_(float x) {
     return s * (1.f + x * (1.f - s));
 }
 
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f;
+}
+
 #define DISPATCH_DTYPE(dtype, ...)                                   \
     if ((dtype) == SVDX_F16) { typedef f16 T; __VA_ARGS__; }         \
     else if ((dtype) == SVDX_BF16) { typedef bf16 T; __VA_ARGS__; }  \

@@ -8,10 +8,6 @@ namespace {
 constexpr int EW_THREADS = 256;
 static inline int ew_blocks(long n_items) { return (int)std::min<long>((n_items + EW_THREADS - 1) / EW_THREADS, 256 * 16); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f;
-}
 
 template <typename T>
 __global__ void geglu_fwd_kernel(const T* __restrict__ pre, T* __restrict__ out, int M, int F) {

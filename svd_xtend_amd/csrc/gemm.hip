@@ -30,6 +30,7 @@ struct GemmParams {
     const void* res; int ldres;
     svdx_gather g; const void* zero_page;
     int out_mode; float alpha; int split_k; int tiles_m, tiles_n; int vec_ok; long slab_stride; int a_bytes, b_bytes;
+    int epi; const void* aux_in; void* aux_out; int aux_dim;   // fused GEGLU epilogues (variant 4)
 };
 
 struct RowInfo { int a, b, base; };   // per gathered A row (meaning depends on gather mode)
@@ -774,8 +775,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
         a_m[i] = min(m0 + i * 32 + ld_row, p.M - 1);
         a_ri[i] = decode_row(p.g, a_m[i]);
     }
+    // GEGLU-forward tiles pair 16 value columns with their 16 gate columns: local n-block 2q is rows F*0 + c, block 2q+1 is rows
+    // F + c of the [2F, K] projection, so a lane ends up holding a value and its gate (no weight re-packing needed).
+    const int Fdim = p.aux_dim;
+    auto brow = [&](int nl) __attribute__((always_inline)) {
+        return p.epi == SVDX_EPI_GEGLU_FWD ? (((nl >> 4) & 1) ? Fdim : 0) + pid_n * (BN3 / 2) + (nl >> 5) * 16 + (nl & 15)
+                                           : min(n0 + nl, p.N - 1);
+    };
 #pragma unroll
-    for (int i = 0; i < NB; ++i) vob[i] = (min(n0 + i * 32 + ld_row, p.N - 1) * p.ldb + lc * 8) * 2;
+    for (int i = 0; i < NB; ++i) vob[i] = (brow(i * 32 + ld_row) * p.ldb + lc * 8) * 2;
     const bool plain = p.g.mode == SVDX_GATHER_PLAIN;
     const int cin = plain ? p.K : p.g.cin;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
@@ -847,7 +855,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
     // ---- epilogue A (activation output): coalesced.  Each lane adds bias / row vector to its 4-column groups, rounds to the
     //      activation dtype and parks them in LDS (the stage buffers are free now); then every thread moves 16-byte row
     //      pieces: residual add + store with full-line coalescing (20 lanes cover one 320-byte output row of the tile).
-    if (p.out_mode == SVDX_OUT_ACT && p.vec_ok && (p.ldc % 8 == 0) && (!p.res || p.ldres % 8 == 0) && (n0 + BN3 <= p.N)) {
+    if (p.out_mode == SVDX_OUT_ACT && p.vec_ok && (p.ldc % 8 == 0) && (!p.res || p.ldres % 8 == 0) &&
+        (n0 + BN3 <= p.N || p.epi == SVDX_EPI_GEGLU_FWD)) {
         constexpr int PITCH = (BN3 + 8) * 2;              // bytes per staged row (multiple of 16)
         __syncthreads();
         {
@@ -857,7 +866,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
             for (int i = 0; i < NB; ++i) {
                 float bb[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bb[e] = (lead0 && p.bias) ? p.bias[nb0 + i * 16 + e] : 0.f;
+                for (int e = 0; e < 4; ++e)
+                    bb[e] = (lead0 && p.bias) ? p.bias[p.epi == SVDX_EPI_GEGLU_FWD ? brow(wn * WN3 + i * 16 + fg * 4 + e) : nb0 + i * 16 + e] : 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int ml = wm * 64 + j * 16 + fr;
@@ -878,7 +888,54 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
             }
         }
         __syncthreads();
+        if (p.epi == SVDX_EPI_GEGLU_FWD) {
+            // tile = 128 rows x (BN3/32) pairs of [16 values | 16 gates]; emit pre (both halves) and h = value * gelu(gate)
+            T* pre = reinterpret_cast<T*>(p.C);
+            T* hh = reinterpret_cast<T*>(p.aux_out);
+            constexpr int NPAIR = BN3 / 32;
+            for (int id = tid; id < BM * NPAIR * 2; id += NTHREADS) {
+                const int row = id / (NPAIR * 2), r2 = id - row * (NPAIR * 2);
+                const int pr = r2 >> 1, c2 = r2 & 1;
+                const int m = m0 + row;
+                if (m >= p.M) continue;
+                const Vec8<T> a8 = *reinterpret_cast<const Vec8<T>*>(smem + row * PITCH + (pr * 32 + c2 * 8) * 2);
+                const Vec8<T> g8 = *reinterpret_cast<const Vec8<T>*>(smem + row * PITCH + (pr * 32 + 16 + c2 * 8) * 2);
+                const int fc = pid_n * (BN3 / 2) + pr * 16 + c2 * 8;
+                if (fc >= Fdim) continue;
+                Vec8<T> h8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h8.v[e] = from_f<T>(to_f<T>(a8.v[e]) * gelu_erf(to_f<T>(g8.v[e])));
+                *reinterpret_cast<Vec8<T>*>(pre + (size_t)m * p.ldc + fc) = a8;
+                *reinterpret_cast<Vec8<T>*>(pre + (size_t)m * p.ldc + Fdim + fc) = g8;
+                *reinterpret_cast<Vec8<T>*>(hh + (size_t)m * Fdim + fc) = h8;
+            }
+            return;
+        }
         constexpr int CPR = BN3 / 8;                      // 16-byte chunks per row
+        if (p.epi == SVDX_EPI_GEGLU_BWD) {
+            // the tile holds d(h) for columns n0..; read (value, gate) from pre and emit d(pre) = [dh*gelu(g) | dh*a*gelu'(g)]
+            const T* pre = reinterpret_cast<const T*>(p.aux_in);
+            T* dpre = reinterpret_cast<T*>(p.C);
+            for (int id = tid; id < BM * CPR; id += NTHREADS) {
+                const int row = id / CPR, c = id - row * CPR;
+                const int m = m0 + row;
+                if (m >= p.M) continue;
+                const Vec8<T> d8 = *reinterpret_cast<const Vec8<T>*>(smem + row * PITCH + c * 16);
+                const size_t po = (size_t)m * (2 * Fdim) + n0 + c * 8;
+                const Vec8<T> a8 = *reinterpret_cast<const Vec8<T>*>(pre + po);
+                const Vec8<T> g8 = *reinterpret_cast<const Vec8<T>*>(pre + po + Fdim);
+                Vec8<T> da, dg;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = to_f<T>(d8.v[e]), gv = to_f<T>(g8.v[e]);
+                    da.v[e] = from_f<T>(d * gelu_erf(gv));
+                    dg.v[e] = from_f<T>(d * to_f<T>(a8.v[e]) * gelu_erf_grad(gv));
+                }
+                *reinterpret_cast<Vec8<T>*>(dpre + po) = da;
+                *reinterpret_cast<Vec8<T>*>(dpre + po + Fdim) = dg;
+            }
+            return;
+        }
         T* Ct2 = reinterpret_cast<T*>(p.C);
         const T* R2 = (z == 0) ? reinterpret_cast<const T*>(p.res) : nullptr;
 #pragma unroll 2
@@ -1142,10 +1199,8 @@ int launch_gemm_v4(GemmParams p, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    p.tiles_n = cdiv(p.N, 32 * NB);
-    const int esz = p.out_mode == SVDX_OUT_ACT ? 2 : 4;
+    p.tiles_n = p.epi == SVDX_EPI_GEGLU_FWD ? cdiv(p.aux_dim, 16 * NB) : cdiv(p.N, 32 * NB);
     p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 15) == 0));
-    (void)esz;
     dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
     hipLaunchKernelGGL((gemm_v4_kernel<T, NB>), grid, dim3(NTHREADS), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm");
@@ -1195,6 +1250,7 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
     p.A = A; p.B = B; p.C = C; p.M = N; p.N = K; p.K = R; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = nullptr; p.rowvec = nullptr; p.rv_ld = 0; p.rv_rpg = 0; p.rv_mod = 0; p.res = nullptr; p.ldres = 0;
     p.g = svdx_gather{}; p.zero_page = zero_page; p.out_mode = out_mode; p.alpha = 1.f; p.split_k = split_k;
+    p.epi = 0; p.aux_in = nullptr; p.aux_out = nullptr; p.aux_dim = 0; p.a_bytes = 0; p.b_bytes = 0;
     p.tiles_m = cdiv(N, BM); p.tiles_n = cdiv(K, BN);
     p.vec_ok = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) && (K % 8 == 0);
     p.slab_stride = (long)N * ldc;
@@ -1204,8 +1260,19 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
 extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                          const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
                          const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
-                         int out_mode, float alpha, int split_k, int variant, int dtype, void* stream) {
+                         int out_mode, float alpha, int split_k, int variant, int epilogue, const void* aux_in, void* aux_out,
+                         int aux_dim, int dtype, void* stream) {
     SVDX_CHECK_ARG(A && B && C, "svdx_gemm: null operand");
+    if (epilogue != SVDX_EPI_NONE) {
+        SVDX_CHECK_ARG(variant == 4 && out_mode == SVDX_OUT_ACT && split_k == 1 && !res && !rowvec && aux_dim > 0 && aux_dim % 64 == 0 &&
+                           (!gather || gather->mode == SVDX_GATHER_PLAIN), "svdx_gemm: fused GEGLU epilogue needs variant 4, plain A, no split-K");
+        SVDX_CHECK_ARG(((uintptr_t)C & 15) == 0, "svdx_gemm: fused epilogue output must be 16-byte aligned");
+        if (epilogue == SVDX_EPI_GEGLU_FWD)
+            SVDX_CHECK_ARG(N == 2 * aux_dim && ldc == N && aux_out && ((uintptr_t)aux_out & 15) == 0, "svdx_gemm: GEGLU fwd wants C=[M,2F], aux_out=[M,F]");
+        else
+            SVDX_CHECK_ARG(epilogue == SVDX_EPI_GEGLU_BWD && N == aux_dim && ldc == 2 * aux_dim && aux_in && ((uintptr_t)aux_in & 15) == 0 &&
+                               (N % 160 == 0 || N % 128 == 0), "svdx_gemm: GEGLU bwd wants N=F (multiple of 128 or 160), C=dpre [M,2F], aux_in=pre [M,2F]");
+    }
     SVDX_CHECK_ARG(M > 0 && N > 0 && K > 0, "svdx_gemm: bad sizes M=%d N=%d K=%d", M, N, K);
     SVDX_CHECK_ARG(K % BK == 0, "svdx_gemm: K=%d must be a multiple of %d", K, BK);
     SVDX_CHECK_ARG(ldb % 8 == 0 && ((uintptr_t)B & 15) == 0, "svdx_gemm: B must be 16-byte aligned (ldb=%d)", ldb);
@@ -1217,6 +1284,7 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
     p.bias = bias; p.rowvec = rowvec; p.rv_ld = rv_ld; p.rv_rpg = rv_rows_per_group; p.rv_mod = rv_mod;
     p.res = res; p.ldres = ldres; p.zero_page = zero_page;
     p.out_mode = out_mode; p.alpha = alpha; p.split_k = split_k; p.slab_stride = (long)M * ldc;
+    p.epi = epilogue; p.aux_in = aux_in; p.aux_out = aux_out; p.aux_dim = aux_dim;
     if (gather && gather->mode != SVDX_GATHER_PLAIN) {
         p.g = *gather;
         SVDX_CHECK_ARG(p.g.cin % BK == 0, "svdx_gemm: gather cin=%d must be a multiple of %d", p.g.cin, BK);
@@ -1260,8 +1328,10 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
         if (variant == 3) return (N % 160 == 0) ? launch_gemm_v3<T, 5>(p, st) : launch_gemm_v3<T, 4>(p, st);
         if (variant == 4 && a_bytes > 0 && b_bytes > 0) {
             p.a_bytes = (int)a_bytes; p.b_bytes = (int)b_bytes;
-            return (N % 160 == 0) ? launch_gemm_v4<T, 5>(p, st) : launch_gemm_v4<T, 4>(p, st);
+            const bool nb5 = epilogue == SVDX_EPI_GEGLU_FWD ? false : (N % 160 == 0);
+            return nb5 ? launch_gemm_v4<T, 5>(p, st) : launch_gemm_v4<T, 4>(p, st);
         }
+        if (epilogue != SVDX_EPI_NONE) { svdx_set_error("svdx_gemm: fused epilogue unavailable (buffer too large for variant 4)"); return -2; }
         return variant == 2 ? launch_gemm_pipe<T>(p, st) : variant == 1 ? launch_gemm<T, true>(p, st) : launch_gemm<T, false>(p, st);
     });
 }

@@ -308,11 +308,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 
 }  // namespace
 
-extern "C" int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int C, int G, int dtype, void* stream) {
+extern "C" int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int C, int G, int prezeroed, int dtype, void* stream) {
     GnGeom q; int threads;
     if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * n_s * G, st);
+    if (!prezeroed) (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * n_s * G, st);
     dim3 grid(n_s, cdiv(rows, q.slab));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_reduce_kernel<T, 0>), grid, dim3(threads), 0, st, (const T*)x,
                                              (const T*)nullptr, (const float*)nullptr, (const float*)nullptr,
@@ -335,11 +335,11 @@ extern "C" int svdx_gn_apply(const void* x, const float* stats, const float* gam
 
 extern "C" int svdx_gn_bwd_stats(const void* dy, const void* x, const float* stats, const float* gamma,
                                  const float* beta, float* bstats, int n_s, int rows, int C, int G, float eps,
-                                 int silu, int dtype, void* stream) {
+                                 int silu, int prezeroed, int dtype, void* stream) {
     GnGeom q; int threads;
     if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * n_s * G, st);
+    if (!prezeroed) (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * n_s * G, st);
     dim3 grid(n_s, cdiv(rows, q.slab));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_reduce_kernel<T, 1>), grid, dim3(threads), 0, st, (const T*)x,
                                              (const T*)dy, stats, gamma, beta, bstats, q, eps, silu));

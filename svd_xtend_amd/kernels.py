@@ -21,6 +21,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsvdx.so")
 
 F16, BF16 = 0, 1
 OUT_ACT, OUT_F32, OUT_F32_ATOMIC, OUT_F32_SLAB, OUT_F32_ADD = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GEGLU_FWD, EPI_GEGLU_BWD = 0, 1, 2
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3 = 0, 1, 2, 3
 
 
@@ -56,15 +57,15 @@ class Gather:
 
 # signature table: p void*, i int, f float, l int64, z size_t
 _SIGS = {
-    "svdx_gemm": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifii" "ip",
+    "svdx_gemm": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifii" "ippi" "ip",
     "svdx_gemm_tn": "ppp" "iiiiii" "p" "ii" "ip",
     "svdx_gemm_finalize": "pil" "pi" "iii" "pp" "iii" "pi" "ip",
     "svdx_small_linear": "pppp" "iiii" "iii" "ip",
     "svdx_outer_acc": "ppp" "iii" "f" "p",
     "svdx_timestep_embed": "pp" "ii" "p",
-    "svdx_gn_stats": "pp" "iiii" "ip",
+    "svdx_gn_stats": "pp" "iiii" "i" "ip",
     "svdx_gn_apply": "ppppp" "iiii" "fi" "ip",
-    "svdx_gn_bwd_stats": "pppppp" "iiii" "fi" "ip",
+    "svdx_gn_bwd_stats": "pppppp" "iiii" "fi" "i" "ip",
     "svdx_gn_bwd_apply": "pppppppp" "iiii" "fi" "ip",
     "svdx_ln_fwd": "ppppp" "ii" "f" "ip",
     "svdx_ln_bwd": "pppppppp" "ii" "ip",
@@ -164,12 +165,13 @@ class HipBackend:
     # ---- GEMM family ------------------------------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
              res=None, ldres=0, gather: Optional[Gather] = None, out_mode=OUT_ACT, alpha=1.0, split_k=1,
-             variant=0):
+             variant=0, epilogue=EPI_NONE, aux_in=None, aux_out=None, aux_dim=0):
         g = gather.to_c() if gather is not None else None
         self._call("svdx_gemm", _p(A), _p(B), _p(C), M, N, K, lda, ldb, ldc, _f32(bias),
                    _f32(rowvec), rv_ld, rv_rpg, rv_mod, _p(res), ldres,
                    ctypes.cast(ctypes.pointer(g), ctypes.c_void_p) if g is not None else None,
-                   _p(self._zero_page), out_mode, float(alpha), split_k, variant, _dt(A), self._stream())
+                   _p(self._zero_page), out_mode, float(alpha), split_k, variant, epilogue, _p(aux_in), _p(aux_out), aux_dim,
+                   _dt(A), self._stream())
 
     def gemm_tn(self, A, B, C, R, N, K, lda, ldb, ldc, out_mode=OUT_F32_ADD, split_k=1):
         self._call("svdx_gemm_tn", _p(A), _p(B), _f32(C), R, N, K, lda, ldb, ldc, _p(self._zero_page), out_mode, split_k,
@@ -192,16 +194,16 @@ class HipBackend:
         self._call("svdx_timestep_embed", _f32(t), _f32(out), n, dim, self._stream())
 
     # ---- norms ------------------------------------------------------------------------------------
-    def gn_stats(self, x, stats, n_s, rows, C, G):
-        self._call("svdx_gn_stats", _p(x), _f32(stats), n_s, rows, C, G, _dt(x), self._stream())
+    def gn_stats(self, x, stats, n_s, rows, C, G, prezeroed=0):
+        self._call("svdx_gn_stats", _p(x), _f32(stats), n_s, rows, C, G, int(prezeroed), _dt(x), self._stream())
 
     def gn_apply(self, x, stats, gamma, beta, y, n_s, rows, C, G, eps, silu):
         self._call("svdx_gn_apply", _p(x), _f32(stats), _f32(gamma), _f32(beta), _p(y), n_s, rows, C, G,
                    float(eps), int(silu), _dt(x), self._stream())
 
-    def gn_bwd_stats(self, dy, x, stats, gamma, beta, bstats, n_s, rows, C, G, eps, silu):
+    def gn_bwd_stats(self, dy, x, stats, gamma, beta, bstats, n_s, rows, C, G, eps, silu, prezeroed=0):
         self._call("svdx_gn_bwd_stats", _p(dy), _p(x), _f32(stats), _f32(gamma), _f32(beta), _f32(bstats),
-                   n_s, rows, C, G, float(eps), int(silu), _dt(x), self._stream())
+                   n_s, rows, C, G, float(eps), int(silu), int(prezeroed), _dt(x), self._stream())
 
     def gn_bwd_apply(self, dy, x, stats, bstats, gamma, beta, add, dx, n_s, rows, C, G, eps, silu):
         self._call("svdx_gn_bwd_apply", _p(dy), _p(x), _f32(stats), _f32(bstats), _f32(gamma), _f32(beta),

@@ -52,8 +52,31 @@ class Runtime:
         self.k = K.backend()
         self.gemm_variant = 4      # 0 reg-staged, 1 global_load_lds, 2 deep ring, 3 BN160+direct epilogue, 4 = 3 + lean buffer_load-lds loop
         self.split_k = True
+        self.fuse_geglu = True
+        self.arenas = [None, None]
+        self.arena_cap = 1 << 20    # floats
+        self.arena_cur, self.arena_pos = None, 0
         self.p_flat = None          # flat float master buffer of the trainables (ops.flatten_trainables)
         self.w16_flat = None        # same layout in the activation dtype, written by svdx_adamw / one cast per refresh
+
+    def begin_pass(self, which: int) -> None:
+        """Start of a forward (0) or backward (1) sweep: re-zero that sweep's statistics arena with ONE memset (GroupNorm
+        statistics are accumulated with atomics; ~200 per-op memsets per step otherwise).  Forward statistics are saved
+        for the backward, so the two sweeps use separate arenas."""
+        if self.arenas[which] is None:
+            self.arenas[which] = torch.empty(self.arena_cap, dtype=torch.float32, device=self.dev)
+        self.k.zero(self.arenas[which])
+        self.arena_cur, self.arena_pos = which, 0
+
+    def take_zeroed(self, n: int):
+        """-> (tensor of n zeroed floats, prezeroed flag)"""
+        n64 = rup(n, 64)
+        arena = self.arenas[self.arena_cur] if self.arena_cur is not None else None
+        if arena is not None and self.arena_pos + n64 <= self.arena_cap:
+            t = arena[self.arena_pos:self.arena_pos + n]
+            self.arena_pos += n64
+            return t, 1
+        return self.f32(n), 0
 
     def act_view(self, master: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
         """The activation-dtype twin of a contiguous float tensor living inside p_flat (None otherwise)."""
@@ -77,12 +100,7 @@ class Runtime:
         return t
 
 
-def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
-             res=None, ldres=0, gather=None) -> None:
-    """Activation-dtype GEMM.  When the 128x128 output grid cannot fill the 256 CUs and K is long (the 10x16 / 5x8
-    latent levels: M = 2240 / 560 rows against K up to 23040) the reduction is split across blocks: partial sums are
-    accumulated with float atomics into a scratch buffer and a small epilogue kernel applies bias/row-vector/residual."""
-    k = rt.k
+def choose_split(rt: "Runtime", M: int, N: int, Kd: int, ldc: int) -> int:
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     kt = Kd // 64
     split = 1
@@ -90,6 +108,16 @@ def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowve
         split = max(1, min(512 // tiles, kt // 8, 16))
         while split > 1 and (kt + split - 1) // split * (split - 1) >= kt:     # every split must own >= 1 K-tile
             split -= 1
+    return split
+
+
+def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
+             res=None, ldres=0, gather=None) -> None:
+    """Activation-dtype GEMM.  When the 128x128 output grid cannot fill the 256 CUs and K is long (the 10x16 / 5x8
+    latent levels: M = 2240 / 560 rows against K up to 23040) the reduction is split across blocks: partial sums are
+    accumulated with float atomics into a scratch buffer and a small epilogue kernel applies bias/row-vector/residual."""
+    k = rt.k
+    split = choose_split(rt, M, N, Kd, ldc)
     if split == 1:
         k.gemm(A, B, out, M, N, Kd, lda, ldb, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod,
                res=res, ldres=ldres, gather=gather, variant=rt.gemm_variant)
@@ -397,18 +425,18 @@ class GroupNormOp:
             raise NotImplementedError("GroupNorm affine grads are outside this round's trainable set")
 
     def fwd(self, rt: Runtime, x: torch.Tensor, n_s: int, rows: int):
-        stats = rt.f32(n_s, GN_GROUPS, 2)
+        stats, pz = rt.take_zeroed(n_s * GN_GROUPS * 2)
         y = rt.empty(n_s * rows, self.C)
-        rt.k.gn_stats(x, stats, n_s, rows, self.C, GN_GROUPS)
+        rt.k.gn_stats(x, stats, n_s, rows, self.C, GN_GROUPS, prezeroed=pz)
         rt.k.gn_apply(x, stats, self.mod.weight.data, self.mod.bias.data, y, n_s, rows, self.C, GN_GROUPS,
                       self.eps, self.silu)
         return y, stats
 
     def bwd(self, rt: Runtime, dy, x, stats, n_s: int, rows: int, add: Optional[torch.Tensor] = None):
-        bst = rt.f32(n_s, GN_GROUPS, 2)
+        bst, pz = rt.take_zeroed(n_s * GN_GROUPS * 2)
         dx = rt.empty(n_s * rows, self.C)
         g, b = self.mod.weight.data, self.mod.bias.data
-        rt.k.gn_bwd_stats(dy, x, stats, g, b, bst, n_s, rows, self.C, GN_GROUPS, self.eps, self.silu)
+        rt.k.gn_bwd_stats(dy, x, stats, g, b, bst, n_s, rows, self.C, GN_GROUPS, self.eps, self.silu, prezeroed=pz)
         rt.k.gn_bwd_apply(dy, x, stats, bst, g, b, add, dx, n_s, rows, self.C, GN_GROUPS, self.eps, self.silu)
         return dx
 

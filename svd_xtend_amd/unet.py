@@ -21,7 +21,8 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .ops import ConvOp, GroupNormOp, LayerNormOp, LinearOp, Runtime, SmallLinearOp, flatten_trainables, rup
+from .ops import (ConvOp, GroupNormOp, LayerNormOp, LinearOp, Runtime, SmallLinearOp, choose_split, flatten_trainables,
+                  rup)
 
 HEAD_DIM = 64
 
@@ -90,22 +91,40 @@ class _FeedForward(nn.Module):
         self.p1.refresh(rt)
         self.p2.refresh(rt)
 
+    def _fusable(self, rt, M):
+        F = self.inner
+        return (rt.gemm_variant == 4 and rt.fuse_geglu and F % 128 == 0 and choose_split(rt, M, 2 * F, self.dim, 2 * F) == 1
+                and choose_split(rt, M, F, self.p2.N, 2 * F) == 1)
+
     def fwd(self, rt, x, M, res):
-        pre = self.p1.fwd(rt, x, M)
-        g = rt.empty(M, self.inner)
-        rt.k.geglu_fwd(pre, g, M, self.inner)
+        F = self.inner
+        g = rt.empty(M, F)
+        if self._fusable(rt, M):
+            # GEGLU fused into the projection GEMM: one launch emits pre [M,2F] (saved for the backward) and h = a * gelu(gate)
+            pre = rt.empty(M, 2 * F)
+            rt.k.gemm(x, self.p1.w, pre, M, 2 * F, self.dim, self.dim, self.dim, 2 * F, bias=self.p1.b, variant=4,
+                      epilogue=K.EPI_GEGLU_FWD, aux_out=g, aux_dim=F)
+        else:
+            pre = self.p1.fwd(rt, x, M)
+            rt.k.geglu_fwd(pre, g, M, F)
         y = self.p2.fwd(rt, g, M, res=res)
         return y, pre, g
 
     def bwd(self, rt, dy, x_saved, pre, g, M):
         """returns d(input of p1); accumulates weight grads when trainable."""
         k = rt.k
-        dg = self.p2.bwd_dx(rt, dy, M)
+        F = self.inner
+        dpre = rt.empty(M, 2 * F)
+        if self._fusable(rt, M):
+            # d(h) = dy W2 never reaches HBM: the data-grad GEMM's epilogue applies the GEGLU backward and writes d(pre)
+            k.gemm(dy, self.p2.wt, dpre, M, F, self.p2.N, self.p2.N, self.p2.N, 2 * F, variant=4, epilogue=K.EPI_GEGLU_BWD,
+                   aux_in=pre, aux_dim=F)
+        else:
+            dg = self.p2.bwd_dx(rt, dy, M)
+            k.geglu_bwd(dg, pre, dpre, M, F)
+            del dg
         if self.p2.trainable:
             self.p2.bwd_dw(rt, dy, g, M)
-        dpre = rt.empty(M, 2 * self.inner)
-        k.geglu_bwd(dg, pre, dpre, M, self.inner)
-        del dg
         dx = self.p1.bwd_dx(rt, dpre, M)
         if self.p1.trainable:
             self.p1.bwd_dw(rt, dpre, x_saved, M)
@@ -821,6 +840,7 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         """Forward up to the channels-last prediction rows [B*T*h*w, out_channels] (activation dtype)."""
         rt = self.rt
         k = rt.k
+        rt.begin_pass(0)
         B, T, Cin, h, w = sample.shape
         if h % 8 or w % 8:
             raise ValueError("latent height/width must be multiples of 8 (3 stride-2 levels; SURVEY.md 0.8)")
@@ -903,6 +923,7 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         k = rt.k
         fs = self._fwd_state
         self._fwd_state = None
+        rt.begin_pass(1)
         g0 = fs["g0"]
         B, T = g0.B, g0.T
         cur = g0

@@ -83,7 +83,8 @@ def gather_rows(A, g: K.Gather, M):
 class EmuBackend:
     # ---- GEMM family ----
     def gemm(self, A, B, C, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
-             res=None, ldres=0, gather=None, out_mode=K.OUT_ACT, alpha=1.0, split_k=1, variant=0):
+             res=None, ldres=0, gather=None, out_mode=K.OUT_ACT, alpha=1.0, split_k=1, variant=0, epilogue=0, aux_in=None,
+             aux_out=None, aux_dim=0):
         assert Kd % 64 == 0, "GEMM K must be a multiple of 64"
         if gather is None or gather.mode == K.GATHER_PLAIN:
             a = V(A, M, Kd, lda).float()
@@ -101,6 +102,21 @@ class EmuBackend:
             v = v + V(rowvec, ng, N, rv_ld)[gi]
         if res is not None:
             v = v + V(res, M, N, ldres).float()
+        if epilogue == K.EPI_GEGLU_FWD:
+            Fd = aux_dim
+            pre = (alpha * (a @ b.t()) + (V1(bias, N)[None] if bias is not None else 0)).to(C.dtype)
+            V(C, M, N, ldc).copy_(pre)
+            pf = pre.float()
+            V(aux_out, M, Fd, Fd).copy_((pf[:, :Fd] * gelu(pf[:, Fd:])).to(C.dtype))
+            return
+        if epilogue == K.EPI_GEGLU_BWD:
+            Fd = aux_dim
+            dh = (alpha * (a @ b.t()) + (V1(bias, N)[None] if bias is not None else 0)).to(C.dtype).float()
+            pf = V(aux_in, M, 2 * Fd, 2 * Fd).float()
+            o = V(C, M, 2 * Fd, ldc)
+            o[:, :Fd] = (dh * gelu(pf[:, Fd:])).to(C.dtype)
+            o[:, Fd:] = (dh * pf[:, :Fd] * gelu_grad(pf[:, Fd:])).to(C.dtype)
+            return
         if out_mode == K.OUT_F32_SLAB:
             assert bias is None and rowvec is None and res is None and C.dtype == torch.float32 and ldc == N
             ksz = (Kd // 64 + split_k - 1) // split_k * 64
@@ -189,11 +205,13 @@ class EmuBackend:
         rstd = torch.rsqrt(var + eps)
         return xf, mean[:, None, :, None], rstd[:, None, :, None], cnt
 
-    def gn_stats(self, x, stats, n_s, rows, C, G):
+    def gn_stats(self, x, stats, n_s, rows, C, G, prezeroed=0):
         xf = V(x, n_s * rows, C, C).float().view(n_s, rows, G, C // G)
         st = V(stats, n_s * G, 2, 2).view(n_s, G, 2)
-        st[..., 0] = xf.sum((1, 3))
-        st[..., 1] = (xf * xf).sum((1, 3))
+        if not prezeroed:
+            st.zero_()
+        st[..., 0] += xf.sum((1, 3))
+        st[..., 1] += (xf * xf).sum((1, 3))
 
     def gn_apply(self, x, stats, gamma, beta, y, n_s, rows, C, G, eps, silu_):
         xf, mean, rstd, _ = self._gn_parts(x, stats, n_s, rows, C, G, eps)
@@ -212,11 +230,13 @@ class EmuBackend:
         dzg = (dz * V1(gamma, C)).view(n_s, rows, G, C // G)
         return xhat, dzg, rstd, cnt
 
-    def gn_bwd_stats(self, dy, x, stats, gamma, beta, bstats, n_s, rows, C, G, eps, silu_):
+    def gn_bwd_stats(self, dy, x, stats, gamma, beta, bstats, n_s, rows, C, G, eps, silu_, prezeroed=0):
         xhat, dzg, _, _ = self._gn_dz(dy, x, stats, gamma, beta, n_s, rows, C, G, eps, silu_)
         bs = V(bstats, n_s * G, 2, 2).view(n_s, G, 2)
-        bs[..., 0] = dzg.sum((1, 3))
-        bs[..., 1] = (dzg * xhat).sum((1, 3))
+        if not prezeroed:
+            bs.zero_()
+        bs[..., 0] += dzg.sum((1, 3))
+        bs[..., 1] += (dzg * xhat).sum((1, 3))
 
     def gn_bwd_apply(self, dy, x, stats, bstats, gamma, beta, add, dx, n_s, rows, C, G, eps, silu_):
         xhat, dzg, rstd, cnt = self._gn_dz(dy, x, stats, gamma, beta, n_s, rows, C, G, eps, silu_)

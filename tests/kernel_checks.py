@@ -132,6 +132,25 @@ def check_gemm_tn(P, dt):
     return res
 
 
+def check_gemm_geglu(P, dt):
+    g = torch.Generator().manual_seed(12)
+    res = []
+    for (M, C, F) in [(200, 64, 128), (300, 320, 1280), (130, 128, 640)]:
+        x, W1, b1 = rnd((M, C), dt, P.dev, g), rnd((2 * F, C), dt, P.dev, g, C ** -0.5), rndf((2 * F,), P.dev, g)
+        o1, o2 = P.run("gemm", lambda o: ((x, W1, o["pre"], M, 2 * F, C, C, C, 2 * F),
+                                          dict(bias=b1, variant=4, epilogue=K.EPI_GEGLU_FWD, aux_out=o["h"], aux_dim=F)),
+                       dict(pre=torch.zeros(M, 2 * F, dtype=dt, device=P.dev), h=torch.zeros(M, F, dtype=dt, device=P.dev)))
+        res.append((f"gemm geglu-fwd {M}x{C}x{F} pre", relerr(o1["pre"], o2["pre"]), tol_for(dt)))
+        res.append((f"gemm geglu-fwd {M}x{C}x{F} h", relerr(o1["h"], o2["h"]), tol_for(dt, 2)))
+        pre = o2["pre"]
+        dy, W2t = rnd((M, C), dt, P.dev, g), rnd((F, C), dt, P.dev, g, C ** -0.5)
+        o1, o2 = P.run("gemm", lambda o: ((dy, W2t, o["dpre"], M, F, C, C, C, 2 * F),
+                                          dict(variant=4, epilogue=K.EPI_GEGLU_BWD, aux_in=pre, aux_dim=F)),
+                       dict(dpre=torch.zeros(M, 2 * F, dtype=dt, device=P.dev)))
+        res.append((f"gemm geglu-bwd {M}x{C}x{F}", relerr(o1["dpre"], o2["dpre"]), tol_for(dt, 2)))
+    return res
+
+
 def check_gemm_gather(P, dt, variant):
     g = torch.Generator().manual_seed(2)
     res = []
@@ -400,7 +419,7 @@ def run_all(impl, dev, dtypes=DTYPES, verbose=True):
                   ("gemm_plain_v2", lambda: check_gemm_plain(P, dt, 2)), ("gemm_gather_v2", lambda: check_gemm_gather(P, dt, 2)),
                   ("gemm_plain_v3", lambda: check_gemm_plain(P, dt, 3)), ("gemm_gather_v3", lambda: check_gemm_gather(P, dt, 3)),
                   ("gemm_plain_v4", lambda: check_gemm_plain(P, dt, 4)), ("gemm_gather_v4", lambda: check_gemm_gather(P, dt, 4)),
-                  ("gemm_tn", lambda: check_gemm_tn(P, dt)), ("gemm_gather_v0", lambda: check_gemm_gather(P, dt, 0)), ("gemm_gather_v1", lambda: check_gemm_gather(P, dt, 1)),
+                  ("gemm_tn", lambda: check_gemm_tn(P, dt)), ("gemm_geglu", lambda: check_gemm_geglu(P, dt)), ("gemm_gather_v0", lambda: check_gemm_gather(P, dt, 0)), ("gemm_gather_v1", lambda: check_gemm_gather(P, dt, 1)),
                   ("small", lambda: check_small(P, dt)), ("groupnorm", lambda: check_groupnorm(P, dt)),
                   ("layernorm", lambda: check_layernorm(P, dt)), ("attention", lambda: check_attention(P, dt)),
                   ("temporal_attention", lambda: check_temporal_attention(P, dt)), ("elementwise", lambda: check_elementwise(P, dt)),

@@ -36,7 +36,8 @@ def test_library_exports_every_declared_symbol(lib):
 def test_error_reporting_without_device(lib):
     import ctypes
     # argument validation happens before any launch, so it can be exercised without a GPU
-    rc = lib.svdx_gemm(None, None, None, 0, 0, 0, 0, 0, 0, None, None, 0, 0, 0, None, 0, None, None, 0, 1.0, 1, 0, 0, None)
+    rc = lib.svdx_gemm(None, None, None, 0, 0, 0, 0, 0, 0, None, None, 0, 0, 0, None, 0, None, None, 0, 1.0, 1, 0, 0, None, None, 0,
+                       0, None)
     assert rc != 0
     buf = ctypes.create_string_buffer(256)
     lib.svdx_last_error(buf, 256)
