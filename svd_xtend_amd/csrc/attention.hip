@@ -47,6 +47,41 @@ __device__ __forceinline__ void stage_trans(char* lds, const T* base, int s_pad,
         *reinterpret_cast<uint2*>(lds + r * TP + c * 16 + 8) = make_uint2(v.z, v.w);
     }
 }
+// two-phase staging (global -> registers early, registers -> LDS after the barrier): the loads of tile t+1 are in flight while
+// tile t is being multiplied (cdna_hip_programming.md T14)
+struct Tile2 { uint4 a, b; };       // returned / passed BY VALUE so the staging registers stay in SSA form (no scratch)
+template <typename T>
+__device__ __forceinline__ Tile2 load_rows(const T* base, size_t ld, int row0, int s_max, int tid) {
+    Tile2 r;
+    {
+        const int id = tid, rr = id >> 3, pc = id & 7, lc = pc ^ (rr & 7);
+        r.a = *reinterpret_cast<const uint4*>(base + (size_t)min(row0 + rr, s_max - 1) * ld + lc * 8);
+    }
+    {
+        const int id = 256 + tid, rr = id >> 3, pc = id & 7, lc = pc ^ (rr & 7);
+        r.b = *reinterpret_cast<const uint4*>(base + (size_t)min(row0 + rr, s_max - 1) * ld + lc * 8);
+    }
+    return r;
+}
+__device__ __forceinline__ void store_rows(char* lds, const Tile2 r, int tid) {
+    *reinterpret_cast<uint4*>(lds + (tid >> 3) * 128 + (tid & 7) * 16) = r.a;
+    *reinterpret_cast<uint4*>(lds + ((256 + tid) >> 3) * 128 + (tid & 7) * 16) = r.b;
+}
+template <typename T>
+__device__ __forceinline__ Tile2 load_trans(const T* base, int s_pad, int col0, int tid) {
+    Tile2 r;
+    r.a = *reinterpret_cast<const uint4*>(base + (size_t)(tid >> 3) * s_pad + col0 + (tid & 7) * 8);
+    r.b = *reinterpret_cast<const uint4*>(base + (size_t)((256 + tid) >> 3) * s_pad + col0 + (tid & 7) * 8);
+    return r;
+}
+__device__ __forceinline__ void store_trans(char* lds, const Tile2 r, int tid) {
+    char* d0 = lds + (tid >> 3) * TP + (tid & 7) * 16;
+    char* d1 = lds + ((256 + tid) >> 3) * TP + (tid & 7) * 16;
+    *reinterpret_cast<uint2*>(d0) = make_uint2(r.a.x, r.a.y);
+    *reinterpret_cast<uint2*>(d0 + 8) = make_uint2(r.a.z, r.a.w);
+    *reinterpret_cast<uint2*>(d1) = make_uint2(r.b.x, r.b.y);
+    *reinterpret_cast<uint2*>(d1 + 8) = make_uint2(r.b.z, r.b.w);
+}
 // row-major fragment: row (blk*16 + fr), logical 16-byte chunk (ks*4 + fg)
 template <typename T>
 __device__ __forceinline__ typename TT<T>::v8 frag_rows(const char* lds, int blk, int ks, int fr, int fg) {
@@ -113,11 +148,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
     float mrow[2] = {-1e30f, -1e30f}, lrow[2] = {0.f, 0.f};
 
     const int ntiles = (S + 63) / 64;
+    Tile2 rk = load_rows<T>(kb_, ld, 0, S, tid);
+    Tile2 rv = load_trans<T>(vtb, s_pad, 0, tid);
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
-        stage_rows<T>(Ks, kb_, ld, t * 64, S, tid);
-        stage_trans<T>(Vs, vtb, s_pad, t * 64, tid);
+        store_rows(Ks, rk, tid);
+        store_trans(Vs, rv, tid);
         __syncthreads();
+        {   // unconditional (the last iteration re-reads its own tile): keeps the staging registers out of scratch
+            const int tn = min(t + 1, ntiles - 1);
+            rk = load_rows<T>(kb_, ld, tn * 64, S, tid);
+            rv = load_trans<T>(vtb, s_pad, tn * 64, tid);
+        }
         f32x4 s[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -258,12 +300,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ntiles = (S + 63) / 64;
+    Tile2 rk = load_rows<T>(kb_, ld, 0, S, tid);
+    Tile2 rv = load_rows<T>(vb_, ld, 0, S, tid);
+    Tile2 rkt = load_trans<T>(ktb, s_pad, 0, tid);
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
-        stage_rows<T>(Ks, kb_, ld, t * 64, S, tid);
-        stage_rows<T>(Vs, vb_, ld, t * 64, S, tid);
-        stage_trans<T>(Kts, ktb, s_pad, t * 64, tid);
+        store_rows(Ks, rk, tid);
+        store_rows(Vs, rv, tid);
+        store_trans(Kts, rkt, tid);
         __syncthreads();
+        {
+            const int tn = min(t + 1, ntiles - 1);
+            rk = load_rows<T>(kb_, ld, tn * 64, S, tid);
+            rv = load_rows<T>(vb_, ld, tn * 64, S, tid);
+            rkt = load_trans<T>(ktb, s_pad, tn * 64, tid);
+        }
         f32x4 s[4][2], dp[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -361,20 +412,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
         for (int j = 0; j < 2; ++j) { dka[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dva[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const int ntiles = (S + 63) / 64;
+    Tile2 rq, rdo, rqt, rdot;
+    float rls = 0.f;
+#define SVDX_DKV_PREFETCH(t_)                                               \
+    {                                                                       \
+        const int tt_ = (t_);                                               \
+        rq = load_rows<T>(qb_, ld, tt_ * 64, S, tid);                       \
+        rdo = load_rows<T>(dob, ld_o, tt_ * 64, S, tid);                    \
+        rqt = load_trans<T>(qtb, s_pad, tt_ * 64, tid);                     \
+        rdot = load_trans<T>(dotb, s_pad, tt_ * 64, tid);                   \
+        const int qi_ = min(tt_ * 64 + (tid & 63), S - 1);                  \
+        rls = tid < 64 ? lsb[qi_] * LOG2E : dvb[qi_];                       \
+    }
+    SVDX_DKV_PREFETCH(0);
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
-        stage_rows<T>(Qs, qb_, ld, t * 64, S, tid);
-        stage_rows<T>(dOs, dob, ld_o, t * 64, S, tid);
-        stage_trans<T>(Qts, qtb, s_pad, t * 64, tid);
-        stage_trans<T>(dOts, dotb, s_pad, t * 64, tid);
-        if (tid < 64) {
-            const int qi = min(t * 64 + tid, S - 1);
-            Ls[tid] = lsb[qi] * LOG2E;
-        } else if (tid < 128) {
-            const int qi = min(t * 64 + tid - 64, S - 1);
-            Ls[tid] = dvb[qi];
-        }
+        store_rows(Qs, rq, tid);
+        store_rows(dOs, rdo, tid);
+        store_trans(Qts, rqt, tid);
+        store_trans(dOts, rdot, tid);
+        if (tid < 128) Ls[tid] = rls;
         __syncthreads();
+        SVDX_DKV_PREFETCH(min(t + 1, ntiles - 1));
         // S[q,key] and dP[q,key]: rows = queries (A from LDS), cols = this lane's key (B resident)
         f32x4 s[4][2], dp[4][2];
 #pragma unroll
