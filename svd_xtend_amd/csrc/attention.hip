@@ -20,6 +20,9 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
+// raw v_exp_f32: inputs here are <= ~8 and underflow to 0 is exactly what masked / far-below-max scores want
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+constexpr float RESCALE_THR = 8.f;   // defer the O/l rescale while the running max grows by less than this (log2 units)
 constexpr int TP = 136;   // byte pitch of transposed LDS tiles ([64 d][64 keys] halfs + 8 B pad)
 
 // ---- LDS tile staging -------------------------------------------------------------------------------------------
@@ -118,7 +121,7 @@ __device__ __forceinline__ void store4(T* p, const f32x4& v, float mul) {
 // forward: block = (128 queries, head, frame); 4 waves x 32 queries; KV tiles of 64 keys
 // ================================================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                        const T* __restrict__ vt, T* __restrict__ o, float* __restrict__ lse,
                                                        int heads, int S, int ld, int ld_o, int s_pad, float sl2) {
     typedef typename TT<T>::v8 v8;
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) s[kb][qb] = TT<T>::mfma(kf, qf[qb][ks], s[kb][qb]);
             }
+        const bool tail = (t == ntiles - 1) && (S & 63);          // only the last KV tile can hold out-of-range keys
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             float mx = -1e30f;
@@ -180,28 +184,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = t * 64 + kb * 16 + fg * 4 + r;
-                    const float v = key < S ? s[kb][qb][r] * sl2 : -1e30f;
-                    s[kb][qb][r] = v;
-                    mx = fmaxf(mx, v);
+                    if (tail && t * 64 + kb * 16 + fg * 4 + r >= S) s[kb][qb][r] = -1e30f;
+                    mx = fmaxf(mx, s[kb][qb][r]);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(mrow[qb], mx);
-            const float alpha = exp2f(mrow[qb] - mn);
-            mrow[qb] = mn;
+            mx = fmaxf(mx * sl2, -1e30f);                           // scaled (log2) domain; keeps -1e30 finite
+            // deferred rescale: keep the old reference max while the new one is within RESCALE_THR (P stays <= 2^8)
+            if (!__all(mx - mrow[qb] <= RESCALE_THR)) {
+                const float mn = fmaxf(mrow[qb], mx);
+                const float alpha = fexp2(mrow[qb] - mn);
+                mrow[qb] = mn;
+                lrow[qb] *= alpha;
+#pragma unroll
+                for (int db = 0; db < 4; ++db) oacc[db][qb] *= alpha;
+            }
+            const float mref = mrow[qb];
             float ps = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f(s[kb][qb][r] - mn);
+                    const float p = fexp2(fmaf(s[kb][qb][r], sl2, -mref));
                     s[kb][qb][r] = p;
                     ps += p;
                 }
-            lrow[qb] = lrow[qb] * alpha + ps;
-#pragma unroll
-            for (int db = 0; db < 4; ++db) oacc[db][qb] *= alpha;
+            lrow[qb] += ps;
         }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
@@ -260,7 +268,7 @@ __global__ void attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restric
 // backward dQ: same orientation as the forward (lanes own queries), loops over KV tiles
 // ================================================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                           const T* __restrict__ kt, const T* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ Dv,
                                                           T* __restrict__ dq, int heads, int S, int ld, int ld_o, int ld_d,
@@ -332,14 +340,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
                     dp[kb][qb] = TT<T>::mfma(vf, dof[qb][ks], dp[kb][qb]);
                 }
             }
+        const bool tail = (t == ntiles - 1) && (S & 63);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = t * 64 + kb * 16 + fg * 4 + r;
-                    const float p = key < S ? exp2f(s[kb][qb][r] * sl2 - lse2[qb]) : 0.f;
+                    float p = fexp2(fmaf(s[kb][qb][r], sl2, -lse2[qb]));
+                    if (tail && t * 64 + kb * 16 + fg * 4 + r >= S) p = 0.f;
                     s[kb][qb][r] = p * (dp[kb][qb][r] - dd[qb]);      // dS^T
                 }
 #pragma unroll
@@ -452,6 +461,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
                     dp[qb][kb] = TT<T>::mfma(df, vf[kb][ks], dp[qb][kb]);
                 }
             }
+        const bool tail = (t == ntiles - 1) && (S & 63);
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qb * 16 + fg * 4);
@@ -460,8 +470,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int qi = t * 64 + qb * 16 + fg * 4 + r;
-                    const float p = qi < S ? exp2f(s[qb][kb][r] * sl2 - l4[r]) : 0.f;
+                    float p = fexp2(fmaf(s[qb][kb][r], sl2, -l4[r]));
+                    if (tail && t * 64 + qb * 16 + fg * 4 + r >= S) p = 0.f;
                     s[qb][kb][r] = p;
                     dp[qb][kb][r] = p * (dp[qb][kb][r] - d4[r]);   // dS
                 }
@@ -574,7 +584,7 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const T* __restrict__ q,
     }
     float sum = 0.f;
 #pragma unroll
-    for (int tk = 0; tk < TPAD; ++tk) { sc[tk] = exp2f(sc[tk] - mx); sum += sc[tk]; }
+    for (int tk = 0; tk < TPAD; ++tk) { sc[tk] = fexp2(sc[tk] - mx); sum += sc[tk]; }
     const float inv = 1.f / sum;
     float ov[Cfg::DCH];
 #pragma unroll
@@ -667,7 +677,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ q,
     }
     float sum = 0.f;
 #pragma unroll
-    for (int tk = 0; tk < TPAD; ++tk) { sc[tk] = exp2f(sc[tk] - mx); sum += sc[tk]; }
+    for (int tk = 0; tk < TPAD; ++tk) { sc[tk] = fexp2(sc[tk] - mx); sum += sc[tk]; }
     const float inv = 1.f / sum;
     float dsum = 0.f;
 #pragma unroll

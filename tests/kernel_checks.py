@@ -260,6 +260,11 @@ def check_attention(P, dt):
         C = heads * 64
         s_pad = (S + 63) // 64 * 64
         qkv = rnd((nb * S, 3 * C), dt, P.dev, g, 1.0)
+        if S >= 160:
+            # force the online-softmax rescale branch: keys grow along the sequence, so the running max jumps by far more than the
+            # deferred-rescale threshold at later KV tiles (cdna_hip_programming.md rule 26)
+            ramp = torch.linspace(0.3, 4.0, S, device=P.dev).repeat(nb)[:, None]
+            qkv[:, C:2 * C] = (qkv[:, C:2 * C].float() * ramp).to(dt)
         d_o = rnd((nb * S, C), dt, P.dev, g)
         q, k, v = qkv, qkv[:, C:], qkv[:, 2 * C:]
         nhs = nb * heads * 64 * s_pad
