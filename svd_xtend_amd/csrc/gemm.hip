@@ -743,14 +743,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v3_kernel(GemmParams p) {
 // computed once per filter tap, the K position is a single scalar soffset, and zero padding comes from the buffer
 // bounds check (offset >= num_records reads 0) instead of a zero page + select.
 // ================================================================================================================
-template <typename T, int NB>
+template <typename T, int NB, bool RING>
 __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and LDS-DMA builtin only exist in the device pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
     constexpr int BN3 = 32 * NB;                      // 2 waves along N, NB/2... each wave owns NB*16 columns
     constexpr int WN3 = 16 * NB;                      // columns per wave
-    constexpr int STAGE3 = (BM + BN3) * BK * 2;
+    // RING = false: two 64-deep stages, vmcnt(0) + __syncthreads per K-tile.
+    // RING = true : four 32-deep stages (3 tiles of prefetch in flight), counted vmcnt + raw s_barrier per K-step.
+    constexpr int KT = RING ? 32 : BK;                 // K extent of one stage
+    constexpr int NSTG = RING ? 4 : 2;
+    constexpr int STAGE3 = (BM + BN3) * KT * 2;
+    constexpr int CPRW = KT / 8;                       // 16-byte chunks per staged row (8 | 4)
+    constexpr int RPP = NTHREADS / CPRW;               // rows covered by one load pass (32 | 64)
+    constexpr int NLA = BM / RPP;                      // A loads per thread per stage (4 | 2)
+    constexpr int NLB = (BN3 + RPP - 1) / RPP;         // B loads per thread per stage (NB | 3 or 2)
+    constexpr int ROWB = KT * 2;                       // bytes per staged row (128 | 64)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int nwg = p.tiles_m * p.tiles_n;
@@ -759,20 +768,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
     const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
     const int pid_m = swz / p.tiles_n, pid_n = swz - pid_m * p.tiles_n;
     const int m0 = pid_m * BM, n0 = pid_n * BN3;
-    const int kt_total = p.K / BK;
+    const int kt_total = p.K / KT;
     const int z = blockIdx.y;
-    const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
+    int kt_per = (kt_total + p.split_k - 1) / p.split_k;
+    if (RING) kt_per += kt_per & 1;                    // split boundaries stay on the 64-deep grid
     const int kt_begin = z * kt_per;
     const int kt_end = min(kt_total, kt_begin + kt_per);
     if (kt_begin >= kt_end) return;
 
     // ---- lean staging: buffer_load ... lds with per-lane byte offsets (fixed per filter tap) + one scalar K offset ----
-    const int ld_row = tid >> 3, pc = tid & 7, lc = pc ^ (ld_row & 7);
-    RowInfo a_ri[4];
-    int a_m[4], voa[4], vob[NB];
+    const int ld_row = tid / CPRW, pc = tid % CPRW;
+    const int lc = RING ? (pc ^ (((ld_row >> 2) & 1) * 3)) : (pc ^ (ld_row & 7));
+    RowInfo a_ri[NLA];
+    int a_m[NLA], voa[NLA], vob[NLB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a_m[i] = min(m0 + i * 32 + ld_row, p.M - 1);
+    for (int i = 0; i < NLA; ++i) {
+        a_m[i] = min(m0 + i * RPP + ld_row, p.M - 1);
         a_ri[i] = decode_row(p.g, a_m[i]);
     }
     // GEGLU-forward tiles pair 16 value columns with their 16 gate columns: local n-block 2q is rows F*0 + c, block 2q+1 is rows
@@ -783,7 +794,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
                                            : min(n0 + nl, p.N - 1);
     };
 #pragma unroll
-    for (int i = 0; i < NB; ++i) vob[i] = (brow(i * 32 + ld_row) * p.ldb + lc * 8) * 2;
+    for (int i = 0; i < NLB; ++i) {
+        const int nl = i * RPP + ld_row;               // tile-local B row; rows >= BN3 (ring, NB = 5) are dummy loads that keep vmcnt uniform
+        vob[i] = nl < BN3 ? (brow(nl) * p.ldb + lc * 8) * 2 : (int)0x80000000;
+    }
     const bool plain = p.g.mode == SVDX_GATHER_PLAIN;
     const int cin = plain ? p.K : p.g.cin;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
@@ -793,7 +807,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
     int ci0 = kt_begin * BK - tap * cin;                // channel offset inside the tap (plain: k offset)
     auto set_tap = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NLA; ++i) {
             bool valid;
             const T* ptr = a_row_ptr<T>(p, a_ri[i], a_m[i], 0, tap, 0, valid);
             // invalid (zero-padding) rows: an offset beyond num_records makes the buffer load return zeros
@@ -803,17 +817,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
     set_tap();
     auto issue = [&](int stage) __attribute__((always_inline)) {
         char* As = smem + stage * STAGE3;
-        char* Bs = As + BM * BK * 2;
+        char* Bs = As + BM * KT * 2;
         const int soa = ci0 * 2, sob = (tap * cin + ci0) * 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NLA; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(As + (i * 256 + wave_u * 64) * 16), 16,
                                                      voa[i], soa, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(Bs + (i * 256 + wave_u * 64) * 16), 16,
-                                                     vob[i], sob, 0, 0);
-        ci0 += BK;
+        for (int i = 0; i < NLB; ++i) {
+            // the dummy pass (tile rows >= BN3: waves 2,3 of the last pass) lands zeros in a scratch area behind the stages
+            char* dst = ((i * RPP + RPP <= BN3) || wave_u * 64 / CPRW + i * RPP < BN3) ? Bs + (i * 256 + wave_u * 64) * 16
+                                                                                        : smem + NSTG * STAGE3 + wave_u * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)dst, 16, vob[i], sob, 0, 0);
+        }
+        ci0 += KT;
         if (!plain && ci0 == cin) { ci0 = 0; ++tap; set_tap(); }
     };
     f32x4 acc[NB][4];                                   // [n-block][m-block], transposed: rows = n, cols = m
@@ -824,33 +841,52 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
     const int fr = lane & 15, fg = lane >> 4;
     auto compute = [&](int stage) __attribute__((always_inline)) {
         const char* As = smem + stage * STAGE3;
-        const char* Bs = As + BM * BK * 2;
+        const char* Bs = As + BM * KT * 2;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int chunk = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+        for (int kk = 0; kk < KT / 32; ++kk) {
+            const int chunk = RING ? ((fg ^ (((fr >> 2) & 1) * 3)) * 16) : (((kk * 4 + fg) ^ (fr & 7)) * 16);
             v8 af[4], bf[NB];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(As + (wm * 64 + i * 16 + fr) * 128 + chunk);
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(As + (wm * 64 + i * 16 + fr) * ROWB + chunk);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) bf[i] = *reinterpret_cast<const v8*>(Bs + (wn * WN3 + i * 16 + fr) * 128 + chunk);
+            for (int i = 0; i < NB; ++i) bf[i] = *reinterpret_cast<const v8*>(Bs + (wn * WN3 + i * 16 + fr) * ROWB + chunk);
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = TT<T>::mfma(bf[i], af[j], acc[i][j]);
         }
     };
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
-        issue(cur ^ 1);
-        compute(cur);
+    if constexpr (RING) {
+        constexpr int D = NSTG - 1, L = NLA + NLB;          // tiles of prefetch, loads per thread per tile
+        const int nt = kt_end - kt_begin;
+#pragma unroll
+        for (int s_ = 0; s_ < D; ++s_)
+            if (s_ < nt) issue(s_);
+        int stage = 0;
+        for (int it = 0; it < nt; ++it) {
+            const int after = min(D - 1, nt - 1 - it);        // younger tiles allowed to stay in flight
+            if (after >= 2) wait_vmcnt<2 * L>();
+            else if (after == 1) wait_vmcnt<L>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                     // tile `it` landed for every wave; the stage of tile it-1 is free
+            if (it + D < nt) issue(stage == 0 ? NSTG - 1 : stage - 1);
+            compute(stage);
+            stage = stage + 1 == NSTG ? 0 : stage + 1;
+        }
+    } else {
+        issue(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        cur ^= 1;
+        int cur = 0;
+        for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
+            issue(cur ^ 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+        compute(cur);
     }
-    compute(cur);
 
     // ---- epilogue A (activation output): coalesced.  Each lane adds bias / row vector to its 4-column groups, rounds to the
     //      activation dtype and parks them in LDS (the stage buffers are free now); then every thread moves 16-byte row
@@ -1191,18 +1227,18 @@ int launch_gemm_v3(GemmParams p, hipStream_t st) {
     return 0;
 }
 
-template <typename T, int NB>
+template <typename T, int NB, bool RING>
 int launch_gemm_v4(GemmParams p, hipStream_t st) {
-    constexpr int LDS = 2 * (BM + 32 * NB) * BK * 2;
+    constexpr int LDS = RING ? 4 * (BM + 32 * NB) * 32 * 2 + 4096 : 2 * (BM + 32 * NB) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     p.tiles_n = p.epi == SVDX_EPI_GEGLU_FWD ? cdiv(p.aux_dim, 16 * NB) : cdiv(p.N, 32 * NB);
     p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 15) == 0));
     dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
-    hipLaunchKernelGGL((gemm_v4_kernel<T, NB>), grid, dim3(NTHREADS), LDS, st, p);
+    hipLaunchKernelGGL((gemm_v4_kernel<T, NB, RING>), grid, dim3(NTHREADS), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm");
     return 0;
 }
@@ -1264,7 +1300,7 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
                          int aux_dim, int dtype, void* stream) {
     SVDX_CHECK_ARG(A && B && C, "svdx_gemm: null operand");
     if (epilogue != SVDX_EPI_NONE) {
-        SVDX_CHECK_ARG(variant == 4 && out_mode == SVDX_OUT_ACT && split_k == 1 && !res && !rowvec && aux_dim > 0 && aux_dim % 64 == 0 &&
+        SVDX_CHECK_ARG((variant == 4 || variant == 5) && out_mode == SVDX_OUT_ACT && split_k == 1 && !res && !rowvec && aux_dim > 0 && aux_dim % 64 == 0 &&
                            (!gather || gather->mode == SVDX_GATHER_PLAIN), "svdx_gemm: fused GEGLU epilogue needs variant 4, plain A, no split-K");
         SVDX_CHECK_ARG(((uintptr_t)C & 15) == 0, "svdx_gemm: fused epilogue output must be 16-byte aligned");
         if (epilogue == SVDX_EPI_GEGLU_FWD)
@@ -1323,13 +1359,14 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
     const int a_ld = p.g.mode == SVDX_GATHER_PLAIN ? lda : p.g.lda;
     const int a_w = p.g.mode == SVDX_GATHER_PLAIN ? K : p.g.cin;
     long a_bytes = ((a_rows - 1) * a_ld + a_w) * 2, b_bytes = ((long)(N - 1) * ldb + K) * 2;
-    if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) { a_bytes = 0; b_bytes = 0; if (variant == 4) variant = 3; }
+    if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) { a_bytes = 0; b_bytes = 0; if (variant >= 4) variant = 3; }
     DISPATCH_DTYPE(dtype, {
         if (variant == 3) return (N % 160 == 0) ? launch_gemm_v3<T, 5>(p, st) : launch_gemm_v3<T, 4>(p, st);
-        if (variant == 4 && a_bytes > 0 && b_bytes > 0) {
+        if ((variant == 4 || variant == 5) && a_bytes > 0 && b_bytes > 0) {
             p.a_bytes = (int)a_bytes; p.b_bytes = (int)b_bytes;
             const bool nb5 = epilogue == SVDX_EPI_GEGLU_FWD ? false : (N % 160 == 0);
-            return nb5 ? launch_gemm_v4<T, 5>(p, st) : launch_gemm_v4<T, 4>(p, st);
+            if (variant == 5) return nb5 ? launch_gemm_v4<T, 5, true>(p, st) : launch_gemm_v4<T, 4, true>(p, st);
+            return nb5 ? launch_gemm_v4<T, 5, false>(p, st) : launch_gemm_v4<T, 4, false>(p, st);
         }
         if (epilogue != SVDX_EPI_NONE) { svdx_set_error("svdx_gemm: fused epilogue unavailable (buffer too large for variant 4)"); return -2; }
         return variant == 2 ? launch_gemm_pipe<T>(p, st) : variant == 1 ? launch_gemm<T, true>(p, st) : launch_gemm<T, false>(p, st);
