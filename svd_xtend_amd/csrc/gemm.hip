@@ -7,14 +7,15 @@
 // Convolutions never materialise im2col: each K-tile of 64 channels belongs to one filter tap, and the A
 // rows of that tile are fetched from the tap's shifted pixel (or from a zero page outside the image).
 //
-// Tile: 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16 fragments.
-// LDS: two stages x (A 16 KiB + B 16 KiB); rows are 128 B and the 16-byte chunk index is XOR-swizzled with
-// (row & 7) so that the ds_read_b128 fragment reads are bank-conflict free.  Two staging paths:
-//   variant 0: global -> VGPR -> ds_write_b128, loads issued before the MFMA phase (latency hidden)
-//   variant 1: global_load_lds_dwordx4 (LDS-DMA), swizzle applied on the per-lane SOURCE address
-// Epilogue: accumulators are staged through LDS (f32, padded rows) so that bias / per-clip row vector /
-// residual are applied and stored with 16-byte coalesced accesses.
-// Block -> tile mapping is XCD-aware (consecutive tiles of one A row-panel stay on one XCD's L2).
+// Kernels in this file (variant argument of svdx_gemm):
+//   variant 0  gemm_kernel<GLDS=false>: 128x128x64, global -> VGPR -> ds_write_b128 staging (reference structure)
+//   variant 1  gemm_kernel<GLDS=true> : same with global_load_lds_dwordx4 (LDS-DMA), swizzle on the per-lane SOURCE address;
+//              also the fallback when a buffer exceeds the 2 GiB range of variant 4's 32-bit offsets
+//   variant 4  gemm_v4_kernel         : production (see its banner): 128x160 tiles, lean buffer_load...lds loop, coalesced epilogue
+//   gemm_tn_kernel                    : weight gradients straight from row-major dY / X via ds_read_b64_tr_b16
+// Common: 256 threads = 4 waves (2x2); LDS rows of 128 B with the 16-byte chunk index XOR-swizzled by (row & 7) so the
+// ds_read_b128 fragment reads are bank-conflict free (SQ_LDS_BANK_CONFLICT = 0 measured); XCD-aware block -> tile mapping
+// (consecutive tiles of one A row-panel stay on one XCD's L2); split-K into float slabs + svdx_gemm_finalize.
 #include "common.h"
 
 namespace {
@@ -441,319 +442,30 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
 
 
 // ================================================================================================================
-// variant 2: deep LDS ring.  Same 128x128 output tile and wave layout, but K is consumed 32 at a time through a
-// 5-stage ring of 16-KiB stages filled by LDS-DMA (global_load_lds_dwordx4), 4 tiles of prefetch in flight per block
-// and 2 blocks per CU (2 x 80 KiB LDS).  The HBM/L2 latency (~1-2 us under load) is hidden behind 4 MFMA phases
-// instead of one.  Synchronisation is one raw s_barrier per K-step plus a COUNTED s_waitcnt vmcnt(4*tiles_after):
-// a __syncthreads() would drain the whole DMA queue (cdna_hip_programming.md, "Pipelining across barriers").
-// 64-byte LDS rows; the 16-byte chunk index is XORed with 3*((row>>2)&1), which makes the ds_read_b128 fragment
-// reads conflict free for this pitch.
-// ================================================================================================================
-constexpr int PK = 32, PNS = 5, PSTAGE = (BM + BN) * PK * 2;     // 16 KiB per stage
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
-
-template <typename T>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef typename TT<T>::v8 v8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int pid_m = swz / p.tiles_n, pid_n = swz - pid_m * p.tiles_n;
-    const int m0 = pid_m * BM, n0 = pid_n * BN;
-    const int kt_total = p.K / PK;
-    const int z = blockIdx.y;
-    int kt_per = (kt_total + p.split_k - 1) / p.split_k;
-    kt_per += kt_per & 1;                                   // keep split boundaries on the 64-deep grid of variant 0/1
-    const int kt_begin = z * kt_per;
-    const int kt_end = min(kt_total, kt_begin + kt_per);
-    if (kt_begin >= kt_end) return;
-    const int nt = kt_end - kt_begin;
-
-    // staging: tile = 128 rows x 4 chunks; thread handles rows (tid>>2) and 64+(tid>>2), one physical chunk
-    const int ld_row = tid >> 2, pc = tid & 3;
-    const int lc = pc ^ (((ld_row >> 2) & 1) * 3);
-    int a_m[2];
-    RowInfo a_ri[2];
-    const T* b_ptr[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = min(m0 + i * 64 + ld_row, p.M - 1);
-        a_m[i] = m;
-        a_ri[i] = decode_row(p.g, m);
-        const int n = min(n0 + i * 64 + ld_row, p.N - 1);
-        b_ptr[i] = reinterpret_cast<const T*>(p.B) + (size_t)n * p.ldb + lc * 8;
-    }
-    const int cin = p.g.mode == SVDX_GATHER_PLAIN ? p.K : p.g.cin;
-    const T* zero = reinterpret_cast<const T*>(p.zero_page);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
-        const int k0 = kt * PK;
-        int tap = 0, ci0 = k0;
-        if (p.g.mode != SVDX_GATHER_PLAIN) { tap = k0 / cin; ci0 = k0 - tap * cin; }
-        char* As = smem + stage * PSTAGE;
-        char* Bs = As + BM * PK * 2;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            bool valid;
-            const T* ptr = a_row_ptr<T>(p, a_ri[i], a_m[i], k0, tap, ci0, valid);
-            const T* pa = valid ? ptr + lc * 8 : zero;
-            const T* pb = b_ptr[i] + k0;
-            const int base = (i * 256 + wave_u * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa,
-                                             (__attribute__((address_space(3))) void*)(As + base), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb,
-                                             (__attribute__((address_space(3))) void*)(Bs + base), 16, 0, 0);
-        }
-    };
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, fg = lane >> 4;
-    const int fchunk = (fg ^ (((fr >> 2) & 1) * 3)) * 16;        // (row>>2)&1 == (fr>>2)&1: row offsets are multiples of 16
-    auto compute = [&](int stage) __attribute__((always_inline)) {
-        const char* As = smem + stage * PSTAGE;
-        const char* Bs = As + BM * PK * 2;
-        v8 af[4], bf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i] = *reinterpret_cast<const v8*>(As + (wm * 64 + i * 16 + fr) * 64 + fchunk);
-            bf[i] = *reinterpret_cast<const v8*>(Bs + (wn * 64 + i * 16 + fr) * 64 + fchunk);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = TT<T>::mfma(af[i], bf[j], acc[i][j]);
-    };
-
-    constexpr int D = PNS - 1;                                   // tiles of prefetch
-#pragma unroll
-    for (int s = 0; s < D; ++s)
-        if (s < nt) issue(kt_begin + s, s);
-    int stage = 0;
-    for (int it = 0; it < nt; ++it) {
-        const int after = min(D - 1, nt - 1 - it);               // tiles issued after tile `it` and still allowed in flight
-        if (after >= 3) wait_vmcnt<12>();
-        else if (after == 2) wait_vmcnt<8>();
-        else if (after == 1) wait_vmcnt<4>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                            // tile `it` is complete in LDS; stage of tile it-1 is free
-        if (it + D < nt) issue(kt_begin + it + D, stage == 0 ? PNS - 1 : stage - 1);
-        compute(stage);
-        stage = stage + 1 == PNS ? 0 : stage + 1;
-    }
-    __syncthreads();
-    gemm_epilogue<T>(p, acc, smem, m0, n0, z, tid, lane, wm, wn);
-}
-
-
-// ================================================================================================================
-// variant 3: 128 x (32*NB) x 64 tile, NB = 4 or 5.  All channel counts of the SVD UNet are multiples of 320, so
-// BN = 160 tiles N exactly (BN = 128 wastes 17 % of the MFMA work at N = 320) and raises the MFMA : ds_read ratio
-// (40 : 18 per wave per K-tile).  The accumulators are kept TRANSPOSED (acc = mfma(B_frag, A_frag)): a lane then owns
-// 4 consecutive output columns of one row, so the epilogue adds bias / row vector / residual and stores straight
-// from registers with 8-byte (activation) or 16-byte (float) accesses -- no LDS staging, no barriers.  Short-K
-// GEMMs (K = 320 at the 40x64 level: 5 K-tiles) spend a third of their time in the epilogue otherwise.
+// variant 4 (production): 128 x (32*NB) x 64 tile, NB = 4 or 5, lean K-loop.
+//  * All channel counts of the SVD UNet are multiples of 320, so BN = 160 tiles N exactly (BN = 128 wastes 17 % of the MFMA
+//    work at N = 320) and raises the MFMA : ds_read ratio (40 : 18 per wave per K-tile).
+//  * Accumulators are kept TRANSPOSED (acc = mfma(B_frag, A_frag)): a lane owns 4 consecutive output columns of one row.
+//    Activation outputs are rounded, parked in LDS and written with full-line coalesced 16-byte stores (bias / row vector /
+//    residual / GEGLU forward+backward fused there); float outputs (slabs, += for weight-grad style uses) go straight from
+//    registers with 16-byte stores.
+//  * Staging: buffer_load_dwordx4 ... lds with per-lane 32-bit byte offsets computed once per filter tap, the K position as a
+//    single scalar soffset, and zero padding from the buffer bounds check (offset >= num_records reads 0) -- no zero page,
+//    no select, no 64-bit pointer arithmetic in the loop.  PMC counters that motivated this (profiles/r1_gemm_pmc.txt): the
+//    pointer-arithmetic loop issued 2.4 VALU + 2.9 SALU instructions per MFMA (issue bound, MFMA busy ~33 %); this loop issues
+//    0.3 VALU + 0.95 SALU.
+//  * Tried and dropped: a 5-stage / 4-stage LDS ring with counted vmcnt + raw s_barrier (no gain in
+//    situ, slower in isolation: the loop is not latency bound), direct 8-byte epilogue stores (worse DRAM efficiency).
 // ================================================================================================================
 template <typename T, int NB>
-__global__ __launch_bounds__(NTHREADS) void gemm_v3_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef typename TT<T>::v8 v8;
-    constexpr int BN3 = 32 * NB;                      // 2 waves along N, NB/2... each wave owns NB*16 columns
-    constexpr int WN3 = 16 * NB;                      // columns per wave
-    constexpr int STAGE3 = (BM + BN3) * BK * 2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int pid_m = swz / p.tiles_n, pid_n = swz - pid_m * p.tiles_n;
-    const int m0 = pid_m * BM, n0 = pid_n * BN3;
-    const int kt_total = p.K / BK;
-    const int z = blockIdx.y;
-    const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
-    const int kt_begin = z * kt_per;
-    const int kt_end = min(kt_total, kt_begin + kt_per);
-    if (kt_begin >= kt_end) return;
-
-    const int ld_row = tid >> 3, pc = tid & 7, lc = pc ^ (ld_row & 7);
-    int a_m[4];
-    RowInfo a_ri[4];
-    const T* b_ptr[NB];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = min(m0 + i * 32 + ld_row, p.M - 1);
-        a_m[i] = m;
-        a_ri[i] = decode_row(p.g, m);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int n = min(n0 + i * 32 + ld_row, p.N - 1);
-        b_ptr[i] = reinterpret_cast<const T*>(p.B) + (size_t)n * p.ldb + lc * 8;
-    }
-    const int cin = p.g.mode == SVDX_GATHER_PLAIN ? p.K : p.g.cin;
-    const T* zero = reinterpret_cast<const T*>(p.zero_page);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
-        const int k0 = kt * BK;
-        int tap = 0, ci0 = k0;
-        if (p.g.mode != SVDX_GATHER_PLAIN) { tap = k0 / cin; ci0 = k0 - tap * cin; }
-        char* As = smem + stage * STAGE3;
-        char* Bs = As + BM * BK * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bool valid;
-            const T* ptr = a_row_ptr<T>(p, a_ri[i], a_m[i], k0, tap, ci0, valid);
-            const T* pa = valid ? ptr + lc * 8 : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa,
-                                             (__attribute__((address_space(3))) void*)(As + (i * 256 + wave_u * 64) * 16), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(Bs + (i * 256 + wave_u * 64) * 16), 16, 0, 0);
-    };
-    f32x4 acc[NB][4];                                   // [n-block][m-block], transposed: rows = n, cols = m
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, fg = lane >> 4;
-    auto compute = [&](int stage) __attribute__((always_inline)) {
-        const char* As = smem + stage * STAGE3;
-        const char* Bs = As + BM * BK * 2;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int chunk = ((kk * 4 + fg) ^ (fr & 7)) * 16;
-            v8 af[4], bf[NB];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(As + (wm * 64 + i * 16 + fr) * 128 + chunk);
-#pragma unroll
-            for (int i = 0; i < NB; ++i) bf[i] = *reinterpret_cast<const v8*>(Bs + (wn * WN3 + i * 16 + fr) * 128 + chunk);
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = TT<T>::mfma(bf[i], af[j], acc[i][j]);
-        }
-    };
-    issue(kt_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
-        issue(kt + 1, cur ^ 1);
-        compute(cur);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
-    }
-    compute(cur);
-
-    // ---- direct epilogue: lane (fr, fg) owns row m = .. + fr and columns n = .. + fg*4 + {0..3} of every 16x16 block ----
-    const bool lead = (z == 0) && p.out_mode != SVDX_OUT_F32_SLAB;
-    T* Ct = reinterpret_cast<T*>(p.C);
-    float* Cf = reinterpret_cast<float*>(p.C) + (p.out_mode == SVDX_OUT_F32_SLAB ? (size_t)z * p.slab_stride : 0);
-    const T* R = reinterpret_cast<const T*>(p.res);
-    const int nbase = n0 + wn * WN3 + fg * 4;
-    float bv[NB][4];
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int n = nbase + i * 16 + e;
-            bv[i][e] = (lead && p.bias && n < p.N) ? p.bias[n] : 0.f;
-        }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + fr;
-        if (m >= p.M) continue;
-        const float* rv = nullptr;
-        if (lead && p.rowvec) rv = p.rowvec + (size_t)(p.rv_mod ? (m % p.rv_mod) : (m / p.rv_rpg)) * p.rv_ld;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int n = nbase + i * 16;
-            if (n >= p.N) continue;
-            const int nvalid = min(4, p.N - n);
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha + bv[i][e];
-            if (rv) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += rv[n + e];
-            }
-            const bool full = p.vec_ok && nvalid == 4;
-            if (lead && R) {
-                const T* rp = R + (size_t)m * p.ldres + n;
-                if (full) {
-                    const Vec4<T> r4 = *reinterpret_cast<const Vec4<T>*>(rp);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += to_f<T>(r4.v[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += to_f<T>(rp[e]);
-                }
-            }
-            const size_t co = (size_t)m * p.ldc + n;
-            if (p.out_mode == SVDX_OUT_ACT) {
-                if (full) {
-                    Vec4<T> o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(v[e]);
-                    *reinterpret_cast<Vec4<T>*>(Ct + co) = o;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (e < nvalid) Ct[co + e] = from_f<T>(v[e]);
-                }
-            } else if (p.out_mode == SVDX_OUT_F32 || p.out_mode == SVDX_OUT_F32_SLAB) {
-                if (full) *reinterpret_cast<f32x4*>(Cf + co) = f32x4{v[0], v[1], v[2], v[3]};
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (e < nvalid) Cf[co + e] = v[e];
-                }
-            } else if (p.out_mode == SVDX_OUT_F32_ADD) {
-                if (full) {
-                    f32x4 c = *reinterpret_cast<const f32x4*>(Cf + co);
-                    c += f32x4{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(Cf + co) = c;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (e < nvalid) Cf[co + e] += v[e];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (e < nvalid) atomicAdd(Cf + co + e, v[e]);
-            }
-        }
-    }
-}
-
-// ================================================================================================================
-// variant 4 = variant 3 with a LEAN K-loop.  PMC counters on variant 3 (profiles/r1_gemm_pmc.txt): 2.4 VALU + 2.9 SALU
-// instructions per MFMA -- 64-bit pointer arithmetic, gather-mode branches and M0 setup -- make the loop issue-bound
-// (MFMA busy ~33 %).  Here the tiles are staged with buffer_load_dwordx4 ... lds: per-lane 32-bit byte offsets are
-// computed once per filter tap, the K position is a single scalar soffset, and zero padding comes from the buffer
-// bounds check (offset >= num_records reads 0) instead of a zero page + select.
-// ================================================================================================================
-template <typename T, int NB, bool RING>
 __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and LDS-DMA builtin only exist in the device pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
     constexpr int BN3 = 32 * NB;                      // 2 waves along N, NB/2... each wave owns NB*16 columns
     constexpr int WN3 = 16 * NB;                      // columns per wave
-    // RING = false: two 64-deep stages, vmcnt(0) + __syncthreads per K-tile.
-    // RING = true : four 32-deep stages (3 tiles of prefetch in flight), counted vmcnt + raw s_barrier per K-step.
-    constexpr int KT = RING ? 32 : BK;                 // K extent of one stage
-    constexpr int NSTG = RING ? 4 : 2;
+    constexpr int KT = BK;                             // K extent of one stage
+    constexpr int NSTG = 2;
     constexpr int STAGE3 = (BM + BN3) * KT * 2;
     constexpr int CPRW = KT / 8;                       // 16-byte chunks per staged row (8 | 4)
     constexpr int RPP = NTHREADS / CPRW;               // rows covered by one load pass (32 | 64)
@@ -770,15 +482,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
     const int m0 = pid_m * BM, n0 = pid_n * BN3;
     const int kt_total = p.K / KT;
     const int z = blockIdx.y;
-    int kt_per = (kt_total + p.split_k - 1) / p.split_k;
-    if (RING) kt_per += kt_per & 1;                    // split boundaries stay on the 64-deep grid
+    const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
     const int kt_begin = z * kt_per;
     const int kt_end = min(kt_total, kt_begin + kt_per);
     if (kt_begin >= kt_end) return;
 
     // ---- lean staging: buffer_load ... lds with per-lane byte offsets (fixed per filter tap) + one scalar K offset ----
     const int ld_row = tid / CPRW, pc = tid % CPRW;
-    const int lc = RING ? (pc ^ (((ld_row >> 2) & 1) * 3)) : (pc ^ (ld_row & 7));
+    const int lc = pc ^ (ld_row & 7);
     RowInfo a_ri[NLA];
     int a_m[NLA], voa[NLA], vob[NLB];
 #pragma unroll
@@ -803,8 +514,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    int tap = plain ? 0 : (kt_begin * BK) / cin;
-    int ci0 = kt_begin * BK - tap * cin;                // channel offset inside the tap (plain: k offset)
+    int tap = plain ? 0 : (kt_begin * KT) / cin;
+    int ci0 = kt_begin * KT - tap * cin;                // channel offset inside the tap (plain: k offset)
     auto set_tap = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
@@ -844,7 +555,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
         const char* Bs = As + BM * KT * 2;
 #pragma unroll
         for (int kk = 0; kk < KT / 32; ++kk) {
-            const int chunk = RING ? ((fg ^ (((fr >> 2) & 1) * 3)) * 16) : (((kk * 4 + fg) ^ (fr & 7)) * 16);
+            const int chunk = ((kk * 4 + fg) ^ (fr & 7)) * 16;
             v8 af[4], bf[NB];
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(As + (wm * 64 + i * 16 + fr) * ROWB + chunk);
@@ -856,24 +567,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
                 for (int j = 0; j < 4; ++j) acc[i][j] = TT<T>::mfma(bf[i], af[j], acc[i][j]);
         }
     };
-    if constexpr (RING) {
-        constexpr int D = NSTG - 1, L = NLA + NLB;          // tiles of prefetch, loads per thread per tile
-        const int nt = kt_end - kt_begin;
-#pragma unroll
-        for (int s_ = 0; s_ < D; ++s_)
-            if (s_ < nt) issue(s_);
-        int stage = 0;
-        for (int it = 0; it < nt; ++it) {
-            const int after = min(D - 1, nt - 1 - it);        // younger tiles allowed to stay in flight
-            if (after >= 2) wait_vmcnt<2 * L>();
-            else if (after == 1) wait_vmcnt<L>();
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();                     // tile `it` landed for every wave; the stage of tile it-1 is free
-            if (it + D < nt) issue(stage == 0 ? NSTG - 1 : stage - 1);
-            compute(stage);
-            stage = stage + 1 == NSTG ? 0 : stage + 1;
-        }
-    } else {
+    {
         issue(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1209,50 +903,17 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
 }
 
 template <typename T, int NB>
-int launch_gemm_v3(GemmParams p, hipStream_t st) {
+int launch_gemm_v4(GemmParams p, hipStream_t st) {
     constexpr int LDS = 2 * (BM + 32 * NB) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v3_kernel<T, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
-    p.tiles_n = cdiv(p.N, 32 * NB);
-    // 4-wide vector access needs ldc % 4 and 8-byte (act) / 16-byte (float) aligned bases
-    const int esz = p.out_mode == SVDX_OUT_ACT ? 2 : 4;
-    p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C % (esz == 2 ? 8 : 16)) == 0) &&
-               (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 7) == 0));
-    dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
-    hipLaunchKernelGGL((gemm_v3_kernel<T, NB>), grid, dim3(NTHREADS), LDS, st, p);
-    SVDX_LAUNCH_CHECK("svdx_gemm");
-    return 0;
-}
-
-template <typename T, int NB, bool RING>
-int launch_gemm_v4(GemmParams p, hipStream_t st) {
-    constexpr int LDS = RING ? 4 * (BM + 32 * NB) * 32 * 2 + 4096 : 2 * (BM + 32 * NB) * BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     p.tiles_n = p.epi == SVDX_EPI_GEGLU_FWD ? cdiv(p.aux_dim, 16 * NB) : cdiv(p.N, 32 * NB);
     p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 15) == 0));
     dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
-    hipLaunchKernelGGL((gemm_v4_kernel<T, NB, RING>), grid, dim3(NTHREADS), LDS, st, p);
-    SVDX_LAUNCH_CHECK("svdx_gemm");
-    return 0;
-}
-
-template <typename T>
-int launch_gemm_pipe(const GemmParams& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  PNS * PSTAGE);
-        attr_set = true;
-    }
-    dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
-    hipLaunchKernelGGL((gemm_pipe_kernel<T>), grid, dim3(NTHREADS), PNS * PSTAGE, st, p);
+    hipLaunchKernelGGL((gemm_v4_kernel<T, NB>), grid, dim3(NTHREADS), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm");
     return 0;
 }
@@ -1300,7 +961,7 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
                          int aux_dim, int dtype, void* stream) {
     SVDX_CHECK_ARG(A && B && C, "svdx_gemm: null operand");
     if (epilogue != SVDX_EPI_NONE) {
-        SVDX_CHECK_ARG((variant == 4 || variant == 5) && out_mode == SVDX_OUT_ACT && split_k == 1 && !res && !rowvec && aux_dim > 0 && aux_dim % 64 == 0 &&
+        SVDX_CHECK_ARG(variant >= 2 && out_mode == SVDX_OUT_ACT && split_k == 1 && !res && !rowvec && aux_dim > 0 && aux_dim % 64 == 0 &&
                            (!gather || gather->mode == SVDX_GATHER_PLAIN), "svdx_gemm: fused GEGLU epilogue needs variant 4, plain A, no split-K");
         SVDX_CHECK_ARG(((uintptr_t)C & 15) == 0, "svdx_gemm: fused epilogue output must be 16-byte aligned");
         if (epilogue == SVDX_EPI_GEGLU_FWD)
@@ -1359,17 +1020,15 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
     const int a_ld = p.g.mode == SVDX_GATHER_PLAIN ? lda : p.g.lda;
     const int a_w = p.g.mode == SVDX_GATHER_PLAIN ? K : p.g.cin;
     long a_bytes = ((a_rows - 1) * a_ld + a_w) * 2, b_bytes = ((long)(N - 1) * ldb + K) * 2;
-    if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) { a_bytes = 0; b_bytes = 0; if (variant >= 4) variant = 3; }
+    if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) { a_bytes = 0; b_bytes = 0; }   // falls back to variant 1 (64-bit pointers)
     DISPATCH_DTYPE(dtype, {
-        if (variant == 3) return (N % 160 == 0) ? launch_gemm_v3<T, 5>(p, st) : launch_gemm_v3<T, 4>(p, st);
-        if ((variant == 4 || variant == 5) && a_bytes > 0 && b_bytes > 0) {
+        if (variant >= 2 && a_bytes > 0 && b_bytes > 0) {
             p.a_bytes = (int)a_bytes; p.b_bytes = (int)b_bytes;
             const bool nb5 = epilogue == SVDX_EPI_GEGLU_FWD ? false : (N % 160 == 0);
-            if (variant == 5) return nb5 ? launch_gemm_v4<T, 5, true>(p, st) : launch_gemm_v4<T, 4, true>(p, st);
-            return nb5 ? launch_gemm_v4<T, 5, false>(p, st) : launch_gemm_v4<T, 4, false>(p, st);
+            return nb5 ? launch_gemm_v4<T, 5>(p, st) : launch_gemm_v4<T, 4>(p, st);
         }
         if (epilogue != SVDX_EPI_NONE) { svdx_set_error("svdx_gemm: fused epilogue unavailable (buffer too large for variant 4)"); return -2; }
-        return variant == 2 ? launch_gemm_pipe<T>(p, st) : variant == 1 ? launch_gemm<T, true>(p, st) : launch_gemm<T, false>(p, st);
+        return variant == 0 ? launch_gemm<T, false>(p, st) : launch_gemm<T, true>(p, st);
     });
 }
 

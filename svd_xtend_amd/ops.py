@@ -50,7 +50,7 @@ class Runtime:
         self.dt = dtype
         self.dev = device
         self.k = K.backend()
-        self.gemm_variant = 4      # 0 reg-staged, 1 global_load_lds, 2 deep ring, 3 BN160+direct epilogue, 4 = 3 + lean buffer_load-lds loop
+        self.gemm_variant = 4      # 0 register-staged reference, 1 global_load_lds, 4 production (lean buffer_load-lds loop, 128x160 tiles)
         self.split_k = True
         self.fuse_geglu = True
         self.arenas = [None, None]

@@ -421,10 +421,7 @@ def run_all(impl, dev, dtypes=DTYPES, verbose=True):
     out = []
     for dt in dtypes:
         checks = [("gemm_plain_v0", lambda: check_gemm_plain(P, dt, 0)), ("gemm_plain_v1", lambda: check_gemm_plain(P, dt, 1)),
-                  ("gemm_plain_v2", lambda: check_gemm_plain(P, dt, 2)), ("gemm_gather_v2", lambda: check_gemm_gather(P, dt, 2)),
-                  ("gemm_plain_v3", lambda: check_gemm_plain(P, dt, 3)), ("gemm_gather_v3", lambda: check_gemm_gather(P, dt, 3)),
                   ("gemm_plain_v4", lambda: check_gemm_plain(P, dt, 4)), ("gemm_gather_v4", lambda: check_gemm_gather(P, dt, 4)),
-                  ("gemm_plain_v5", lambda: check_gemm_plain(P, dt, 5)), ("gemm_gather_v5", lambda: check_gemm_gather(P, dt, 5)),
                   ("gemm_tn", lambda: check_gemm_tn(P, dt)), ("gemm_geglu", lambda: check_gemm_geglu(P, dt)), ("gemm_gather_v0", lambda: check_gemm_gather(P, dt, 0)), ("gemm_gather_v1", lambda: check_gemm_gather(P, dt, 1)),
                   ("small", lambda: check_small(P, dt)), ("groupnorm", lambda: check_groupnorm(P, dt)),
                   ("layernorm", lambda: check_layernorm(P, dt)), ("attention", lambda: check_attention(P, dt)),

@@ -28,7 +28,7 @@ def main():
     be = K.backend()
     dev = torch.device("cuda")
     dt = torch.float16
-    variants = [int(v) for v in os.environ.get("VARIANTS", "4,5").split(",")]
+    variants = [int(v) for v in os.environ.get("VARIANTS", "1,4").split(",")]
     shapes = [("sq4096", 4096, 4096, 4096, None), ("sq8192", 8192, 8192, 8192, None),
               ("L0 ff1 35840x2560x320", 35840, 2560, 320, None), ("L0 ff2 35840x320x1280", 35840, 320, 1280, None),
               ("L0 qkv 35840x960x320", 35840, 960, 320, None), ("L0 proj 35840x320x320", 35840, 320, 320, None),
