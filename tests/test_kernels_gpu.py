@@ -22,9 +22,9 @@ def pair():
 @pytest.mark.parametrize("group", GROUPS)
 def test_kernel_group(pair, group, dt):
     import kernel_checks as kc
-    fns = {"gemm_tn": lambda: kc.check_gemm_tn(pair, dt), "gemm_geglu": lambda: kc.check_gemm_geglu(pair, dt), "gemm_plain_v2": lambda: kc.check_gemm_plain(pair, dt, 2),
-           "gemm_gather_v2": lambda: kc.check_gemm_gather(pair, dt, 2),
-           "gemm_plain_v4": lambda: kc.check_gemm_plain(pair, dt, 4), "gemm_gather_v4": lambda: kc.check_gemm_gather(pair, dt, 4), "gemm_plain_v0": lambda: kc.check_gemm_plain(pair, dt, 0), "gemm_plain_v1": lambda: kc.check_gemm_plain(pair, dt, 1),
+    fns = {"gemm_tn": lambda: kc.check_gemm_tn(pair, dt), "gemm_geglu": lambda: kc.check_gemm_geglu(pair, dt),
+           "gemm_plain_v4": lambda: kc.check_gemm_plain(pair, dt, 4), "gemm_gather_v4": lambda: kc.check_gemm_gather(pair, dt, 4),
+           "gemm_plain_v0": lambda: kc.check_gemm_plain(pair, dt, 0), "gemm_plain_v1": lambda: kc.check_gemm_plain(pair, dt, 1),
            "gemm_gather_v0": lambda: kc.check_gemm_gather(pair, dt, 0), "gemm_gather_v1": lambda: kc.check_gemm_gather(pair, dt, 1),
            "small": lambda: kc.check_small(pair, dt), "groupnorm": lambda: kc.check_groupnorm(pair, dt),
            "layernorm": lambda: kc.check_layernorm(pair, dt), "attention": lambda: kc.check_attention(pair, dt),
