@@ -164,9 +164,10 @@ def main():
                 opt_step()
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
-            with torch.cuda.graph(g1):
+            # thread_local: RCCL's watchdog thread may query events while we capture (N > 1)
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                 fwd_bwd()
-            with torch.cuda.graph(g2):
+            with torch.cuda.graph(g2, capture_error_mode="thread_local"):
                 opt_step()
 
             def step_graph():
