@@ -457,19 +457,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
 //  * Tried and dropped: a 5-stage / 4-stage LDS ring with counted vmcnt + raw s_barrier (no gain in
 //    situ, slower in isolation: the loop is not latency bound), direct 8-byte epilogue stores (worse DRAM efficiency).
 // ================================================================================================================
-template <typename T, int NB>
+template <typename T, int NB, int MB>
 __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and LDS-DMA builtin only exist in the device pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
+    constexpr int BM4 = 32 * MB;                      // tile rows: 128 (MB = 4) or 160 (MB = 5, one wave of blocks at M = 35840, N = 320)
+    constexpr int WM4 = 16 * MB;                      // rows per wave
     constexpr int BN3 = 32 * NB;                      // 2 waves along N, NB/2... each wave owns NB*16 columns
     constexpr int WN3 = 16 * NB;                      // columns per wave
     constexpr int KT = BK;                             // K extent of one stage
     constexpr int NSTG = 2;
-    constexpr int STAGE3 = (BM + BN3) * KT * 2;
+    constexpr int STAGE3 = (BM4 + BN3) * KT * 2;
     constexpr int CPRW = KT / 8;                       // 16-byte chunks per staged row (8 | 4)
     constexpr int RPP = NTHREADS / CPRW;               // rows covered by one load pass (32 | 64)
-    constexpr int NLA = BM / RPP;                      // A loads per thread per stage (4 | 2)
+    constexpr int NLA = BM4 / RPP;                      // A loads per thread per stage (4 | 2)
     constexpr int NLB = (BN3 + RPP - 1) / RPP;         // B loads per thread per stage (NB | 3 or 2)
     constexpr int ROWB = KT * 2;                       // bytes per staged row (128 | 64)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
     const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
     const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
     const int pid_m = swz / p.tiles_n, pid_n = swz - pid_m * p.tiles_n;
-    const int m0 = pid_m * BM, n0 = pid_n * BN3;
+    const int m0 = pid_m * BM4, n0 = pid_n * BN3;
     const int kt_total = p.K / KT;
     const int z = blockIdx.y;
     const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
     set_tap();
     auto issue = [&](int stage) __attribute__((always_inline)) {
         char* As = smem + stage * STAGE3;
-        char* Bs = As + BM * KT * 2;
+        char* Bs = As + BM4 * KT * 2;
         const int soa = ci0 * 2, sob = (tap * cin + ci0) * 2;
 #pragma unroll
         for (int i = 0; i < NLA; ++i)
@@ -544,27 +546,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
         ci0 += KT;
         if (!plain && ci0 == cin) { ci0 = 0; ++tap; set_tap(); }
     };
-    f32x4 acc[NB][4];                                   // [n-block][m-block], transposed: rows = n, cols = m
+    f32x4 acc[NB][MB];                                   // [n-block][m-block], transposed: rows = n, cols = m
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
     auto compute = [&](int stage) __attribute__((always_inline)) {
         const char* As = smem + stage * STAGE3;
-        const char* Bs = As + BM * KT * 2;
+        const char* Bs = As + BM4 * KT * 2;
 #pragma unroll
         for (int kk = 0; kk < KT / 32; ++kk) {
             const int chunk = ((kk * 4 + fg) ^ (fr & 7)) * 16;
-            v8 af[4], bf[NB];
+            v8 af[MB], bf[NB];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(As + (wm * 64 + i * 16 + fr) * ROWB + chunk);
+            for (int i = 0; i < MB; ++i) af[i] = *reinterpret_cast<const v8*>(As + (wm * WM4 + i * 16 + fr) * ROWB + chunk);
 #pragma unroll
             for (int i = 0; i < NB; ++i) bf[i] = *reinterpret_cast<const v8*>(Bs + (wn * WN3 + i * 16 + fr) * ROWB + chunk);
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = TT<T>::mfma(bf[i], af[j], acc[i][j]);
+                for (int j = 0; j < MB; ++j) acc[i][j] = TT<T>::mfma(bf[i], af[j], acc[i][j]);
         }
     };
     {
@@ -599,8 +601,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
                 for (int e = 0; e < 4; ++e)
                     bb[e] = (lead0 && p.bias) ? p.bias[p.epi == SVDX_EPI_GEGLU_FWD ? brow(wn * WN3 + i * 16 + fg * 4 + e) : nb0 + i * 16 + e] : 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ml = wm * 64 + j * 16 + fr;
+                for (int j = 0; j < MB; ++j) {
+                    const int ml = wm * WM4 + j * 16 + fr;
                     const int m = min(m0 + ml, p.M - 1);
                     float v[4];
 #pragma unroll
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
             T* pre = reinterpret_cast<T*>(p.C);
             T* hh = reinterpret_cast<T*>(p.aux_out);
             constexpr int NPAIR = BN3 / 32;
-            for (int id = tid; id < BM * NPAIR * 2; id += NTHREADS) {
+            for (int id = tid; id < BM4 * NPAIR * 2; id += NTHREADS) {
                 const int row = id / (NPAIR * 2), r2 = id - row * (NPAIR * 2);
                 const int pr = r2 >> 1, c2 = r2 & 1;
                 const int m = m0 + row;
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
             // the tile holds d(h) for columns n0..; read (value, gate) from pre and emit d(pre) = [dh*gelu(g) | dh*a*gelu'(g)]
             const T* pre = reinterpret_cast<const T*>(p.aux_in);
             T* dpre = reinterpret_cast<T*>(p.C);
-            for (int id = tid; id < BM * CPR; id += NTHREADS) {
+            for (int id = tid; id < BM4 * CPR; id += NTHREADS) {
                 const int row = id / CPR, c = id - row * CPR;
                 const int m = m0 + row;
                 if (m >= p.M) continue;
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
         T* Ct2 = reinterpret_cast<T*>(p.C);
         const T* R2 = (z == 0) ? reinterpret_cast<const T*>(p.res) : nullptr;
 #pragma unroll 2
-        for (int id = tid; id < BM * CPR; id += NTHREADS) {
+        for (int id = tid; id < BM4 * CPR; id += NTHREADS) {
             const int row = id / CPR, c = id - row * CPR;
             const int m = m0 + row;
             if (m >= p.M) continue;
@@ -702,8 +704,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
             bv[i][e] = (lead && p.bias && n < p.N) ? p.bias[n] : 0.f;
         }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + fr;
+    for (int j = 0; j < MB; ++j) {
+        const int m = m0 + wm * WM4 + j * 16 + fr;
         if (m >= p.M) continue;
         const float* rv = nullptr;
         if (lead && p.rowvec) rv = p.rowvec + (size_t)(p.rv_mod ? (m % p.rv_mod) : (m / p.rv_rpg)) * p.rv_ld;
@@ -902,18 +904,19 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
     return 0;
 }
 
-template <typename T, int NB>
+template <typename T, int NB, int MB>
 int launch_gemm_v4(GemmParams p, hipStream_t st) {
-    constexpr int LDS = 2 * (BM + 32 * NB) * BK * 2;
+    constexpr int LDS = 2 * (32 * MB + 32 * NB) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
+    p.tiles_m = cdiv(p.M, 32 * MB);
     p.tiles_n = p.epi == SVDX_EPI_GEGLU_FWD ? cdiv(p.aux_dim, 16 * NB) : cdiv(p.N, 32 * NB);
     p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 15) == 0));
     dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
-    hipLaunchKernelGGL((gemm_v4_kernel<T, NB>), grid, dim3(NTHREADS), LDS, st, p);
+    hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB>), grid, dim3(NTHREADS), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm");
     return 0;
 }
@@ -1025,7 +1028,13 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
         if (variant >= 2 && a_bytes > 0 && b_bytes > 0) {
             p.a_bytes = (int)a_bytes; p.b_bytes = (int)b_bytes;
             const bool nb5 = epilogue == SVDX_EPI_GEGLU_FWD ? false : (N % 160 == 0);
-            return nb5 ? launch_gemm_v4<T, 5>(p, st) : launch_gemm_v4<T, 4>(p, st);
+            // 160-row tiles when they turn a 1.1-wave grid (512 resident blocks) into a single wave, e.g. M = 35840, N = 320:
+            // 280 x 2 = 560 tiles of 128 rows vs 224 x 2 = 448 tiles of 160 rows
+            const long t128 = (long)cdiv(M, 128) * cdiv(N, 160), t160 = (long)cdiv(M, 160) * cdiv(N, 160);
+            const bool mb5 = nb5 && ((variant == 6) ||          // variant 6: force the 160-row tile (tests)
+                                     (split_k == 1 && (cdiv(t128, 512) * 4 > cdiv(t160, 512) * 5) && t160 >= 384));
+            if (mb5) return launch_gemm_v4<T, 5, 5>(p, st);
+            return nb5 ? launch_gemm_v4<T, 5, 4>(p, st) : launch_gemm_v4<T, 4, 4>(p, st);
         }
         if (epilogue != SVDX_EPI_NONE) { svdx_set_error("svdx_gemm: fused epilogue unavailable (buffer too large for variant 4)"); return -2; }
         return variant == 0 ? launch_gemm<T, false>(p, st) : launch_gemm<T, true>(p, st);

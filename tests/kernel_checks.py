@@ -170,6 +170,10 @@ def check_gemm_gather(P, dt, variant):
     cases.append(("temporal3", K.Gather(K.GATHER_TEMPORAL3, n_img=Bc, cin=ci, t=T, hw=hw, lda=ci), Bc * T * hw, ci, co,
                   Bc * T * hw, 3))
     cases.append(("temporal3 T=1", K.Gather(K.GATHER_TEMPORAL3, n_img=3, cin=ci, t=1, hw=hw, lda=ci), 3 * hw, ci, co, 3 * hw, 3))
+    cases.append(("conv3x3 s1 cout=320", K.Gather(K.GATHER_CONV3X3, n_img=n, hi=h, wi=w, ho=h, wo=w, cin=ci, stride=1, lda=ci),
+                  n * h * w, ci, 320, n * h * w, 9))
+    cases.append(("temporal3 cout=160", K.Gather(K.GATHER_TEMPORAL3, n_img=Bc, cin=ci, t=T, hw=hw, lda=ci), Bc * T * hw, ci, 160,
+                  Bc * T * hw, 3))
     for label, ga, M, ci_, co_, nsrc, taps in cases:
         A = rnd((nsrc, ci_), dt, P.dev, g)
         B = rnd((co_, taps * ci_), dt, P.dev, g, (taps * ci_) ** -0.5)
@@ -422,6 +426,7 @@ def run_all(impl, dev, dtypes=DTYPES, verbose=True):
     for dt in dtypes:
         checks = [("gemm_plain_v0", lambda: check_gemm_plain(P, dt, 0)), ("gemm_plain_v1", lambda: check_gemm_plain(P, dt, 1)),
                   ("gemm_plain_v4", lambda: check_gemm_plain(P, dt, 4)), ("gemm_gather_v4", lambda: check_gemm_gather(P, dt, 4)),
+                  ("gemm_plain_v6", lambda: check_gemm_plain(P, dt, 6)), ("gemm_gather_v6", lambda: check_gemm_gather(P, dt, 6)),
                   ("gemm_tn", lambda: check_gemm_tn(P, dt)), ("gemm_geglu", lambda: check_gemm_geglu(P, dt)), ("gemm_gather_v0", lambda: check_gemm_gather(P, dt, 0)), ("gemm_gather_v1", lambda: check_gemm_gather(P, dt, 1)),
                   ("small", lambda: check_small(P, dt)), ("groupnorm", lambda: check_groupnorm(P, dt)),
                   ("layernorm", lambda: check_layernorm(P, dt)), ("attention", lambda: check_attention(P, dt)),

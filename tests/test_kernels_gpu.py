@@ -5,7 +5,7 @@ import pytest
 import torch
 
 gpu = pytest.mark.gpu
-GROUPS = ["gemm_tn", "gemm_geglu", "gemm_plain_v4", "gemm_gather_v4", "gemm_plain_v0", "gemm_plain_v1", "gemm_gather_v0", "gemm_gather_v1", "small", "groupnorm", "layernorm",
+GROUPS = ["gemm_tn", "gemm_geglu", "gemm_plain_v4", "gemm_gather_v4", "gemm_plain_v6", "gemm_gather_v6", "gemm_plain_v0", "gemm_plain_v1", "gemm_gather_v0", "gemm_gather_v1", "small", "groupnorm", "layernorm",
           "attention", "temporal_attention", "elementwise", "optim"]
 
 
@@ -24,6 +24,7 @@ def test_kernel_group(pair, group, dt):
     import kernel_checks as kc
     fns = {"gemm_tn": lambda: kc.check_gemm_tn(pair, dt), "gemm_geglu": lambda: kc.check_gemm_geglu(pair, dt),
            "gemm_plain_v4": lambda: kc.check_gemm_plain(pair, dt, 4), "gemm_gather_v4": lambda: kc.check_gemm_gather(pair, dt, 4),
+           "gemm_plain_v6": lambda: kc.check_gemm_plain(pair, dt, 6), "gemm_gather_v6": lambda: kc.check_gemm_gather(pair, dt, 6),
            "gemm_plain_v0": lambda: kc.check_gemm_plain(pair, dt, 0), "gemm_plain_v1": lambda: kc.check_gemm_plain(pair, dt, 1),
            "gemm_gather_v0": lambda: kc.check_gemm_gather(pair, dt, 0), "gemm_gather_v1": lambda: kc.check_gemm_gather(pair, dt, 1),
            "small": lambda: kc.check_small(pair, dt), "groupnorm": lambda: kc.check_groupnorm(pair, dt),
