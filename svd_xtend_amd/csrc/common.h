@@ -80,16 +80,35 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float silu_gradf_(float x) {
     float s = sigmoidf_(x);
     return s * (1.f + x * (1.f - s));
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// Exact-erf GELU (what F.gelu computes) through Abramowitz-Stegun 7.1.26: |erf error| <= 1.5e-7, far inside the 16-bit output
+// rounding.  One v_exp + one v_rcp + ~12 FMAs give the normal CDF and, from the same exponential, the density for the
+// gradient -- the fused GEGLU GEMM epilogues are VALU-bound on this, so libm's branchy erff is not affordable there.
+struct GeluParts { float cdf, pdf_x; };      // Phi(x), x * phi(x)
+__device__ __forceinline__ GeluParts gelu_parts(float x) {
+    const float ax = fabsf(x);
+    const float E = __builtin_amdgcn_exp2f(-0.7213475204444817f * x * x);          // exp(-x^2/2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.f));
+    float q = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    q = fmaf(t, q, 0.5f * 1.421413741f);
+    q = fmaf(t, q, 0.5f * -0.284496736f);
+    q = fmaf(t, q, 0.5f * 0.254829592f);
+    const float h = q * t * E;                                                     // 0.5 * erfc(|x|/sqrt2)
+    GeluParts r;
+    r.cdf = x < 0.f ? h : 1.f - h;
+    r.pdf_x = x * E * 0.3989422804014327f;
+    return r;
+}
+__device__ __forceinline__ float gelu_erf(float x) { return x * gelu_parts(x).cdf; }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f;
+    const GeluParts g = gelu_parts(x);
+    return g.cdf + g.pdf_x;
 }
 
 #define DISPATCH_DTYPE(dtype, ...)                                   \

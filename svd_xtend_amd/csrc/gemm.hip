@@ -660,8 +660,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float d = to_f<T>(d8.v[e]), gv = to_f<T>(g8.v[e]);
-                    da.v[e] = from_f<T>(d * gelu_erf(gv));
-                    dg.v[e] = from_f<T>(d * to_f<T>(a8.v[e]) * gelu_erf_grad(gv));
+                    const GeluParts gp = gelu_parts(gv);
+                    da.v[e] = from_f<T>(d * gv * gp.cdf);
+                    dg.v[e] = from_f<T>(d * to_f<T>(a8.v[e]) * (gp.cdf + gp.pdf_x));
                 }
                 *reinterpret_cast<Vec8<T>*>(dpre + po) = da;
                 *reinterpret_cast<Vec8<T>*>(dpre + po + Fdim) = dg;
