@@ -98,8 +98,10 @@ int svdx_outer_acc(const float* dY, const float* X, float* dW, int M, int N, int
 int svdx_timestep_embed(const float* t, float* out, int n, int dim, void* stream);
 
 /* ---- GroupNorm(32) (+SiLU) over n_s samples of `rows` rows x C channels (2-D: sample = frame;
- *      3-D: sample = clip, rows = T*HW).  stats[n_s, G, 2] = (sum, sumsq), accumulated with atomics: the kernels zero
- *      the buffer first unless `prezeroed` (the host zeroes one arena per pass instead of ~200 tiny memsets). -------- */
+ *      3-D: sample = clip, rows = T*HW).  stats / bstats are float[SVDX_GN_REPLICAS][n_s][G][2] partial (sum, sumsq):
+ *      blocks spread their atomics over the replicas, readers add them.  The kernels zero the buffer first unless
+ *      `prezeroed` (the host zeroes one arena per pass instead of ~200 tiny memsets). ------------------------------- */
+#define SVDX_GN_REPLICAS 8
 int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int C, int G, int prezeroed, int dtype, void* stream);
 int svdx_gn_apply(const void* x, const float* stats, const float* gamma, const float* beta, void* y,
                   int n_s, int rows, int C, int G, float eps, int silu, int dtype, void* stream);
@@ -114,9 +116,11 @@ int svdx_gn_bwd_apply(const void* dy, const void* x, const float* stats, const f
 /* ---- LayerNorm over C; stats[rows,2] = (mean, rstd) ------------------------------------------------- */
 int svdx_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                 int rows, int C, float eps, int dtype, void* stream);
-/* dx = LN'(dy) (+ add);  dgamma/dbeta (float, atomicAdd, may be NULL) */
+/* dx = LN'(dy) (+ add);  dgamma/dbeta (float, accumulated into, may both be NULL).  scratch: NULL (block sums go in by
+ * float atomics) or SVDX_LN_PARTIAL_ROWS*2*C floats of workspace (per-block partial rows + a reducing pass: ~4x faster). */
+#define SVDX_LN_PARTIAL_ROWS 512
 int svdx_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* add,
-                void* dx, float* dgamma, float* dbeta, int rows, int C, int dtype, void* stream);
+                void* dx, float* dgamma, float* dbeta, float* scratch, int rows, int C, int dtype, void* stream);
 
 /* ---- spatial self-attention (head_dim 64), flash form; replaces F.scaled_dot_product_attention in
  *      diffusers AttnProcessor2_0.  q,k element (n,s,h,d) at (n*S+s)*ld + h*64 + d;

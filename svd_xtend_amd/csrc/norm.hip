@@ -15,9 +15,20 @@ struct GnGeom {
     int slab;                           // rows per block: sized so that even the 5x8 latent level launches >= ~1000 blocks
 };
 
-__device__ __forceinline__ void group_mean_rstd(const float* stats, int n, int G, int g, float cnt, float eps,
+// Group sums live in SVDX_GN_REPLICAS partial copies ([rep][n_s][G][2]): blocks spread their atomics over the copies (a clip-wide
+// temporal norm has only 64 distinct addresses and >1000 blocks: same-address float atomics serialise), readers add them up.
+__device__ __forceinline__ void group_sums(const float* stats, int n_s, int n, int G, int g, float& s, float& ss) {
+    s = 0.f; ss = 0.f;
+#pragma unroll
+    for (int r = 0; r < SVDX_GN_REPLICAS; ++r) {
+        const float2 v = *reinterpret_cast<const float2*>(stats + (((size_t)r * n_s + n) * G + g) * 2);
+        s += v.x; ss += v.y;
+    }
+}
+__device__ __forceinline__ void group_mean_rstd(const float* stats, int n_s, int n, int G, int g, float cnt, float eps,
                                                 float& mean, float& rstd) {
-    const float s = stats[((size_t)n * G + g) * 2], ss = stats[((size_t)n * G + g) * 2 + 1];
+    float s, ss;
+    group_sums(stats, n_s, n, G, g, s, ss);
     mean = s / cnt;
     const float var = fmaxf(ss / cnt - mean * mean, 0.f);
     rstd = rsqrtf(var + eps);
@@ -41,11 +52,15 @@ __global__ void gn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ 
     float sc[8], sh[8], gm[8], mu[8], rs[8];
     if (MODE == 1) {
         const float cnt = (float)q.rows * q.cg;
+        const int gA = (j * 8) / q.cg, gB = min((j * 8 + 7) / q.cg, q.G - 1);   // a chunk of 8 channels touches <= 2 groups when cg >= 8
+        float meanA, rstdA, meanB, rstdB;
+        group_mean_rstd(stats, q.n_s, n, q.G, gA, cnt, eps, meanA, rstdA);
+        group_mean_rstd(stats, q.n_s, n, q.G, gB, cnt, eps, meanB, rstdB);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int c = j * 8 + e;
-            float mean, rstd;
-            group_mean_rstd(stats, n, q.G, c / q.cg, cnt, eps, mean, rstd);
+            const int c = j * 8 + e, g = c / q.cg;
+            float mean = g == gA ? meanA : meanB, rstd = g == gA ? rstdA : rstdB;
+            if (g != gA && g != gB) group_mean_rstd(stats, q.n_s, n, q.G, g, cnt, eps, mean, rstd);
             mu[e] = mean; rs[e] = rstd; gm[e] = gamma[c];
             sc[e] = rstd * gm[e];
             sh[e] = beta[c] - mean * sc[e];
@@ -103,7 +118,7 @@ __global__ void gn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ 
         atomicAdd(&gacc[cur * 2 + 1], s1);
     }
     __syncthreads();
-    if (t < 2 * q.G) atomicAdd(out + (size_t)n * q.G * 2 + t, gacc[t]);
+    if (t < 2 * q.G) atomicAdd(out + ((size_t)(slab % SVDX_GN_REPLICAS) * q.n_s + n) * q.G * 2 + t, gacc[t]);
 }
 
 // MODE 0: y = act(xhat*gamma+beta).  MODE 1: dx = rstd*(dz*gamma - (s1 + xhat*s2)/cnt) (+ add).
@@ -119,18 +134,27 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ d
     const int r0 = slab * q.slab, r1 = min(q.rows, r0 + q.slab);
     const float cnt = (float)q.rows * q.cg;
     float sc[8], sh[8], gm[8], mu[8], rs[8], b1[8], b2[8];
+    const int gA = (j * 8) / q.cg, gB = min((j * 8 + 7) / q.cg, q.G - 1);
+    float meanA, rstdA, meanB, rstdB, b1A = 0.f, b2A = 0.f, b1B = 0.f, b2B = 0.f;
+    group_mean_rstd(stats, q.n_s, n, q.G, gA, cnt, eps, meanA, rstdA);
+    group_mean_rstd(stats, q.n_s, n, q.G, gB, cnt, eps, meanB, rstdB);
+    if (MODE == 1) {
+        group_sums(bstats, q.n_s, n, q.G, gA, b1A, b2A);
+        group_sums(bstats, q.n_s, n, q.G, gB, b1B, b2B);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = j * 8 + e, g = c / q.cg;
-        float mean, rstd;
-        group_mean_rstd(stats, n, q.G, g, cnt, eps, mean, rstd);
+        float mean = g == gA ? meanA : meanB, rstd = g == gA ? rstdA : rstdB;
+        float s1 = g == gA ? b1A : b1B, s2 = g == gA ? b2A : b2B;
+        if (g != gA && g != gB) {                    // cg < 4: more than two groups per chunk (not an SVD shape; kept correct)
+            group_mean_rstd(stats, q.n_s, n, q.G, g, cnt, eps, mean, rstd);
+            if (MODE == 1) group_sums(bstats, q.n_s, n, q.G, g, s1, s2);
+        }
         mu[e] = mean; rs[e] = rstd; gm[e] = gamma[c];
         sc[e] = rstd * gm[e];
         sh[e] = beta[c] - mean * sc[e];
-        if (MODE == 1) {
-            b1[e] = bstats[((size_t)n * q.G + g) * 2] / cnt;
-            b2[e] = bstats[((size_t)n * q.G + g) * 2 + 1] / cnt;
-        }
+        if (MODE == 1) { b1[e] = s1 / cnt; b2[e] = s2 / cnt; }
     }
 #pragma unroll 2
     for (int r = r0 + ry; r < r1; r += q.rpi) {
@@ -222,11 +246,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
 }
 
-template <typename T, int LN_MAXCH>
+// R rows per wave in flight (latency hiding: a C=320 row is a single 640-byte load per operand).  Affine gradients are
+// block-reduced in LDS and then either written to `partial[block][2C]` (reduced by ln_param_reduce_kernel: no global atomics --
+// device-scope float atomics run at ~15/ns chip-wide, which made this kernel atomic-bound) or, without scratch, added atomically.
+template <typename T, int LN_MAXCH, int R>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const T* __restrict__ add, T* __restrict__ dx, float* dgamma,
-                                                     float* dbeta, int rows, int C) {
+                                                     float* dbeta, float* partial, int rows, int C) {
     extern __shared__ float red[];   // [2][C] when affine grads are requested
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cc = C / 8;
@@ -245,44 +272,56 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             pg[i][e] = pb[i][e] = 0.f;
         }
     const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-#pragma unroll 2
-    for (int row = wid; row < rows; row += nw) {
-        const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
-        float xh[LN_MAXCH][8], dg[LN_MAXCH][8];
-        float s1 = 0.f, s2 = 0.f;
+    for (int row0 = wid * R; row0 < rows; row0 += nw * R) {
+        float xh[R][LN_MAXCH][8], dg[R][LN_MAXCH][8], s1[R], s2[R], rstd[R];
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; ++i) {
-            const int j = lane + i * 64;
-            if (j < cc) {
-                float xv[8], dv[8];
-                load8<T>(x + (size_t)row * C + j * 8, xv);
-                load8<T>(dy + (size_t)row * C + j * 8, dv);
+        for (int k = 0; k < R; ++k) {
+            const int row = min(row0 + k, rows - 1);
+            const bool live = row0 + k < rows;
+            const float mean = stats[(size_t)row * 2];
+            rstd[k] = stats[(size_t)row * 2 + 1];
+            s1[k] = s2[k] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    xh[i][e] = (xv[e] - mean) * rstd;
-                    dg[i][e] = dv[e] * gmv[i][e];
-                    s1 += dg[i][e];
-                    s2 += dg[i][e] * xh[i][e];
-                    pg[i][e] += dv[e] * xh[i][e];
-                    pb[i][e] += dv[e];
+            for (int i = 0; i < LN_MAXCH; ++i) {
+                const int j = lane + i * 64;
+                if (j < cc) {
+                    float xv[8], dv[8];
+                    load8<T>(x + (size_t)row * C + j * 8, xv);
+                    load8<T>(dy + (size_t)row * C + j * 8, dv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float d = live ? dv[e] : 0.f;
+                        xh[k][i][e] = (xv[e] - mean) * rstd[k];
+                        dg[k][i][e] = d * gmv[i][e];
+                        s1[k] += dg[k][i][e];
+                        s2[k] += dg[k][i][e] * xh[k][i][e];
+                        pg[i][e] += d * xh[k][i][e];
+                        pb[i][e] += d;
+                    }
                 }
             }
         }
-        const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; ++i) {
-            const int j = lane + i * 64;
-            if (j < cc) {
-                float o[8];
+        for (int k = 0; k < R; ++k) {
+            const int row = row0 + k;
+            const float m1 = wave_sum(s1[k]) / C, m2 = wave_sum(s2[k]) / C;
+            if (row < rows) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = rstd * (dg[i][e] - m1 - xh[i][e] * m2);
-                if (add) {
-                    float av[8];
-                    load8<T>(add + (size_t)row * C + j * 8, av);
+                for (int i = 0; i < LN_MAXCH; ++i) {
+                    const int j = lane + i * 64;
+                    if (j < cc) {
+                        float o[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] += av[e];
+                        for (int e = 0; e < 8; ++e) o[e] = rstd[k] * (dg[k][i][e] - m1 - xh[k][i][e] * m2);
+                        if (add) {
+                            float av[8];
+                            load8<T>(add + (size_t)row * C + j * 8, av);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] += av[e];
+                        }
+                        store8<T>(dx + (size_t)row * C + j * 8, o);
+                    }
                 }
-                store8<T>(dx + (size_t)row * C + j * 8, o);
             }
         }
     }
@@ -299,10 +338,35 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < C; i += 256) {
-            atomicAdd(dgamma + i, red[i]);
-            atomicAdd(dbeta + i, red[C + i]);
+        if (partial) {
+            for (int i = threadIdx.x; i < 2 * C; i += 256) partial[(size_t)blockIdx.x * 2 * C + i] = red[i];
+        } else {
+            for (int i = threadIdx.x; i < C; i += 256) {
+                atomicAdd(dgamma + i, red[i]);
+                atomicAdd(dbeta + i, red[C + i]);
+            }
         }
+    }
+}
+
+// dgamma[c] += sum_b partial[b][c], dbeta[c] += sum_b partial[b][C + c]: 64 columns x 16 row groups per block.
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                               float* dgamma, float* dbeta) {
+    __shared__ float sm[16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (col < 2 * C) {
+#pragma unroll 8
+        for (int b = rg; b < nblk; b += 16) s += partial[(size_t)b * 2 * C + col];
+    }
+    sm[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && col < 2 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sm[i][cl];
+        if (col < C) dgamma[col] += t; else dbeta[col - C] += t;
     }
 }
 
@@ -312,7 +376,7 @@ extern "C" int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int
     GnGeom q; int threads;
     if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (!prezeroed) (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * n_s * G, st);
+    if (!prezeroed) (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * n_s * G * SVDX_GN_REPLICAS, st);
     dim3 grid(n_s, cdiv(rows, q.slab));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_reduce_kernel<T, 0>), grid, dim3(threads), 0, st, (const T*)x,
                                              (const T*)nullptr, (const float*)nullptr, (const float*)nullptr,
@@ -339,7 +403,7 @@ extern "C" int svdx_gn_bwd_stats(const void* dy, const void* x, const float* sta
     GnGeom q; int threads;
     if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (!prezeroed) (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * n_s * G, st);
+    if (!prezeroed) (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * n_s * G * SVDX_GN_REPLICAS, st);
     dim3 grid(n_s, cdiv(rows, q.slab));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_reduce_kernel<T, 1>), grid, dim3(threads), 0, st, (const T*)x,
                                              (const T*)dy, stats, gamma, beta, bstats, q, eps, silu));
@@ -374,17 +438,25 @@ extern "C" int svdx_ln_fwd(const void* x, const float* gamma, const float* beta,
 }
 
 extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* add,
-                           void* dx, float* dgamma, float* dbeta, int rows, int C, int dtype, void* stream) {
+                           void* dx, float* dgamma, float* dbeta, float* scratch, int rows, int C, int dtype, void* stream) {
     SVDX_CHECK_ARG(rows > 0 && C % 8 == 0 && C / 8 <= 64 * LN_MAXCH_LIMIT, "svdx_ln_bwd: C=%d unsupported", C);
     SVDX_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "svdx_ln_bwd: dgamma/dbeta must come together");
-    // with affine grads every block ends with 2*C float atomics: keep one block per CU there
-    const int blocks = min(cdiv(rows, 4), dgamma ? 256 : 2048);
-    const size_t sh = dgamma ? sizeof(float) * 2 * C : 0;
     const int nch = (C / 8 + 63) / 64;
-#define LN_BWD(NCH) hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(blocks), dim3(256), sh, (hipStream_t)stream, (const T*)dy, \
-                                       (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, rows, C)
-    DISPATCH_DTYPE(dtype, { if (nch == 1) LN_BWD(1); else if (nch == 2) LN_BWD(2); else if (nch == 3) LN_BWD(3); else LN_BWD(4); });
+    const int R = nch == 1 ? 4 : (nch == 2 ? 2 : 1);
+    // affine grads: with scratch, up to SVDX_LN_PARTIAL_ROWS blocks each leave one [2C] partial row (>= 4 iterations per wave);
+    // without, every block ends with 2*C float atomics, so keep one block per CU there
+    int blocks = min(cdiv(rows, 4 * R), 2048);
+    if (dgamma) blocks = scratch ? max(1, min(cdiv(rows, 16 * R), SVDX_LN_PARTIAL_ROWS)) : min(blocks, 256);
+    const size_t sh = dgamma ? sizeof(float) * 2 * C : 0;
+    hipStream_t st = (hipStream_t)stream;
+#define LN_BWD(NCH, RR) hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, RR>), dim3(blocks), dim3(256), sh, st, (const T*)dy, \
+                                           (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, scratch, rows, C)
+    DISPATCH_DTYPE(dtype, { if (nch == 1) LN_BWD(1, 4); else if (nch == 2) LN_BWD(2, 2); else if (nch == 3) LN_BWD(3, 1); else LN_BWD(4, 1); });
 #undef LN_BWD
     SVDX_LAUNCH_CHECK("svdx_ln_bwd");
+    if (dgamma && scratch) {
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, st, scratch, blocks, C, dgamma, dbeta);
+        SVDX_LAUNCH_CHECK("svdx_ln_bwd(param reduce)");
+    }
     return 0;
 }

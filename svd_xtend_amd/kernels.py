@@ -22,6 +22,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsvdx.so")
 F16, BF16 = 0, 1
 OUT_ACT, OUT_F32, OUT_F32_ATOMIC, OUT_F32_SLAB, OUT_F32_ADD = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GEGLU_FWD, EPI_GEGLU_BWD = 0, 1, 2
+LN_PARTIAL_ROWS = 512
+GN_REPLICAS = 8
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3 = 0, 1, 2, 3
 
 
@@ -68,7 +70,7 @@ _SIGS = {
     "svdx_gn_bwd_stats": "pppppp" "iiii" "fi" "i" "ip",
     "svdx_gn_bwd_apply": "pppppppp" "iiii" "fi" "ip",
     "svdx_ln_fwd": "ppppp" "ii" "f" "ip",
-    "svdx_ln_bwd": "pppppppp" "ii" "ip",
+    "svdx_ln_bwd": "ppppppppp" "ii" "ip",
     "svdx_head_transpose": "pi" "p" "iiii" "ip",
     "svdx_attn_fwd": "ppppp" "iii" "iii" "f" "ip",
     "svdx_attn_bwd_prep": "ppp" "iii" "i" "ip",
@@ -213,9 +215,11 @@ class HipBackend:
         self._call("svdx_ln_fwd", _p(x), _f32(gamma), _f32(beta), _p(y), _f32(stats), rows, C, float(eps),
                    _dt(x), self._stream())
 
-    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C):
+    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C, scratch=None):
+        if scratch is not None:
+            assert scratch.dtype == torch.float32 and scratch.numel() >= LN_PARTIAL_ROWS * 2 * C
         self._call("svdx_ln_bwd", _p(dy), _p(x), _f32(stats), _f32(gamma), _p(add), _p(dx), _f32(dgamma),
-                   _f32(dbeta), rows, C, _dt(x), self._stream())
+                   _f32(dbeta), _f32(scratch), rows, C, _dt(x), self._stream())
 
     # ---- attention --------------------------------------------------------------------------------
     def head_transpose(self, inp, ld, out, nb, heads, S, s_pad):

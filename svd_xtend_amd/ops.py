@@ -425,7 +425,7 @@ class GroupNormOp:
             raise NotImplementedError("GroupNorm affine grads are outside this round's trainable set")
 
     def fwd(self, rt: Runtime, x: torch.Tensor, n_s: int, rows: int):
-        stats, pz = rt.take_zeroed(n_s * GN_GROUPS * 2)
+        stats, pz = rt.take_zeroed(K.GN_REPLICAS * n_s * GN_GROUPS * 2)
         y = rt.empty(n_s * rows, self.C)
         rt.k.gn_stats(x, stats, n_s, rows, self.C, GN_GROUPS, prezeroed=pz)
         rt.k.gn_apply(x, stats, self.mod.weight.data, self.mod.bias.data, y, n_s, rows, self.C, GN_GROUPS,
@@ -433,7 +433,7 @@ class GroupNormOp:
         return y, stats
 
     def bwd(self, rt: Runtime, dy, x, stats, n_s: int, rows: int, add: Optional[torch.Tensor] = None):
-        bst, pz = rt.take_zeroed(n_s * GN_GROUPS * 2)
+        bst, pz = rt.take_zeroed(K.GN_REPLICAS * n_s * GN_GROUPS * 2)
         dx = rt.empty(n_s * rows, self.C)
         g, b = self.mod.weight.data, self.mod.bias.data
         rt.k.gn_bwd_stats(dy, x, stats, g, b, bst, n_s, rows, self.C, GN_GROUPS, self.eps, self.silu, prezeroed=pz)
@@ -457,5 +457,6 @@ class LayerNormOp:
         dx = rt.empty(M, self.C)
         dg = self.mod.weight.grad if self.trainable else None
         db = self.mod.bias.grad if self.trainable else None
-        rt.k.ln_bwd(dy, x, stats, self.mod.weight.data, add, dx, dg, db, M, self.C)
+        scratch = rt.f32(K.LN_PARTIAL_ROWS * 2 * self.C) if self.trainable else None
+        rt.k.ln_bwd(dy, x, stats, self.mod.weight.data, add, dx, dg, db, M, self.C, scratch=scratch)
         return dx

@@ -11,6 +11,8 @@ import torch
 
 from svd_xtend_amd import kernels as K
 
+GN_REPLICAS = K.GN_REPLICAS
+
 
 def V(t, rows, cols, ld):
     return torch.as_strided(t, (rows, cols), (ld, 1), t.storage_offset())
@@ -199,7 +201,7 @@ class EmuBackend:
     def _gn_parts(x, stats, n_s, rows, C, G, eps):
         xf = V(x, n_s * rows, C, C).float().view(n_s, rows, G, C // G)
         cnt = rows * (C // G)
-        st = V(stats, n_s * G, 2, 2).view(n_s, G, 2)
+        st = V(stats, GN_REPLICAS * n_s * G, 2, 2).view(GN_REPLICAS, n_s, G, 2).sum(0)
         mean = st[..., 0] / cnt
         var = (st[..., 1] / cnt - mean * mean).clamp(min=0)
         rstd = torch.rsqrt(var + eps)
@@ -207,11 +209,11 @@ class EmuBackend:
 
     def gn_stats(self, x, stats, n_s, rows, C, G, prezeroed=0):
         xf = V(x, n_s * rows, C, C).float().view(n_s, rows, G, C // G)
-        st = V(stats, n_s * G, 2, 2).view(n_s, G, 2)
+        st = V(stats, GN_REPLICAS * n_s * G, 2, 2).view(GN_REPLICAS, n_s, G, 2)
         if not prezeroed:
             st.zero_()
-        st[..., 0] += xf.sum((1, 3))
-        st[..., 1] += (xf * xf).sum((1, 3))
+        st[0, ..., 0] += xf.sum((1, 3))          # the replica split is the kernel's business; only the sum is specified
+        st[0, ..., 1] += (xf * xf).sum((1, 3))
 
     def gn_apply(self, x, stats, gamma, beta, y, n_s, rows, C, G, eps, silu_):
         xf, mean, rstd, _ = self._gn_parts(x, stats, n_s, rows, C, G, eps)
@@ -232,15 +234,15 @@ class EmuBackend:
 
     def gn_bwd_stats(self, dy, x, stats, gamma, beta, bstats, n_s, rows, C, G, eps, silu_, prezeroed=0):
         xhat, dzg, _, _ = self._gn_dz(dy, x, stats, gamma, beta, n_s, rows, C, G, eps, silu_)
-        bs = V(bstats, n_s * G, 2, 2).view(n_s, G, 2)
+        bs = V(bstats, GN_REPLICAS * n_s * G, 2, 2).view(GN_REPLICAS, n_s, G, 2)
         if not prezeroed:
             bs.zero_()
-        bs[..., 0] += dzg.sum((1, 3))
-        bs[..., 1] += (dzg * xhat).sum((1, 3))
+        bs[0, ..., 0] += dzg.sum((1, 3))
+        bs[0, ..., 1] += (dzg * xhat).sum((1, 3))
 
     def gn_bwd_apply(self, dy, x, stats, bstats, gamma, beta, add, dx, n_s, rows, C, G, eps, silu_):
         xhat, dzg, rstd, cnt = self._gn_dz(dy, x, stats, gamma, beta, n_s, rows, C, G, eps, silu_)
-        bs = V(bstats, n_s * G, 2, 2).view(n_s, G, 2)
+        bs = V(bstats, GN_REPLICAS * n_s * G, 2, 2).view(GN_REPLICAS, n_s, G, 2).sum(0)
         s1 = bs[..., 0][:, None, :, None]
         s2 = bs[..., 1][:, None, :, None]
         d = rstd * (dzg - (s1 + xhat * s2) / cnt)
@@ -260,7 +262,7 @@ class EmuBackend:
         st[:, 1:2] = rstd
         V(y, rows, C, C).copy_((((xf - mean) * rstd) * V1(gamma, C) + V1(beta, C)).to(y.dtype))
 
-    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C):
+    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C, scratch=None):
         xf = V(x, rows, C, C).float()
         st = V(stats, rows, 2, 2)
         xhat = (xf - st[:, 0:1]) * st[:, 1:2]

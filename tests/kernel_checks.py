@@ -210,22 +210,22 @@ def check_small(P, dt):
 def check_groupnorm(P, dt):
     g = torch.Generator().manual_seed(4)
     res = []
-    for (n_s, rows, C) in [(3, 70, 64), (2, 200, 320), (1, 333, 960), (2, 64, 2560), (5, 16, 192)]:
+    for (n_s, rows, C) in [(3, 70, 64), (2, 200, 320), (1, 333, 960), (2, 64, 2560), (5, 16, 192), (1, 4000, 320)]:
         x = (rnd((n_s * rows, C), dt, P.dev, g) * 1.5 + 0.3).to(dt)
         dy = rnd((n_s * rows, C), dt, P.dev, g)
         add = rnd((n_s * rows, C), dt, P.dev, g)
         gamma, beta = 1 + 0.1 * rndf((C,), P.dev, g), 0.1 * rndf((C,), P.dev, g)
-        st = torch.zeros(n_s, 32, 2, device=P.dev)
+        st = torch.zeros(K.GN_REPLICAS, n_s, 32, 2, device=P.dev)
         o1, o2 = P.run("gn_stats", lambda o: ((x, o["st"], n_s, rows, C, 32), {}), dict(st=st))
-        res.append((f"gn_stats {n_s}x{rows}x{C}", relerr(o1["st"], o2["st"]), 1e-4))
+        res.append((f"gn_stats {n_s}x{rows}x{C}", relerr(o1["st"].sum(0), o2["st"].sum(0)), 1e-4))
         stats = o2["st"]
         for silu in (0, 1):
             o1, o2 = P.run("gn_apply", lambda o: ((x, stats, gamma, beta, o["y"], n_s, rows, C, 32, 1e-5, silu), {}),
                            dict(y=torch.zeros_like(x)))
             res.append((f"gn_apply {n_s}x{rows}x{C} silu={silu}", relerr(o1["y"], o2["y"]), tol_for(dt)))
             o1, o2 = P.run("gn_bwd_stats", lambda o: ((dy, x, stats, gamma, beta, o["b"], n_s, rows, C, 32, 1e-5, silu), {}),
-                           dict(b=torch.zeros(n_s, 32, 2, device=P.dev)))
-            res.append((f"gn_bwd_stats {n_s}x{rows}x{C} silu={silu}", relerr(o1["b"], o2["b"]), 2e-3))
+                           dict(b=torch.zeros(K.GN_REPLICAS, n_s, 32, 2, device=P.dev)))
+            res.append((f"gn_bwd_stats {n_s}x{rows}x{C} silu={silu}", relerr(o1["b"].sum(0), o2["b"].sum(0)), 2e-3))
             bst = o2["b"]
             for ad in (None, add):
                 o1, o2 = P.run("gn_bwd_apply", lambda o: ((dy, x, stats, bst, gamma, beta, ad, o["dx"], n_s, rows, C, 32, 1e-5, silu), {}),
@@ -237,7 +237,7 @@ def check_groupnorm(P, dt):
 def check_layernorm(P, dt):
     g = torch.Generator().manual_seed(5)
     res = []
-    for (rows, C) in [(100, 64), (777, 320), (130, 640), (50, 1280), (9, 128)]:
+    for (rows, C) in [(100, 64), (777, 320), (130, 640), (50, 1280), (9, 128), (9001, 320), (3000, 640)]:
         x = (rnd((rows, C), dt, P.dev, g) * 2 + 0.5).to(dt)
         dy, add = rnd((rows, C), dt, P.dev, g), rnd((rows, C), dt, P.dev, g)
         gamma, beta = 1 + 0.1 * rndf((C,), P.dev, g), 0.1 * rndf((C,), P.dev, g)
@@ -246,14 +246,16 @@ def check_layernorm(P, dt):
         res.append((f"ln_fwd {rows}x{C} y", relerr(o1["y"], o2["y"]), tol_for(dt)))
         res.append((f"ln_fwd {rows}x{C} stats", relerr(o1["st"], o2["st"]), 1e-4))
         st = o2["st"]
-        for affine in (False, True):
+        for affine in (False, True, "scratch"):
             outs = dict(dx=torch.zeros_like(x), dg=torch.ones(C, device=P.dev), db=torch.ones(C, device=P.dev))
+            scr = torch.full((512 * 2 * C,), float("nan"), device=P.dev) if affine == "scratch" else None
             o1, o2 = P.run("ln_bwd", lambda o: ((dy, x, st, gamma, add if affine else None, o["dx"],
-                                                 o["dg"] if affine else None, o["db"] if affine else None, rows, C), {}), outs)
+                                                 o["dg"] if affine else None, o["db"] if affine else None, rows, C),
+                                                dict(scratch=scr)), outs)
             res.append((f"ln_bwd {rows}x{C} affine={affine} dx", relerr(o1["dx"], o2["dx"]), tol_for(dt)))
             if affine:
-                res.append((f"ln_bwd {rows}x{C} dgamma", relerr(o1["dg"], o2["dg"]), 2e-3))
-                res.append((f"ln_bwd {rows}x{C} dbeta", relerr(o1["db"], o2["db"]), 2e-3))
+                res.append((f"ln_bwd {rows}x{C} affine={affine} dgamma", relerr(o1["dg"], o2["dg"]), 2e-3))
+                res.append((f"ln_bwd {rows}x{C} affine={affine} dbeta", relerr(o1["db"], o2["db"]), 2e-3))
     return res
 
 

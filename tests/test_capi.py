@@ -27,6 +27,37 @@ def test_header_and_binding_agree():
     assert header_symbols() == sorted(kernels.EXPORTED_SYMBOLS)
 
 
+def header_prototypes():
+    """name -> list of 'p' / 'i' / 'f' / 'l' per argument, parsed from the header's prototypes."""
+    src = open(os.path.join(ROOT, "include", "svdx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(svdx_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src):
+        args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
+        kinds = []
+        for a in args:
+            if "*" in a:
+                kinds.append("p")
+            elif re.match(r"(const\s+)?float\b", a):
+                kinds.append("f")
+            elif re.match(r"(const\s+)?(long|int64_t|size_t)\b", a):
+                kinds.append("l")
+            else:
+                kinds.append("i")
+        out[m.group(1)] = "".join(kinds)
+    return out
+
+
+def test_binding_signatures_match_header_prototypes():
+    """A ctypes table that drifts from the header corrupts the call frame silently: compare them argument by argument."""
+    from svd_xtend_amd import kernels
+    protos = header_prototypes()
+    for name, sig in kernels._SIGS.items():
+        assert name in protos, name
+        norm = sig.replace("z", "l")          # the table spells size_t 'z' and long 'l': same register class
+        assert norm == protos[name], f"{name}: binding {sig} vs header {protos[name]}"
+
+
 def test_library_exports_every_declared_symbol(lib):
     for name in header_symbols():
         assert hasattr(lib, name), name
