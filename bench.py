@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tune", action="store_true",
+                    help="in-situ GEMM tile/split-K tuning sweeps before timing (faster while the GPU is cool, ~1%% slower "
+                         "than the built-in formula once the step is power-limited: off by default)")
     ap.add_argument("--gemm-table", action="store_true", help="dump per-shape GEMM timings of one step")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny topology instead of the SVD config")
     args = ap.parse_args()
@@ -148,7 +151,10 @@ def main():
         trainer.allreduce_grads()
         opt_step()
 
-    # ---- warmup (eager), then try to capture the two halves of the step into hipGraphs ---------------------
+    # ---- one-off GEMM tuning (untimed set-up, like graph capture), warmup (eager), then capture -------------
+    tune_sweeps = 0
+    if args.tune and args.gemm_variant == 4:
+        tune_sweeps = trainer.tune_gemms(batch)
     for _ in range(max(1, args.warmup)):
         step_eager()
     torch.cuda.synchronize()
@@ -243,6 +249,11 @@ def main():
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "gemm_table.json"), "w") as f:
                 json.dump(rows, f)
+            tn = trainer.rt.tuner
+            if tn is not None:
+                with open(os.path.join(ROOT, "gpurun_out", "gemm_tuned.json"), "w") as f:
+                    json.dump([[repr(kk), repr(tn.table.get(kk)), [[c if not isinstance(c, tuple) else list(c), (st[0] / st[1]) if st[1] else None]
+                                                                  for c, st in zip(tn.cands[kk], tn.stats[kk])]] for kk in tn.cands], f)
         recs = [(a, b, f) for a, b, f, _ in recs]
         t_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
         fl = sum(f for _, _, f in recs)
@@ -268,7 +279,7 @@ def main():
             "config": {"workload": f"SVD UNet train step, {T} frames {args.width}x{args.height}, batch 1/GPU, "
                                    f"{n_params} params ({n_train} trainable: temporal_transformer_block*), "
                                    "fwd + EDM loss + bwd + grad all-reduce + AdamW",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "exec": exec_mode,
+                       "global_batch": world * B, "parallelism": f"dp{world}", "exec": exec_mode, "gemm_tuning_sweeps": tune_sweeps,
                        "gemm_variant": args.gemm_variant, "loss": loss, "loss_scale": state[1], "opt_steps": state[0],
                        "step_tflops_per_gpu": (STEP_TFLOP_C2 / (ms * 1e-3) if full else None),
                        "step_frac_of_mfma_peak": (STEP_TFLOP_C2 / (ms * 1e-3) / MFMA_PEAK_TFLOPS if full else None)},

@@ -76,9 +76,11 @@ int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int ld
 
 /* Weight-gradient GEMM in TN form: C[n*ldc + k] (+)= sum_r A[r*lda + n] * B[r*ldb + k]  (A = dY [R,N], B = X [R,K], float C).
  * Replaces the dW part of autograd's Linear backward (train_svd.py:1044) without materialising transposes.
- * out_mode: F32 (store), F32_ADD (+=), F32_SLAB (split z -> C + z*N*ldc), F32_ATOMIC. */
+ * out_mode: F32 (store), F32_ADD (+=), F32_SLAB (split z -> C + z*N*ldc), F32_ATOMIC.
+ * a_colsum (may be NULL): a_colsum[n] += sum_r A[r*lda + n] -- the Linear bias gradient, computed on the MFMA pipe from the dY
+ * tiles the GEMM stages anyway (float atomics, one per column per split). */
 int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
-                 const void* zero_page, int out_mode, int split_k, int dtype, void* stream);
+                 float* a_colsum, const void* zero_page, int out_mode, int split_k, int dtype, void* stream);
 
 /* Epilogue of a split-K GEMM run with SVDX_OUT_F32_SLAB: v = sum_z acc[z*slab_stride + m*N + n] + bias + rowvec + res (same operand
  * meaning as svdx_gemm); c_is_f32_accumulate ? ((float*)C)[m*ldc+n] += v : C[m*ldc+n] = (dtype)v. */

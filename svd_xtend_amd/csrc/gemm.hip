@@ -32,6 +32,7 @@ struct GemmParams {
     svdx_gather g; const void* zero_page;
     int out_mode; float alpha; int split_k; int tiles_m, tiles_n; int vec_ok; long slab_stride; int a_bytes, b_bytes;
     int epi; const void* aux_in; void* aux_out; int aux_dim;   // fused GEGLU epilogues (variant 4)
+    float* a_colsum;                                           // TN form: += column sums of A (the bias gradient), or null
 };
 
 struct RowInfo { int a, b, base; };   // per gathered A row (meaning depends on gather mode)
@@ -406,6 +407,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient = column sums of A = A^T * ones: the first column tile's wn == 0 waves spend 4 extra MFMAs per k-half on an
+    // all-ones B fragment (no LDS traffic, float accumulation) instead of a separate pass over dY
+    const bool do_cs = p.a_colsum != nullptr && pid_n == 0 && wn == 0;
+    f32x4 accb[4];
+    v8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int stage) __attribute__((always_inline)) {
         const char* As = smem + stage * STAGE_BYTES;
         const char* Bs = As + BM * BK * 2;
@@ -422,6 +432,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = TT<T>::mfma(af[i], bf[j], acc[i][j]);
+            if (do_cs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accb[i] = TT<T>::mfma(af[i], ones, accb[i]);
+            }
         }
     };
     issue(kt_begin, 0);
@@ -437,6 +451,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
     }
     compute(cur);
     __syncthreads();
+    if (do_cs && (lane & 15) == 0) {        // every column of the 16x16 result holds the sums: lanes 0/16/32/48 own rows 4*(lane>>4)..+3
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + e;
+                if (n < p.M) atomicAdd(p.a_colsum + n, accb[i][e]);
+            }
+    }
     gemm_epilogue<T>(p, acc, smem, m0, n0, z, tid, lane, wm, wn);
 }
 
@@ -939,7 +962,7 @@ int launch_gemm_tn(const GemmParams& p, hipStream_t st) {
 }  // namespace
 
 extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
-                            const void* zero_page, int out_mode, int split_k, int dtype, void* stream) {
+                            float* a_colsum, const void* zero_page, int out_mode, int split_k, int dtype, void* stream) {
     SVDX_CHECK_ARG(A && B && C && zero_page && R > 0 && N > 0 && K > 0, "svdx_gemm_tn: bad args");
     SVDX_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
                        ((uintptr_t)zero_page & 15) == 0, "svdx_gemm_tn: operands must be 16-byte aligned, N/K multiples of 8");
@@ -951,7 +974,7 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
     p.A = A; p.B = B; p.C = C; p.M = N; p.N = K; p.K = R; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = nullptr; p.rowvec = nullptr; p.rv_ld = 0; p.rv_rpg = 0; p.rv_mod = 0; p.res = nullptr; p.ldres = 0;
     p.g = svdx_gather{}; p.zero_page = zero_page; p.out_mode = out_mode; p.alpha = 1.f; p.split_k = split_k;
-    p.epi = 0; p.aux_in = nullptr; p.aux_out = nullptr; p.aux_dim = 0; p.a_bytes = 0; p.b_bytes = 0;
+    p.epi = 0; p.aux_in = nullptr; p.aux_out = nullptr; p.aux_dim = 0; p.a_bytes = 0; p.b_bytes = 0; p.a_colsum = a_colsum;
     p.tiles_m = cdiv(N, BM); p.tiles_n = cdiv(K, BN);
     p.vec_ok = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) && (K % 8 == 0);
     p.slab_stride = (long)N * ldc;
@@ -985,7 +1008,7 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
     p.bias = bias; p.rowvec = rowvec; p.rv_ld = rv_ld; p.rv_rpg = rv_rows_per_group; p.rv_mod = rv_mod;
     p.res = res; p.ldres = ldres; p.zero_page = zero_page;
     p.out_mode = out_mode; p.alpha = alpha; p.split_k = split_k; p.slab_stride = (long)M * ldc;
-    p.epi = epilogue; p.aux_in = aux_in; p.aux_out = aux_out; p.aux_dim = aux_dim;
+    p.epi = epilogue; p.aux_in = aux_in; p.aux_out = aux_out; p.aux_dim = aux_dim; p.a_colsum = nullptr;
     if (gather && gather->mode != SVDX_GATHER_PLAIN) {
         p.g = *gather;
         SVDX_CHECK_ARG(p.g.cin % BK == 0, "svdx_gemm: gather cin=%d must be a multiple of %d", p.g.cin, BK);
@@ -1028,12 +1051,13 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
     DISPATCH_DTYPE(dtype, {
         if (variant >= 2 && a_bytes > 0 && b_bytes > 0) {
             p.a_bytes = (int)a_bytes; p.b_bytes = (int)b_bytes;
-            const bool nb5 = epilogue == SVDX_EPI_GEGLU_FWD ? false : (N % 160 == 0);
+            // tile choice: variant 4 = heuristic; 6 / 7 / 8 force 160x160 / 128x160 / 128x128 (the host autotuner times them)
+            const bool nb5 = epilogue == SVDX_EPI_GEGLU_FWD || variant == 8 ? false : (N % 160 == 0);
             // 160-row tiles when they turn a 1.1-wave grid (512 resident blocks) into a single wave, e.g. M = 35840, N = 320:
             // 280 x 2 = 560 tiles of 128 rows vs 224 x 2 = 448 tiles of 160 rows
             const long t128 = (long)cdiv(M, 128) * cdiv(N, 160), t160 = (long)cdiv(M, 160) * cdiv(N, 160);
-            const bool mb5 = nb5 && ((variant == 6) ||          // variant 6: force the 160-row tile (tests)
-                                     (split_k == 1 && (cdiv(t128, 512) * 4 > cdiv(t160, 512) * 5) && t160 >= 384));
+            const bool mb5 = nb5 && ((variant == 6) ||
+                                     (variant == 4 && split_k == 1 && (cdiv(t128, 512) * 4 > cdiv(t160, 512) * 5) && t160 >= 384));
             if (mb5) return launch_gemm_v4<T, 5, 5>(p, st);
             return nb5 ? launch_gemm_v4<T, 5, 4>(p, st) : launch_gemm_v4<T, 4, 4>(p, st);
         }

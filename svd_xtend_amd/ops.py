@@ -53,6 +53,7 @@ class Runtime:
         self.gemm_variant = 4      # 0 register-staged reference, 1 global_load_lds, 4 production (lean buffer_load-lds loop, 128x160 tiles)
         self.split_k = True
         self.fuse_geglu = True
+        self.tuner = None           # GemmTuner (Trainer.tune_gemms): measured tile / split-K per GEMM problem
         self.arenas = [None, None]
         self.arena_cap = 1 << 20    # floats
         self.arena_cur, self.arena_pos = None, 0
@@ -86,7 +87,6 @@ class Runtime:
         if master.untyped_storage().data_ptr() != self.p_flat.untyped_storage().data_ptr() or off < 0:
             return None
         return self.w16_flat[off:off + master.numel()]
-        self.profile = None     # optional callable(kind, flops, bytes) -> context manager (bench instrumentation)
 
     def empty(self, *shape, dtype=None) -> torch.Tensor:
         return torch.empty(*shape, dtype=dtype or self.dt, device=self.dev)
@@ -111,22 +111,115 @@ def choose_split(rt: "Runtime", M: int, N: int, Kd: int, ldc: int) -> int:
     return split
 
 
+class GemmTuner:
+    """In-situ choice of tile shape / split-K per distinct GEMM problem.
+
+    While `active`, every tuned call site asks `pick(key, candidates)`; all calls of one problem use the same candidate
+    during one step and are bracketed by events on the launch stream, so each candidate is timed inside the real step
+    (real cache state, real neighbours -- isolated back-to-back timing of one GEMM is MALL-warm and picked configurations
+    that were slower in the step).  `end_step()` folds the timings in and moves every problem to its next candidate; after
+    `rounds` sweeps the fastest candidate per problem is frozen into `table`."""
+
+    def __init__(self, rounds: int = 2):
+        self.rounds = rounds
+        self.active = True
+        self.step = 0
+        self.cands = {}
+        self.stats = {}
+        self.pending = []
+        self.table = {}
+
+    def pick(self, key, make_cands):
+        if key not in self.cands:
+            self.cands[key] = list(make_cands())
+            self.stats[key] = [[0.0, 0] for _ in self.cands[key]]
+        idx = self.step % len(self.cands[key])
+        return self.cands[key][idx], idx
+
+    def record(self, key, idx, e0, e1) -> None:
+        self.pending.append((key, idx, e0, e1))
+
+    def end_step(self) -> bool:
+        """-> True once every problem has been swept `rounds` times and the table is frozen."""
+        if self.pending:
+            self.pending[-1][3].synchronize()
+        for key, idx, e0, e1 in self.pending:
+            st = self.stats[key][idx]
+            st[0] += e0.elapsed_time(e1)
+            st[1] += 1
+        self.pending = []
+        self.step += 1
+        if self.cands and self.step >= self.rounds * max(len(c) for c in self.cands.values()):
+            self.freeze()
+        return not self.active
+
+    def freeze(self) -> None:
+        """Adopt the fastest measured candidate of every problem (unmeasured ones never win) and stop exploring."""
+        for key, cands in self.cands.items():
+            avg = [(st[0] / st[1]) if st[1] else float("inf") for st in self.stats[key]]
+            i = min(range(len(cands)), key=avg.__getitem__)
+            if avg[i] < float("inf"):
+                self.table[key] = cands[i]
+        self.active = False
+
+
+def _tuning(rt: "Runtime") -> bool:
+    t = rt.tuner
+    return t is not None and t.active and rt.dev.type == "cuda" and not torch.cuda.is_current_stream_capturing()
+
+
+def tuned_call(rt: "Runtime", key, make_cands, fallback, run) -> None:
+    """Run `run(cfg)` with the frozen choice for `key`, the tuner's candidate of this step (timed), or `fallback()`."""
+    if _tuning(rt):
+        cfg, idx = rt.tuner.pick(key, make_cands)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run(cfg)
+        e1.record()
+        rt.tuner.record(key, idx, e0, e1)
+        return
+    cfg = rt.tuner.table.get(key) if rt.tuner is not None else None
+    run(cfg if cfg is not None else fallback())
+
+
+def _nt_candidates(M: int, N: int, Kd: int, splittable: bool):
+    kt = (Kd + 63) // 64
+    variants = (7, 6, 8) if N % 160 == 0 and N % 128 == 0 else ((7, 6) if N % 160 == 0 else (8,))
+    out = []
+    for v in variants:
+        bm, bn = (160, 160) if v == 6 else ((128, 160) if v == 7 else (128, 128))
+        tiles = -(-M // bm) * -(-N // bn)
+        for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
+            if s > 1 and (not splittable or tiles * s > 1024 or kt // s < 4 or -(-kt // s) * (s - 1) >= kt):
+                continue
+            out.append((s, v))
+    return out
+
+
 def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
              res=None, ldres=0, gather=None) -> None:
-    """Activation-dtype GEMM.  When the 128x128 output grid cannot fill the 256 CUs and K is long (the 10x16 / 5x8
-    latent levels: M = 2240 / 560 rows against K up to 23040) the reduction is split across blocks: partial sums are
-    accumulated with float atomics into a scratch buffer and a small epilogue kernel applies bias/row-vector/residual."""
+    """Activation-dtype GEMM.  Tile shape and split-K factor come from the GemmTuner table when the model was tuned
+    (Trainer.tune_gemms), else from a formula: the 10x16 / 5x8 latent levels (M = 2240 / 560 rows against K up to 23040)
+    cannot fill 256 CUs with output tiles alone, so the reduction is split across blocks -- partial sums go to float slabs
+    that a small epilogue kernel reduces, applying bias/row-vector/residual."""
     k = rt.k
-    split = choose_split(rt, M, N, Kd, ldc)
-    if split == 1:
-        k.gemm(A, B, out, M, N, Kd, lda, ldb, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod,
-               res=res, ldres=ldres, gather=gather, variant=rt.gemm_variant)
-        return
-    acc = rt.f32(split, M, N)
-    k.gemm(A, B, acc, M, N, Kd, lda, ldb, N, gather=gather, out_mode=K.OUT_F32_SLAB, split_k=split,
-           variant=rt.gemm_variant)
-    k.gemm_finalize(acc, split, M * N, out, M, N, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod,
-                    res=res, ldres=ldres)
+    splittable = rt.split_k and N % 4 == 0 and ldc % 4 == 0
+    key = ("nt", M, N, Kd, lda, ldc, 0 if gather is None else (gather.mode, gather.stride, gather.ups, gather.cin),
+           bias is not None, rowvec is not None, res is not None)
+
+    def run(cfg):
+        split, variant = cfg
+        if split == 1:
+            k.gemm(A, B, out, M, N, Kd, lda, ldb, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod,
+                   res=res, ldres=ldres, gather=gather, variant=variant)
+            return
+        acc = rt.f32(split, M, N)
+        k.gemm(A, B, acc, M, N, Kd, lda, ldb, N, gather=gather, out_mode=K.OUT_F32_SLAB, split_k=split, variant=variant)
+        k.gemm_finalize(acc, split, M * N, out, M, N, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg,
+                        rv_mod=rv_mod, res=res, ldres=ldres)
+
+    tuned_call(rt, key, lambda: _nt_candidates(M, N, Kd, splittable),
+               lambda: (choose_split(rt, M, N, Kd, ldc), rt.gemm_variant), run)
 
 
 def _choose_split_k(M: int, N: int, Kdim: int) -> int:
@@ -213,7 +306,10 @@ class LinearOp:
         if not getattr(self, "w_is_view", False):
             rt.k.cast_from_f32(master, self.w, self.N * self.Kdim)
         if self.wt is not None:
-            rt.k.cast_transpose_from_f32(master, self.wt, self.N, self.Kdim)
+            if getattr(self, "w_is_view", False):       # the 16-bit twin is current: 2+2 bytes per weight instead of 4+2
+                rt.k.transpose(self.w, self.Kdim, self.wt, self.N, self.N, self.Kdim)
+            else:
+                rt.k.cast_transpose_from_f32(master, self.wt, self.N, self.Kdim)
 
     # ---- compute ----
     def fwd(self, rt: Runtime, x: torch.Tensor, M: int, res: Optional[torch.Tensor] = None,
@@ -235,22 +331,35 @@ class LinearOp:
         if not self.trainable:
             return
         k = rt.k
-        tiles = ((self.N + 127) // 128) * ((self.Kdim + 127) // 128)
         rtiles = (M + 63) // 64
-        sk = 1
-        if tiles < 256 and rtiles >= 16:
-            sk = max(1, min(512 // tiles, rtiles // 4, 32))
-            while sk > 1 and (rtiles + sk - 1) // sk * (sk - 1) >= rtiles:
-                sk -= 1
-        if sk == 1:
-            k.gemm_tn(dy, x, self.w_grad, M, self.N, self.Kdim, self.N, self.Kdim, self.Kdim, out_mode=K.OUT_F32_ADD)
-        else:
-            slabs = rt.f32(sk, self.N, self.Kdim)
-            k.gemm_tn(dy, x, slabs, M, self.N, self.Kdim, self.N, self.Kdim, self.Kdim, out_mode=K.OUT_F32_SLAB, split_k=sk)
-            k.gemm_finalize(slabs, sk, self.N * self.Kdim, self.w_grad, self.N, self.Kdim, self.Kdim, accumulate_f32=True,
-                            dtype=rt.dt)
-        if self.b_grad is not None:
-            k.colsum(dy, self.b_grad, M, self.N, self.N, 1, M, 0, accumulate=1)
+
+        def run(sk, dst):
+            # the bias gradient (column sums of dy) rides on the same launch
+            if sk == 1:
+                k.gemm_tn(dy, x, dst, M, self.N, self.Kdim, self.N, self.Kdim, self.Kdim, out_mode=K.OUT_F32_ADD,
+                          a_colsum=self.b_grad)
+            else:
+                slabs = rt.f32(sk, self.N, self.Kdim)
+                k.gemm_tn(dy, x, slabs, M, self.N, self.Kdim, self.N, self.Kdim, self.Kdim, out_mode=K.OUT_F32_SLAB, split_k=sk,
+                          a_colsum=self.b_grad)
+                k.gemm_finalize(slabs, sk, self.N * self.Kdim, dst, self.N, self.Kdim, self.Kdim, accumulate_f32=True,
+                                dtype=rt.dt)
+
+        tiles = ((self.N + 127) // 128) * ((self.Kdim + 127) // 128)
+
+        def cands():
+            return [s for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32)
+                    if s == 1 or (tiles * s <= 2048 and rtiles // s >= 2 and -(-rtiles // s) * (s - 1) < rtiles)]
+
+        def formula():
+            sk = 1
+            if tiles < 256 and rtiles >= 16:
+                sk = max(1, min(512 // tiles, rtiles // 4, 32))
+                while sk > 1 and (rtiles + sk - 1) // sk * (sk - 1) >= rtiles:
+                    sk -= 1
+            return sk
+
+        tuned_call(rt, ("tn", M, self.N, self.Kdim), cands, formula, lambda sk: run(sk, self.w_grad))
 
 
 def transpose_pad(rt: Runtime, x: torch.Tensor, M: int, C: int) -> torch.Tensor:

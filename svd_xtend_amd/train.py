@@ -76,6 +76,25 @@ class Trainer:
         m.backward_rows(dpred)
         self.micro += 1
 
+    def tune_gemms(self, batch: Dict[str, torch.Tensor], rounds: int = 1, max_steps: int = 40) -> int:
+        """Measure tile shape / split-K for every GEMM problem of this model inside real forward+backward sweeps on `batch`
+        (ops.GemmTuner) and freeze the fastest per problem.  Run once before timing or graph capture; no optimizer step is
+        taken, gradients and the loss slot are cleared afterwards.  Returns the number of sweeps used."""
+        from .ops import GemmTuner
+        self.rt.tuner = GemmTuner(rounds)
+        n = 0
+        while n < max_steps:
+            self.zero_grad()
+            self.forward_backward(**batch)
+            n += 1
+            if self.rt.tuner.end_step():
+                break
+        if self.rt.tuner.active:
+            self.rt.tuner.freeze()
+        self.zero_grad()
+        self.micro = 0
+        return n
+
     def zero_grad(self):
         self.rt.k.zero(self.g_flat)
 

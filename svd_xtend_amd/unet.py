@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .ops import (ConvOp, GroupNormOp, LayerNormOp, LinearOp, Runtime, SmallLinearOp, choose_split, flatten_trainables,
+from .ops import (ConvOp, GroupNormOp, LayerNormOp, LinearOp, Runtime, SmallLinearOp, choose_split, flatten_trainables, tuned_call,
                   rup)
 
 HEAD_DIM = 64
@@ -117,8 +117,9 @@ class _FeedForward(nn.Module):
         dpre = rt.empty(M, 2 * F)
         if self._fusable(rt, M):
             # d(h) = dy W2 never reaches HBM: the data-grad GEMM's epilogue applies the GEGLU backward and writes d(pre)
-            k.gemm(dy, self.p2.wt, dpre, M, F, self.p2.N, self.p2.N, self.p2.N, 2 * F, variant=4, epilogue=K.EPI_GEGLU_BWD,
-                   aux_in=pre, aux_dim=F)
+            tuned_call(rt, ("geglu_bwd", M, F, self.p2.N), lambda: [7, 6] if F % 160 == 0 else [8], lambda: 4,
+                       lambda v: k.gemm(dy, self.p2.wt, dpre, M, F, self.p2.N, self.p2.N, self.p2.N, 2 * F, variant=v,
+                                        epilogue=K.EPI_GEGLU_BWD, aux_in=pre, aux_dim=F))
         else:
             dg = self.p2.bwd_dx(rt, dy, M)
             k.geglu_bwd(dg, pre, dpre, M, F)

@@ -134,8 +134,10 @@ class EmuBackend:
             assert C.dtype == torch.float32 or out_mode == K.OUT_ACT
             c.copy_(v.to(C.dtype))
 
-    def gemm_tn(self, A, B, C, R, N, Kd, lda, ldb, ldc, out_mode=K.OUT_F32_ADD, split_k=1):
+    def gemm_tn(self, A, B, C, R, N, Kd, lda, ldb, ldc, out_mode=K.OUT_F32_ADD, split_k=1, a_colsum=None):
         a, b = V(A, R, N, lda).float(), V(B, R, Kd, ldb).float()
+        if a_colsum is not None:
+            V1(a_colsum, N).add_(a.sum(0))
         if out_mode == K.OUT_F32_SLAB:
             assert ldc == Kd
             rt = (R + 63) // 64

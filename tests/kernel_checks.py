@@ -122,8 +122,11 @@ def check_gemm_tn(P, dt):
                 outs = dict(C=torch.zeros(3, N, Kd, device=P.dev))
             else:
                 outs = dict(C=torch.ones(N, Kd, device=P.dev))
-            o1, o2 = P.run("gemm_tn", lambda o: ((A, B, o["C"], R, N, Kd, N, Kd, Kd), dict(out_mode=mode, split_k=sk)), outs)
+            outs["cs"] = torch.ones(N, device=P.dev)
+            o1, o2 = P.run("gemm_tn", lambda o: ((A, B, o["C"], R, N, Kd, N, Kd, Kd),
+                                                 dict(out_mode=mode, split_k=sk, a_colsum=o["cs"])), outs)
             res.append((f"gemm_tn {R}x{N}x{Kd} mode={mode}", relerr(o1["C"], o2["C"]), tol_for(dt)))
+            res.append((f"gemm_tn {R}x{N}x{Kd} mode={mode} colsum(A)", relerr(o1["cs"], o2["cs"]), 2e-3))
     big = rnd((300, 3 * 128), dt, P.dev, g)
     X = rnd((300, 64), dt, P.dev, g)
     o1, o2 = P.run("gemm_tn", lambda o: ((big[:, 128:], X, o["C"], 300, 128, 64, 384, 64, 64), dict(out_mode=K.OUT_F32)),

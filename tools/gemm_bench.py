@@ -75,7 +75,11 @@ def main():
             ms = bench(lambda: be.gemm(A, B, C, M, N, Kd, lda, Kd, N, gather=gather, variant=v, **kw))
             row[f"v{v}_ms"] = ms
             row[f"v{v}_tflops"] = 2.0 * M * N * Kd / ms / 1e9
-        print(json.dumps(row), flush=True)
+        if kind is None:       # yardstick only: the vendor library on the same shape (never a product path)
+            Bt = B.t()
+            ms = bench(lambda: torch.matmul(A, Bt))
+            row["hipblaslt_tflops"] = 2.0 * M * N * Kd / ms / 1e9
+        print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in row.items()}), flush=True)
         out.append(row)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "gemm_bench.json"), "w"), indent=1)
