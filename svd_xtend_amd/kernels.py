@@ -17,7 +17,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsvdx.so")
+LIB_PATH = os.environ.get("SVDX_LIB") or os.path.join(_HERE, "csrc", "libsvdx.so")   # SVDX_LIB: A/B a second build of the library
 
 F16, BF16 = 0, 1
 OUT_ACT, OUT_F32, OUT_F32_ATOMIC, OUT_F32_SLAB, OUT_F32_ADD = 0, 1, 2, 3, 4
