@@ -16,6 +16,7 @@
 // Common: 256 threads = 4 waves (2x2); LDS rows of 128 B with the 16-byte chunk index XOR-swizzled by (row & 7) so the
 // ds_read_b128 fragment reads are bank-conflict free (SQ_LDS_BANK_CONFLICT = 0 measured); XCD-aware block -> tile mapping
 // (consecutive tiles of one A row-panel stay on one XCD's L2); split-K into float slabs + svdx_gemm_finalize.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -31,6 +32,7 @@ struct GemmParams {
     const void* res; int ldres;
     svdx_gather g; const void* zero_page;
     int out_mode; float alpha; int split_k; int tiles_m, tiles_n; int vec_ok; long slab_stride; int a_bytes, b_bytes;
+    int xcd_n, sub_m, sub_n;   // variant 4: the 8 XCDs form an (8/xcd_n) x xcd_n grid, each owning sub_m x sub_n tiles (0: balanced row-major split)
     int epi; const void* aux_in; void* aux_out; int aux_dim;   // fused GEGLU epilogues (variant 4)
     float* a_colsum;                                           // TN form: += column sums of A (the bias gradient), or null
 };
@@ -499,11 +501,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
     constexpr int ROWB = KT * 2;                       // bytes per staged row (128 | 64)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = p.tiles_m * p.tiles_n;
+    // Workgroup ids go round-robin to the 8 XCDs (id & 7), each with a private 4 MiB L2.  Every XCD re-fetches whatever operand
+    // rows its tiles touch, so the host picks an (8/xcd_n) x xcd_n arrangement of XCDs over the tile grid that minimises
+    // A_bytes * xcd_n + B_bytes * (8 / xcd_n): row bands when A dominates (the 64x40 level: A = 23 MB x taps, B < 2 MB), column
+    // bands when the weights dominate (10x16 / 5x8 levels: B = 30-60 MB, A = 1-6 MB; measured 8x weight re-fetch before).
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int pid_m = swz / p.tiles_n, pid_n = swz - pid_m * p.tiles_n;
+    int pid_m, pid_n;
+    if (p.xcd_n > 0) {
+        const int xcd = bid & 7, l = bid >> 3;
+        const int xi_m = xcd / p.xcd_n, xi_n = xcd - xi_m * p.xcd_n;
+        const int lm = l / p.sub_n;
+        pid_m = xi_m * p.sub_m + lm;
+        pid_n = xi_n * p.sub_n + (l - lm * p.sub_n);
+        if (lm >= p.sub_m || pid_m >= p.tiles_m || pid_n >= p.tiles_n) return;
+    } else {
+        const int nwg = p.tiles_m * p.tiles_n;
+        const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+        const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+        pid_m = swz / p.tiles_n;
+        pid_n = swz - pid_m * p.tiles_n;
+    }
     const int m0 = pid_m * BM4, n0 = pid_n * BN3;
     const int kt_total = p.K / KT;
     const int z = blockIdx.y;
@@ -952,7 +969,29 @@ int launch_gemm_v4(GemmParams p, hipStream_t st) {
     p.tiles_m = cdiv(p.M, 32 * MB);
     p.tiles_n = p.epi == SVDX_EPI_GEGLU_FWD ? cdiv(p.aux_dim, 16 * NB) : cdiv(p.N, 32 * NB);
     p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 15) == 0));
-    dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
+    // XCD arrangement (see the kernel): least operand re-fetch among the arrangements that keep >= 90 % of the best tile balance
+    static const int force_xn = getenv("SVDX_XCD_N") ? atoi(getenv("SVDX_XCD_N")) : -1;     // developer knob: 0 = old split, 1/2/4/8
+    const double a_bytes = 2.0 * p.M * (p.g.mode == SVDX_GATHER_PLAIN ? p.K : 2 * p.g.cin);   // conv: unique rows + halo
+    const double b_bytes = 2.0 * (p.epi == SVDX_EPI_GEGLU_FWD ? 2 * p.aux_dim : p.N) * p.K;
+    int best_xn = 0;
+    double best_cost = 0, best_eff = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int xn = 1; xn <= 8; xn *= 2) {
+            const int xm = 8 / xn, sm = cdiv(p.tiles_m, xm), sn = cdiv(p.tiles_n, xn);
+            const double eff = (double)p.tiles_m * p.tiles_n / (8.0 * sm * sn);
+            if (pass == 0) { best_eff = eff > best_eff ? eff : best_eff; continue; }
+            const double cost = a_bytes * xn + b_bytes * xm;
+            if (eff >= 0.9 * best_eff && (best_xn == 0 || cost < best_cost)) { best_xn = xn; best_cost = cost; }
+        }
+    if (force_xn >= 0) best_xn = force_xn;
+    p.xcd_n = best_xn;
+    int gx = p.tiles_m * p.tiles_n;
+    if (best_xn > 0) {
+        p.sub_m = cdiv(p.tiles_m, 8 / best_xn);
+        p.sub_n = cdiv(p.tiles_n, best_xn);
+        gx = 8 * p.sub_m * p.sub_n;
+    }
+    dim3 grid(gx, p.split_k);
     hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB>), grid, dim3(NTHREADS), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm");
     return 0;
