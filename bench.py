@@ -121,7 +121,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from svd_xtend_amd.train import Trainer
+    from svd_xtend_amd.train import GraphedStep, Trainer
     from svd_xtend_amd.unet import UNetSpatioTemporalConditionModel
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     cfg = {}
@@ -162,24 +162,9 @@ def main():
     step = step_eager
     if not args.no_graph:
         try:
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                fwd_bwd()
-                opt_step()
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            # thread_local: RCCL's watchdog thread may query events while we capture (N > 1)
-            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                fwd_bwd()
-            with torch.cuda.graph(g2, capture_error_mode="thread_local"):
-                opt_step()
-
-            def step_graph():
-                g1.replay()
-                trainer.allreduce_grads()
-                g2.replay()
+            # chain of graph segments cut at the transformer blocks: each block's gradient slice starts its all-reduce
+            # (eager RCCL call between two replays) while the rest of the backward sweep runs -- svd_xtend_amd.train.GraphedStep
+            step_graph = GraphedStep(trainer, batch)
             step_graph()
             torch.cuda.synchronize()
             step = step_graph
@@ -214,7 +199,7 @@ def main():
     if not args.no_roofline and rank == 0:
         k = trainer.rt.k
         orig, orig_tn = k.gemm, k.gemm_tn
-        recs = []
+        recs, recs_bytes = [], []
 
         def timed_gemm(A, Bm, C, M, N, Kd, *a, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -223,6 +208,9 @@ def main():
             e1.record()
             g = kw.get("gather")
             recs.append((e0, e1, 2.0 * M * N * Kd, ("nt", M, N, Kd, g.mode if g is not None else 0, kw.get("split_k", 1))))
+            taps = {0: 1, 1: 9, 2: 9, 3: 3}.get(g.mode if g is not None else 0, 1)
+            osz = 4 * kw.get("split_k", 1) if kw.get("out_mode", 0) != 0 else 2       # float slabs vs 16-bit activations
+            recs_bytes.append((0, 0, 0, 2.0 * M * Kd / taps + 2.0 * N * Kd + osz * M * N))
 
         def timed_gemm_tn(A, Bm, C, R, N, Kd, *a, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -230,6 +218,7 @@ def main():
             orig_tn(A, Bm, C, R, N, Kd, *a, **kw)
             e1.record()
             recs.append((e0, e1, 2.0 * R * N * Kd, ("tn", N, Kd, R, 0, kw.get("split_k", 1))))
+            recs_bytes.append((0, 0, 0, 2.0 * R * N + 2.0 * R * Kd + 4.0 * N * Kd * max(2, kw.get("split_k", 1))))
         k.gemm, k.gemm_tn = timed_gemm, timed_gemm_tn
         try:
             fwd_bwd()
@@ -258,9 +247,19 @@ def main():
         t_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
         fl = sum(f for _, _, f in recs)
         ach = fl / (t_ms * 1e-3) / 1e12
+        # HBM-side bytes per launch of the same kernel family: rocprofv3 FETCH_SIZE / WRITE_SIZE passes over this exact command
+        # (tools/pmc_traffic.py, gfx950 FETCH_SIZE x2 correction), committed under profiles/ -- bench.py cannot run a profiler
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if (not args.tiny) and (T, h, w) == (14, 40, 64) and args.dtype == "fp16" and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath))["gemm"]["bytes_per_launch"]
+            except Exception:  # noqa: BLE001
+                traffic = None
         roof = {"bound": "mfma", "kernel": "MFMA GEMM family (NT + implicit conv, TN weight-grad)", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None, "launches": len(recs),
-                "flops_per_step": fl, "kernel_ms_per_step": t_ms}
+                "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "launches": len(recs),
+                "flops_per_step": fl, "kernel_ms_per_step": t_ms,
+                "algorithmic_bytes_per_launch": sum(b for _, _, _, b in recs_bytes) / max(len(recs_bytes), 1)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

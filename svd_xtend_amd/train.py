@@ -60,12 +60,38 @@ class Trainer:
         model.prepare(dtype)
         self.rt = model.rt
         self.micro = 0
-        self.comm_stream = None
+        # gradient buckets for overlapping the all-reduce with the backward sweep: one contiguous slice of g_flat per transformer
+        # block (its trainables are adjacent in named_parameters order), reduced as soon as backward_rows leaves the block
+        self.overlap = True
+        self._pending = []
+        self._buckets = {}
+        off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
+        for kind, m in model.steps:
+            if kind != "attn":
+                continue
+            ps = [p for p in m.parameters() if p.requires_grad and id(p) in off_of]
+            if ps:
+                lo = min(off_of[id(p)] for p in ps)
+                hi = max(off_of[id(p)] + p.numel() for p in ps)
+                self._buckets[id(m)] = (lo, -(-hi // ALIGN) * ALIGN)
+        spans = sorted(self._buckets.values())
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), "gradient buckets must not overlap"
+        # whatever the buckets leave out (alignment gaps, trainables outside transformer blocks, the loss slot at the tail)
+        self._rest, pos = [], 0
+        for lo, hi in spans + [(self.n_total, self.n_total)]:
+            if lo > pos:
+                self._rest.append((pos, lo))
+            pos = max(pos, hi)
 
     # ---- one micro-step: fwd + loss + bwd, grads accumulate into g_flat ---------------------------------
     def forward_backward(self, unet_in, timesteps, ehs, added_time_ids, noisy_latents, target, sigmas):
         """unet_in [B,T,8,h,w]; noisy_latents/target float [B,T,4,h,w]; sigmas float [B].
         Adds this micro-batch's loss into the loss slot and its grads into the flat buffer."""
+        self.forward_loss(unet_in, timesteps, ehs, added_time_ids, noisy_latents, target, sigmas)
+        self.backward()
+
+    def forward_loss(self, unet_in, timesteps, ehs, added_time_ids, noisy_latents, target, sigmas):
+        """Forward sweep + EDM loss (added into the loss slot); keeps d(loss)/d(prediction) for `backward()`."""
         m, k = self.model, self.rt.k
         pred = m.forward_rows(unet_in, timesteps, ehs, added_time_ids)
         B, T, _, h, w = unet_in.shape
@@ -73,8 +99,30 @@ class Trainer:
         k.zero(dpred)
         k.edm_loss(pred, m.out_channels, noisy_latents.contiguous(), target.contiguous(), sigmas.contiguous(),
                    self.loss_slot, dpred, B, T, m.out_channels, h * w, self.opt_state)
-        m.backward_rows(dpred)
+        self._dpred = dpred
+
+    def backward(self, on_block=None):
+        """Backward sweep of the last `forward_loss`.  On the last micro-batch of a multi-rank step every transformer block's
+        gradient slice starts its all-reduce the moment the sweep leaves the block (`allreduce_grads` then only waits).
+        `on_block(module)` replaces that hook (GraphedStep cuts its graph segments there)."""
+        m = self.model
+        dpred, self._dpred = self._dpred, None
+        last = self.micro + 1 == self.grad_accum
+        m.grads_ready_cb = on_block if on_block is not None else (
+            self._reduce_bucket if (self.world > 1 and self.overlap and last) else None)
+        try:
+            m.backward_rows(dpred)
+        finally:
+            m.grads_ready_cb = None
         self.micro += 1
+
+    def _reduce_bucket(self, module) -> None:
+        """Start the all-reduce of one transformer block's gradient slice while the backward sweep continues (the collective
+        is ordered after the kernels already queued on the current stream, not after the ones that follow)."""
+        span = self._buckets.get(id(module))
+        if span is not None:
+            lo, hi = span
+            self._pending.append((span, dist.all_reduce(self.g_flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
 
     def tune_gemms(self, batch: Dict[str, torch.Tensor], rounds: int = 1, max_steps: int = 40) -> int:
         """Measure tile shape / split-K for every GEMM problem of this model inside real forward+backward sweeps on `batch`
@@ -100,9 +148,23 @@ class Trainer:
 
     # ---- gradient mean over ranks: ONE collective on the flat buffer -----------------------------------
     def allreduce_grads(self, async_op: bool = False):
+        """Finish the gradient sum over ranks: wait for the buckets started during the backward sweep and reduce what they did
+        not cover (always the loss slot); without overlap, ONE collective on the whole flat buffer."""
         if self.world == 1:
             return None
-        return dist.all_reduce(self.g_flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+        if not self._pending:
+            return dist.all_reduce(self.g_flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+        done = {span for span, _ in self._pending}
+        for span in self._buckets.values():          # a block whose backward was pruned never reported: reduce it now
+            if span not in done:
+                self._pending.append((span, dist.all_reduce(self.g_flat[span[0]:span[1]], op=dist.ReduceOp.SUM, group=self.pg,
+                                                            async_op=True)))
+        for lo, hi in self._rest:
+            self._pending.append(((lo, hi), dist.all_reduce(self.g_flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
+        for _, w in self._pending:
+            w.wait()
+        self._pending = []
+        return None
 
     # ---- optimizer step (unscale + inf check + AdamW + re-pack), no host sync -----------------------------
     def optimizer_step(self):
@@ -127,6 +189,68 @@ class Trainer:
         """Mean (unscaled) loss over ranks/micro-batches of the last reduced step (device scalar; read it
         before the next zero_grad)."""
         return self.loss_slot / (self.world * self.grad_accum)
+
+
+class GraphedStep:
+    """One optimizer step (grad_accum == 1) replayed from hipGraphs, with the gradient all-reduce overlapped.
+
+    The step is captured once, on fixed input tensors, as a CHAIN of graphs sharing one memory pool: the first holds zero_grad,
+    the forward sweep, the loss and the backward sweep down to the first transformer block; every later one holds the backward
+    sweep between two transformer blocks; the last holds the rest of it; one more holds the optimizer.  Replaying them in order
+    is the whole step, and between two replays -- outside any graph, so RCCL is never captured -- the slice of the flat gradient
+    buffer that the previous segment completed starts its all-reduce (async: it runs beside the next segments' kernels).
+    On one rank the collectives vanish and the chain is just the step."""
+
+    def __init__(self, trainer: "Trainer", batch: Dict[str, torch.Tensor]):
+        assert trainer.grad_accum == 1, "GraphedStep captures a whole step: use grad_accum == 1"
+        self.tr = trainer
+        self.graphs: List[torch.cuda.CUDAGraph] = []
+        self.spans: List[Optional[tuple]] = []
+        tr = trainer
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                       # warm-up on the capture stream (allocator, lazy module state)
+            tr.zero_grad()
+            tr.forward_loss(**batch)
+            tr.backward(on_block=lambda m: None)
+            tr.optimizer_step()
+            torch.cuda.synchronize()
+            # thread_local: RCCL's watchdog thread may query events while we capture (world > 1)
+            pool = torch.cuda.graph_pool_handle()
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=pool, capture_error_mode="thread_local")
+            self.graphs.append(g)
+            try:
+                def cut(module):
+                    self.graphs[-1].capture_end()
+                    self.spans.append(tr._buckets.get(id(module)))
+                    g2 = torch.cuda.CUDAGraph()
+                    g2.capture_begin(pool=pool, capture_error_mode="thread_local")
+                    self.graphs.append(g2)
+                tr.zero_grad()
+                tr.forward_loss(**batch)
+                tr.backward(on_block=cut)
+            finally:
+                self.graphs[-1].capture_end()
+            self.g_opt = torch.cuda.CUDAGraph()
+            self.g_opt.capture_begin(pool=pool, capture_error_mode="thread_local")
+            try:
+                tr.optimizer_step()
+            finally:
+                self.g_opt.capture_end()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+
+    def __call__(self) -> None:
+        tr = self.tr
+        multi = tr.world > 1
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if multi and tr.overlap and i < len(self.spans) and self.spans[i] is not None:
+                lo, hi = self.spans[i]
+                tr._pending.append(((lo, hi), dist.all_reduce(tr.g_flat[lo:hi], op=dist.ReduceOp.SUM, group=tr.pg, async_op=True)))
+        tr.allreduce_grads()
+        self.g_opt.replay()
 
 
 def edm_prepare(latents, noise, cond_latents, sigmas):

@@ -750,6 +750,7 @@ class UNetSpatioTemporalConditionModel(nn.Module):
             rt.w16_flat = torch.empty(rt.p_flat.numel(), dtype=dtype, device=dev)
             rt.k.cast_from_f32(rt.p_flat, rt.w16_flat, rt.p_flat.numel())
         self.steps = self._steps()
+        self.grads_ready_cb = None       # callable(module) invoked by backward_rows after each transformer block (gradient overlap)
         # which modules need an input gradient: only those executed after the first trainable parameter
         seen = False
         skip_flags = [seen]                       # conv_in output
@@ -973,6 +974,8 @@ class UNetSpatioTemporalConditionModel(nn.Module):
                 continue
             if kind == "res" or kind == "attn":
                 dx = m.bwd(rt, dx, cur)
+                if kind == "attn" and self.grads_ready_cb is not None:
+                    self.grads_ready_cb(m)          # this block's weight gradients are final: the trainer may start reducing them
             elif kind == "up":
                 low = level_geoms[lvl]
                 dx = m.op.bwd_dx(rt, dx, low.N, low.h, low.w) if m.need_dx else None

@@ -82,3 +82,37 @@ def run_all(verbose=False, dev=None):
             if verbose:
                 print(key, res[key], f"{time.time() - t0:.1f}s", flush=True)
     return res
+
+
+def graphed_vs_eager(dev=None, dtype=torch.float16, steps=3):
+    """The chained-hipGraph step (train.GraphedStep) must walk the same trajectory as eager `Trainer.step` calls."""
+    from svd_xtend_amd.train import GraphedStep
+    dev = dev or torch.device("cuda")
+    cfg = TINY_CONFIG
+    orc = UNetSpatioTemporalConditionOracle(**cfg)
+    scaled_init_(orc, 5)
+    b = make_synthetic_batch(1, 3, 16, 16, 77, cross_dim=cfg["cross_attention_dim"])
+    unet_in, ts, ehs, ids, noisy, _ = edm_inputs(b)
+    batch = {k: v.to(dev) for k, v in dict(unet_in=unet_in, timesteps=ts, ehs=ehs, added_time_ids=ids, noisy_latents=noisy,
+                                           target=b["latents"], sigmas=b["sigmas"]).items()}
+    out = []
+    for mode in ("eager", "graph"):
+        m = UNetSpatioTemporalConditionModel(**cfg)
+        m.load_state_dict(orc.state_dict(), strict=True)
+        m.to(dev)
+        tr = Trainer(m, dtype=dtype, lr=1e-3)
+        if mode == "eager":
+            for _ in range(steps):
+                tr.step(batch)
+            segs = 0
+        else:
+            gs = GraphedStep(tr, batch)              # its warm-up pass is one real step
+            for _ in range(steps - 1):
+                gs()
+            segs = len(gs.graphs)
+        torch.cuda.synchronize()
+        out.append(dict(p=tr.p_flat.clone(), loss=float(tr.last_loss()), state=tr.opt_state.cpu().tolist(), segments=segs))
+    e, g = out
+    return dict(loss_eager=e["loss"], loss_graph=g["loss"], param_max_diff=float((e["p"] - g["p"]).abs().max()),
+                param_mean_diff=float((e["p"] - g["p"]).abs().mean()),
+                param_abs_max=float(e["p"].abs().max()), opt_steps=(e["state"][0], g["state"][0]), segments=g["segments"])

@@ -46,11 +46,20 @@ def _worker(rank, world, port, out):
     _setup()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from svd_xtend_amd.train import Trainer
-    tr = Trainer(_make(0), dtype=torch.float32, lr=1e-3)
-    assert tr.world == world
-    for step in range(2):
-        tr.step(_batch(100 + 10 * step + rank))          # rank-distinct data
-    torch.save(dict(p=tr.p_flat.clone(), loss=tr.last_loss().clone()), os.path.join(out, f"r{rank}.pt"))
+    res = {}
+    for overlap in (True, False):                        # bucketed all-reduce during the backward sweep vs one collective after it
+        tr = Trainer(_make(0), dtype=torch.float32, lr=1e-3)
+        tr.overlap = overlap
+        assert tr.world == world and len(tr._buckets) >= 2 and tr._rest[-1][1] == tr.n_total
+        started = []
+        orig = tr._reduce_bucket
+        tr._reduce_bucket = lambda m, orig=orig: (started.append(1), orig(m))[1]
+        for step in range(2):
+            tr.step(_batch(100 + 10 * step + rank))      # rank-distinct data
+        assert (len(started) > 0) == overlap and not tr._pending
+        res[overlap] = dict(p=tr.p_flat.clone(), loss=tr.last_loss().clone())
+    assert torch.equal(res[True]["p"], res[False]["p"]) and torch.equal(res[True]["loss"], res[False]["loss"])
+    torch.save(res[True], os.path.join(out, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 

@@ -14,3 +14,19 @@ def test_train_step_matches_oracle_tiny():
         tol = 1e-3 if "float16" in key else 8e-3     # north_star tolerance is stated for fp16; bf16 has 8x less mantissa
         assert r["loss_rel"] <= tol, f"{key}: loss rel err {r['loss_rel']:.3e}"
         assert r["grad_cos_min"] >= (0.99 if "float16" in key else 0.95), f"{key}: {r}"
+
+
+@gpu
+def test_graphed_step_follows_eager_trajectory():
+    """hipGraph segments cut at the transformer blocks (where the overlapped all-reduce starts) replay the same step."""
+    import e2e_checks
+    r = e2e_checks.graphed_vs_eager()
+    print(r)
+    assert r["segments"] >= 3, r                         # the tiny UNet has several transformer blocks -> several segments
+    assert r["opt_steps"][0] == r["opt_steps"][1] == 3.0, r
+    assert abs(r["loss_eager"] - r["loss_graph"]) <= 2e-3 * abs(r["loss_eager"]), r
+    # same kernels, same order; only float-atomic summation order differs between the two runs.  Adam moves every weight by
+    # ~lr = 1e-3 per step in the direction of sign(g), so a gradient at rounding level can flip a weight by 2*lr per step:
+    # bound the worst case by that, and require the typical weight to agree far below one update
+    assert r["param_max_diff"] <= 2 * 1e-3 * 3 + 1e-4, r
+    assert r["param_mean_diff"] <= 1e-4, r
