@@ -213,6 +213,7 @@ class GraphedStep:
             tr.zero_grad()
             tr.forward_loss(**batch)
             tr.backward(on_block=lambda m: None)
+            tr.allreduce_grads()                         # the warm-up pass is a real step: keep the replicas identical
             tr.optimizer_step()
             torch.cuda.synchronize()
             # thread_local: RCCL's watchdog thread may query events while we capture (world > 1)
