@@ -602,6 +602,21 @@ class UNetSpatioTemporalConditionOutput(SimpleNamespace):
     pass
 
 
+class FrozenConfig(dict):
+    """diffusers' FrozenDict in miniature: `config.addition_time_embed_dim` (train_svd.py:887) and
+    `model.register_to_config(**other.config)` (train_svd.py:723) both work."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+CONFIG_NAME = "config.json"
+WEIGHTS_NAME = "diffusion_pytorch_model{variant}.safetensors"
+
+
 class _UNetFn(torch.autograd.Function):
     """Thin autograd boundary so `loss.backward()` in a host script reaches the hand-written backward."""
 
@@ -631,7 +646,7 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         n = len(down_block_types)
         if len(up_block_types) != n or len(block_out_channels) != n:
             raise ValueError("down_block_types, up_block_types and block_out_channels must have the same length")
-        self.config = SimpleNamespace(
+        self.config = FrozenConfig(
             sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
             down_block_types=tuple(down_block_types), up_block_types=tuple(up_block_types),
             block_out_channels=tuple(block_out_channels), addition_time_embed_dim=addition_time_embed_dim,
@@ -705,6 +720,47 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         self.gradient_checkpointing = False
 
     # ---- reference-script surface ------------------------------------------------------
+    def register_to_config(self, **kwargs) -> None:                     # train_svd.py:723
+        self.config = FrozenConfig({**self.config, **kwargs})
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder: Optional[str] = None, variant: Optional[str] = None, torch_dtype=None,
+                        **unused):
+        """diffusers folder layout (train_svd.py:651-656, 721): `<path>/<subfolder>/config.json` +
+        `diffusion_pytorch_model[.<variant>].safetensors`, diffusers key names, strict load.  Local folders only."""
+        import json
+        import os
+
+        from safetensors.torch import load_file
+        folder = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(folder, CONFIG_NAME)) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        ctor = {k: v for k, v in cfg.items() if k in cls.__init__.__code__.co_varnames}
+        model = cls(**ctor)
+        wpath = os.path.join(folder, WEIGHTS_NAME.format(variant=f".{variant}" if variant else ""))
+        if not os.path.exists(wpath) and variant:                         # diffusers falls back to the un-suffixed file
+            wpath = os.path.join(folder, WEIGHTS_NAME.format(variant=""))
+        sd = load_file(wpath)
+        model.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)   # float masters; kernels use packed copies
+        if torch_dtype is not None and torch_dtype != torch.float32:
+            model._requested_dtype = torch_dtype
+        return model
+
+    def save_pretrained(self, folder, variant: Optional[str] = None, **unused) -> None:    # train_svd.py:703, 1088-1090
+        import json
+        import os
+
+        from safetensors.torch import save_file
+        os.makedirs(folder, exist_ok=True)
+        cfg = {"_class_name": "UNetSpatioTemporalConditionModel", "_svd_xtend_amd": True}
+        cfg.update({k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()})
+        with open(os.path.join(folder, CONFIG_NAME), "w") as f:
+            json.dump(cfg, f, indent=2)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        if variant == "fp16":
+            sd = {k: v.half() for k, v in sd.items()}
+        save_file(sd, os.path.join(folder, WEIGHTS_NAME.format(variant=f".{variant}" if variant else "")))
+
     def enable_gradient_checkpointing(self):      # train_svd.py:732 -- 288 GB HBM: not needed, accepted as no-op
         self.gradient_checkpointing = False
 

@@ -138,3 +138,29 @@ def test_backward_stops_before_first_trainable_block(emu_backend):
     Trainer(m, dtype=torch.float32)
     kinds = [(k, getattr(mod, "need_dx", None)) for k, mod in m.steps if k in ("res", "attn")]
     assert kinds[0] == ("res", False) and kinds[1] == ("attn", False) and kinds[2] == ("res", True)
+
+
+def test_pretrained_folder_round_trip(tmp_path):
+    """`save_pretrained` / `from_pretrained` / `register_to_config` (train_svd.py:651-656, 698-725): diffusers folder layout,
+    diffusers key names, strict load, config usable both as attributes and as a mapping."""
+    import json
+
+    from oracle.unet import TINY_CONFIG, UNetSpatioTemporalConditionOracle, scaled_init_
+    from svd_xtend_amd.unet import UNetSpatioTemporalConditionModel
+    orc = UNetSpatioTemporalConditionOracle(**TINY_CONFIG)
+    scaled_init_(orc, 9)
+    m = UNetSpatioTemporalConditionModel(**TINY_CONFIG)
+    m.load_state_dict(orc.state_dict(), strict=True)
+    m.save_pretrained(str(tmp_path / "ckpt" / "unet"))
+    m.save_pretrained(str(tmp_path / "ckpt" / "unet"), variant="fp16")
+    cfg = json.load(open(tmp_path / "ckpt" / "unet" / "config.json"))
+    assert cfg["block_out_channels"] == list(TINY_CONFIG["block_out_channels"])
+    m2 = UNetSpatioTemporalConditionModel.from_pretrained(str(tmp_path / "ckpt"), subfolder="unet")
+    assert m2.config.addition_time_embed_dim == TINY_CONFIG["addition_time_embed_dim"]
+    assert set(m2.state_dict()) == set(orc.state_dict())
+    assert all(torch.equal(v, m2.state_dict()[k]) for k, v in m.state_dict().items())
+    m3 = UNetSpatioTemporalConditionModel.from_pretrained(str(tmp_path / "ckpt"), subfolder="unet", variant="fp16")
+    k0 = "down_blocks.0.attentions.0.temporal_transformer_blocks.0.attn1.to_q.weight"
+    assert torch.equal(m3.state_dict()[k0], m.state_dict()[k0].half().float())
+    m3.register_to_config(**m2.config)                   # train_svd.py:723
+    assert m3.config["num_frames"] == m2.config.num_frames
