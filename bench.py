@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--lora-rank", type=int, default=0,
+                    help="reference config 5 (train_svd_lora.py): LoRA adapters of this rank on every attention projection are the "
+                         "trainable set (the reference runs it in bf16: pass --dtype bf16); 0 = config 2 (default)")
     ap.add_argument("--tune", action="store_true",
                     help="in-situ GEMM tile/split-K tuning sweeps before timing (faster while the GPU is cool, ~1%% slower "
                          "than the built-in formula once the step is power-limited: off by default)")
@@ -131,6 +134,12 @@ def main():
     with torch.device(dev):
         model = UNetSpatioTemporalConditionModel(**cfg)
     init_weights_(model, seed=1234)            # identical on every rank (DDP's init broadcast)
+    if args.lora_rank:
+        from svd_xtend_amd.lora import LoraConfig
+        for p in model.parameters():           # train_svd_lora.py:655-671
+            p.requires_grad_(False)
+        with torch.device(dev):
+            model.add_adapter(LoraConfig(r=args.lora_rank, lora_alpha=args.lora_rank, init_lora_weights="gaussian"))
     trainer = Trainer(model, dtype=dt, lr=1e-5)
     trainer.rt.gemm_variant = args.gemm_variant
     n_params = sum(p.numel() for p in model.parameters())
@@ -251,7 +260,7 @@ def main():
         # (tools/pmc_traffic.py, gfx950 FETCH_SIZE x2 correction), committed under profiles/ -- bench.py cannot run a profiler
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if (not args.tiny) and (T, h, w) == (14, 40, 64) and args.dtype == "fp16" and os.path.exists(tpath):
+        if (not args.tiny) and (T, h, w) == (14, 40, 64) and args.dtype == "fp16" and not args.lora_rank and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath))["gemm"]["bytes_per_launch"]
             except Exception:  # noqa: BLE001
@@ -269,14 +278,16 @@ def main():
             cpu = {"error": repr(e)[:200]}
 
     if rank == 0:
-        full = (not args.tiny) and (T, h, w) == (14, 40, 64)
+        full = (not args.tiny) and (T, h, w) == (14, 40, 64) and not args.lora_rank
         line = {
-            "metric": "train-step samples/sec (14-frame 512x320 fp16 SVD UNet)",
+            "metric": "train-step samples/sec (14-frame 512x320 fp16 SVD UNet)" if not args.lora_rank else
+                      f"train-step samples/sec (14-frame 512x320 {args.dtype} SVD UNet, LoRA r={args.lora_rank})",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic latents/CLIP embed, random-init weights (no checkpoints offline)",
             "config": {"workload": f"SVD UNet train step, {T} frames {args.width}x{args.height}, batch 1/GPU, "
-                                   f"{n_params} params ({n_train} trainable: temporal_transformer_block*), "
+                                   f"{n_params} params ({n_train} trainable: "
+                                   f"{'LoRA r=%d adapters on to_q/to_k/to_v/to_out.0' % args.lora_rank if args.lora_rank else 'temporal_transformer_block*'}), "
                                    "fwd + EDM loss + bwd + grad all-reduce + AdamW",
                        "global_batch": world * B, "parallelism": f"dp{world}", "exec": exec_mode, "gemm_tuning_sweeps": tune_sweeps,
                        "gemm_variant": args.gemm_variant, "loss": loss, "loss_scale": state[1], "opt_steps": state[0],

@@ -330,36 +330,41 @@ class LinearOp:
         """w.grad += dy^T x ; b.grad += colsum(dy).  TN GEMM straight from the row-major dy [M,N] and x [M,K]."""
         if not self.trainable:
             return
-        k = rt.k
-        rtiles = (M + 63) // 64
+        gemm_tn_acc(rt, dy, x, self.w_grad, M, self.N, self.Kdim, self.N, self.Kdim, a_colsum=self.b_grad)
 
-        def run(sk, dst):
-            # the bias gradient (column sums of dy) rides on the same launch
-            if sk == 1:
-                k.gemm_tn(dy, x, dst, M, self.N, self.Kdim, self.N, self.Kdim, self.Kdim, out_mode=K.OUT_F32_ADD,
-                          a_colsum=self.b_grad)
-            else:
-                slabs = rt.f32(sk, self.N, self.Kdim)
-                k.gemm_tn(dy, x, slabs, M, self.N, self.Kdim, self.N, self.Kdim, self.Kdim, out_mode=K.OUT_F32_SLAB, split_k=sk,
-                          a_colsum=self.b_grad)
-                k.gemm_finalize(slabs, sk, self.N * self.Kdim, dst, self.N, self.Kdim, self.Kdim, accumulate_f32=True,
-                                dtype=rt.dt)
 
-        tiles = ((self.N + 127) // 128) * ((self.Kdim + 127) // 128)
+def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tensor, M: int, N: int, Kd: int, lda: int, ldb: int,
+                a_colsum: Optional[torch.Tensor] = None) -> None:
+    """dst[N, Kd] (float, contiguous) += dy[:, :N]^T x[:, :Kd] over M rows (row pitches lda / ldb); a_colsum += colsum(dy).
+    The reduction over rows is split across blocks when the [N, Kd] tile grid cannot fill the chip (float slabs + finalize):
+    weight-grad outputs are small (down to 320 x 64 for a LoRA factor) while M is 35840."""
+    k = rt.k
+    rtiles = (M + 63) // 64
 
-        def cands():
-            return [s for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32)
-                    if s == 1 or (tiles * s <= 2048 and rtiles // s >= 2 and -(-rtiles // s) * (s - 1) < rtiles)]
+    def run(sk):
+        # the bias gradient (column sums of dy) rides on the same launch
+        if sk == 1:
+            k.gemm_tn(dy, x, dst, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32_ADD, a_colsum=a_colsum)
+        else:
+            slabs = rt.f32(sk, N, Kd)
+            k.gemm_tn(dy, x, slabs, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32_SLAB, split_k=sk, a_colsum=a_colsum)
+            k.gemm_finalize(slabs, sk, N * Kd, dst, N, Kd, Kd, accumulate_f32=True, dtype=rt.dt)
 
-        def formula():
-            sk = 1
-            if tiles < 256 and rtiles >= 16:
-                sk = max(1, min(512 // tiles, rtiles // 4, 32))
-                while sk > 1 and (rtiles + sk - 1) // sk * (sk - 1) >= rtiles:
-                    sk -= 1
-            return sk
+    tiles = ((N + 127) // 128) * ((Kd + 127) // 128)
 
-        tuned_call(rt, ("tn", M, self.N, self.Kdim), cands, formula, lambda sk: run(sk, self.w_grad))
+    def cands():
+        return [s for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 96)
+                if s == 1 or (tiles * s <= 2048 and rtiles // s >= 2 and -(-rtiles // s) * (s - 1) < rtiles)]
+
+    def formula():
+        sk = 1
+        if tiles < 256 and rtiles >= 16:
+            sk = max(1, min(512 // tiles, rtiles // 4, 128 if tiles <= 4 else 32))
+            while sk > 1 and (rtiles + sk - 1) // sk * (sk - 1) >= rtiles:
+                sk -= 1
+        return sk
+
+    tuned_call(rt, ("tn", M, N, Kd, lda, ldb), cands, formula, run)
 
 
 def transpose_pad(rt: Runtime, x: torch.Tensor, M: int, C: int) -> torch.Tensor:
@@ -421,6 +426,126 @@ class SmallLinearOp:
         dx = rt.f32(M, self.Kdim)
         k.small_linear(dy, self.w, None, dx, M, self.N, self.Kdim, self.Kdim, 1, 0, 0)
         return dx
+
+
+# --------------------------------------------------------------------------------------------------
+# LoRA branches (reference config 5: train_svd_lora.py:659-674; peft.tuners.lora.Linear restated in lora.py)
+# --------------------------------------------------------------------------------------------------
+class LoraOp:
+    """Adapter branch of a (possibly fused) LinearOp: y[:, seg_j] += s * (x A_j^T) B_j^T for the J wrapped projections that
+    share the input x (J = 3 for fused q/k/v, 1 for to_out).  Two skinny NT GEMMs forward; backward is one skinny NT GEMM per
+    segment for d(xA^T) (scaled by s through the GEMM alpha), TN GEMMs for dB_j and dA_j, and one NT GEMM that adds
+    d(xA^T) A into dx.  The rank is zero-padded to a multiple of 64 (the GEMM K granule); packed 16-bit copies of the small
+    A / B matrices (stacked A, its transpose, B_j and B_j^T) are refreshed after every optimizer step."""
+
+    def __init__(self, mods):
+        self.mods = list(mods)
+        self.J = len(self.mods)
+        self.r = self.mods[0].r
+        self.rp = rup(self.r, 64)
+        self.s = self.mods[0].scaling
+        self.in_f = self.mods[0].in_features
+        self.outs = [m.out_features for m in self.mods]
+        assert all(m.r == self.r and m.in_features == self.in_f and m.scaling == self.s for m in self.mods)
+        self.trainable = any(m.A.requires_grad or m.B.requires_grad for m in self.mods)
+        self.A3 = self.A3T = None
+        self.Bp: List[torch.Tensor] = []
+        self.BTp: List[torch.Tensor] = []
+
+    def pack(self, rt: Runtime) -> None:
+        J, rp = self.J, self.rp
+        self.A3 = torch.zeros(J * rp, self.in_f, dtype=rt.dt, device=rt.dev)
+        self.A3T = rt.empty(self.in_f, J * rp)
+        self.Bp = [torch.zeros(n, rp, dtype=rt.dt, device=rt.dev) for n in self.outs]
+        self.BTp = [rt.empty(rp, n) for n in self.outs]
+        self.refresh(rt)
+
+    def refresh(self, rt: Runtime) -> None:
+        k, r, rp = rt.k, self.r, self.rp
+        for j, m in enumerate(self.mods):
+            if r == rp:
+                k.cast_from_f32(m.A.data, self.A3[j * rp:(j + 1) * rp], r * self.in_f)
+                k.cast_from_f32(m.B.data, self.Bp[j], self.outs[j] * r)
+            else:                                   # padded rank: strided re-layout of two tiny matrices
+                self.A3[j * rp:j * rp + r].copy_(m.A.data)
+                self.Bp[j][:, :r].copy_(m.B.data)
+            k.transpose(self.Bp[j], rp, self.BTp[j], self.outs[j], self.outs[j], rp)
+        k.transpose(self.A3, self.in_f, self.A3T, self.J * rp, self.J * rp, self.in_f)
+
+    def fwd(self, rt: Runtime, x: torch.Tensor, y: torch.Tensor, M: int, ldy: int) -> torch.Tensor:
+        """y (already holding the base projection) gets the adapter term added in place; returns xs = s * x A^T [M, J*rp]."""
+        k, rp, J = rt.k, self.rp, self.J
+        xs = rt.empty(M, J * rp)
+        k.gemm(x, self.A3, xs, M, J * rp, self.in_f, self.in_f, self.in_f, J * rp, alpha=self.s, variant=rt.gemm_variant)
+        off = 0
+        for j, n in enumerate(self.outs):
+            yj = y[:, off:off + n]
+            k.gemm(xs[:, j * rp:], self.Bp[j], yj, M, n, rp, J * rp, rp, ldy, res=yj, ldres=ldy, variant=rt.gemm_variant)
+            off += n
+        return xs
+
+    def bwd(self, rt: Runtime, dy: torch.Tensor, lddy: int, x: torch.Tensor, xs: torch.Tensor, dx: Optional[torch.Tensor],
+            M: int) -> None:
+        """dy [M, sum N_j] (row pitch lddy); accumulates A_j.grad / B_j.grad and, when dx is given, dx += d(xA^T) A."""
+        k, r, rp, J = rt.k, self.r, self.rp, self.J
+        dxa = rt.empty(M, J * rp)
+        off = 0
+        for j, n in enumerate(self.outs):
+            dyj = dy[:, off:off + n]
+            k.gemm(dyj, self.BTp[j], dxa[:, j * rp:], M, rp, n, lddy, n, J * rp, alpha=self.s, variant=rt.gemm_variant)
+            m = self.mods[j]
+            if m.B.requires_grad:
+                if r == rp:
+                    gemm_tn_acc(rt, dyj, xs[:, j * rp:], m.B.grad, M, n, rp, lddy, J * rp)
+                else:
+                    tmp = rt.zeros_f32(n, rp)
+                    gemm_tn_acc(rt, dyj, xs[:, j * rp:], tmp, M, n, rp, lddy, J * rp)
+                    m.B.grad.add_(tmp[:, :r])
+            off += n
+        for j, m in enumerate(self.mods):
+            if m.A.requires_grad:
+                if r == rp:
+                    gemm_tn_acc(rt, dxa[:, j * rp:], x, m.A.grad, M, rp, self.in_f, J * rp, self.in_f)
+                else:
+                    tmp = rt.zeros_f32(rp, self.in_f)
+                    gemm_tn_acc(rt, dxa[:, j * rp:], x, tmp, M, rp, self.in_f, J * rp, self.in_f)
+                    m.A.grad.add_(tmp[:r])
+        if dx is not None:
+            k.gemm(dxa, self.A3T, dx, M, self.in_f, J * rp, J * rp, J * rp, self.in_f, res=dx, ldres=self.in_f,
+                   variant=rt.gemm_variant)
+
+
+class SmallLoraOp:
+    """Adapter branch of a SmallLinearOp (float activations, a handful of rows: the KV-length-1 cross-attention's to_v / to_out
+    act on one context vector per clip)."""
+
+    def __init__(self, mod):
+        self.mod = mod
+        self.s = mod.scaling
+        self.a = SmallLinearOp(mod.A, None)
+        self.b = SmallLinearOp(mod.B, None)
+        self.trainable = mod.A.requires_grad or mod.B.requires_grad
+
+    def pack(self, rt: Runtime) -> None:
+        self.a.pack(rt)
+        self.b.pack(rt)
+
+    def refresh(self, rt: Runtime) -> None:
+        self.a.refresh(rt)
+        self.b.refresh(rt)
+
+    def fwd(self, rt: Runtime, x: torch.Tensor, y: torch.Tensor, M: int) -> torch.Tensor:
+        xs = self.a.fwd(rt, x, M)
+        if self.s != 1.0:
+            xs.mul_(self.s)                          # [M, r] floats; the reference always uses lora_alpha == r (s = 1)
+        self.b.fwd(rt, xs, M, out=y, accumulate=True)
+        return xs
+
+    def bwd(self, rt: Runtime, dy: torch.Tensor, x: torch.Tensor, xs: torch.Tensor, M: int, need_dx: bool):
+        dxa = self.b.bwd(rt, dy, xs, M, need_dx=True)
+        if self.s != 1.0:
+            dxa.mul_(self.s)
+        return self.a.bwd(rt, dxa, x, M, need_dx=need_dx)
 
 
 # --------------------------------------------------------------------------------------------------

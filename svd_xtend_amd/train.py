@@ -20,10 +20,12 @@ ALIGN = 64  # floats
 
 
 def select_trainable(model: torch.nn.Module, substr: str = "temporal_transformer_block") -> List[str]:
-    """train_svd.py:761-766."""
+    """train_svd.py:761-766 (names containing `temporal_transformer_block`); with LoRA adapters injected
+    (train_svd_lora.py:655-671: everything frozen, then `add_adapter`) the adapters are the trainable set."""
+    has_lora = any(".lora_" in name for name, _ in model.named_parameters())
     names = []
     for name, p in model.named_parameters():
-        p.requires_grad = substr in name
+        p.requires_grad = (".lora_" in name) if has_lora else (substr in name)
         if p.requires_grad:
             names.append(name)
     return names

@@ -21,7 +21,8 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .ops import (ConvOp, GroupNormOp, LayerNormOp, LinearOp, Runtime, SmallLinearOp, choose_split, flatten_trainables, tuned_call,
+from .lora import LoraLinear, base_linear, inject
+from .ops import (ConvOp, GroupNormOp, LayerNormOp, LinearOp, LoraOp, Runtime, SmallLinearOp, SmallLoraOp, choose_split, flatten_trainables, tuned_call,
                   rup)
 
 HEAD_DIM = 64
@@ -144,12 +145,25 @@ class _Attention(nn.Module):
         self.to_out = nn.ModuleList([nn.Linear(inner, dim, bias=True), nn.Dropout(0.0)])
 
     def build(self):
+        q, kk, v, o = (base_linear(m) for m in (self.to_q, self.to_k, self.to_v, self.to_out[0]))
+        is_l = [isinstance(m, LoraLinear) for m in (self.to_q, self.to_k, self.to_v, self.to_out[0])]
+        self.qkv_lora = self.o_lora = self.v_lora = None
         if self.cross:
-            self.v = SmallLinearOp(self.to_v.weight, None)
-            self.o = SmallLinearOp(self.to_out[0].weight, self.to_out[0].bias)
+            self.v = SmallLinearOp(v.weight, None)
+            self.o = SmallLinearOp(o.weight, o.bias)
+            # KV length 1: to_q / to_k (and their adapters) never influence the output -> zero gradient, nothing to run
+            self.v_lora = SmallLoraOp(self.to_v) if is_l[2] else None
+            self.o_lora = SmallLoraOp(self.to_out[0]) if is_l[3] else None
         else:
-            self.qkv = LinearOp([self.to_q.weight, self.to_k.weight, self.to_v.weight])
-            self.o = LinearOp([self.to_out[0].weight], [self.to_out[0].bias])
+            self.qkv = LinearOp([q.weight, kk.weight, v.weight])
+            self.o = LinearOp([o.weight], [o.bias])
+            if any(is_l[:3]):
+                if not all(is_l[:3]):
+                    raise NotImplementedError("LoRA on a subset of to_q/to_k/to_v is not supported (the projection is fused)")
+                self.qkv_lora = LoraOp([self.to_q, self.to_k, self.to_v])
+            self.o_lora = LoraOp([self.to_out[0]]) if is_l[3] else None
+        self.loras = [l for l in (self.qkv_lora, self.o_lora, self.v_lora) if l is not None]
+        self.lora_trainable = any(l.trainable for l in self.loras)
 
     def pack(self, rt):
         if self.cross:
@@ -158,19 +172,43 @@ class _Attention(nn.Module):
         else:
             self.qkv.pack(rt)
             self.o.pack(rt)
+        for l in self.loras:
+            l.pack(rt)
 
-    refresh = pack
+    def refresh(self, rt):
+        """After an optimizer step: re-pack whatever is trainable (base projections in config 2-4, adapters in config 5)."""
+        for op in ((self.v, self.o) if self.cross else (self.qkv, self.o)):
+            if op.trainable:
+                op.refresh(rt)
+        for l in self.loras:
+            if l.trainable:
+                l.refresh(rt)
 
     # KV-length-1 cross attention: softmax over one key == 1, so attn2(x, ctx) = to_out(to_v(ctx)) for every
     # query row; to_q / to_k (and the LayerNorm feeding to_q) receive exactly zero gradient.
     def cross_vec(self, rt, ctx, Bn):
         v = self.v.fwd(rt, ctx, Bn)
-        return self.o.fwd(rt, v, Bn), v
+        va = self.v_lora.fwd(rt, ctx, v, Bn) if self.v_lora is not None else None
+        out = self.o.fwd(rt, v, Bn)
+        oa = self.o_lora.fwd(rt, v, out, Bn) if self.o_lora is not None else None
+        return out, (v, va, oa)
 
-    def cross_vec_bwd(self, rt, dvec, v, ctx, Bn):
-        dv = self.o.bwd(rt, dvec, v, Bn, need_dx=self.v.trainable)
+    @property
+    def cross_trainable(self):
+        return self.o.trainable or self.v.trainable or self.lora_trainable
+
+    def cross_vec_bwd(self, rt, dvec, saved, ctx, Bn):
+        v, va, oa = saved
+        need_dv = self.v.trainable or (self.v_lora is not None and self.v_lora.trainable)
+        dv = self.o.bwd(rt, dvec, v, Bn, need_dx=need_dv)
+        if self.o_lora is not None and self.o_lora.trainable:
+            dv2 = self.o_lora.bwd(rt, dvec, v, oa, Bn, need_dx=need_dv)
+            if need_dv:
+                dv.add_(dv2)                        # [B, C] floats
         if self.v.trainable:
             self.v.bwd(rt, dv, ctx, Bn, need_dx=False)
+        if self.v_lora is not None and self.v_lora.trainable:
+            self.v_lora.bwd(rt, dv, ctx, va, Bn, need_dx=False)
 
 
 # ==================================================================================================
@@ -193,8 +231,14 @@ class BasicTransformerBlock(nn.Module):
         for m in (self.attn1, self.attn2, self.ff):
             m.build()
         self.ln1, self.ln3 = LayerNormOp(self.norm1), LayerNormOp(self.norm3)
-        if any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("spatial transformer blocks are frozen on this path (train_svd.py:761-766)")
+        if any(p.requires_grad for n, p in self.named_parameters() if ".lora_" not in n):
+            raise NotImplementedError("spatial transformer blocks are frozen on this path (train_svd.py:761-766); only LoRA "
+                                      "adapters on their attention projections may train (train_svd_lora.py:659-674)")
+        self.trainable = any(p.requires_grad for p in self.parameters())
+
+    def refresh(self, rt):
+        self.attn1.refresh(rt)
+        self.attn2.refresh(rt)
 
     def pack(self, rt):
         for m in (self.attn1, self.attn2, self.ff):
@@ -204,7 +248,9 @@ class BasicTransformerBlock(nn.Module):
         k, C, M, S = rt.k, self.dim, g.M, g.HW
         n1, st1 = self.ln1.fwd(rt, h, M)
         qkv = self.attn1.qkv.fwd(rt, n1, M)
-        del n1
+        xs_qkv = self.attn1.qkv_lora.fwd(rt, n1, qkv, M, 3 * C) if self.attn1.qkv_lora is not None else None
+        if not (self.attn1.qkv_lora is not None and self.attn1.qkv_lora.trainable):
+            n1 = None
         s_pad = rup(S, 64)
         vt = rt.empty(g.N * self.heads * HEAD_DIM * s_pad)
         k.head_transpose(qkv[:, 2 * C:], 3 * C, vt, g.N, self.heads, S, s_pad)
@@ -212,21 +258,28 @@ class BasicTransformerBlock(nn.Module):
         lse = rt.f32(g.N * self.heads * S)
         k.attn_fwd(qkv, qkv[:, C:], vt, o, lse, g.N, self.heads, S, 3 * C, C, s_pad, HEAD_DIM ** -0.5)
         del vt
-        cvec, _ = self.attn2.cross_vec(rt, ctx, g.B)
+        cvec, cv = self.attn2.cross_vec(rt, ctx, g.B)
         h2 = self.attn1.o.fwd(rt, o, M, res=h, rowvec=cvec, rv_ld=C, rv_rpg=g.T * g.HW)
+        xs_o = self.attn1.o_lora.fwd(rt, o, h2, M, C) if self.attn1.o_lora is not None else None
         n3, st3 = self.ln3.fwd(rt, h2, M)
         h3, pre, _ = self.ff.fwd(rt, n3, M, res=h2)
-        self.sv = (h, st1, qkv, o, lse, h2, st3, pre)
+        self.sv = (h, st1, qkv, o, lse, h2, st3, pre, n1, xs_qkv, xs_o, cv, ctx)
         return h3
 
-    def bwd(self, rt: Runtime, dh3, g: Geom):
+    def bwd(self, rt: Runtime, dh3, g: Geom, need_dx: bool = True):
         k, C, M, S = rt.k, self.dim, g.M, g.HW
-        h, st1, qkv, o, lse, h2, st3, pre = self.sv
+        h, st1, qkv, o, lse, h2, st3, pre, n1, xs_qkv, xs_o, cv, ctx = self.sv
         self.sv = None
         dn3 = self.ff.bwd(rt, dh3, None, pre, None, M)
         dh2 = self.ln3.bwd(rt, dn3, h2, st3, M, add=dh3)
         del dn3, pre, h2
+        if self.attn2.cross_trainable:               # adapters on the cross-attention's to_v / to_out (per-clip vectors)
+            dvec = rt.f32(g.B, C)
+            k.colsum(dh2, dvec, M, C, C, g.B, g.T * g.HW, 0)
+            self.attn2.cross_vec_bwd(rt, dvec, cv, ctx, g.B)
         d_o = self.attn1.o.bwd_dx(rt, dh2, M)
+        if self.attn1.o_lora is not None and self.attn1.o_lora.trainable:
+            self.attn1.o_lora.bwd(rt, dh2, C, o, xs_o, d_o, M)
         s_pad = rup(S, 64)
         nhs = g.N * self.heads * HEAD_DIM * s_pad
         D = rt.f32(g.N * self.heads * S)
@@ -242,8 +295,15 @@ class BasicTransformerBlock(nn.Module):
                        3 * C, C, 3 * C, s_pad, scale)
         k.attn_bwd_dq(q_, k_, v_, kt, d_o, lse, D, dqkv, g.N, self.heads, S, 3 * C, C, 3 * C, s_pad, scale)
         del qt, kt, dot, d_o
-        dn1 = self.attn1.qkv.bwd_dx(rt, dqkv, M)
+        lora_q = self.attn1.qkv_lora is not None and self.attn1.qkv_lora.trainable
+        if not need_dx and not lora_q:
+            return None
+        dn1 = self.attn1.qkv.bwd_dx(rt, dqkv, M) if need_dx else None
+        if lora_q:
+            self.attn1.qkv_lora.bwd(rt, dqkv, 3 * C, n1, xs_qkv, dn1, M)
         del dqkv
+        if not need_dx:
+            return None
         return self.ln1.bwd(rt, dn1, h, st1, M, add=dh2)
 
 
@@ -292,25 +352,29 @@ class TemporalBasicTransformerBlock(nn.Module):
         h, pre0, g0 = self.ff_in.fwd(rt, n0, M, res=x)
         n1, st1 = self.ln1.fwd(rt, h, M)
         qkv = self.attn1.qkv.fwd(rt, n1, M)
+        xs_qkv = self.attn1.qkv_lora.fwd(rt, n1, qkv, M, 3 * C) if self.attn1.qkv_lora is not None else None
         o = rt.empty(M, C)
         k.tattn_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], o, g.B, g.T, g.HW, self.heads, 3 * C, C, HEAD_DIM ** -0.5)
         cvec, cv = self.attn2.cross_vec(rt, tctx, g.B)
         h1 = self.attn1.o.fwd(rt, o, M, res=h, rowvec=cvec, rv_ld=C, **self._rv(g))
+        xs_o = self.attn1.o_lora.fwd(rt, o, h1, M, C) if self.attn1.o_lora is not None else None
         n3, st3 = self.ln3.fwd(rt, h1, M)
         out, pre, gg = self.ff.fwd(rt, n3, M, res=h1)
         if not self.trainable:
             n0 = g0 = n1 = n3 = gg = None
-        self.sv = (x, st0, n0, pre0, g0, h, st1, n1, qkv, o, cv, tctx, h1, st3, n3, pre, gg)
+        elif not self.ff.p1.trainable:               # adapters only (config 5): the feed-forwards are frozen
+            n0 = g0 = n3 = gg = None
+        self.sv = (x, st0, n0, pre0, g0, h, st1, n1, qkv, o, cv, tctx, h1, st3, n3, pre, gg, xs_qkv, xs_o)
         return out
 
     def bwd(self, rt: Runtime, dout, g: Geom, need_dx: bool = True, add: Optional[torch.Tensor] = None):
         k, C, M = rt.k, self.dim, g.M
-        x, st0, n0, pre0, g0, h, st1, n1, qkv, o, cv, tctx, h1, st3, n3, pre, gg = self.sv
+        x, st0, n0, pre0, g0, h, st1, n1, qkv, o, cv, tctx, h1, st3, n3, pre, gg, xs_qkv, xs_o = self.sv
         self.sv = None
         dn3 = self.ff.bwd(rt, dout, n3, pre, gg, M)
         dh1 = self.ln3.bwd(rt, dn3, h1, st3, M, add=dout)
         del dn3, pre, gg, n3, h1
-        if self.attn2.o.trainable or self.attn2.v.trainable:
+        if self.attn2.cross_trainable:
             rv = self._rv(g)
             dvec = rt.f32(g.B, C)
             k.colsum(dh1, dvec, M, C, C, g.B, rv["rv_rpg"], rv["rv_mod"])
@@ -318,6 +382,8 @@ class TemporalBasicTransformerBlock(nn.Module):
         d_o = self.attn1.o.bwd_dx(rt, dh1, M)
         if self.attn1.o.trainable:
             self.attn1.o.bwd_dw(rt, dh1, o, M)
+        if self.attn1.o_lora is not None and self.attn1.o_lora.trainable:
+            self.attn1.o_lora.bwd(rt, dh1, C, o, xs_o, d_o, M)
         dqkv = rt.empty(M, 3 * C)
         k.tattn_bwd(qkv, qkv[:, C:], qkv[:, 2 * C:], d_o, dqkv, dqkv[:, C:], dqkv[:, 2 * C:], g.B, g.T, g.HW,
                     self.heads, 3 * C, C, 3 * C, HEAD_DIM ** -0.5)
@@ -325,6 +391,8 @@ class TemporalBasicTransformerBlock(nn.Module):
         dn1 = self.attn1.qkv.bwd_dx(rt, dqkv, M)
         if self.attn1.qkv.trainable:
             self.attn1.qkv.bwd_dw(rt, dqkv, n1, M)
+        if self.attn1.qkv_lora is not None and self.attn1.qkv_lora.trainable:
+            self.attn1.qkv_lora.bwd(rt, dqkv, 3 * C, n1, xs_qkv, dn1, M)
         del dqkv, n1
         dh = self.ln1.bwd(rt, dn1, h, st1, M, add=dh1)
         del dn1, dh1, h
@@ -365,8 +433,8 @@ class TransformerSpatioTemporalModel(nn.Module):
         for b in list(self.transformer_blocks) + list(self.temporal_transformer_blocks):
             b.build()
         for n, p in self.named_parameters():
-            if p.requires_grad and "temporal_transformer_blocks" not in n:
-                raise NotImplementedError(f"{n}: only temporal_transformer_blocks.* may be trainable this round")
+            if p.requires_grad and "temporal_transformer_blocks" not in n and ".lora_" not in n:
+                raise NotImplementedError(f"{n}: only temporal_transformer_blocks.* or LoRA adapters may be trainable this round")
 
     def has_trainable(self):
         return any(p.requires_grad for p in self.parameters())
@@ -380,7 +448,7 @@ class TransformerSpatioTemporalModel(nn.Module):
             b.pack(rt)
 
     def refresh(self, rt):
-        for b in self.temporal_transformer_blocks:
+        for b in list(self.transformer_blocks) + list(self.temporal_transformer_blocks):
             if b.trainable:
                 b.refresh(rt)
 
@@ -421,16 +489,19 @@ class TransformerSpatioTemporalModel(nn.Module):
         for i in reversed(range(nl)):
             blk, tblk = self.transformer_blocks[i], self.temporal_transformer_blocks[i]
             last = (i == 0) and not self.need_dx
+            stop = last and not blk.trainable        # nothing trainable at or before the spatial block: the sweep ends here
             dh_s, dhm = rt.empty(M, C), rt.empty(M, C)
             k.blend_bwd(dh, self.time_mixer.mix_factor.data, dh_s, dhm, M * C)
             del dh
             # d(h + e) = dhm_in ; the spatial output h feeds both the blend and the temporal block
-            dh = tblk.bwd(rt, dhm, g, need_dx=not last, add=None if last else dh_s)
+            dh = tblk.bwd(rt, dhm, g, need_dx=not stop, add=None if stop else dh_s)
             del dhm, dh_s
-            if last:
+            if stop:
                 blk.sv = None
                 return None
-            dh = blk.bwd(rt, dh, g)
+            dh = blk.bwd(rt, dh, g, need_dx=not last)    # with adapters (config 5) the spatial block has gradients of its own
+            if last:
+                return None
         dxn = self.pin.bwd_dx(rt, dh, M)
         return self.gn.bwd(rt, dxn, x, st, g.N, g.HW, add=dout)
 
@@ -761,6 +832,16 @@ class UNetSpatioTemporalConditionModel(nn.Module):
             sd = {k: v.half() for k, v in sd.items()}
         save_file(sd, os.path.join(folder, WEIGHTS_NAME.format(variant=f".{variant}" if variant else "")))
 
+    def add_adapter(self, adapter_config, adapter_name: str = "default") -> int:
+        """train_svd_lora.py:671 (`unet.add_adapter(LoraConfig(...))`, diffusers -> peft): wrap every targeted attention
+        projection (lora.py) and freeze its base layer; the adapters are the new trainables.  Call before `prepare()` /
+        `Trainer(...)`.  Returns the number of wrapped layers (256 for the SVD UNet with the reference's target list)."""
+        if adapter_name != "default":
+            raise NotImplementedError("a single adapter named 'default' is supported")
+        if self.rt is not None:
+            raise RuntimeError("add_adapter must be called before prepare()")
+        return inject(self, adapter_config)
+
     def enable_gradient_checkpointing(self):      # train_svd.py:732 -- 288 GB HBM: not needed, accepted as no-op
         self.gradient_checkpointing = False
 
@@ -820,8 +901,8 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         self._skip_needs_grad = skip_flags
         self._any_trainable = seen
         for p_name, p in self.named_parameters():
-            if p.requires_grad and "temporal_transformer_blocks" not in p_name:
-                raise NotImplementedError(f"{p_name}: only temporal_transformer_blocks.* may be trainable this round")
+            if p.requires_grad and "temporal_transformer_blocks" not in p_name and ".lora_" not in p_name:
+                raise NotImplementedError(f"{p_name}: only temporal_transformer_blocks.* or LoRA adapters may be trainable this round")
 
         self.time_embedding.build()
         self.add_embedding.build()

@@ -16,11 +16,21 @@ def cosine(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-def oracle_step(cfg, B, T, h, w, seed, lr, cross_dim):
+def oracle_step(cfg, B, T, h, w, seed, lr, cross_dim, lora_r=0):
     orc = UNetSpatioTemporalConditionOracle(**cfg)
     scaled_init_(orc, seed)
+    if lora_r:                                   # config 5: adapters are the trainable set (B randomised so dA is non-zero)
+        from oracle.lora import add_adapter
+        for p in orc.parameters():
+            p.requires_grad_(False)
+        add_adapter(orc, lora_r, lora_r)
+        gen = torch.Generator().manual_seed(seed + 17)
+        for n, p in orc.named_parameters():
+            if ".lora_B." in n:
+                p.data.copy_(torch.randn(p.shape, generator=gen) * 0.05)
     batch = make_synthetic_batch(B, T, h, w, seed + 1, cross_dim=cross_dim)
-    opt = make_optimizer(orc, lr=lr)
+    opt = make_optimizer(orc, lr=lr) if not lora_r else torch.optim.AdamW([p for p in orc.parameters() if p.requires_grad], lr=lr,
+                                                                          betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
     sd0 = copy.deepcopy(orc.state_dict())
     unet_in, ts, ehs, ids, noisy, sig = edm_inputs(batch)
     pred = orc(unet_in, ts, ehs, added_time_ids=ids).sample
@@ -32,8 +42,11 @@ def oracle_step(cfg, B, T, h, w, seed, lr, cross_dim):
                 grads=grads, params_after={n: p.detach().clone() for n, p in orc.named_parameters() if p.requires_grad})
 
 
-def product_step(ref, cfg, dtype, dev, lr):
+def product_step(ref, cfg, dtype, dev, lr, lora_r=0):
     m = UNetSpatioTemporalConditionModel(**cfg)
+    if lora_r:
+        from svd_xtend_amd.lora import LoraConfig
+        m.add_adapter(LoraConfig(r=lora_r, lora_alpha=lora_r, init_lora_weights="gaussian"))
     m.load_state_dict(ref["sd0"], strict=True)
     m.to(dev)
     tr = Trainer(m, dtype=dtype, lr=lr)
@@ -53,7 +66,7 @@ def product_step(ref, cfg, dtype, dev, lr):
 
 def compare(ref, got):
     out = dict(loss_ref=ref["loss"], loss=got["loss"], loss_rel=abs(got["loss"] - ref["loss"]) / abs(ref["loss"]))
-    cos = {n: cosine(got["grads"][n], g) for n, g in ref["grads"].items() if n in got["grads"] and float(g.abs().max()) > 0}
+    cos = {n: cosine(got["grads"][n], g) for n, g in ref["grads"].items() if n in got["grads"] and float(g.abs().max()) > 1e-12}
     out["grad_cos_min"] = min(cos.values())
     out["grad_cos_worst"] = min(cos, key=cos.get)
     gn_ref = sum(float(g.double().pow(2).sum()) for g in ref["grads"].values()) ** 0.5
@@ -116,3 +129,23 @@ def graphed_vs_eager(dev=None, dtype=torch.float16, steps=3):
     return dict(loss_eager=e["loss"], loss_graph=g["loss"], param_max_diff=float((e["p"] - g["p"]).abs().max()),
                 param_mean_diff=float((e["p"] - g["p"]).abs().mean()),
                 param_abs_max=float(e["p"].abs().max()), opt_steps=(e["state"][0], g["state"][0]), segments=g["segments"])
+
+
+def run_lora(verbose=False, dev=None, ranks=(64, 8)):
+    """Config 5 on the tiny topology: LoRA adapters (train_svd_lora.py:659-674) through libsvdx vs the oracle's peft restatement."""
+    dev = dev or torch.device("cuda")
+    cfg = TINY_CONFIG
+    res = {}
+    for r in ranks:
+        ref = oracle_step(cfg, 1, 3, 16, 16, seed=4, lr=1e-4, cross_dim=cfg["cross_attention_dim"], lora_r=r)
+        for dt in (torch.bfloat16, torch.float16):
+            key = f"lora r={r} {str(dt).split('.')[-1]}"
+            try:
+                res[key] = compare(ref, product_step(ref, cfg, dt, dev, 1e-4, lora_r=r))
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                res[key] = {"error": repr(e)[:400]}
+            if verbose:
+                print(key, res[key], flush=True)
+    return res

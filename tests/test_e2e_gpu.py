@@ -30,3 +30,15 @@ def test_graphed_step_follows_eager_trajectory():
     # bound the worst case by that, and require the typical weight to agree far below one update
     assert r["param_max_diff"] <= 2 * 1e-3 * 3 + 1e-4, r
     assert r["param_mean_diff"] <= 1e-4, r
+
+
+@gpu
+def test_lora_train_step_matches_oracle_tiny():
+    """Reference config 5 (bf16 LoRA, r = 64; r = 8 exercises the zero-padded rank)."""
+    import e2e_checks
+    res = e2e_checks.run_lora(verbose=True)
+    for key, r in res.items():
+        assert "error" not in r, f"{key}: {r}"
+        tol = 1e-3 if "float16" in key else 8e-3
+        assert r["loss_rel"] <= tol, f"{key}: loss rel err {r['loss_rel']:.3e}"
+        assert r["grad_cos_min"] >= (0.99 if "float16" in key else 0.95), f"{key}: {r}"
