@@ -23,6 +23,7 @@ def oracle_step(cfg, B, T, h, w, seed, lr, cross_dim, lora_r=0):
         from oracle.lora import add_adapter
         for p in orc.parameters():
             p.requires_grad_(False)
+        torch.manual_seed(seed + 5)              # peft's "gaussian" init of A draws from the global generator
         add_adapter(orc, lora_r, lora_r)
         gen = torch.Generator().manual_seed(seed + 17)
         for n, p in orc.named_parameters():

@@ -14,6 +14,14 @@ def test_train_step_matches_oracle_tiny():
         tol = 1e-3 if "float16" in key else 8e-3     # north_star tolerance is stated for fp16; bf16 has 8x less mantissa
         assert r["loss_rel"] <= tol, f"{key}: loss rel err {r['loss_rel']:.3e}"
         assert r["grad_cos_min"] >= (0.99 if "float16" in key else 0.95), f"{key}: {r}"
+    # second anchor: the committed fixture of the same seeded step (tests/golden/make_golden.py), read without the oracle
+    import os
+
+    from safetensors.torch import load_file
+    gold = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_step.safetensors"))
+    g_loss = float(gold["full.loss"])
+    r = res["tiny B=1 T=4 16x16 float16"]
+    assert abs(r["loss"] - g_loss) <= 1e-3 * g_loss, (r["loss"], g_loss)
 
 
 @gpu

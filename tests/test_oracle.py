@@ -78,3 +78,25 @@ def test_rand_log_normal_matches_reference_formula():
     g = torch.Generator().manual_seed(5)
     s = rand_log_normal([1000], loc=0.7, scale=1.6, generator=g)
     assert (s > 0).all() and abs(float(s.log().mean()) - 0.7) < 0.2
+
+
+def test_oracle_reproduces_committed_golden_step():
+    """tests/golden/tiny_step.safetensors (made by tests/golden/make_golden.py) freezes one seeded oracle train step, full-parameter
+    and LoRA: the restatement must keep reproducing it (same torch CPU kernels -> tight tolerance)."""
+    import os
+    import sys
+
+    from safetensors.torch import load_file
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import e2e_checks
+    from oracle.unet import TINY_CONFIG
+    gold = load_file(os.path.join(here, "golden", "tiny_step.safetensors"))
+    for tag, r in (("full", 0), ("lora8", 8)):
+        ref = e2e_checks.oracle_step(TINY_CONFIG, 1, 4, 16, 16, seed=3, lr=1e-4, cross_dim=TINY_CONFIG["cross_attention_dim"], lora_r=r)
+        assert abs(ref["loss"] - float(gold[f"{tag}.loss"])) <= 1e-5 * abs(ref["loss"]), tag
+        assert torch.allclose(ref["pred"], gold[f"{tag}.pred"], atol=1e-4, rtol=1e-4), tag
+        names = open(os.path.join(here, "golden", f"tiny_step_{tag}_grad_names.txt")).read().split()
+        assert names == sorted(ref["grads"]), tag
+        norms = torch.tensor([float(ref["grads"][n].double().norm()) for n in names], dtype=torch.float64)
+        assert torch.allclose(norms, gold[f"{tag}.grad_norms"], rtol=1e-3, atol=1e-9), tag
