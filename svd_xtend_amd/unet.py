@@ -874,9 +874,26 @@ class UNetSpatioTemporalConditionModel(nn.Module):
                 steps.append(("up", blk.upsamplers[0]))
         return steps
 
-    def prepare(self, dtype: torch.dtype = torch.float16) -> "UNetSpatioTemporalConditionModel":
+    def to(self, *args, **kwargs):
+        """`unet.to(device, dtype=weight_dtype)` (train_svd_lora.py:669, train_svd.py:739): the float masters stay fp32 (the
+        kernels run on their packed 16-bit copies); a half / bfloat16 request only selects the activation dtype."""
+        device, dtype, non_blocking, _ = torch._C._nn._parse_to(*args, **kwargs)
+        if dtype is not None and dtype.is_floating_point and dtype != torch.float32:
+            self._requested_dtype = dtype
+            return super().to(device=device, non_blocking=non_blocking) if device is not None else self
+        return super().to(*args, **kwargs)
+
+    def half(self):
+        return self.to(dtype=torch.float16)
+
+    def bfloat16(self):
+        return self.to(dtype=torch.bfloat16)
+
+    def prepare(self, dtype: Optional[torch.dtype] = None) -> "UNetSpatioTemporalConditionModel":
         """Build operator objects and pack weights into kernel layouts.  Call after weights are loaded, after
-        `requires_grad` flags are final and (for training) after the Trainer has installed flat grads."""
+        `requires_grad` flags are final and (for training) after the Trainer has installed flat grads.  dtype: activation
+        dtype (default: what `.to(dtype=...)` / `from_pretrained(torch_dtype=...)` asked for, else float16)."""
+        dtype = dtype or getattr(self, "_requested_dtype", None) or torch.float16
         dev = next(self.parameters()).device
         if any(p.requires_grad and p.grad is None for p in self.parameters()):
             # stand-alone use (host script keeps its own optimizer): give the trainables flat, adjacent storage

@@ -209,3 +209,16 @@ def test_lora_fp32_train_step_matches_oracle(emu_backend, r):
     tr.zero_grad()
     tr.forward_backward(unet_in, ts, ehs, ids, noisy, batch["latents"], batch["sigmas"])
     assert float(tr.last_loss()) < float(loss)          # one lr = 1e-3 step on the same batch lowers the loss
+
+
+def test_to_dtype_keeps_float_masters(emu_backend):
+    """`unet.to(device, dtype=torch.float16)` as the reference scripts do must not destroy the fp32 masters."""
+    _, m = build_pair(4)
+    m2 = m.to(torch.device("cpu"), dtype=torch.bfloat16)
+    assert m2 is m and all(p.dtype == torch.float32 for p in m.parameters()) and m._requested_dtype == torch.bfloat16
+    assert m.half()._requested_dtype == torch.float16
+    m.to(dtype=torch.float32)
+    select_trainable(m)
+    m._requested_dtype = torch.float32         # the CPU emulator stores activations in the requested dtype
+    m.prepare()
+    assert m.rt.dt == torch.float32
