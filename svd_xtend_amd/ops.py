@@ -222,20 +222,6 @@ def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowve
                lambda: (choose_split(rt, M, N, Kd, ldc), rt.gemm_variant), run)
 
 
-def _choose_split_k(M: int, N: int, Kdim: int) -> int:
-    """Split the reduction when the output grid cannot fill 256 CUs (weight-grad GEMMs: tiny [N,K] outputs,
-    reduction over all rows)."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 256 or Kdim < 1024:
-        return 1
-    want = max(1, 512 // tiles)
-    ksteps = Kdim // 64
-    split = max(1, min(want, ksteps // 4, 32))
-    while split > 1 and (ksteps + split - 1) // split * (split - 1) >= ksteps:
-        split -= 1
-    return split
-
-
 # --------------------------------------------------------------------------------------------------
 # Linear
 # --------------------------------------------------------------------------------------------------
@@ -365,14 +351,6 @@ def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tenso
         return sk
 
     tuned_call(rt, ("tn", M, N, Kd, lda, ldb), cands, formula, run)
-
-
-def transpose_pad(rt: Runtime, x: torch.Tensor, M: int, C: int) -> torch.Tensor:
-    """[M, C] -> [C, rup(M,64)] zero-padded (operand of the weight-grad GEMM)."""
-    Mp = rup(M, 64)
-    xt = rt.empty(C, Mp)
-    rt.k.transpose(x, C, xt, Mp, M, C)
-    return xt
 
 
 _ONES = {}

@@ -1148,8 +1148,3 @@ class UNetSpatioTemporalConditionModel(nn.Module):
             cur = level_geoms[lvl]
         # the conv_in skip (index 0) and conv_in itself carry no trainable parameters upstream
         return None
-
-    # ---- convenience for tests / weight exchange ------------------------------------------------------
-    @property
-    def add_embedding_linear_1_in_features(self):
-        return self.add_embedding.linear_1.in_features
