@@ -117,11 +117,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # developer knobs (single-GPU rehearsal of the multi-rank path: all ranks on one device over gloo; RCCL refuses that)
+    backend = os.environ.get("SVDX_DIST_BACKEND", "nccl")
+    if os.environ.get("SVDX_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["SVDX_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from svd_xtend_amd.train import GraphedStep, Trainer
