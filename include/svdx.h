@@ -187,6 +187,15 @@ int svdx_optim_prep(float* opt_state, float beta1, float beta2, float growth, fl
 int svdx_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                float eps, float wd, float grad_mul, const float* opt_state, void* p_act, int dtype, void* stream);
 
+/* Same update over a table of tiles (6 ints each: element offset, row pitch, rows <= 64, cols <= 64 -- multiples of 4 --,
+ * transposed-twin offset or -1, transposed-twin row pitch): every tile updates p/m/v, writes the row-major 16-bit twin
+ * p_act[off + r*ld + c] and, when its transposed-twin offset is >= 0, pt_act[wt_off + c*ldwt + r] (the [K,N] operand of the
+ * data-grad GEMM of a trainable nn.Linear), so no separate transposition pass is needed after the optimizer step.
+ * All offsets must be multiples of 4 elements; tiles must not overlap. */
+int svdx_adamw_tiled(float* p, const float* g, float* m, float* v, const int* tiles, int n_tiles, float lr, float beta1,
+                     float beta2, float eps, float wd, float grad_mul, const float* opt_state, void* p_act, void* pt_act,
+                     int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,65 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// AdamW over a table of <= 64 x 64 tiles of the flat buffers: tile {off, ld, rows, cols, wt_off, ldwt} covers elements
+// off + r*ld + c.  Besides the float update and the row-major 16-bit twin (p_act), a tile with wt_off >= 0 also writes the
+// TRANSPOSED 16-bit twin pt_act[wt_off + c*ldwt + r] through LDS -- the [K, N] operand of the data-grad GEMMs -- so the
+// per-step re-transposition of all trainable weights (a separate read + write of every weight) disappears.
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_tiled_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, const int* __restrict__ tiles, float lr, float beta1,
+                                                          float beta2, float eps, float wd, float grad_mul,
+                                                          const float* __restrict__ st, T* __restrict__ p_act, T* __restrict__ pt_act) {
+    if (st[7] > 0.f) return;     // inf/nan in the gradients: skip the step (GradScaler semantics)
+    __shared__ T tile[64][68];
+    const int* tl = tiles + (size_t)blockIdx.x * 6;
+    const int off = tl[0], ld = tl[1], rows = tl[2], cols = tl[3], wt_off = tl[4], ldwt = tl[5];
+    const float gmul = st[4] * grad_mul;
+    const float step_size = lr / st[5];
+    const float inv_bc2_sqrt = rsqrtf(st[6]);
+    const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 16 * i;
+        if (r < rows && c4 < cols) {
+            const long idx = (long)off + (long)r * ld + c4;
+            f32x4 pv = *reinterpret_cast<const f32x4*>(p + idx);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + idx);
+            f32x4 mv = *reinterpret_cast<const f32x4*>(m + idx);
+            f32x4 vv = *reinterpret_cast<const f32x4*>(v + idx);
+            Vec4<T> o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gg = gv[e] * gmul;
+                pv[e] *= (1.f - lr * wd);
+                mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
+                vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
+                const float denom = sqrtf(vv[e]) * inv_bc2_sqrt + eps;
+                pv[e] -= step_size * mv[e] / denom;
+                o.v[e] = from_f<T>(pv[e]);
+            }
+            *reinterpret_cast<f32x4*>(p + idx) = pv;
+            *reinterpret_cast<f32x4*>(m + idx) = mv;
+            *reinterpret_cast<f32x4*>(v + idx) = vv;
+            if (p_act) *reinterpret_cast<Vec4<T>*>(p_act + idx) = o;
+            if (wt_off >= 0) *reinterpret_cast<Vec4<T>*>(&tile[r][c4]) = o;
+        }
+    }
+    if (wt_off < 0) return;      // block-uniform
+    __syncthreads();
+    // transposed store: thread -> wt row (= tile column) cc, 4 consecutive wt columns (= tile rows) r4..r4+3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = r0 + 16 * i, r4 = c4;
+        if (cc < cols && r4 < rows) {
+            Vec4<T> o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.v[e] = tile[r4 + e][cc];
+            *reinterpret_cast<Vec4<T>*>(pt_act + (long)wt_off + (long)cc * ldwt + r4) = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int svdx_edm_loss(const void* pred, int ld, const float* noisy, const float* target, const float* sigma,
@@ -148,5 +207,15 @@ extern "C" int svdx_adamw(float* p, const float* g, float* m, float* v, int64_t 
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((adamw_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                                              (long)n, lr, beta1, beta2, eps, wd, grad_mul, opt_state, (T*)p_act));
     SVDX_LAUNCH_CHECK("svdx_adamw");
+    return 0;
+}
+
+extern "C" int svdx_adamw_tiled(float* p, const float* g, float* m, float* v, const int* tiles, int n_tiles, float lr, float beta1,
+                                float beta2, float eps, float wd, float grad_mul, const float* opt_state, void* p_act, void* pt_act,
+                                int dtype, void* stream) {
+    SVDX_CHECK_ARG(p && g && m && v && tiles && opt_state && n_tiles > 0, "svdx_adamw_tiled: bad args");
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((adamw_tiled_kernel<T>), dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, p, g, m, v, tiles,
+                                             lr, beta1, beta2, eps, wd, grad_mul, opt_state, (T*)p_act, (T*)pt_act));
+    SVDX_LAUNCH_CHECK("svdx_adamw_tiled");
     return 0;
 }

@@ -98,6 +98,7 @@ _SIGS = {
     "svdx_check_finite": "plpp",
     "svdx_optim_prep": "p" "ffff" "ii" "p",
     "svdx_adamw": "pppp" "l" "ffffff" "pp" "ip",
+    "svdx_adamw_tiled": "ppppp" "i" "ffffff" "ppp" "ip",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "l": ctypes.c_int64, "z": ctypes.c_size_t}
 
@@ -314,6 +315,12 @@ class HipBackend:
         self._call("svdx_adamw", _f32(p), _f32(g), _f32(m), _f32(v), n, float(lr), float(beta1), float(beta2),
                    float(eps), float(wd), float(grad_mul), _f32(opt_state), _p(p_act),
                    _dt(p_act) if p_act is not None else F16, self._stream())
+
+    def adamw_tiled(self, p, g, m, v, tiles, n_tiles, lr, beta1, beta2, eps, wd, grad_mul, opt_state, p_act, pt_act):
+        assert tiles.dtype == torch.int32 and tiles.is_contiguous() and tiles.numel() >= 6 * n_tiles
+        self._call("svdx_adamw_tiled", _f32(p), _f32(g), _f32(m), _f32(v), tiles.data_ptr(), n_tiles, float(lr), float(beta1),
+                   float(beta2), float(eps), float(wd), float(grad_mul), _f32(opt_state), _p(p_act), _p(pt_act),
+                   _dt(p_act), self._stream())
 
 
 _backend = None

@@ -54,6 +54,12 @@ class Runtime:
         self.split_k = True
         self.fuse_geglu = True
         self.tuner = None           # GemmTuner (Trainer.tune_gemms): measured tile / split-K per GEMM problem
+        # transposed 16-bit twins ([K,N], operand of the data-grad GEMM) of the trainable nn.Linear weights live in one arena so
+        # that the tiled AdamW kernel can write them (wt_map: id(weight) -> (element offset of W^T[0, n0], row pitch))
+        self.wt16_flat = None
+        self.wt_pos = 0
+        self.wt_map = {}
+        self.adam_writes_wt = False  # set by the Trainer: LinearOp.refresh then has nothing to re-transpose
         self.arenas = [None, None]
         self.arena_cap = 1 << 20    # floats
         self.arena_cur, self.arena_pos = None, 0
@@ -254,8 +260,20 @@ class LinearOp:
         else:
             self.w = rt.empty(self.N, self.Kdim)
             k.cast_from_f32(master, self.w, self.N * self.Kdim)
+        self.wt_managed = False
         if need_dx:
-            self.wt = rt.empty(self.Kdim, self.N)
+            n_el = self.Kdim * self.N
+            if twin is not None and rt.wt16_flat is not None and rt.wt_pos + n_el <= rt.wt16_flat.numel():
+                off = rt.wt_pos
+                rt.wt_pos += rup(n_el, 64)
+                self.wt = rt.wt16_flat[off:off + n_el].view(self.Kdim, self.N)
+                n0 = 0
+                for w in self.weights:               # fused q/k/v: each weight owns a column block of the [K, 3C] twin
+                    rt.wt_map[id(w)] = (off + n0, self.N)
+                    n0 += w.shape[0]
+                self.wt_managed = True
+            else:
+                self.wt = rt.empty(self.Kdim, self.N)
             k.cast_transpose_from_f32(master, self.wt, self.N, self.Kdim)
         if self.biases is not None and self.biases[0] is not None:
             b = self._flat_view([b.data for b in self.biases])
@@ -291,7 +309,7 @@ class LinearOp:
         master = self._flat_view([w.data for w in self.weights])
         if not getattr(self, "w_is_view", False):
             rt.k.cast_from_f32(master, self.w, self.N * self.Kdim)
-        if self.wt is not None:
+        if self.wt is not None and not (rt.adam_writes_wt and getattr(self, "wt_managed", False)):
             if getattr(self, "w_is_view", False):       # the 16-bit twin is current: 2+2 bytes per weight instead of 4+2
                 rt.k.transpose(self.w, self.Kdim, self.wt, self.N, self.N, self.Kdim)
             else:

@@ -8,6 +8,7 @@ Everything on the timed path is libsvdx kernels; torch supplies memory, streams 
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -29,6 +30,39 @@ def select_trainable(model: torch.nn.Module, substr: str = "temporal_transformer
         if p.requires_grad:
             names.append(name)
     return names
+
+
+def build_adam_tiles(params, offsets, wt_map, device) -> torch.Tensor:
+    """Tile table of svdx_adamw_tiled: every trainable parameter is cut into <= 64 x 64 tiles of its [rows, cols] view
+    (matrices as they are, everything else as one row); weights with a transposed 16-bit twin (wt_map: id -> (offset, pitch))
+    carry its location so the optimizer kernel writes it.  int32 [n_tiles, 6] = off, ld, rows, cols, wt_off, ldwt."""
+    rows_out = []
+    for p, off in zip(params, offsets):
+        if p.ndim == 2:
+            R, C = p.shape
+        else:
+            R, C = 1, p.numel()
+        assert C % 4 == 0 and off % 4 == 0, "parameters must be multiples of 4 elements (16-byte vector access)"
+        wt = wt_map.get(id(p))
+        r0 = torch.arange(0, R, 64)
+        c0 = torch.arange(0, C, 64)
+        rr, cc = torch.meshgrid(r0, c0, indexing="ij")
+        rr, cc = rr.reshape(-1), cc.reshape(-1)
+        t = torch.empty(rr.numel(), 6, dtype=torch.int64)
+        t[:, 0] = off + rr * C + cc
+        t[:, 1] = C
+        t[:, 2] = torch.clamp(R - rr, max=64)
+        t[:, 3] = torch.clamp(C - cc, max=64)
+        if wt is None:
+            t[:, 4], t[:, 5] = -1, 0
+        else:
+            assert R % 4 == 0 and wt[0] % 4 == 0 and wt[1] % 4 == 0
+            t[:, 4] = wt[0] + cc * wt[1] + rr
+            t[:, 5] = wt[1]
+        rows_out.append(t)
+    tiles = torch.cat(rows_out, 0)
+    assert int(tiles.max()) < 2 ** 31
+    return tiles.to(torch.int32).contiguous().to(device)
 
 
 class Trainer:
@@ -62,6 +96,10 @@ class Trainer:
         model.prepare(dtype)
         self.rt = model.rt
         self.micro = 0
+        # AdamW walks a tile table so that it can also emit the transposed 16-bit twins the data-grad GEMMs read
+        tiled = bool(self.params) and os.environ.get("SVDX_ADAM_TILED", "1") != "0"      # developer knob for A/B runs
+        self.adam_tiles = build_adam_tiles(self.params, self.offsets, self.rt.wt_map, dev) if tiled else None
+        self.rt.adam_writes_wt = self.adam_tiles is not None
         # gradient buckets for overlapping the all-reduce with the backward sweep: one contiguous slice of g_flat per transformer
         # block (its trainables are adjacent in named_parameters order), reduced as soon as backward_rows leaves the block
         self.overlap = True
@@ -175,8 +213,13 @@ class Trainer:
         k.check_finite(self.g_flat, n, self.opt_state)
         k.optim_prep(self.opt_state, self.betas[0], self.betas[1], 2.0, 0.5, self.growth_interval, int(self.dynamic))
         grad_mul = 1.0 / (self.world * self.grad_accum)
-        k.adamw(self.p_flat, self.g_flat, self.m_flat, self.v_flat, n, self.lr, self.betas[0], self.betas[1],
-                self.eps, self.wd, grad_mul, self.opt_state, self.rt.w16_flat)
+        if self.adam_tiles is not None:
+            k.adamw_tiled(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.adam_tiles, self.adam_tiles.shape[0], self.lr,
+                          self.betas[0], self.betas[1], self.eps, self.wd, grad_mul, self.opt_state, self.rt.w16_flat,
+                          self.rt.wt16_flat)
+        else:
+            k.adamw(self.p_flat, self.g_flat, self.m_flat, self.v_flat, n, self.lr, self.betas[0], self.betas[1],
+                    self.eps, self.wd, grad_mul, self.opt_state, self.rt.w16_flat)
         self.model.refresh_trainable(masters_changed_on_host=False)
         self.micro = 0
 

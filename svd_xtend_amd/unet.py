@@ -903,6 +903,7 @@ class UNetSpatioTemporalConditionModel(nn.Module):
             rt.p_flat = self._flat[3]
             rt.w16_flat = torch.empty(rt.p_flat.numel(), dtype=dtype, device=dev)
             rt.k.cast_from_f32(rt.p_flat, rt.w16_flat, rt.p_flat.numel())
+            rt.wt16_flat = torch.empty(rt.p_flat.numel(), dtype=dtype, device=dev)     # transposed twins (ops.LinearOp.pack)
         self.steps = self._steps()
         self.grads_ready_cb = None       # callable(module) invoked by backward_rows after each transformer block (gradient overlap)
         # which modules need an input gradient: only those executed after the first trainable parameter

@@ -462,6 +462,24 @@ class EmuBackend:
         st.copy_(torch.tensor([step, scale, tracker, 0.0, inv, 1 - beta1 ** step, 1 - beta2 ** step,
                                1.0 if found else 0.0], dtype=torch.float32))
 
+    def adamw_tiled(self, p, g, m, v, tiles, n_tiles, lr, beta1, beta2, eps, wd, grad_mul, st, p_act, pt_act):
+        if float(st[7]) > 0:
+            return
+        gm, ss, bc2 = float(st[4]) * grad_mul, lr / float(st[5]), math.sqrt(float(st[6]))
+        for off, ld, rows, cols, wt_off, ldwt in tiles[:n_tiles].view(-1, 6).tolist():
+            def T2(t):
+                return torch.as_strided(t, (rows, cols), (ld, 1), t.storage_offset() + off)
+            P, G, Mm, Vv = T2(p), T2(g), T2(m), T2(v)
+            gg = G * gm
+            P.mul_(1 - lr * wd)
+            Mm.mul_(beta1).add_(gg, alpha=1 - beta1)
+            Vv.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+            P.addcdiv_(Mm, Vv.sqrt() / bc2 + eps, value=-ss)
+            if p_act is not None:
+                T2(p_act).copy_(P.to(p_act.dtype))
+            if wt_off >= 0:
+                torch.as_strided(pt_act, (cols, rows), (ldwt, 1), pt_act.storage_offset() + wt_off).copy_(P.t().to(pt_act.dtype))
+
     def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, grad_mul, st, p_act):
         if float(st[7]) > 0:
             return

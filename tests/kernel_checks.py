@@ -422,6 +422,31 @@ def check_optim(P, dt):
         for nm in ("p", "m", "v"):
             res.append((f"adamw found_inf={found} {nm}", relerr(o1[nm], o2[nm]), 1e-5))
         res.append((f"adamw found_inf={found} p_act", relerr(o1["pa"], o2["pa"]), tol_for(dt)))
+    # tiled AdamW with transposed twins: two matrices fused into one [K, N1+N2] twin, a plain matrix, a bias
+    from svd_xtend_amd.train import build_adam_tiles
+    shapes = [(128, 192), (68, 192), (100, 64), (320,)]
+    ps = [torch.nn.Parameter(rndf(sh, P.dev, g)) for sh in shapes]
+    offs, off = [], 0
+    for q in ps:
+        offs.append(off)
+        off = (off + q.numel() + 63) // 64 * 64
+    n = off
+    wt_map = {id(ps[0]): (64, 196), id(ps[1]): (64 + 128, 196)}       # twin [192, 196] at offset 64
+    tiles = build_adam_tiles(ps, offs, wt_map, P.dev)
+    p0 = torch.zeros(n, device=P.dev)
+    for q, o in zip(ps, offs):
+        p0[o:o + q.numel()] = q.data.reshape(-1)
+    gr, m, v = rndf((n,), P.dev, g, 10.0), rndf((n,), P.dev, g, 0.1), rndf((n,), P.dev, g).abs()
+    st = torch.tensor([3, 64.0, 5, 0, 1 / 64.0, 0.271, 0.003, 0], dtype=torch.float32, device=P.dev)
+    outs = dict(p=p0, m=m, v=v, pa=torch.zeros(n, dtype=dt, device=P.dev), pt=torch.zeros(64 + 192 * 196, dtype=dt, device=P.dev))
+    o1, o2 = P.run("adamw_tiled", lambda o: ((o["p"], gr, o["m"], o["v"], tiles, tiles.shape[0], 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0.5, st,
+                                              o["pa"], o["pt"]), {}), outs)
+    for nm in ("p", "m", "v"):
+        res.append((f"adamw_tiled {nm}", relerr(o1[nm], o2[nm]), 1e-5))
+    res.append(("adamw_tiled p_act", relerr(o1["pa"], o2["pa"]), tol_for(dt)))
+    res.append(("adamw_tiled transposed twin", relerr(o1["pt"], o2["pt"]), tol_for(dt)))
+    wt = o1["pt"][64:].view(192, 196)
+    res.append(("adamw_tiled twin == W^T", relerr(wt[:, :128].float(), o1["pa"][offs[0]:offs[0] + 128 * 192].view(128, 192).t().float()), 0.0))
     return res
 
 
