@@ -564,8 +564,10 @@ class ConvOp:
         if weight.requires_grad:
             raise NotImplementedError("conv weight-grad is outside this round's trainable set")
 
-    def pack(self, rt: Runtime, need_dx: bool = True) -> None:
-        W = self.weight.data
+    def pack(self, rt: Runtime, need_dx: bool = True, out_scale: float = 1.0) -> None:
+        """out_scale: constant folded into the packed weights, data-grad weights and bias (a frozen AlphaBlender after the conv:
+        unet.SpatioTemporalResBlock)."""
+        W = self.weight.data * out_scale if out_scale != 1.0 else self.weight.data
         co, ci, tp = self.cout, self.cin, self.taps
         w4 = W.reshape(co, ci, tp)                                   # taps flattened dy*3+dx / dt
         wp = torch.zeros(co, tp, self.cin_p, dtype=torch.float32, device=W.device)
@@ -579,7 +581,7 @@ class ConvOp:
             wd[:, :, :co] = src.permute(1, 2, 0)
             self.wd = rt.empty(ci, tp * self.cout_p)
             rt.k.cast_from_f32(wd.reshape(-1), self.wd, wd.numel())
-        self.b = None if self.bias is None else self.bias.data
+        self.b = None if self.bias is None else (self.bias.data * out_scale if out_scale != 1.0 else self.bias.data)
 
     def _gather(self, n_img, hi, wi, ho, wo, cin, lda, T=0, hw=0, dgrad=False) -> Optional[K.Gather]:
         if self.kind == "1x1":

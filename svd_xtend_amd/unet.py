@@ -540,9 +540,9 @@ class _ResnetHalf(nn.Module):
         if self.time_emb_proj.weight.requires_grad:
             raise NotImplementedError("time_emb_proj is frozen on this path")
 
-    def pack(self, rt, need_dx):
+    def pack(self, rt, need_dx, out_scale: float = 1.0):
         self.c1.pack(rt, need_dx)
-        self.c2.pack(rt, need_dx)
+        self.c2.pack(rt, need_dx, out_scale=out_scale)
         if self.sc is not None:
             self.sc.pack(rt, need_dx)
 
@@ -604,26 +604,24 @@ class SpatioTemporalResBlock(nn.Module):
         return False
 
     def pack(self, rt):
+        # AlphaBlender folded away.  The temporal half has an identity shortcut, t = s + H(s) with H ending in conv2, so
+        #   out = a*s + (1-a)*t = s + (1-a)*H(s),   a = sigmoid(mix_factor)   (frozen: train_svd.py:761-766)
+        # i.e. the temporal half itself with conv2's weights and bias scaled by (1-a): no blend pass forward, and backward
+        # d s = dout + H'^T((1-a) dout) is the temporal half's own backward on dout (scaled data-grad weights).
+        assert self.temporal_res_block.conv_shortcut is None
+        one_minus_a = 1.0 - float(torch.sigmoid(self.time_mixer.mix_factor.data.float()))
         self.spatial_res_block.pack(rt, self.need_dx)
-        self.temporal_res_block.pack(rt, self.need_dx)
+        self.temporal_res_block.pack(rt, self.need_dx, out_scale=one_minus_a)
 
     def fwd(self, rt: Runtime, x, g: Geom, temb_all):
         s = self.spatial_res_block.fwd(rt, x, g, temb_all)
-        t = self.temporal_res_block.fwd(rt, s, g, temb_all)
-        out = rt.empty(g.M, self.cout)
-        rt.k.blend(s, t, self.time_mixer.mix_factor.data, out, g.M * self.cout)
-        return out
+        return self.temporal_res_block.fwd(rt, s, g, temb_all)
 
     def bwd(self, rt: Runtime, dout, g: Geom):
         if not self.need_dx:
             self.spatial_res_block.sv = self.temporal_res_block.sv = None
             return None
-        k = rt.k
-        ds, dt_ = rt.empty(g.M, self.cout), rt.empty(g.M, self.cout)
-        k.blend_bwd(dout, self.time_mixer.mix_factor.data, ds, dt_, g.M * self.cout)
-        # s receives alpha*dout from the blend and the temporal block's input gradient
-        ds_total = self.temporal_res_block.bwd(rt, dt_, g, add=ds)
-        del ds, dt_
+        ds_total = self.temporal_res_block.bwd(rt, dout, g)
         return self.spatial_res_block.bwd(rt, ds_total, g)
 
 
