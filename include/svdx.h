@@ -83,7 +83,8 @@ int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, in
                  float* a_colsum, const void* zero_page, int out_mode, int split_k, int dtype, void* stream);
 
 /* Epilogue of a split-K GEMM run with SVDX_OUT_F32_SLAB: v = sum_z acc[z*slab_stride + m*N + n] + bias + rowvec + res (same operand
- * meaning as svdx_gemm); c_is_f32_accumulate ? ((float*)C)[m*ldc+n] += v : C[m*ldc+n] = (dtype)v. */
+ * meaning as svdx_gemm); c_is_f32_accumulate: 0 -> C[m*ldc+n] = (dtype)v, 1 -> ((float*)C)[m*ldc+n] += v, 2 -> ((float*)C)[m*ldc+n] = v
+ * (a weight gradient that is written exactly once per step needs neither a zeroed destination nor the read of it). */
 int svdx_gemm_finalize(const float* acc, int nsplit, int64_t slab_stride, void* C, int c_is_f32_accumulate, int M, int N, int ldc,
                        const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
                        const void* res, int ldres, int dtype, void* stream);
@@ -171,6 +172,9 @@ int svdx_cast_transpose_from_f32(const float* in, void* out, int R, int Ccols, i
 int svdx_nchw_to_rows(const float* in, void* out, int n_img, int C, int H, int W, int ld, float mul, int dtype, void* stream);
 int svdx_rows_to_nchw(const void* in, float* out, int n_img, int C, int H, int W, int ld, int dtype, void* stream);
 int svdx_zero(void* p, size_t bytes, void* stream);
+/* base[off .. off+cnt) = 0 for each (off, cnt) pair of `spans` (int pairs; off and cnt multiples of 4): ONE launch for the scattered
+ * gradient slots that are accumulated with atomics and so must start from zero (biases, LayerNorm, skinny cross-attention weights). */
+int svdx_zero_spans(float* base, const int* spans, int n_spans, void* stream);
 
 /* ---- EDM loss (train_svd.py:1025-1036) fused with its gradient.  pred rows [B*T*HW, ld]; noisy/target
  *      float NCHW-per-frame [B,T,4,H,W]; sigma[B].  loss (float, accumulated; zero it first) and

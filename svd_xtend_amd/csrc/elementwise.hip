@@ -388,6 +388,22 @@ extern "C" int svdx_rows_to_nchw(const void* in, float* out, int n_img, int C, i
     return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void zero_spans_kernel(float* base, const int* __restrict__ spans) {
+    const int off = spans[blockIdx.x * 2], cnt = spans[blockIdx.x * 2 + 1];
+    f32x4* p = reinterpret_cast<f32x4*>(base + off);
+    for (int i = threadIdx.x; i < cnt / 4; i += 256) p[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+}  // namespace
+
+extern "C" int svdx_zero_spans(float* base, const int* spans, int n_spans, void* stream) {
+    if (n_spans <= 0) return 0;
+    SVDX_CHECK_ARG(base && spans && ((uintptr_t)base & 15) == 0, "svdx_zero_spans: bad args");
+    hipLaunchKernelGGL(zero_spans_kernel, dim3(n_spans), dim3(256), 0, (hipStream_t)stream, base, spans);
+    SVDX_LAUNCH_CHECK("svdx_zero_spans");
+    return 0;
+}
+
 extern "C" int svdx_zero(void* p, size_t bytes, void* stream) {
     if (bytes == 0) return 0;
     hipError_t e = hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);

@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256) void small_linear_nn(const float* X, const T* 
 // split-K epilogue: v = sum over `nsplit` float slabs (+ bias + rowvec + res);  C = (dtype)v, or Cf += v (weight grads)
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_finalize_kernel(const float* __restrict__ acc, int nsplit, long slab_stride, T* __restrict__ C,
-                                                            float* __restrict__ Cf, int M, int N, int ldc,
+                                                            float* __restrict__ Cf, int f32_store, int M, int N, int ldc,
                                                             const float* __restrict__ bias, const float* __restrict__ rowvec,
                                                             int rv_ld, int rv_rpg, int rv_mod, const T* __restrict__ res, int ldres) {
     const long total4 = (long)M * N / 4;       // N % 4 == 0
@@ -913,8 +913,13 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const float* __restr
         }
         if (Cf) {
             float* o = Cf + (size_t)m * ldc + n;
+            if (f32_store) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += v[e];
+                for (int e = 0; e < 4; ++e) o[e] = v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += v[e];
+            }
         } else {
             Vec4<T> o;
 #pragma unroll
@@ -1156,7 +1161,7 @@ extern "C" int svdx_gemm_finalize(const float* acc, int nsplit, int64_t slab_str
     const int blocks = (int)std::min<long>(((long)M * N / 4 + 255) / 256, 4096);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_finalize_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, nsplit,
                                              (long)slab_stride, c_is_f32_accumulate ? (T*)nullptr : (T*)C,
-                                             c_is_f32_accumulate ? (float*)C : (float*)nullptr, M, N, ldc, bias, rowvec, rv_ld,
+                                             c_is_f32_accumulate ? (float*)C : (float*)nullptr, c_is_f32_accumulate == 2, M, N, ldc, bias, rowvec, rv_ld,
                                              rv_rows_per_group, rv_mod, (const T*)res, ldres));
     SVDX_LAUNCH_CHECK("svdx_gemm_finalize");
     return 0;

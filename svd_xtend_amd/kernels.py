@@ -94,6 +94,7 @@ _SIGS = {
     "svdx_nchw_to_rows": "pp" "iiiii" "f" "ip",
     "svdx_rows_to_nchw": "pp" "iiiii" "ip",
     "svdx_zero": "pzp",
+    "svdx_zero_spans": "pp" "ip",
     "svdx_edm_loss": "pi" "ppppp" "iiii" "p" "ip",
     "svdx_check_finite": "plpp",
     "svdx_optim_prep": "p" "ffff" "ii" "p",
@@ -315,6 +316,10 @@ class HipBackend:
         self._call("svdx_adamw", _f32(p), _f32(g), _f32(m), _f32(v), n, float(lr), float(beta1), float(beta2),
                    float(eps), float(wd), float(grad_mul), _f32(opt_state), _p(p_act),
                    _dt(p_act) if p_act is not None else F16, self._stream())
+
+    def zero_spans(self, base, spans, n_spans):
+        assert spans.dtype == torch.int32 and spans.is_contiguous()
+        self._call("svdx_zero_spans", _f32(base), spans.data_ptr(), n_spans, self._stream())
 
     def adamw_tiled(self, p, g, m, v, tiles, n_tiles, lr, beta1, beta2, eps, wd, grad_mul, opt_state, p_act, pt_act):
         assert tiles.dtype == torch.int32 and tiles.is_contiguous() and tiles.numel() >= 6 * n_tiles

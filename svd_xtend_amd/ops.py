@@ -60,6 +60,11 @@ class Runtime:
         self.wt_pos = 0
         self.wt_map = {}
         self.adam_writes_wt = False  # set by the Trainer: LinearOp.refresh then has nothing to re-transpose
+        # weight gradients produced by ONE GEMM per step can be stored instead of accumulated on the first micro-batch: no
+        # zeroed destination, no read of it.  write_once: ids of the parameters whose gradient has that property.
+        self.grad_overwrite = False
+        self.grads_fresh = False     # Trainer.zero_grad(): the next backward sweep stores the write-once gradients
+        self.write_once = set()
         self.arenas = [None, None]
         self.arena_cap = 1 << 20    # floats
         self.arena_cur, self.arena_pos = None, 0
@@ -282,6 +287,7 @@ class LinearOp:
             self.w_grad = self._flat_view([w.grad for w in self.weights])
             if self.w_grad is None:
                 raise RuntimeError("trainable fused weights must have contiguous .grad views (use Trainer)")
+            rt.write_once.update(id(w) for w in self.weights)     # bwd_dw is their only gradient producer
             if self.b is not None:
                 self.b_grad = self._flat_view([b.grad for b in self.biases])
 
@@ -334,25 +340,27 @@ class LinearOp:
         """w.grad += dy^T x ; b.grad += colsum(dy).  TN GEMM straight from the row-major dy [M,N] and x [M,K]."""
         if not self.trainable:
             return
-        gemm_tn_acc(rt, dy, x, self.w_grad, M, self.N, self.Kdim, self.N, self.Kdim, a_colsum=self.b_grad)
+        gemm_tn_acc(rt, dy, x, self.w_grad, M, self.N, self.Kdim, self.N, self.Kdim, a_colsum=self.b_grad, write_once=True)
 
 
 def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tensor, M: int, N: int, Kd: int, lda: int, ldb: int,
-                a_colsum: Optional[torch.Tensor] = None) -> None:
+                a_colsum: Optional[torch.Tensor] = None, write_once: bool = False) -> None:
     """dst[N, Kd] (float, contiguous) += dy[:, :N]^T x[:, :Kd] over M rows (row pitches lda / ldb); a_colsum += colsum(dy).
     The reduction over rows is split across blocks when the [N, Kd] tile grid cannot fill the chip (float slabs + finalize):
     weight-grad outputs are small (down to 320 x 64 for a LoRA factor) while M is 35840."""
     k = rt.k
     rtiles = (M + 63) // 64
 
+    store = rt.grad_overwrite and write_once       # first micro-batch of a step: dst = ..., later ones: dst += ...
+
     def run(sk):
         # the bias gradient (column sums of dy) rides on the same launch
         if sk == 1:
-            k.gemm_tn(dy, x, dst, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32_ADD, a_colsum=a_colsum)
+            k.gemm_tn(dy, x, dst, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32 if store else K.OUT_F32_ADD, a_colsum=a_colsum)
         else:
             slabs = rt.f32(sk, N, Kd)
             k.gemm_tn(dy, x, slabs, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32_SLAB, split_k=sk, a_colsum=a_colsum)
-            k.gemm_finalize(slabs, sk, N * Kd, dst, N, Kd, Kd, accumulate_f32=True, dtype=rt.dt)
+            k.gemm_finalize(slabs, sk, N * Kd, dst, N, Kd, Kd, accumulate_f32=2 if store else 1, dtype=rt.dt)
 
     tiles = ((N + 127) // 128) * ((Kd + 127) // 128)
 
@@ -454,6 +462,8 @@ class LoraOp:
         self.A3T = rt.empty(self.in_f, J * rp)
         self.Bp = [torch.zeros(n, rp, dtype=rt.dt, device=rt.dev) for n in self.outs]
         self.BTp = [rt.empty(rp, n) for n in self.outs]
+        if self.r == rp:
+            rt.write_once.update(id(q) for m in self.mods for q in (m.A, m.B) if q.requires_grad)
         self.refresh(rt)
 
     def refresh(self, rt: Runtime) -> None:
@@ -492,7 +502,7 @@ class LoraOp:
             m = self.mods[j]
             if m.B.requires_grad:
                 if r == rp:
-                    gemm_tn_acc(rt, dyj, xs[:, j * rp:], m.B.grad, M, n, rp, lddy, J * rp)
+                    gemm_tn_acc(rt, dyj, xs[:, j * rp:], m.B.grad, M, n, rp, lddy, J * rp, write_once=True)
                 else:
                     tmp = rt.zeros_f32(n, rp)
                     gemm_tn_acc(rt, dyj, xs[:, j * rp:], tmp, M, n, rp, lddy, J * rp)
@@ -501,7 +511,7 @@ class LoraOp:
         for j, m in enumerate(self.mods):
             if m.A.requires_grad:
                 if r == rp:
-                    gemm_tn_acc(rt, dxa[:, j * rp:], x, m.A.grad, M, rp, self.in_f, J * rp, self.in_f)
+                    gemm_tn_acc(rt, dxa[:, j * rp:], x, m.A.grad, M, rp, self.in_f, J * rp, self.in_f, write_once=True)
                 else:
                     tmp = rt.zeros_f32(rp, self.in_f)
                     gemm_tn_acc(rt, dxa[:, j * rp:], x, tmp, M, rp, self.in_f, J * rp, self.in_f)

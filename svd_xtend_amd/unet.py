@@ -1075,6 +1075,14 @@ class UNetSpatioTemporalConditionModel(nn.Module):
     def backward_rows(self, dy):
         """dy: [B*T*h*w, rup(out_channels,64)] channels-last gradient of the prediction rows (zero padded)."""
         rt = self.rt
+        rt.grad_overwrite, rt.grads_fresh = rt.grads_fresh, False
+        try:
+            return self._backward_rows(dy)
+        finally:
+            rt.grad_overwrite = False
+
+    def _backward_rows(self, dy):
+        rt = self.rt
         k = rt.k
         fs = self._fwd_state
         self._fwd_state = None

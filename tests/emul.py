@@ -166,9 +166,9 @@ class EmuBackend:
             v = v + V(rowvec, int(gi.max()) + 1, N, rv_ld)[gi]
         if res is not None:
             v = v + V(res, M, N, ldres).float()
-        if accumulate_f32:
+        if int(accumulate_f32) == 1:
             V(C, M, N, ldc).add_(v)
-        else:
+        else:                                        # 0: activation store, 2: float store
             V(C, M, N, ldc).copy_(v.to(C.dtype))
 
     def small_linear(self, X, W, bias, Y, M, N, Kd, ldw, trans=0, silu_in=0, accumulate=0):
@@ -461,6 +461,10 @@ class EmuBackend:
             step += 1
         st.copy_(torch.tensor([step, scale, tracker, 0.0, inv, 1 - beta1 ** step, 1 - beta2 ** step,
                                1.0 if found else 0.0], dtype=torch.float32))
+
+    def zero_spans(self, base, spans, n_spans):
+        for off, cnt in spans[:n_spans].view(-1, 2).tolist():
+            V1(base, off + cnt)[off:off + cnt].zero_()
 
     def adamw_tiled(self, p, g, m, v, tiles, n_tiles, lr, beta1, beta2, eps, wd, grad_mul, st, p_act, pt_act):
         if float(st[7]) > 0:

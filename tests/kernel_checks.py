@@ -422,6 +422,16 @@ def check_optim(P, dt):
         for nm in ("p", "m", "v"):
             res.append((f"adamw found_inf={found} {nm}", relerr(o1[nm], o2[nm]), 1e-5))
         res.append((f"adamw found_inf={found} p_act", relerr(o1["pa"], o2["pa"]), tol_for(dt)))
+    # span zeroing and the float-store finalize (write-once weight gradients)
+    buf = rndf((5000,), P.dev, g)
+    spans = torch.tensor([[0, 64], [128, 4], [1000, 2048], [4996, 4]], dtype=torch.int32, device=P.dev)
+    o1, o2 = P.run("zero_spans", lambda o: ((o["b"], spans, 4), {}), dict(b=buf))
+    res.append(("zero_spans", relerr(o1["b"], o2["b"]), 0.0))
+    slabs = rndf((3, 40, 64), P.dev, g)
+    for mode in (1, 2):
+        o1, o2 = P.run("gemm_finalize", lambda o: ((slabs, 3, 40 * 64, o["c"], 40, 64, 64), dict(accumulate_f32=mode, dtype=dt)),
+                       dict(c=torch.full((40, 64), 3.0, device=P.dev)))
+        res.append((f"gemm_finalize float mode {mode}", relerr(o1["c"], o2["c"]), 1e-6))
     # tiled AdamW with transposed twins: two matrices fused into one [K, N1+N2] twin, a plain matrix, a bias
     from svd_xtend_amd.train import build_adam_tiles
     shapes = [(128, 192), (68, 192), (100, 64), (320,)]

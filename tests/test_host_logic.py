@@ -222,3 +222,39 @@ def test_to_dtype_keeps_float_masters(emu_backend):
     m._requested_dtype = torch.float32         # the CPU emulator stores activations in the requested dtype
     m.prepare()
     assert m.rt.dt == torch.float32
+
+
+def test_zero_grad_then_stale_gradients_are_overwritten(emu_backend):
+    """Trainer.zero_grad() clears only the atomically-accumulated slots; the big matrices are STORED by the next backward sweep.
+    Two consecutive steps on different batches must therefore give the gradients of the second batch alone -- through
+    Trainer.backward() and through the autograd route (`loss.backward()`), and a second backward without zero_grad must add."""
+    _, m = build_pair(6)
+    tr = Trainer(m, dtype=torch.float32, lr=1e-3)
+    b1, b2 = make_synthetic_batch(1, 2, 16, 16, 21, cross_dim=64), make_synthetic_batch(1, 2, 16, 16, 22, cross_dim=64)
+
+    def args(b):
+        unet_in, ts, ehs, ids, noisy, sig = edm_inputs(b)
+        return (unet_in, ts, ehs, ids, noisy, b["latents"], b["sigmas"]), sig
+
+    a1, _ = args(b1)
+    a2, sig2 = args(b2)
+    tr.g_flat.fill_(7.0)                      # garbage everywhere: nothing may survive zero_grad + backward
+    tr.zero_grad()
+    tr.forward_backward(*a2)
+    ref = tr.g_flat[:tr.n_flat].clone()
+    assert float(ref.abs().max()) < 7.0 and torch.isfinite(ref).all()
+    tr.micro = 0
+    tr.zero_grad()
+    tr.forward_backward(*a1)                  # stale = gradients of batch 1
+    tr.micro = 0
+    tr.zero_grad()
+    tr.forward_backward(*a2)
+    assert torch.equal(tr.g_flat[:tr.n_flat], ref)
+    tr.micro = 0
+    tr.zero_grad()                            # autograd route after Trainer.zero_grad()
+    loss = edm_loss(m(a2[0], a2[1], a2[2], added_time_ids=a2[3]).sample, a2[4], b2["latents"], sig2)
+    loss.backward()
+    assert torch.allclose(tr.g_flat[:tr.n_flat], ref, rtol=1e-5, atol=1e-7)
+    tr.forward_backward(*a2)                  # no zero_grad: accumulates
+    tr.micro = 0
+    assert torch.allclose(tr.g_flat[:tr.n_flat], 2 * ref, rtol=1e-5, atol=1e-7)
