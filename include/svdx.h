@@ -126,19 +126,19 @@ int svdx_ln_bwd(const void* dy, const void* x, const float* stats, const float* 
                 void* dx, float* dgamma, float* dbeta, float* scratch, int rows, int C, int dtype, void* stream);
 
 /* ---- spatial self-attention (head_dim 64), flash form; replaces F.scaled_dot_product_attention in
- *      diffusers AttnProcessor2_0.  q,k element (n,s,h,d) at (n*S+s)*ld + h*64 + d;
- *      vt/kt/qt/dot are head-transposed copies [nb, heads, 64, s_pad] made by svdx_head_transpose. ---- */
-int svdx_head_transpose(const void* in, int ld, void* out, int nb, int heads, int S, int s_pad, int dtype, void* stream);
-int svdx_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int nb, int heads, int S,
-                  int ld, int ld_o, int s_pad, float scale, int dtype, void* stream);
+ *      diffusers AttnProcessor2_0.  q,k,v element (n,s,h,d) at (n*S+s)*ld + h*64 + d; o at pitch ld_o.
+ *      Operands whose reduction index must be contiguous (V^T, K^T, Q^T, dO^T) are read from the row-major tiles with
+ *      gfx950's transposing LDS read: no transposed copies exist. ---- */
+int svdx_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int nb, int heads, int S,
+                  int ld, int ld_o, float scale, int dtype, void* stream);
 /* D[n,h,s] = sum_d o*do */
 int svdx_attn_bwd_prep(const void* o, const void* d_o, float* D, int nb, int heads, int S, int ld_o, int dtype, void* stream);
-int svdx_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* d_o, const void* qt, const void* dot,
+int svdx_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* d_o,
                       const float* lse, const float* D, void* dk, void* dv, int nb, int heads, int S,
-                      int ld, int ld_o, int ld_d, int s_pad, float scale, int dtype, void* stream);
-int svdx_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o,
+                      int ld, int ld_o, int ld_d, float scale, int dtype, void* stream);
+int svdx_attn_bwd_dq(const void* q, const void* k, const void* v, const void* d_o,
                      const float* lse, const float* D, void* dq, int nb, int heads, int S,
-                     int ld, int ld_o, int ld_d, int s_pad, float scale, int dtype, void* stream);
+                     int ld, int ld_o, int ld_d, float scale, int dtype, void* stream);
 
 /* ---- temporal self-attention across frames: element (b,t,p,h,d) at
  *      ((b*T+t)*HW+p)*ld + h*64 + d -- addressed in place, no (B*T,HW,C)<->(B*HW,T,C) transpose. ------ */

@@ -4,12 +4,12 @@
 //   The score tile is computed TRANSPOSED (S^T = K Q^T) so that every lane owns one query column: row max /
 //   sum are in-lane reductions plus two shuffles, the O rescale is a per-lane scalar, and the probabilities
 //   feed the second MFMA (O^T = V^T P^T) straight from their accumulator registers -- no LDS round trip.
-//   The k-slot <-> key mapping of that MFMA is arbitrary as long as both operands agree, so the V^T operand
-//   is read from a head-transposed copy of V ([d][key], made by svdx_head_transpose) with two 8-byte LDS
-//   reads per fragment.  The backward uses the same trick in both orientations (dQ kernel: lanes own
-//   queries; dK/dV kernel: lanes own keys), with head-transposed K, Q, dO as the strided operands.
-//   Row-major LDS tiles (128-byte rows) are XOR-swizzled on the 16-byte chunk index; transposed tiles use a
-//   136-byte row pitch; both make the fragment reads bank-conflict free.
+//   The k-slot <-> key mapping of that MFMA is arbitrary as long as both operands agree, and the V^T operand (8 keys of one
+//   head dimension per lane) is read from the ROW-major V tile with ds_read_b64_tr_b16, gfx950's transposing LDS read
+//   (frag_tr).  The backward uses the same trick in both orientations (dQ kernel: lanes own queries, K^T from the K tile;
+//   dK/dV kernel: lanes own keys, Q^T / dO^T from the Q / dO tiles): no head-transposed copies exist in HBM or LDS.
+//   LDS tiles are row-major (128-byte rows), XOR-swizzled on the 16-byte chunk index: plain and transposing fragment reads
+//   are both bank-conflict free.
 //
 // Temporal attention (sequence = frames): T <= 32, so each (clip, pixel, head) problem is one
 //   wave of plain VALU work on data addressed in place with stride HW*ld -- the (B*T,HW,C)<->(B*HW,T,C)
@@ -23,7 +23,6 @@ constexpr float LN2 = 0.6931471805599453f;
 // raw v_exp_f32: inputs here are <= ~8 and underflow to 0 is exactly what masked / far-below-max scores want
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 constexpr float RESCALE_THR = 8.f;   // defer the O/l rescale while the running max grows by less than this (log2 units)
-constexpr int TP = 136;   // byte pitch of transposed LDS tiles ([64 d][64 keys] halfs + 8 B pad)
 
 // ---- LDS tile staging -------------------------------------------------------------------------------------------
 // 64 rows x 64 halfs, row r taken from base + row_index(r)*ld (rows clamped to s_max-1), chunk-swizzled.
@@ -36,18 +35,6 @@ __device__ __forceinline__ void stage_rows(char* lds, const T* base, size_t ld, 
         const int row = min(row0 + r, s_max - 1);
         const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + lc * 8);
         *reinterpret_cast<uint4*>(lds + r * 128 + pc * 16) = v;
-    }
-}
-// 64 rows (d) x 64 halfs (positions col0..col0+63) from a head-transposed tensor [64][s_pad]
-template <typename T>
-__device__ __forceinline__ void stage_trans(char* lds, const T* base, int s_pad, int col0, int tid) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int id = i * 256 + tid;
-        const int r = id >> 3, c = id & 7;
-        const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)r * s_pad + col0 + c * 8);
-        *reinterpret_cast<uint2*>(lds + r * TP + c * 16) = make_uint2(v.x, v.y);
-        *reinterpret_cast<uint2*>(lds + r * TP + c * 16 + 8) = make_uint2(v.z, v.w);
     }
 }
 // two-phase staging (global -> registers early, registers -> LDS after the barrier): the loads of tile t+1 are in flight while
@@ -70,37 +57,29 @@ __device__ __forceinline__ void store_rows(char* lds, const Tile2 r, int tid) {
     *reinterpret_cast<uint4*>(lds + (tid >> 3) * 128 + (tid & 7) * 16) = r.a;
     *reinterpret_cast<uint4*>(lds + ((256 + tid) >> 3) * 128 + (tid & 7) * 16) = r.b;
 }
-template <typename T>
-__device__ __forceinline__ Tile2 load_trans(const T* base, int s_pad, int col0, int tid) {
-    Tile2 r;
-    r.a = *reinterpret_cast<const uint4*>(base + (size_t)(tid >> 3) * s_pad + col0 + (tid & 7) * 8);
-    r.b = *reinterpret_cast<const uint4*>(base + (size_t)((256 + tid) >> 3) * s_pad + col0 + (tid & 7) * 8);
-    return r;
-}
-__device__ __forceinline__ void store_trans(char* lds, const Tile2 r, int tid) {
-    char* d0 = lds + (tid >> 3) * TP + (tid & 7) * 16;
-    char* d1 = lds + ((256 + tid) >> 3) * TP + (tid & 7) * 16;
-    *reinterpret_cast<uint2*>(d0) = make_uint2(r.a.x, r.a.y);
-    *reinterpret_cast<uint2*>(d0 + 8) = make_uint2(r.a.z, r.a.w);
-    *reinterpret_cast<uint2*>(d1) = make_uint2(r.b.x, r.b.y);
-    *reinterpret_cast<uint2*>(d1 + 8) = make_uint2(r.b.z, r.b.w);
-}
 // row-major fragment: row (blk*16 + fr), logical 16-byte chunk (ks*4 + fg)
 template <typename T>
 __device__ __forceinline__ typename TT<T>::v8 frag_rows(const char* lds, int blk, int ks, int fr, int fg) {
     return *reinterpret_cast<const typename TT<T>::v8*>(lds + (blk * 16 + fr) * 128 + (((ks * 4 + fg) ^ (fr & 7)) * 16));
 }
-// transposed fragment: row d = db*16 + fr; k-slots 0..3 <-> positions pb0*16 + fg*4 + e, slots 4..7 <-> pb1*16 + fg*4 + e
+// transposed fragment (row d = db*16 + fr of X^T; k-slots 0..3 <-> positions pb0*16 + fg*4 + e, slots 4..7 <-> pb1*16 + fg*4 + e)
+// read straight from the ROW-major tile X (rows = positions, the swizzle of store_rows): gfx950's transposing LDS read
+// ds_read_b64_tr_b16 hands lane (g, i) of a 16-lane group the (i&3)-th half of the 8-byte unit addressed by lane (g, 4j + (i>>2))
+// for j = 0..3 (probed: tools/probes/tr_probe.hip).  Lane (g, i') therefore points at row pb*16 + g*4 + (i'>>2), unit
+// db*4 + (i'&3), and lane (fg, fr) receives X[pb*16 + fg*4 + j][db*16 + fr] -- with no transposed
+// copy in HBM or LDS.  Rows r..r+7 of one read land in distinct 16-byte chunks per bank half: conflict-free with this swizzle.
 template <typename T>
-__device__ __forceinline__ typename TT<T>::v8 frag_trans(const char* lds, int db, int pb0, int pb1, int fr, int fg) {
-    typedef typename TT<T>::v4 v4;
-    const char* row = lds + (db * 16 + fr) * TP;
-    const v4 lo = *reinterpret_cast<const v4*>(row + (pb0 * 16 + fg * 4) * 2);
-    const v4 hi = *reinterpret_cast<const v4*>(row + (pb1 * 16 + fg * 4) * 2);
-    typename TT<T>::v8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
+__device__ __forceinline__ typename TT<T>::v8 frag_tr(const char* lds, int db, int pb0, int pb1, int fr, int fg) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const int u = db * 4 + (fr & 3);
+    const int r0 = pb0 * 16 + fg * 4 + (fr >> 2), r1 = pb1 * 16 + fg * 4 + (fr >> 2);
+    const int a0 = r0 * 128 + (((u >> 1) ^ (r0 & 7)) * 16) + (u & 1) * 8;
+    const int a1 = r1 * 128 + (((u >> 1) ^ (r1 & 7)) * 16) + (u & 1) * 8;
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(lds + a0));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(lds + a1));
+    const v8s r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(typename TT<T>::v8, r);
 }
 template <typename T>
 __device__ __forceinline__ typename TT<T>::v8 pack8(const f32x4& a, const f32x4& b) {
@@ -122,10 +101,10 @@ __device__ __forceinline__ void store4(T* p, const f32x4& v, float mul) {
 // ================================================================================================================
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                       const T* __restrict__ vt, T* __restrict__ o, float* __restrict__ lse,
-                                                       int heads, int S, int ld, int ld_o, int s_pad, float sl2) {
+                                                       const T* __restrict__ v, T* __restrict__ o, float* __restrict__ lse,
+                                                       int heads, int S, int ld, int ld_o, float sl2) {
     typedef typename TT<T>::v8 v8;
-    __shared__ __attribute__((aligned(16))) char smem[64 * 128 + 64 * TP];
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
     char* Ks = smem;
     char* Vs = smem + 64 * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
@@ -133,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
     const int q0 = blockIdx.x * 128 + wave * 32;
     const T* qb_ = q + (size_t)n * S * ld + h * 64;
     const T* kb_ = k + (size_t)n * S * ld + h * 64;
-    const T* vtb = vt + (size_t)(n * heads + h) * 64 * s_pad;
+    const T* vb_ = v + (size_t)n * S * ld + h * 64;
 
     v8 qf[2][2];
 #pragma unroll
@@ -152,16 +131,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 
     const int ntiles = (S + 63) / 64;
     Tile2 rk = load_rows<T>(kb_, ld, 0, S, tid);
-    Tile2 rv = load_trans<T>(vtb, s_pad, 0, tid);
+    Tile2 rv = load_rows<T>(vb_, ld, 0, S, tid);
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
         store_rows(Ks, rk, tid);
-        store_trans(Vs, rv, tid);
+        store_rows(Vs, rv, tid);
         __syncthreads();
         {   // unconditional (the last iteration re-reads its own tile): keeps the staging registers out of scratch
             const int tn = min(t + 1, ntiles - 1);
             rk = load_rows<T>(kb_, ld, tn * 64, S, tid);
-            rv = load_trans<T>(vtb, s_pad, tn * 64, tid);
+            rv = load_rows<T>(vb_, ld, tn * 64, S, tid);
         }
         f32x4 s[4][2];
 #pragma unroll
@@ -218,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
             for (int qb = 0; qb < 2; ++qb) pf[qb] = pack8<T>(s[2 * k2][qb], s[2 * k2 + 1][qb]);
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const v8 vf = frag_trans<T>(Vs, db, 2 * k2, 2 * k2 + 1, fr, fg);
+                const v8 vf = frag_tr<T>(Vs, db, 2 * k2, 2 * k2 + 1, fr, fg);     // V^T fragment from the row-major V tile
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) oacc[db][qb] = TT<T>::mfma(vf, pf[qb], oacc[db][qb]);
             }
@@ -269,15 +248,14 @@ __global__ void attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restric
 // ================================================================================================================
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                                                          const T* __restrict__ kt, const T* __restrict__ d_o,
+                                                          const T* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ Dv,
                                                           T* __restrict__ dq, int heads, int S, int ld, int ld_o, int ld_d,
-                                                          int s_pad, float scale) {
+                                                          float scale) {
     typedef typename TT<T>::v8 v8;
-    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128 + 64 * TP];
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
     char* Ks = smem;
     char* Vs = smem + 64 * 128;
-    char* Kts = smem + 2 * 64 * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int h = blockIdx.y, n = blockIdx.z;
     const int q0 = blockIdx.x * 128 + wave * 32;
@@ -286,7 +264,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
     const T* kb_ = k + (size_t)n * S * ld + h * 64;
     const T* vb_ = v + (size_t)n * S * ld + h * 64;
     const T* dob = d_o + (size_t)n * S * ld_o + h * 64;
-    const T* ktb = kt + (size_t)(n * heads + h) * 64 * s_pad;
 
     v8 qf[2][2], dof[2][2];
     float lse2[2], dd[2];
@@ -310,18 +287,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
     const int ntiles = (S + 63) / 64;
     Tile2 rk = load_rows<T>(kb_, ld, 0, S, tid);
     Tile2 rv = load_rows<T>(vb_, ld, 0, S, tid);
-    Tile2 rkt = load_trans<T>(ktb, s_pad, 0, tid);
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
         store_rows(Ks, rk, tid);
         store_rows(Vs, rv, tid);
-        store_trans(Kts, rkt, tid);
         __syncthreads();
         {
             const int tn = min(t + 1, ntiles - 1);
             rk = load_rows<T>(kb_, ld, tn * 64, S, tid);
             rv = load_rows<T>(vb_, ld, tn * 64, S, tid);
-            rkt = load_trans<T>(ktb, s_pad, tn * 64, tid);
         }
         f32x4 s[4][2], dp[4][2];
 #pragma unroll
@@ -358,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
             for (int qb = 0; qb < 2; ++qb) df[qb] = pack8<T>(s[2 * k2][qb], s[2 * k2 + 1][qb]);
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const v8 ktf = frag_trans<T>(Kts, db, 2 * k2, 2 * k2 + 1, fr, fg);
+                const v8 ktf = frag_tr<T>(Ks, db, 2 * k2, 2 * k2 + 1, fr, fg);     // K^T fragment from the K tile already staged
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) acc[db][qb] = TT<T>::mfma(ktf, df[qb], acc[db][qb]);
             }
@@ -380,17 +354,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
 // ================================================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                                                           const T* __restrict__ d_o, const T* __restrict__ qt,
-                                                           const T* __restrict__ dot, const float* __restrict__ lse,
+                                                           const T* __restrict__ d_o, const float* __restrict__ lse,
                                                            const float* __restrict__ Dv, T* __restrict__ dk, T* __restrict__ dv,
-                                                           int heads, int S, int ld, int ld_o, int ld_d, int s_pad, float scale) {
+                                                           int heads, int S, int ld, int ld_o, int ld_d, float scale) {
     typedef typename TT<T>::v8 v8;
-    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128 + 2 * 64 * TP + 512];
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128 + 512];
     char* Qs = smem;
     char* dOs = smem + 64 * 128;
-    char* Qts = smem + 2 * 64 * 128;
-    char* dOts = Qts + 64 * TP;
-    float* Ls = reinterpret_cast<float*>(dOts + 64 * TP);   // [64] lse*log2e, then [64] D
+    float* Ls = reinterpret_cast<float*>(smem + 2 * 64 * 128);   // [64] lse*log2e, then [64] D
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int h = blockIdx.y, n = blockIdx.z;
     const int k0 = blockIdx.x * 128 + wave * 32;
@@ -399,8 +370,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     const T* kb_ = k + (size_t)n * S * ld + h * 64;
     const T* vb_ = v + (size_t)n * S * ld + h * 64;
     const T* dob = d_o + (size_t)n * S * ld_o + h * 64;
-    const T* qtb = qt + (size_t)(n * heads + h) * 64 * s_pad;
-    const T* dotb = dot + (size_t)(n * heads + h) * 64 * s_pad;
     const float* lsb = lse + (size_t)(n * heads + h) * S;
     const float* dvb = Dv + (size_t)(n * heads + h) * S;
 
@@ -421,15 +390,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
         for (int j = 0; j < 2; ++j) { dka[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dva[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const int ntiles = (S + 63) / 64;
-    Tile2 rq, rdo, rqt, rdot;
+    Tile2 rq, rdo;
     float rls = 0.f;
 #define SVDX_DKV_PREFETCH(t_)                                               \
     {                                                                       \
         const int tt_ = (t_);                                               \
         rq = load_rows<T>(qb_, ld, tt_ * 64, S, tid);                       \
         rdo = load_rows<T>(dob, ld_o, tt_ * 64, S, tid);                    \
-        rqt = load_trans<T>(qtb, s_pad, tt_ * 64, tid);                     \
-        rdot = load_trans<T>(dotb, s_pad, tt_ * 64, tid);                   \
         const int qi_ = min(tt_ * 64 + (tid & 63), S - 1);                  \
         rls = tid < 64 ? lsb[qi_] * LOG2E : dvb[qi_];                       \
     }
@@ -438,8 +405,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
         __syncthreads();
         store_rows(Qs, rq, tid);
         store_rows(dOs, rdo, tid);
-        store_trans(Qts, rqt, tid);
-        store_trans(dOts, rdot, tid);
         if (tid < 128) Ls[tid] = rls;
         __syncthreads();
         SVDX_DKV_PREFETCH(min(t + 1, ntiles - 1));
@@ -487,8 +452,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
             }
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const v8 dotf = frag_trans<T>(dOts, db, 2 * k2, 2 * k2 + 1, fr, fg);
-                const v8 qtf = frag_trans<T>(Qts, db, 2 * k2, 2 * k2 + 1, fr, fg);
+                const v8 dotf = frag_tr<T>(dOs, db, 2 * k2, 2 * k2 + 1, fr, fg);    // dO^T / Q^T fragments from the row-major tiles
+                const v8 qtf = frag_tr<T>(Qs, db, 2 * k2, 2 * k2 + 1, fr, fg);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     dva[db][kb] = TT<T>::mfma(dotf, pf[kb], dva[db][kb]);
@@ -754,14 +719,14 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ q,
 
 #define ATTN_ARGS_OK(ld_, ptr_) ((ld_) % 8 == 0 && (((uintptr_t)(ptr_)) & 15) == 0)
 
-extern "C" int svdx_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int nb, int heads, int S, int ld,
-                             int ld_o, int s_pad, float scale, int dtype, void* stream) {
-    SVDX_CHECK_ARG(q && k && vt && o && lse && nb > 0 && heads > 0 && S > 0, "svdx_attn_fwd: bad args");
-    SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(s_pad, vt) && ld_o % 4 == 0 && s_pad % 64 == 0 &&
-                       s_pad >= S && (((uintptr_t)o) & 7) == 0, "svdx_attn_fwd: alignment (ld=%d ld_o=%d s_pad=%d)", ld, ld_o, s_pad);
+extern "C" int svdx_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int nb, int heads, int S, int ld,
+                             int ld_o, float scale, int dtype, void* stream) {
+    SVDX_CHECK_ARG(q && k && v && o && lse && nb > 0 && heads > 0 && S > 0, "svdx_attn_fwd: bad args");
+    SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ld_o % 4 == 0 && (((uintptr_t)o) & 7) == 0,
+                   "svdx_attn_fwd: alignment (ld=%d ld_o=%d)", ld, ld_o);
     dim3 grid(cdiv(S, 128), heads, nb);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_fwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q, (const T*)k,
-                                             (const T*)vt, (T*)o, lse, heads, S, ld, ld_o, s_pad, scale * LOG2E));
+                                             (const T*)v, (T*)o, lse, heads, S, ld, ld_o, scale * LOG2E));
     SVDX_LAUNCH_CHECK("svdx_attn_fwd");
     return 0;
 }
@@ -775,31 +740,30 @@ extern "C" int svdx_attn_bwd_prep(const void* o, const void* d_o, float* D, int 
     return 0;
 }
 
-extern "C" int svdx_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* d_o, const void* qt, const void* dot,
-                                 const float* lse, const float* D, void* dk, void* dv, int nb, int heads, int S, int ld, int ld_o,
-                                 int ld_d, int s_pad, float scale, int dtype, void* stream) {
-    SVDX_CHECK_ARG(q && k && v && d_o && qt && dot && lse && D && dk && dv, "svdx_attn_bwd_dkv: null argument");
-    SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ATTN_ARGS_OK(ld_o, d_o) &&
-                       ATTN_ARGS_OK(s_pad, qt) && ATTN_ARGS_OK(s_pad, dot) && ld_d % 4 == 0 && s_pad % 64 == 0 && s_pad >= S,
+extern "C" int svdx_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* d_o, const float* lse, const float* D,
+                                 void* dk, void* dv, int nb, int heads, int S, int ld, int ld_o, int ld_d, float scale, int dtype,
+                                 void* stream) {
+    SVDX_CHECK_ARG(q && k && v && d_o && lse && D && dk && dv, "svdx_attn_bwd_dkv: null argument");
+    SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ATTN_ARGS_OK(ld_o, d_o) && ld_d % 4 == 0,
                    "svdx_attn_bwd_dkv: alignment");
     dim3 grid(cdiv(S, 128), heads, nb);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q,
-                                             (const T*)k, (const T*)v, (const T*)d_o, (const T*)qt, (const T*)dot, lse, D, (T*)dk,
-                                             (T*)dv, heads, S, ld, ld_o, ld_d, s_pad, scale));
+                                             (const T*)k, (const T*)v, (const T*)d_o, lse, D, (T*)dk, (T*)dv, heads, S, ld, ld_o,
+                                             ld_d, scale));
     SVDX_LAUNCH_CHECK("svdx_attn_bwd_dkv");
     return 0;
 }
 
-extern "C" int svdx_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse,
-                                const float* D, void* dq, int nb, int heads, int S, int ld, int ld_o, int ld_d, int s_pad,
-                                float scale, int dtype, void* stream) {
-    SVDX_CHECK_ARG(q && k && v && kt && d_o && lse && D && dq, "svdx_attn_bwd_dq: null argument");
-    SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ATTN_ARGS_OK(ld_o, d_o) &&
-                       ATTN_ARGS_OK(s_pad, kt) && ld_d % 4 == 0 && s_pad % 64 == 0 && s_pad >= S, "svdx_attn_bwd_dq: alignment");
+extern "C" int svdx_attn_bwd_dq(const void* q, const void* k, const void* v, const void* d_o, const float* lse, const float* D,
+                                void* dq, int nb, int heads, int S, int ld, int ld_o, int ld_d, float scale, int dtype,
+                                void* stream) {
+    SVDX_CHECK_ARG(q && k && v && d_o && lse && D && dq, "svdx_attn_bwd_dq: null argument");
+    SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ATTN_ARGS_OK(ld_o, d_o) && ld_d % 4 == 0,
+                   "svdx_attn_bwd_dq: alignment");
     dim3 grid(cdiv(S, 128), heads, nb);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q,
-                                             (const T*)k, (const T*)v, (const T*)kt, (const T*)d_o, lse, D, (T*)dq, heads, S, ld,
-                                             ld_o, ld_d, s_pad, scale));
+                                             (const T*)k, (const T*)v, (const T*)d_o, lse, D, (T*)dq, heads, S, ld, ld_o, ld_d,
+                                             scale));
     SVDX_LAUNCH_CHECK("svdx_attn_bwd_dq");
     return 0;
 }

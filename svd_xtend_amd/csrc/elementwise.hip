@@ -321,15 +321,6 @@ extern "C" int svdx_transpose(const void* in, int ld_in, void* out, int ld_out, 
     return 0;
 }
 
-extern "C" int svdx_head_transpose(const void* in, int ld, void* out, int nb, int heads, int S, int s_pad, int dtype, void* stream) {
-    SVDX_CHECK_ARG(in && out && nb > 0 && heads > 0 && S > 0 && s_pad >= S, "svdx_head_transpose: bad args");
-    dim3 grid(cdiv(s_pad, 64), 1, nb * heads);
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((transpose_kernel<T, T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)in,
-                                             (T*)out, S, 64, ld, s_pad, heads, (long)S * ld, 64L, 64L * s_pad));
-    SVDX_LAUNCH_CHECK("svdx_head_transpose");
-    return 0;
-}
-
 extern "C" int svdx_cast_transpose_from_f32(const float* in, void* out, int R, int Ccols, int dtype, void* stream) {
     SVDX_CHECK_ARG(in && out && R > 0 && Ccols > 0, "svdx_cast_transpose_from_f32: bad args");
     dim3 grid(cdiv(R, 64), cdiv(Ccols, 64), 1);

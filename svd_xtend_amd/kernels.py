@@ -71,11 +71,10 @@ _SIGS = {
     "svdx_gn_bwd_apply": "pppppppp" "iiii" "fi" "ip",
     "svdx_ln_fwd": "ppppp" "ii" "f" "ip",
     "svdx_ln_bwd": "ppppppppp" "ii" "ip",
-    "svdx_head_transpose": "pi" "p" "iiii" "ip",
-    "svdx_attn_fwd": "ppppp" "iii" "iii" "f" "ip",
+    "svdx_attn_fwd": "ppppp" "iiiii" "f" "ip",
     "svdx_attn_bwd_prep": "ppp" "iii" "i" "ip",
-    "svdx_attn_bwd_dkv": "pppppppppp" "iii" "iiii" "f" "ip",
-    "svdx_attn_bwd_dq": "pppppppp" "iii" "iiii" "f" "ip",
+    "svdx_attn_bwd_dkv": "pppppppp" "iiiiii" "f" "ip",
+    "svdx_attn_bwd_dq": "ppppppp" "iiiiii" "f" "ip",
     "svdx_tattn_fwd": "pppp" "iiii" "ii" "f" "ip",
     "svdx_tattn_bwd": "ppppppp" "iiii" "iii" "f" "ip",
     "svdx_geglu_fwd": "pp" "ii" "ip",
@@ -224,23 +223,20 @@ class HipBackend:
                    _f32(dbeta), _f32(scratch), rows, C, _dt(x), self._stream())
 
     # ---- attention --------------------------------------------------------------------------------
-    def head_transpose(self, inp, ld, out, nb, heads, S, s_pad):
-        self._call("svdx_head_transpose", _p(inp), ld, _p(out), nb, heads, S, s_pad, _dt(inp), self._stream())
-
-    def attn_fwd(self, q, k, vt, o, lse, nb, heads, S, ld, ld_o, s_pad, scale):
-        self._call("svdx_attn_fwd", _p(q), _p(k), _p(vt), _p(o), _f32(lse), nb, heads, S, ld, ld_o, s_pad,
+    def attn_fwd(self, q, k, v, o, lse, nb, heads, S, ld, ld_o, scale):
+        self._call("svdx_attn_fwd", _p(q), _p(k), _p(v), _p(o), _f32(lse), nb, heads, S, ld, ld_o,
                    float(scale), _dt(q), self._stream())
 
     def attn_bwd_prep(self, o, d_o, D, nb, heads, S, ld_o):
         self._call("svdx_attn_bwd_prep", _p(o), _p(d_o), _f32(D), nb, heads, S, ld_o, _dt(o), self._stream())
 
-    def attn_bwd_dkv(self, q, k, v, d_o, qt, dot, lse, D, dk, dv, nb, heads, S, ld, ld_o, ld_d, s_pad, scale):
-        self._call("svdx_attn_bwd_dkv", _p(q), _p(k), _p(v), _p(d_o), _p(qt), _p(dot), _f32(lse), _f32(D),
-                   _p(dk), _p(dv), nb, heads, S, ld, ld_o, ld_d, s_pad, float(scale), _dt(q), self._stream())
+    def attn_bwd_dkv(self, q, k, v, d_o, lse, D, dk, dv, nb, heads, S, ld, ld_o, ld_d, scale):
+        self._call("svdx_attn_bwd_dkv", _p(q), _p(k), _p(v), _p(d_o), _f32(lse), _f32(D),
+                   _p(dk), _p(dv), nb, heads, S, ld, ld_o, ld_d, float(scale), _dt(q), self._stream())
 
-    def attn_bwd_dq(self, q, k, v, kt, d_o, lse, D, dq, nb, heads, S, ld, ld_o, ld_d, s_pad, scale):
-        self._call("svdx_attn_bwd_dq", _p(q), _p(k), _p(v), _p(kt), _p(d_o), _f32(lse), _f32(D), _p(dq),
-                   nb, heads, S, ld, ld_o, ld_d, s_pad, float(scale), _dt(q), self._stream())
+    def attn_bwd_dq(self, q, k, v, d_o, lse, D, dq, nb, heads, S, ld, ld_o, ld_d, scale):
+        self._call("svdx_attn_bwd_dq", _p(q), _p(k), _p(v), _p(d_o), _f32(lse), _f32(D), _p(dq),
+                   nb, heads, S, ld, ld_o, ld_d, float(scale), _dt(q), self._stream())
 
     def tattn_fwd(self, q, k, v, o, B, T, HW, heads, ld, ld_o, scale):
         self._call("svdx_tattn_fwd", _p(q), _p(k), _p(v), _p(o), B, T, HW, heads, ld, ld_o, float(scale),

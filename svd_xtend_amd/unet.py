@@ -251,13 +251,9 @@ class BasicTransformerBlock(nn.Module):
         xs_qkv = self.attn1.qkv_lora.fwd(rt, n1, qkv, M, 3 * C) if self.attn1.qkv_lora is not None else None
         if not (self.attn1.qkv_lora is not None and self.attn1.qkv_lora.trainable):
             n1 = None
-        s_pad = rup(S, 64)
-        vt = rt.empty(g.N * self.heads * HEAD_DIM * s_pad)
-        k.head_transpose(qkv[:, 2 * C:], 3 * C, vt, g.N, self.heads, S, s_pad)
         o = rt.empty(M, C)
         lse = rt.f32(g.N * self.heads * S)
-        k.attn_fwd(qkv, qkv[:, C:], vt, o, lse, g.N, self.heads, S, 3 * C, C, s_pad, HEAD_DIM ** -0.5)
-        del vt
+        k.attn_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], o, lse, g.N, self.heads, S, 3 * C, C, HEAD_DIM ** -0.5)
         cvec, cv = self.attn2.cross_vec(rt, ctx, g.B)
         h2 = self.attn1.o.fwd(rt, o, M, res=h, rowvec=cvec, rv_ld=C, rv_rpg=g.T * g.HW)
         xs_o = self.attn1.o_lora.fwd(rt, o, h2, M, C) if self.attn1.o_lora is not None else None
@@ -280,21 +276,14 @@ class BasicTransformerBlock(nn.Module):
         d_o = self.attn1.o.bwd_dx(rt, dh2, M)
         if self.attn1.o_lora is not None and self.attn1.o_lora.trainable:
             self.attn1.o_lora.bwd(rt, dh2, C, o, xs_o, d_o, M)
-        s_pad = rup(S, 64)
-        nhs = g.N * self.heads * HEAD_DIM * s_pad
         D = rt.f32(g.N * self.heads * S)
         k.attn_bwd_prep(o, d_o, D, g.N, self.heads, S, C)
-        qt, kt, dot = rt.empty(nhs), rt.empty(nhs), rt.empty(nhs)
-        k.head_transpose(qkv, 3 * C, qt, g.N, self.heads, S, s_pad)
-        k.head_transpose(qkv[:, C:], 3 * C, kt, g.N, self.heads, S, s_pad)
-        k.head_transpose(d_o, C, dot, g.N, self.heads, S, s_pad)
         dqkv = rt.empty(M, 3 * C)
         q_, k_, v_ = qkv, qkv[:, C:], qkv[:, 2 * C:]
         scale = HEAD_DIM ** -0.5
-        k.attn_bwd_dkv(q_, k_, v_, d_o, qt, dot, lse, D, dqkv[:, C:], dqkv[:, 2 * C:], g.N, self.heads, S,
-                       3 * C, C, 3 * C, s_pad, scale)
-        k.attn_bwd_dq(q_, k_, v_, kt, d_o, lse, D, dqkv, g.N, self.heads, S, 3 * C, C, 3 * C, s_pad, scale)
-        del qt, kt, dot, d_o
+        k.attn_bwd_dkv(q_, k_, v_, d_o, lse, D, dqkv[:, C:], dqkv[:, 2 * C:], g.N, self.heads, S, 3 * C, C, 3 * C, scale)
+        k.attn_bwd_dq(q_, k_, v_, d_o, lse, D, dqkv, g.N, self.heads, S, 3 * C, C, 3 * C, scale)
+        del d_o
         lora_q = self.attn1.qkv_lora is not None and self.attn1.qkv_lora.trainable
         if not need_dx and not lora_q:
             return None

@@ -284,14 +284,8 @@ class EmuBackend:
     def _hv(t, nb, S, heads, ld):
         return torch.as_strided(t, (nb, heads, S, 64), (S * ld, 64, ld, 1), t.storage_offset())
 
-    def head_transpose(self, inp, ld, out, nb, heads, S, s_pad):
-        o = V1(out, nb * heads * 64 * s_pad).view(nb, heads, 64, s_pad)
-        o.zero_()
-        o[..., :S] = self._hv(inp, nb, S, heads, ld).transpose(2, 3)
-
-    def attn_fwd(self, q, k, vt, o, lse, nb, heads, S, ld, ld_o, s_pad, scale):
-        qf, kf = self._hv(q, nb, S, heads, ld).float(), self._hv(k, nb, S, heads, ld).float()
-        vf = V1(vt, nb * heads * 64 * s_pad).view(nb, heads, 64, s_pad)[..., :S].transpose(2, 3).float()
+    def attn_fwd(self, q, k, v, o, lse, nb, heads, S, ld, ld_o, scale):
+        qf, kf, vf = (self._hv(t, nb, S, heads, ld).float() for t in (q, k, v))
         s = (qf @ kf.transpose(2, 3)) * scale
         l = torch.logsumexp(s, -1)
         p = torch.exp(s - l[..., None])
@@ -312,18 +306,13 @@ class EmuBackend:
         ds = p * (dp - Dv[..., None])
         return qf, kf, vf, dof, p, ds
 
-    def attn_bwd_dkv(self, q, k, v, d_o, qt, dot, lse, D, dk, dv, nb, heads, S, ld, ld_o, ld_d, s_pad, scale):
+    def attn_bwd_dkv(self, q, k, v, d_o, lse, D, dk, dv, nb, heads, S, ld, ld_o, ld_d, scale):
         qf, kf, vf, dof, p, ds = self._attn_bwd_common(q, k, v, d_o, lse, D, nb, heads, S, ld, ld_o, scale)
-        qt_ = V1(qt, nb * heads * 64 * s_pad).view(nb, heads, 64, s_pad)[..., :S].transpose(2, 3).float()
-        dot_ = V1(dot, nb * heads * 64 * s_pad).view(nb, heads, 64, s_pad)[..., :S].transpose(2, 3).float()
-        assert torch.equal(qt_, qf) and torch.equal(dot_, dof), "transposed operands do not match"
         self._hv(dv, nb, S, heads, ld_d).copy_((p.transpose(2, 3) @ dof).to(dv.dtype))
         self._hv(dk, nb, S, heads, ld_d).copy_(((ds.transpose(2, 3) @ qf) * scale).to(dk.dtype))
 
-    def attn_bwd_dq(self, q, k, v, kt, d_o, lse, D, dq, nb, heads, S, ld, ld_o, ld_d, s_pad, scale):
+    def attn_bwd_dq(self, q, k, v, d_o, lse, D, dq, nb, heads, S, ld, ld_o, ld_d, scale):
         qf, kf, vf, dof, p, ds = self._attn_bwd_common(q, k, v, d_o, lse, D, nb, heads, S, ld, ld_o, scale)
-        kt_ = V1(kt, nb * heads * 64 * s_pad).view(nb, heads, 64, s_pad)[..., :S].transpose(2, 3).float()
-        assert torch.equal(kt_, kf), "transposed K does not match"
         self._hv(dq, nb, S, heads, ld_d).copy_(((ds @ kf) * scale).to(dq.dtype))
 
     # ---- temporal attention ----

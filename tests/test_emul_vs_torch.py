@@ -122,28 +122,21 @@ def test_layernorm_fwd_bwd():
 
 def test_spatial_attention_fwd_bwd_vs_sdpa():
     nb, heads, S = 2, 2, 40
-    C, s_pad = heads * 64, 64
+    C = heads * 64
     qkv = torch.randn(nb * S, 3 * C, requires_grad=True)
     q, k, v = (qkv[:, i * C:(i + 1) * C].reshape(nb, S, heads, 64).transpose(1, 2) for i in range(3))
     o_ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(nb * S, C)
     d = qkv.detach()
-    nhs = nb * heads * 64 * s_pad
-    vt, kt, qt, dot = (torch.zeros(nhs) for _ in range(4))
-    E.head_transpose(d[:, 2 * C:], 3 * C, vt, nb, heads, S, s_pad)
     o, lse = torch.zeros(nb * S, C), torch.zeros(nb * heads * S)
-    E.attn_fwd(d, d[:, C:], vt, o, lse, nb, heads, S, 3 * C, C, s_pad, 0.125)
+    E.attn_fwd(d, d[:, C:], d[:, 2 * C:], o, lse, nb, heads, S, 3 * C, C, 0.125)
     assert torch.allclose(o, o_ref, atol=1e-5)
     d_o = torch.randn(nb * S, C)
     (dqkv_ref,) = torch.autograd.grad(o_ref, qkv, d_o)
-    E.head_transpose(d, 3 * C, qt, nb, heads, S, s_pad)
-    E.head_transpose(d[:, C:], 3 * C, kt, nb, heads, S, s_pad)
-    E.head_transpose(d_o, C, dot, nb, heads, S, s_pad)
     D = torch.zeros(nb * heads * S)
     E.attn_bwd_prep(o, d_o, D, nb, heads, S, C)
     dqkv = torch.zeros(nb * S, 3 * C)
-    E.attn_bwd_dkv(d, d[:, C:], d[:, 2 * C:], d_o, qt, dot, lse, D, dqkv[:, C:], dqkv[:, 2 * C:], nb, heads, S, 3 * C, C,
-                   3 * C, s_pad, 0.125)
-    E.attn_bwd_dq(d, d[:, C:], d[:, 2 * C:], kt, d_o, lse, D, dqkv, nb, heads, S, 3 * C, C, 3 * C, s_pad, 0.125)
+    E.attn_bwd_dkv(d, d[:, C:], d[:, 2 * C:], d_o, lse, D, dqkv[:, C:], dqkv[:, 2 * C:], nb, heads, S, 3 * C, C, 3 * C, 0.125)
+    E.attn_bwd_dq(d, d[:, C:], d[:, 2 * C:], d_o, lse, D, dqkv, nb, heads, S, 3 * C, C, 3 * C, 0.125)
     assert torch.allclose(dqkv, dqkv_ref, atol=1e-4)
 
 
