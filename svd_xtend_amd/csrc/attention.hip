@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
 // backward dK/dV: lanes own keys (block = 128 keys, 4 waves x 32 keys), loops over query tiles of 64
 // ================================================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                            const T* __restrict__ d_o, const float* __restrict__ lse,
                                                            const float* __restrict__ Dv, T* __restrict__ dk, T* __restrict__ dv,
                                                            int heads, int S, int ld, int ld_o, int ld_d, float scale) {
