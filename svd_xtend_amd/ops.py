@@ -8,6 +8,7 @@ temporal ops address rows with stride HW.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -122,6 +123,21 @@ def choose_split(rt: "Runtime", M: int, N: int, Kd: int, ldc: int) -> int:
     return split
 
 
+def choose_cfg(rt: "Runtime", M: int, N: int, Kd: int, ldc: int):
+    """(split, variant) without a measurement.  One measured rule on top of `choose_split` (in-situ sweeps, bench.py --tune):
+    when 160 x 160 tiles times a split factor land the grid just under the 512 resident workgroups while every split still
+    owns >= 40 K-steps, that shape wins by 5-23 % (8960 x 640 with K >= 5120: 224 tiles x 2; 2240 x 1280 with K >= 10240:
+    112 tiles x 4) over the default 128 x 160 tiles, whose grids leave a third of the slots empty."""
+    if (os.environ.get("SVDX_SPLIT_RULE", "1") != "0" and rt.gemm_variant == 4 and rt.split_k and N % 160 == 0 and N % 4 == 0
+            and ldc % 4 == 0):
+        t160 = -(-M // 160) * (N // 160)
+        kt = Kd // 64
+        s = 512 // t160 if t160 else 0
+        if 2 <= s <= 8 and t160 * s >= 384 and kt // s >= 40:
+            return s, 6
+    return choose_split(rt, M, N, Kd, ldc), rt.gemm_variant
+
+
 class GemmTuner:
     """In-situ choice of tile shape / split-K per distinct GEMM problem.
 
@@ -229,8 +245,7 @@ def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowve
         k.gemm_finalize(acc, split, M * N, out, M, N, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg,
                         rv_mod=rv_mod, res=res, ldres=ldres)
 
-    tuned_call(rt, key, lambda: _nt_candidates(M, N, Kd, splittable),
-               lambda: (choose_split(rt, M, N, Kd, ldc), rt.gemm_variant), run)
+    tuned_call(rt, key, lambda: _nt_candidates(M, N, Kd, splittable), lambda: choose_cfg(rt, M, N, Kd, ldc), run)
 
 
 # --------------------------------------------------------------------------------------------------
