@@ -112,12 +112,17 @@ class Runtime:
         return t
 
 
-def choose_split(rt: "Runtime", M: int, N: int, Kd: int, ldc: int) -> int:
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+def choose_split(rt: "Runtime", M: int, N: int, Kd: int, ldc: int, bn: int = 0) -> int:
+    """Split-K factor for bn-wide output tiles (0: the kernel's default width for this N) when the grid cannot fill the chip."""
+    bn = bn or (160 if N % 160 == 0 else 128)
+    tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
     kt = Kd // 64
     split = 1
     if rt.split_k and tiles <= 192 and kt >= 16 and N % 4 == 0 and ldc % 4 == 0:
-        split = max(1, min(512 // tiles, kt // 8, 16))
+        # every split keeps >= 16 K-steps (measured: below that the float-slab round trip costs more than the idle CUs), except
+        # for the 5x8-level grids of <= 64 tiles where even 4-step splits pay
+        min_k = 4 if tiles <= 64 else 16
+        split = max(1, min(512 // tiles, kt // min_k, 16))
         while split > 1 and (kt + split - 1) // split * (split - 1) >= kt:     # every split must own >= 1 K-tile
             split -= 1
     return split
@@ -128,13 +133,16 @@ def choose_cfg(rt: "Runtime", M: int, N: int, Kd: int, ldc: int):
     when 160 x 160 tiles times a split factor land the grid just under the 512 resident workgroups while every split still
     owns >= 40 K-steps, that shape wins by 5-23 % (8960 x 640 with K >= 5120: 224 tiles x 2; 2240 x 1280 with K >= 10240:
     112 tiles x 4) over the default 128 x 160 tiles, whose grids leave a third of the slots empty."""
-    if (os.environ.get("SVDX_SPLIT_RULE", "1") != "0" and rt.gemm_variant == 4 and rt.split_k and N % 160 == 0 and N % 4 == 0
-            and ldc % 4 == 0):
+    if rt.gemm_variant == 4 and rt.split_k and N % 160 == 0 and N % 4 == 0 and ldc % 4 == 0:
         t160 = -(-M // 160) * (N // 160)
         kt = Kd // 64
         s = 512 // t160 if t160 else 0
         if 2 <= s <= 8 and t160 * s >= 384 and kt // s >= 40:
             return s, 6
+        # N = 640 / 1280 / ... with a short reduction: 128-wide tiles give a fuller single wave (8960 x 640: 350 tiles instead
+        # of 280; 2240 x 1280: 180 instead of 144) and won every sweep by 8-14 %
+        if N % 128 == 0 and kt <= 40 and -(-M // 128) * (N // 128) <= 512:
+            return choose_split(rt, M, N, Kd, ldc, bn=128), 8
     return choose_split(rt, M, N, Kd, ldc), rt.gemm_variant
 
 
