@@ -185,6 +185,25 @@ def check_gemm_gather(P, dt, variant):
         o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, co_, taps * ci_, ci_, taps * ci_, co_),
                                           dict(bias=bias, gather=ga, variant=variant)), dict(C=out))
         res.append((f"gemm v{variant} {label}", relerr(o1["C"], o2["C"]), tol_for(dt)))
+    # stride-1 3x3 convolutions at the image widths of every UNet level: several channel slices, tiles that straddle image / batch
+    # borders, residual epilogue, and split-K into float slabs
+    for (n_, h_, w_, ci_, co_) in [(2, 20, 64, 192, 320), (3, 9, 16, 128, 160), (1, 5, 8, 64, 320), (2, 7, 32, 320, 160)]:
+        ga = K.Gather(K.GATHER_CONV3X3, n_img=n_, hi=h_, wi=w_, ho=h_, wo=w_, cin=ci_, stride=1, lda=ci_)
+        M = n_ * h_ * w_
+        A = rnd((M, ci_), dt, P.dev, g)
+        B = rnd((co_, 9 * ci_), dt, P.dev, g, (9 * ci_) ** -0.5)
+        bias, R = rndf((co_,), P.dev, g), rnd((M, co_), dt, P.dev, g)
+        o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, co_, 9 * ci_, ci_, 9 * ci_, co_),
+                                          dict(bias=bias, res=R, ldres=co_, gather=ga, variant=variant)),
+                       dict(C=torch.zeros(M, co_, dtype=dt, device=P.dev)))
+        res.append((f"gemm v{variant} conv3x3 {n_}x{h_}x{w_} {ci_}->{co_} bias+res", relerr(o1["C"], o2["C"]), tol_for(dt)))
+        sk = ci_ // 64
+        if sk > 1:
+            o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, co_, 9 * ci_, ci_, 9 * ci_, co_),
+                                              dict(gather=ga, variant=variant, out_mode=K.OUT_F32_SLAB, split_k=sk)),
+                           dict(C=torch.zeros(sk, M, co_, device=P.dev)))
+            res.append((f"gemm v{variant} conv3x3 {n_}x{h_}x{w_} {ci_}->{co_} slabs x{sk}",
+                        relerr(o1["C"].sum(0), o2["C"].sum(0)), 1e-3))
     return res
 
 
