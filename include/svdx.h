@@ -119,11 +119,11 @@ int svdx_gn_bwd_apply(const void* dy, const void* x, const float* stats, const f
 /* ---- LayerNorm over C; stats[rows,2] = (mean, rstd) ------------------------------------------------- */
 int svdx_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                 int rows, int C, float eps, int dtype, void* stream);
-/* dx = LN'(dy) (+ add);  dgamma/dbeta (float, accumulated into, may both be NULL).  scratch: NULL (block sums go in by
+/* dx = LN'(dy) (+ add) (+ add2_scale * add2);  dgamma/dbeta (float, accumulated into, may both be NULL).  scratch: NULL (block sums go in by
  * float atomics) or SVDX_LN_PARTIAL_ROWS*2*C floats of workspace (per-block partial rows + a reducing pass: ~4x faster). */
 #define SVDX_LN_PARTIAL_ROWS 512
-int svdx_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* add,
-                void* dx, float* dgamma, float* dbeta, float* scratch, int rows, int C, int dtype, void* stream);
+int svdx_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* add, const void* add2,
+                float add2_scale, void* dx, float* dgamma, float* dbeta, float* scratch, int rows, int C, int dtype, void* stream);
 
 /* ---- spatial self-attention (head_dim 64), flash form; replaces F.scaled_dot_product_attention in
  *      diffusers AttnProcessor2_0.  q,k,v element (n,s,h,d) at (n*S+s)*ld + h*64 + d; o at pitch ld_o.
@@ -153,6 +153,7 @@ int svdx_geglu_bwd(const void* dout, const void* pre, void* dpre, int M, int F, 
 int svdx_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
 /* alpha = sigmoid(*mix_factor) (diffusers AlphaBlender, image_only_indicator == 0) */
 int svdx_blend(const void* a, const void* b, const float* mix_factor, void* out, int64_t n, int dtype, void* stream);
+/* da may be NULL (only db = (1-alpha)*dy is produced) */
 int svdx_blend_bwd(const void* dy, const float* mix_factor, void* da, void* db, int64_t n, int dtype, void* stream);
 int svdx_add_rowvec(const void* x, const float* vec, void* out, int rows, int C, int rv_ld,
                     int rows_per_group, int mod, int dtype, void* stream);

@@ -63,7 +63,7 @@ __global__ void binary_kernel(const T* __restrict__ a, const T* __restrict__ b, 
             else if (OP == 1) r[e] = al * x[e] + (1.f - al) * y[e];
             else { r[e] = al * x[e]; s[e] = (1.f - al) * x[e]; }
         }
-        store8<T>(o1 + i * 8, r);
+        if (OP != 2 || o1) store8<T>(o1 + i * 8, r);
         if (OP == 2) store8<T>(o2 + i * 8, s);
     }
 }
@@ -282,7 +282,7 @@ extern "C" int svdx_blend(const void* a, const void* b, const float* mix_factor,
 }
 
 extern "C" int svdx_blend_bwd(const void* dy, const float* mix_factor, void* da, void* db, int64_t n, int dtype, void* stream) {
-    EW_ALIGN_CHECK("svdx_blend_bwd", n % 8 == 0 && al16(dy) && al16(da) && al16(db) && mix_factor);
+    EW_ALIGN_CHECK("svdx_blend_bwd", n % 8 == 0 && al16(dy) && al16(da) && db && al16(db) && mix_factor);   // da may be NULL
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((binary_kernel<T, 2>), dim3(ew_blocks(n / 8)), dim3(EW_THREADS), 0,
                                              (hipStream_t)stream, (const T*)dy, (const T*)nullptr, mix_factor, (T*)da, (T*)db,
                                              (long)n));

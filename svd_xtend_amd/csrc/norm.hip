@@ -252,8 +252,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 template <typename T, int LN_MAXCH, int R>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                     const T* __restrict__ add, T* __restrict__ dx, float* dgamma,
-                                                     float* dbeta, float* partial, int rows, int C) {
+                                                     const T* __restrict__ add, const T* __restrict__ add2, float add2_scale,
+                                                     T* __restrict__ dx, float* dgamma, float* dbeta, float* partial, int rows,
+                                                     int C) {
     extern __shared__ float red[];   // [2][C] when affine grads are requested
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cc = C / 8;
@@ -318,6 +319,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                             load8<T>(add + (size_t)row * C + j * 8, av);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o[e] += av[e];
+                        }
+                        if (add2) {
+                            float av[8];
+                            load8<T>(add2 + (size_t)row * C + j * 8, av);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] += add2_scale * av[e];
                         }
                         store8<T>(dx + (size_t)row * C + j * 8, o);
                     }
@@ -437,8 +444,9 @@ extern "C" int svdx_ln_fwd(const void* x, const float* gamma, const float* beta,
     return 0;
 }
 
-extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* add,
-                           void* dx, float* dgamma, float* dbeta, float* scratch, int rows, int C, int dtype, void* stream) {
+extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* add, const void* add2,
+                           float add2_scale, void* dx, float* dgamma, float* dbeta, float* scratch, int rows, int C, int dtype,
+                           void* stream) {
     SVDX_CHECK_ARG(rows > 0 && C % 8 == 0 && C / 8 <= 64 * LN_MAXCH_LIMIT, "svdx_ln_bwd: C=%d unsupported", C);
     SVDX_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "svdx_ln_bwd: dgamma/dbeta must come together");
     const int nch = (C / 8 + 63) / 64;
@@ -450,7 +458,7 @@ extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, co
     const size_t sh = dgamma ? sizeof(float) * 2 * C : 0;
     hipStream_t st = (hipStream_t)stream;
 #define LN_BWD(NCH, RR) hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, RR>), dim3(blocks), dim3(256), sh, st, (const T*)dy, \
-                                           (const T*)x, stats, gamma, (const T*)add, (T*)dx, dgamma, dbeta, scratch, rows, C)
+                                           (const T*)x, stats, gamma, (const T*)add, (const T*)add2, add2_scale, (T*)dx, dgamma, dbeta, scratch, rows, C)
     DISPATCH_DTYPE(dtype, { if (nch == 1) LN_BWD(1, 4); else if (nch == 2) LN_BWD(2, 2); else if (nch == 3) LN_BWD(3, 1); else LN_BWD(4, 1); });
 #undef LN_BWD
     SVDX_LAUNCH_CHECK("svdx_ln_bwd");

@@ -70,7 +70,7 @@ _SIGS = {
     "svdx_gn_bwd_stats": "pppppp" "iiii" "fi" "i" "ip",
     "svdx_gn_bwd_apply": "pppppppp" "iiii" "fi" "ip",
     "svdx_ln_fwd": "ppppp" "ii" "f" "ip",
-    "svdx_ln_bwd": "ppppppppp" "ii" "ip",
+    "svdx_ln_bwd": "pppppp" "f" "pppp" "ii" "ip",
     "svdx_attn_fwd": "ppppp" "iiiii" "f" "ip",
     "svdx_attn_bwd_prep": "ppp" "iii" "i" "ip",
     "svdx_attn_bwd_dkv": "pppppppp" "iiiiii" "f" "ip",
@@ -216,11 +216,11 @@ class HipBackend:
         self._call("svdx_ln_fwd", _p(x), _f32(gamma), _f32(beta), _p(y), _f32(stats), rows, C, float(eps),
                    _dt(x), self._stream())
 
-    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C, scratch=None):
+    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C, scratch=None, add2=None, add2_scale=1.0):
         if scratch is not None:
             assert scratch.dtype == torch.float32 and scratch.numel() >= LN_PARTIAL_ROWS * 2 * C
-        self._call("svdx_ln_bwd", _p(dy), _p(x), _f32(stats), _f32(gamma), _p(add), _p(dx), _f32(dgamma),
-                   _f32(dbeta), _f32(scratch), rows, C, _dt(x), self._stream())
+        self._call("svdx_ln_bwd", _p(dy), _p(x), _f32(stats), _f32(gamma), _p(add), _p(add2), float(add2_scale), _p(dx),
+                   _f32(dgamma), _f32(dbeta), _f32(scratch), rows, C, _dt(x), self._stream())
 
     # ---- attention --------------------------------------------------------------------------------
     def attn_fwd(self, q, k, v, o, lse, nb, heads, S, ld, ld_o, scale):

@@ -718,10 +718,13 @@ class LayerNormOp:
         rt.k.ln_fwd(x, self.mod.weight.data, self.mod.bias.data, y, stats, M, self.C, self.eps)
         return y, stats
 
-    def bwd(self, rt: Runtime, dy, x, stats, M: int, add: Optional[torch.Tensor] = None):
+    def bwd(self, rt: Runtime, dy, x, stats, M: int, add: Optional[torch.Tensor] = None, add2: Optional[torch.Tensor] = None,
+            add2_scale: float = 1.0):
+        """dx = LN'(dy) + add + add2_scale * add2 (gradient fan-in folded into the one pass that writes dx)."""
         dx = rt.empty(M, self.C)
         dg = self.mod.weight.grad if self.trainable else None
         db = self.mod.bias.grad if self.trainable else None
         scratch = rt.f32(K.LN_PARTIAL_ROWS * 2 * self.C) if self.trainable else None
-        rt.k.ln_bwd(dy, x, stats, self.mod.weight.data, add, dx, dg, db, M, self.C, scratch=scratch)
+        rt.k.ln_bwd(dy, x, stats, self.mod.weight.data, add, dx, dg, db, M, self.C, scratch=scratch, add2=add2,
+                    add2_scale=add2_scale)
         return dx

@@ -356,7 +356,8 @@ class TemporalBasicTransformerBlock(nn.Module):
         self.sv = (x, st0, n0, pre0, g0, h, st1, n1, qkv, o, cv, tctx, h1, st3, n3, pre, gg, xs_qkv, xs_o)
         return out
 
-    def bwd(self, rt: Runtime, dout, g: Geom, need_dx: bool = True, add: Optional[torch.Tensor] = None):
+    def bwd(self, rt: Runtime, dout, g: Geom, need_dx: bool = True, add: Optional[torch.Tensor] = None, add_scale: float = 1.0):
+        """returns d(input) + add_scale * add (the fan-in is folded into the last LayerNorm backward)."""
         k, C, M = rt.k, self.dim, g.M
         x, st0, n0, pre0, g0, h, st1, n1, qkv, o, cv, tctx, h1, st3, n3, pre, gg, xs_qkv, xs_o = self.sv
         self.sv = None
@@ -386,13 +387,9 @@ class TemporalBasicTransformerBlock(nn.Module):
         dh = self.ln1.bwd(rt, dn1, h, st1, M, add=dh1)
         del dn1, dh1, h
         dn0 = self.ff_in.bwd(rt, dh, n0, pre0, g0, M)
-        if add is not None:
-            dh2 = rt.empty(M, C)
-            k.add(dh, add, dh2, M * C)
-            dh = dh2
         if not need_dx and not self.ln0.trainable:
             return None
-        return self.ln0.bwd(rt, dn0, x, st0, M, add=dh)
+        return self.ln0.bwd(rt, dn0, x, st0, M, add=dh, add2=add, add2_scale=add_scale)
 
 
 class TransformerSpatioTemporalModel(nn.Module):
@@ -430,6 +427,7 @@ class TransformerSpatioTemporalModel(nn.Module):
 
     def pack(self, rt):
         self._pos_cache = None
+        self.alpha = float(torch.sigmoid(self.time_mixer.mix_factor.data.float()))      # frozen (build() checks)
         self.pin.pack(rt)
         self.pout.pack(rt)
         self.time_pos_embed.pack(rt)
@@ -479,12 +477,12 @@ class TransformerSpatioTemporalModel(nn.Module):
             blk, tblk = self.transformer_blocks[i], self.temporal_transformer_blocks[i]
             last = (i == 0) and not self.need_dx
             stop = last and not blk.trainable        # nothing trainable at or before the spatial block: the sweep ends here
-            dh_s, dhm = rt.empty(M, C), rt.empty(M, C)
-            k.blend_bwd(dh, self.time_mixer.mix_factor.data, dh_s, dhm, M * C)
-            del dh
-            # d(h + e) = dhm_in ; the spatial output h feeds both the blend and the temporal block
-            dh = tblk.bwd(rt, dhm, g, need_dx=not stop, add=None if stop else dh_s)
-            del dhm, dh_s
+            dhm = rt.empty(M, C)
+            k.blend_bwd(dh, self.time_mixer.mix_factor.data, None, dhm, M * C)       # (1-a) * dout for the temporal branch
+            # d(h + e) = dhm_in ; the spatial output h feeds both the blend (a * dout) and the temporal block: that fan-in is
+            # folded into the temporal block's last LayerNorm backward (add2 = dout, scale a)
+            dh = tblk.bwd(rt, dhm, g, need_dx=not stop, add=None if stop else dh, add_scale=self.alpha)
+            del dhm
             if stop:
                 blk.sv = None
                 return None

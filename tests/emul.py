@@ -264,7 +264,7 @@ class EmuBackend:
         st[:, 1:2] = rstd
         V(y, rows, C, C).copy_((((xf - mean) * rstd) * V1(gamma, C) + V1(beta, C)).to(y.dtype))
 
-    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C, scratch=None):
+    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C, scratch=None, add2=None, add2_scale=1.0):
         xf = V(x, rows, C, C).float()
         st = V(stats, rows, 2, 2)
         xhat = (xf - st[:, 0:1]) * st[:, 1:2]
@@ -273,6 +273,8 @@ class EmuBackend:
         out = st[:, 1:2] * (dg - dg.mean(1, keepdim=True) - xhat * (dg * xhat).mean(1, keepdim=True))
         if add is not None:
             out = out + V(add, rows, C, C).float()
+        if add2 is not None:
+            out = out + add2_scale * V(add2, rows, C, C).float()
         V(dx, rows, C, C).copy_(out.to(dx.dtype))
         if dgamma is not None:
             V1(dgamma, C).add_((d * xhat).sum(0))
@@ -358,7 +360,8 @@ class EmuBackend:
     def blend_bwd(self, dy, mix, da, db, n):
         al = torch.sigmoid(V1(mix, 1))
         d = V1(dy, n).float()
-        V1(da, n).copy_((al * d).to(da.dtype))
+        if da is not None:
+            V1(da, n).copy_((al * d).to(da.dtype))
         V1(db, n).copy_(((1 - al) * d).to(db.dtype))
 
     @staticmethod

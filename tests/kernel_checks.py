@@ -273,7 +273,7 @@ def check_layernorm(P, dt):
             scr = torch.full((512 * 2 * C,), float("nan"), device=P.dev) if affine == "scratch" else None
             o1, o2 = P.run("ln_bwd", lambda o: ((dy, x, st, gamma, add if affine else None, o["dx"],
                                                  o["dg"] if affine else None, o["db"] if affine else None, rows, C),
-                                                dict(scratch=scr)), outs)
+                                                dict(scratch=scr, add2=dy if affine == "scratch" else None, add2_scale=0.37)), outs)
             res.append((f"ln_bwd {rows}x{C} affine={affine} dx", relerr(o1["dx"], o2["dx"]), tol_for(dt)))
             if affine:
                 res.append((f"ln_bwd {rows}x{C} affine={affine} dgamma", relerr(o1["dg"], o2["dg"]), 2e-3))
