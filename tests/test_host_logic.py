@@ -258,3 +258,69 @@ def test_zero_grad_then_stale_gradients_are_overwritten(emu_backend):
     tr.forward_backward(*a2)                  # no zero_grad: accumulates
     tr.micro = 0
     assert torch.allclose(tr.g_flat[:tr.n_flat], 2 * ref, rtol=1e-5, atol=1e-7)
+
+
+def test_gemm_config_rules_for_the_c2_shapes():
+    """ops.choose_cfg: the measured rules on the shapes they were mined from."""
+    from svd_xtend_amd.ops import choose_cfg, choose_split
+
+    class RT:
+        gemm_variant, split_k = 4, True
+    rt = RT()
+    # 160x160 tiles x split landing just under the 512 resident workgroups, every split keeping >= 40 K-steps
+    assert choose_cfg(rt, 8960, 640, 5760, 640) == (2, 6)
+    assert choose_cfg(rt, 2240, 1280, 11520, 1280) == (4, 6)
+    assert choose_cfg(rt, 8960, 640, 2560, 640) == (1, 8)          # short K: 128-wide tiles, fuller single wave, no split
+    assert choose_cfg(rt, 2240, 1280, 1280, 1280) == (1, 8)
+    assert choose_cfg(rt, 35840, 320, 2880, 320) == (1, 4)         # 64x40 level: the kernel's own 160-row heuristic
+    s, v = choose_cfg(rt, 2240, 1280, 3840, 1280)
+    assert v == 4 and s == 3 and 3840 // 64 // s >= 16             # splits keep >= 16 K-steps
+    for (M, N, Kd) in [(560, 1280, 11520), (560, 1280, 1280), (2240, 640, 5760), (8960, 1920, 640)]:
+        s, v = choose_cfg(rt, M, N, Kd, N)
+        kt = Kd // 64
+        assert s >= 1 and (s == 1 or -(-kt // s) * (s - 1) < kt), (M, N, Kd, s)    # every split owns at least one K-tile
+    rt.split_k = False
+    assert choose_split(rt, 560, 1280, 11520, 1280) == 1
+
+
+def test_gemm_tuner_picks_fastest_candidate_per_problem():
+    from svd_xtend_amd.ops import GemmTuner
+    tn = GemmTuner(rounds=2)
+
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+        def synchronize(self):
+            pass
+    cost = {"a": {1: 5.0, 2: 3.0, 3: 4.0}, "b": {10: 1.0, 20: 2.0}}
+    steps = 0
+    while tn.active:
+        for key, cands in cost.items():
+            cfg, idx = tn.pick(key, lambda c=cands: list(c))
+            tn.record(key, idx, Ev(0.0), Ev(cands[cfg]))
+        steps += 1
+        tn.end_step()
+        assert steps < 20
+    assert tn.table == {"a": 2, "b": 10} and steps == 2 * 3
+
+
+def test_lora_adapter_state_dict_round_trip():
+    """Adapter weights under the reference's on-disk names (train_svd_lora.py:1065-1074: `unet.<module>.lora_A.weight`)."""
+    from svd_xtend_amd.lora import LoraConfig, load_lora_state_dict, lora_state_dict
+    _, m = build_pair(8)
+    n = m.add_adapter(LoraConfig(r=4, lora_alpha=4, init_lora_weights="gaussian"))
+    sd = lora_state_dict(m)
+    assert len(sd) == 2 * n and all(k.startswith("unet.") and (".lora_A.weight" in k or ".lora_B.weight" in k) for k in sd)
+    k0 = "unet.down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.lora_A.weight"
+    assert k0 in sd and sd[k0].shape == (4, 64)
+    _, m2 = build_pair(8)
+    m2.add_adapter(LoraConfig(r=4, lora_alpha=4, init_lora_weights="gaussian"))
+    load_lora_state_dict(m2, {k: v.clone() for k, v in sd.items()})
+    sd2 = lora_state_dict(m2)
+    assert all(torch.equal(sd[k], sd2[k]) for k in sd)
+    with pytest.raises(KeyError):
+        load_lora_state_dict(m2, {"unet.nope.lora_A.weight": torch.zeros(1)})
