@@ -70,25 +70,53 @@ def make_batch(B, T, h, w, cross_dim, seed, dev):
                 noisy_latents=noisy.to(dev), target=latents.to(dev), sigmas=sigmas.to(dev))
 
 
-def cpu_baseline(max_seconds: float = 60.0):
+def cpu_baseline(dev=None, dtype=torch.float16):
     """The oracle (kind 'port': pure-PyTorch restatement; diffusers is not installed) on the host cores.
-    Sample: c1' = one 8-frame 256x192 clip, fp32, full SVD UNet, fwd + loss + bwd + AdamW, 1 step."""
-    from oracle.step import make_optimizer, make_synthetic_batch, train_step
-    from oracle.unet import SVD_CONFIG, UNetSpatioTemporalConditionOracle
+    Sample: c1' = one 8-frame 256x192 clip, fp32, full SVD UNet, fwd + loss + bwd + AdamW, 1 step.
+    The same weights and batch then go through the HIP path once (`parity_full_model`): the checker role of the oracle at the
+    FULL 1.52 B-parameter topology, beside the tiny-topology parity tests."""
+    from oracle.step import edm_inputs, make_optimizer, make_synthetic_batch, train_step
+    from oracle.unet import SVD_CONFIG, UNetSpatioTemporalConditionOracle, scaled_init_
     torch.manual_seed(0)
     cores = torch.get_num_threads()
     t0 = time.time()
     orc = UNetSpatioTemporalConditionOracle(**SVD_CONFIG)
+    scaled_init_(orc, 0)                            # O(1) activations through all 4 levels: the prediction matters in the loss
     opt = make_optimizer(orc, lr=1e-5)
     batch = make_synthetic_batch(1, 8, 24, 32, 1)
     t_build = time.time() - t0
+    parity = None
+    prod = None
+    if dev is not None:
+        try:                                       # copy the oracle's initial weights before its optimizer step changes them
+            from svd_xtend_amd.train import Trainer
+            from svd_xtend_amd.unet import UNetSpatioTemporalConditionModel
+            with torch.device(dev):
+                pm = UNetSpatioTemporalConditionModel(**SVD_CONFIG)
+            pm.load_state_dict(orc.state_dict(), strict=True)
+            prod = Trainer(pm, dtype=dtype, lr=1e-5)
+        except Exception as e:  # noqa: BLE001
+            parity = {"error": repr(e)[:200]}
     t1 = time.time()
     loss, _ = train_step(orc, batch, opt)
     dt = time.time() - t1
+    if prod is not None:
+        try:
+            unet_in, ts, ehs, ids, noisy, _ = edm_inputs(batch)
+            prod.zero_grad()
+            prod.forward_backward(unet_in.to(dev), ts.to(dev), ehs.to(dev), ids.to(dev), noisy.to(dev), batch["latents"].to(dev),
+                                  batch["sigmas"].to(dev))
+            lg = float(prod.last_loss())
+            parity = {"loss_oracle_fp32": float(loss), "loss_hip": lg, "loss_rel_err": abs(lg - float(loss)) / abs(float(loss)),
+                      "tolerance": 1e-3 if dtype == torch.float16 else 8e-3, "dtype": str(dtype).split(".")[-1]}
+        except Exception as e:  # noqa: BLE001
+            parity = {"error": repr(e)[:200]}
+        del prod
+        torch.cuda.empty_cache()
     return {"value": 1.0 / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": "c1': 1 step of the full SVD UNet on one 8-frame 256x192 clip (latent 24x32), fp32, "
                       f"fwd+loss+bwd+AdamW, {dt:.1f}s (+{t_build:.1f}s model build); 4.1 TFLOP/step",
-            "seconds": dt, "loss": float(loss)}
+            "seconds": dt, "loss": float(loss), "parity_full_model": parity}
 
 
 def main():
@@ -280,7 +308,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline()
+            cpu = cpu_baseline(dev, dt)
         except Exception as e:  # noqa: BLE001
             cpu = {"error": repr(e)[:200]}
 
