@@ -249,10 +249,15 @@ class Trainer:
         self.model.refresh_trainable(masters_changed_on_host=False)
         self.micro = 0
 
-    def step(self, batch: Dict[str, torch.Tensor]) -> None:
-        """Whole optimizer step for one micro-batch (grad_accum == 1): zero, fwd/bwd, all-reduce, AdamW."""
+    def step(self, batch) -> None:
+        """Whole optimizer step: zero, fwd/bwd of the `grad_accum` micro-batches (one dict, or a sequence of them -- config 4 of
+        the reference runs gradient_accumulation_steps = 2), all-reduce (overlapped with the last backward sweep), AdamW."""
+        batches = [batch] if isinstance(batch, dict) else list(batch)
+        if len(batches) != self.grad_accum:
+            raise ValueError(f"expected {self.grad_accum} micro-batch(es), got {len(batches)}")
         self.zero_grad()
-        self.forward_backward(**batch)
+        for b in batches:
+            self.forward_backward(**b)
         self.allreduce_grads()
         self.optimizer_step()
 

@@ -75,10 +75,13 @@ def test_two_rank_allreduce_equals_grad_accumulation(tmp_path):
     from svd_xtend_amd.train import Trainer
     tr = Trainer(_make(0), dtype=torch.float32, lr=1e-3, grad_accum=2)
     for step in range(2):
-        tr.zero_grad()
-        tr.forward_backward(**_batch(100 + 10 * step + 0))
-        tr.forward_backward(**_batch(100 + 10 * step + 1))
-        tr.optimizer_step()
+        if step == 0:
+            tr.zero_grad()
+            tr.forward_backward(**_batch(100 + 10 * step + 0))
+            tr.forward_backward(**_batch(100 + 10 * step + 1))
+            tr.optimizer_step()
+        else:
+            tr.step([_batch(100 + 10 * step + 0), _batch(100 + 10 * step + 1)])      # same thing through Trainer.step
     d = (tr.p_flat - r0["p"]).abs()
     # identical up to fp32 summation order (sum over ranks vs in-place accumulation); AdamW's m/sqrt(v) amplifies that
     # only where the gradient itself is at rounding level
