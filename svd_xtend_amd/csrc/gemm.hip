@@ -690,8 +690,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
                 Vec8<T> h8;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) h8.v[e] = from_f<T>(to_f<T>(a8.v[e]) * gelu_erf(to_f<T>(g8.v[e])));
-                *reinterpret_cast<Vec8<T>*>(pre + (size_t)m * p.ldc + fc) = a8;
-                *reinterpret_cast<Vec8<T>*>(pre + (size_t)m * p.ldc + Fdim + fc) = g8;
+                // `pre` is not read again before the backward sweep: streaming (non-temporal) stores keep it out of the L2 / Infinity
+                // Cache lines the next kernels want
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x4, a8), reinterpret_cast<u32x4*>(pre + (size_t)m * p.ldc + fc));
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x4, g8), reinterpret_cast<u32x4*>(pre + (size_t)m * p.ldc + Fdim + fc));
                 *reinterpret_cast<Vec8<T>*>(hh + (size_t)m * Fdim + fc) = h8;
             }
             return;
