@@ -899,8 +899,8 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const float* __restr
     for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
         const long i = i4 * 4;
         const int m = (int)(i / N), n = (int)(i - (long)m * N);
-        f32x4 v = *reinterpret_cast<const f32x4*>(acc + i);
-        for (int z = 1; z < nsplit; ++z) v += *reinterpret_cast<const f32x4*>(acc + (size_t)z * slab_stride + i);
+        f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(acc + i));       // slabs: written once, read once
+        for (int z = 1; z < nsplit; ++z) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(acc + (size_t)z * slab_stride + i));
         if (bias) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += bias[n + e];
@@ -916,9 +916,8 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const float* __restr
         }
         if (Cf) {
             float* o = Cf + (size_t)m * ldc + n;
-            if (f32_store) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = v[e];
+            if (f32_store) {             // a weight gradient: next read by the optimizer, a whole backward sweep later
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += v[e];

@@ -131,10 +131,11 @@ __global__ __launch_bounds__(256) void adamw_tiled_kernel(float* __restrict__ p,
         const int r = r0 + 16 * i;
         if (r < rows && c4 < cols) {
             const long idx = (long)off + (long)r * ld + c4;
-            f32x4 pv = *reinterpret_cast<const f32x4*>(p + idx);
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + idx);
-            f32x4 mv = *reinterpret_cast<const f32x4*>(m + idx);
-            f32x4 vv = *reinterpret_cast<const f32x4*>(v + idx);
+            // one pass over 12.6 GB that nothing re-reads before the next step: streaming loads and stores throughout
+            f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + idx));
+            const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + idx));
+            f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + idx));
+            f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + idx));
             Vec4<T> o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -146,9 +147,9 @@ __global__ __launch_bounds__(256) void adamw_tiled_kernel(float* __restrict__ p,
                 pv[e] -= step_size * mv[e] / denom;
                 o.v[e] = from_f<T>(pv[e]);
             }
-            *reinterpret_cast<f32x4*>(p + idx) = pv;
-            *reinterpret_cast<f32x4*>(m + idx) = mv;
-            *reinterpret_cast<f32x4*>(v + idx) = vv;
+            __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(p + idx));
+            __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m + idx));
+            __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + idx));
             if (p_act) *reinterpret_cast<Vec4<T>*>(p_act + idx) = o;
             if (wt_off >= 0) *reinterpret_cast<Vec4<T>*>(&tile[r][c4]) = o;
         }
