@@ -10,7 +10,6 @@ reference, so its published behaviour is restated: every targeted nn.Linear is w
 Self-pin: r = 64 adds 26,558,464 parameters to the SVD UNet (tests/test_oracle.py)."""
 from typing import Sequence
 
-import torch
 import torch.nn as nn
 
 TARGETS = ("to_k", "to_q", "to_v", "to_out.0")

@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import math
 from types import SimpleNamespace
-from typing import Optional, Sequence, Tuple
+from typing import Optional, Sequence
 
 import torch
 import torch.nn as nn

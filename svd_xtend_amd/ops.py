@@ -1,6 +1,7 @@
 """Host-side operators of the SVD UNet hot path: each op owns its packed weights and has an explicit
-`fwd` / `bwd` made of libsvdx kernel launches (svd_xtend_amd.kernels).  No torch.autograd, no ATen math:
-torch is used for allocation, views and one-off weight re-layout at load time only.
+`fwd` / `bwd` made of libsvdx kernel launches (svd_xtend_amd.kernels).  No torch.autograd, no ATen math on
+activations: torch is used for allocation, views, one-off weight re-layout at load time and a few tiny-tensor corner
+cases noted inline (padded LoRA rank, LoRA scale != 1 on the per-clip cross-attention vectors).
 
 Layout: activations are [rows, C] row-major with rows = (b, t, y, x) -- the "(B*T, HW, C)" layout of
 SURVEY.md section 7 -- so transformer linears need no permute, 2-D convs are implicit GEMMs over rows and
@@ -8,7 +9,6 @@ temporal ops address rows with stride HW.
 """
 from __future__ import annotations
 
-import os
 from typing import List, Optional, Sequence
 
 import torch

@@ -1,6 +1,5 @@
 """`-m gpu`: train-step parity of the HIP UNet against the CPU oracle (loss rel err <= 1e-3 for fp16)."""
 import pytest
-import torch
 
 gpu = pytest.mark.gpu
 

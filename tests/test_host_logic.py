@@ -1,8 +1,6 @@
 """Host-side orchestration (explicit forward/backward schedule, packing, flat buffers, optimizer plumbing) checked
 against the CPU oracle, with the libsvdx kernels replaced by their torch emulation (tests/emul.py).  At fp32 storage
 the hand-written backward must reproduce autograd to rounding; at fp16/bf16 storage the north-star tolerance applies."""
-import copy
-
 import pytest
 import torch
 
