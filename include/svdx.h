@@ -184,8 +184,20 @@ int svdx_edm_loss(const void* pred, int ld, const float* noisy, const float* tar
                   float* loss, void* dpred, int B, int T, int C, int HW, const float* opt_state,
                   int dtype, void* stream);
 
-/* ---- optimizer: AdamW (train_svd.py:767-773) + GradScaler semantics (accelerate fp16), all on device.
- *      opt_state float[8]: 0 step, 1 loss_scale, 2 growth_tracker, 3 found_inf, 4 inv_scale, 5 bc1, 6 bc2, 7 skip */
+/* ---- optimizer: AdamW (train_svd.py:767-773) + GradScaler semantics (accelerate fp16) + the learning-rate schedule
+ *      (diffusers get_scheduler, train_svd.py:807-813, stepped at :1048), all on device.
+ *      opt_state float[SVDX_OPT_STATE_FLOATS]: 0 step (optimizer steps that were not skipped), 1 loss_scale, 2 growth_tracker,
+ *      3 found_inf, 4 inv_scale, 5 bc1, 6 bc2, 7 skip, 8 lr multiplier of the current step (written by svdx_optim_prep),
+ *      9 schedule kind (SVDX_SCHED_*), 10 warmup steps, 11 total steps, 12 cycles, 13 power, 14 lr_end / lr_init (polynomial),
+ *      15 scheduler steps per optimizer step (accelerate: num_processes; 0 is read as 1).
+ *      Step k (1-based, skipped steps not counted) runs at lr * lambda((k - 1) * opt_state[15]). */
+#define SVDX_OPT_STATE_FLOATS 16
+#define SVDX_SCHED_CONSTANT 0
+#define SVDX_SCHED_CONSTANT_WITH_WARMUP 1
+#define SVDX_SCHED_LINEAR 2
+#define SVDX_SCHED_COSINE 3
+#define SVDX_SCHED_COSINE_WITH_RESTARTS 4
+#define SVDX_SCHED_POLYNOMIAL 5
 int svdx_check_finite(const float* g, int64_t n, float* opt_state, void* stream);
 int svdx_optim_prep(float* opt_state, float beta1, float beta2, float growth, float backoff, int growth_interval,
                     int dynamic, void* stream);
@@ -200,6 +212,10 @@ int svdx_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr
 int svdx_adamw_tiled(float* p, const float* g, float* m, float* v, const int* tiles, int n_tiles, float lr, float beta1,
                      float beta2, float eps, float wd, float grad_mul, const float* opt_state, void* p_act, void* pt_act,
                      int dtype, void* stream);
+
+/* ---- EMA of the trainable weights (diffusers EMAModel.step, train_svd.py:1053-1054): shadow -= one_minus_decay * (shadow - p)
+ *      over n floats (both buffers 16-byte aligned).  The decay itself follows EMAModel.get_decay on the host. */
+int svdx_ema_lerp(float* shadow, const float* p, int64_t n, float one_minus_decay, void* stream);
 
 #ifdef __cplusplus
 }

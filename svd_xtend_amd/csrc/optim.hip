@@ -55,11 +55,37 @@ __global__ void check_finite_kernel(const float* __restrict__ g, long n, float* 
     }
 }
 
+// Learning-rate multiplier lambda(n) of diffusers.optimization.get_scheduler (train_svd.py:807-813), n = scheduler steps taken so
+// far.  Evaluated on the device from the optimizer's own step counter so that a step replayed from a hipGraph follows the
+// schedule without host involvement.  st[9] kind, st[10] warmup, st[11] total, st[12] cycles, st[13] power, st[14] lr_end / lr_init.
+__device__ float lr_lambda(const float* st, float n) {
+    const int kind = (int)st[9];
+    const float warm = st[10], total = st[11], cycles = st[12], power = st[13], end_ratio = st[14];
+    if (kind == SVDX_SCHED_CONSTANT) return 1.f;
+    if (kind == SVDX_SCHED_POLYNOMIAL) {
+        if (n < warm) return n / fmaxf(1.f, warm);
+        if (n > total) return end_ratio;
+        const float remaining = 1.f - (n - warm) / (total - warm);
+        return (1.f - end_ratio) * powf(remaining, power) + end_ratio;
+    }
+    if (n < warm) return n / fmaxf(1.f, warm);
+    if (kind == SVDX_SCHED_CONSTANT_WITH_WARMUP) return 1.f;
+    if (kind == SVDX_SCHED_LINEAR) return fmaxf(0.f, (total - n) / fmaxf(1.f, total - warm));
+    const float progress = (n - warm) / fmaxf(1.f, total - warm);
+    const float pi = 3.14159265358979323846f;
+    if (kind == SVDX_SCHED_COSINE) return fmaxf(0.f, 0.5f * (1.f + cosf(pi * cycles * 2.f * progress)));
+    if (progress >= 1.f) return 0.f;                                   // SVDX_SCHED_COSINE_WITH_RESTARTS
+    return fmaxf(0.f, 0.5f * (1.f + cosf(pi * fmodf(cycles * progress, 1.f))));
+}
+
 __global__ void optim_prep_kernel(float* st, float beta1, float beta2, float growth, float backoff, int interval, int dynamic) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const bool found = st[3] > 0.f;
     float step = st[0], scale = st[1], tracker = st[2];
     const float inv = 1.f / scale;
+    // accelerate steps the scheduler st[15] (= num_processes) times after every optimizer step that was not skipped, so the
+    // k-th successful step runs at lambda((k - 1) * st[15])
+    st[8] = lr_lambda(st, step * fmaxf(1.f, st[15]));
     if (dynamic) {
         if (found) { scale *= backoff; tracker = 0.f; }
         else {
@@ -74,11 +100,28 @@ __global__ void optim_prep_kernel(float* st, float beta1, float beta2, float gro
     st[7] = found ? 1.f : 0.f;
 }
 
+// EMA of the trainable weights (diffusers EMAModel.step, train_svd.py:1053-1054): shadow -= (1 - decay) * (shadow - p)
+__global__ __launch_bounds__(256) void ema_lerp_kernel(float* __restrict__ shadow, const float* __restrict__ p, long n, float omd) {
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 s = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(shadow) + i);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(p + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] -= omd * (s[e] - w[e]);
+        __builtin_nontemporal_store(s, reinterpret_cast<f32x4*>(shadow) + i);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = n4 * 4 + threadIdx.x;
+        shadow[i] -= omd * (shadow[i] - p[i]);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
                                                     float wd, float grad_mul, const float* __restrict__ st, T* __restrict__ p_act) {
     if (st[7] > 0.f) return;     // inf/nan in the gradients: skip the step (GradScaler semantics)
+    lr *= st[8];                 // schedule multiplier of this step (optim_prep)
     const float gmul = st[4] * grad_mul;
     const float step_size = lr / st[5];
     const float inv_bc2_sqrt = rsqrtf(st[6]);
@@ -122,6 +165,7 @@ __global__ __launch_bounds__(256) void adamw_tiled_kernel(float* __restrict__ p,
     __shared__ T tile[64][68];
     const int* tl = tiles + (size_t)blockIdx.x * 6;
     const int off = tl[0], ld = tl[1], rows = tl[2], cols = tl[3], wt_off = tl[4], ldwt = tl[5];
+    lr *= st[8];                 // schedule multiplier of this step (optim_prep)
     const float gmul = st[4] * grad_mul;
     const float step_size = lr / st[5];
     const float inv_bc2_sqrt = rsqrtf(st[6]);
@@ -198,6 +242,14 @@ extern "C" int svdx_optim_prep(float* opt_state, float beta1, float beta2, float
     hipLaunchKernelGGL(optim_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, opt_state, beta1, beta2, growth, backoff,
                        growth_interval, dynamic);
     SVDX_LAUNCH_CHECK("svdx_optim_prep");
+    return 0;
+}
+
+extern "C" int svdx_ema_lerp(float* shadow, const float* p, int64_t n, float one_minus_decay, void* stream) {
+    SVDX_CHECK_ARG(shadow && p && n > 0 && (((uintptr_t)shadow | (uintptr_t)p) & 15) == 0, "svdx_ema_lerp: bad args (16-byte aligned buffers)");
+    const int blocks = (int)std::min<long>((n / 4 + 255) / 256 + 1, 256 * 8);
+    hipLaunchKernelGGL(ema_lerp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, shadow, p, (long)n, one_minus_decay);
+    SVDX_LAUNCH_CHECK("svdx_ema_lerp");
     return 0;
 }
 

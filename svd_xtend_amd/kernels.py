@@ -25,6 +25,8 @@ EPI_NONE, EPI_GEGLU_FWD, EPI_GEGLU_BWD = 0, 1, 2
 LN_PARTIAL_ROWS = 512
 GN_REPLICAS = 8
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3 = 0, 1, 2, 3
+OPT_STATE_FLOATS = 16          # include/svdx.h: layout of the optimizer / loss-scale / schedule state
+SCHED_KINDS = {"constant": 0, "constant_with_warmup": 1, "linear": 2, "cosine": 3, "cosine_with_restarts": 4, "polynomial": 5}
 
 
 class SvdxError(RuntimeError):
@@ -99,6 +101,7 @@ _SIGS = {
     "svdx_optim_prep": "p" "ffff" "ii" "p",
     "svdx_adamw": "pppp" "l" "ffffff" "pp" "ip",
     "svdx_adamw_tiled": "ppppp" "i" "ffffff" "ppp" "ip",
+    "svdx_ema_lerp": "pp" "l" "f" "p",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "l": ctypes.c_int64, "z": ctypes.c_size_t}
 
@@ -304,7 +307,11 @@ class HipBackend:
     def check_finite(self, g, n, opt_state):
         self._call("svdx_check_finite", _f32(g), n, _f32(opt_state), self._stream())
 
+    def ema_lerp(self, shadow, p, n, one_minus_decay):
+        self._call("svdx_ema_lerp", _f32(shadow), _f32(p), n, float(one_minus_decay), self._stream())
+
     def optim_prep(self, opt_state, beta1, beta2, growth, backoff, growth_interval, dynamic):
+        assert opt_state.numel() >= OPT_STATE_FLOATS
         self._call("svdx_optim_prep", _f32(opt_state), float(beta1), float(beta2), float(growth),
                    float(backoff), int(growth_interval), int(dynamic), self._stream())
 

@@ -110,3 +110,31 @@ def load_lora_state_dict(model: nn.Module, sd: Dict[str, torch.Tensor], prefix: 
             raise KeyError(f"unexpected adapter key {k}")
         with torch.no_grad():
             own[name].copy_(v.to(own[name].dtype))
+
+
+LORA_WEIGHT_NAME_SAFE = "pytorch_lora_weights.safetensors"     # diffusers' file name for `save_lora_weights(safe_serialization=True)`
+
+
+def save_lora_weights(save_directory: str, unet_lora_layers: Dict[str, torch.Tensor], safe_serialization: bool = True,
+                      weight_name: str = None) -> str:
+    """`StableVideoDiffusionPipeline.save_lora_weights` as the reference calls it (train_svd_lora.py:1069-1073, 1148-1152):
+    one safetensors file of the `unet.`-prefixed adapter tensors (`lora_state_dict(unet)`).  Returns the path written."""
+    import os
+
+    from safetensors.torch import save_file
+    if not safe_serialization:
+        raise NotImplementedError("save_lora_weights: only safetensors output is supported")
+    os.makedirs(save_directory, exist_ok=True)
+    path = os.path.join(save_directory, weight_name or LORA_WEIGHT_NAME_SAFE)
+    save_file({k: v.detach().cpu().contiguous() for k, v in unet_lora_layers.items()}, path)
+    return path
+
+
+def load_lora_weights(model: nn.Module, path: str, weight_name: str = None) -> None:
+    """Read a `pytorch_lora_weights.safetensors` (file or the folder holding it) into an adapter-injected UNet."""
+    import os
+
+    from safetensors.torch import load_file
+    if os.path.isdir(path):
+        path = os.path.join(path, weight_name or LORA_WEIGHT_NAME_SAFE)
+    load_lora_state_dict(model, load_file(path))

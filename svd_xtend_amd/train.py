@@ -14,6 +14,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
+from . import kernels as K
 from .ops import flatten_trainables
 from .unet import UNetSpatioTemporalConditionModel
 
@@ -91,11 +92,20 @@ class Trainer:
         self.loss_slot = self.g_flat[off:off + 1]
         # opt_state: 0 step, 1 loss_scale, 2 growth_tracker, 3 found_inf, 4 inv_scale, 5 bc1, 6 bc2, 7 skip
         self.dynamic = dtype == torch.float16
-        st = [0.0, init_scale if self.dynamic else 1.0, 0.0, 0.0, 1.0, 1.0, 1.0, 0.0]
+        st = [0.0] * K.OPT_STATE_FLOATS
+        st[1], st[4], st[5], st[6], st[8] = (init_scale if self.dynamic else 1.0), 1.0, 1.0, 1.0, 1.0   # slots 9..15: schedule
         self.opt_state = torch.tensor(st, dtype=torch.float32, device=dev)
+        self.micro = 0
+        self.schedule = dict(name="constant", num_warmup_steps=0, num_training_steps=0, num_cycles=0.0, power=1.0, lr_end=1e-7,
+                             steps_per_step=1)
+        self._build_runtime()
+
+    def _build_runtime(self) -> None:
+        """Pack the model for the kernels and derive every table that depends on the packed layout (also after `load_state`
+        replaced the weights)."""
+        model, dtype, dev = self.model, self.dtype, self.dev
         model.prepare(dtype)
         self.rt = model.rt
-        self.micro = 0
         # AdamW walks a tile table so that it can also emit the transposed 16-bit twins the data-grad GEMMs read
         tiled = bool(self.params) and os.environ.get("SVDX_ADAM_TILED", "1") != "0"      # developer knob for A/B runs
         self.adam_tiles = build_adam_tiles(self.params, self.offsets, self.rt.wt_map, dev) if tiled else None
@@ -260,6 +270,37 @@ class Trainer:
             self.forward_backward(**b)
         self.allreduce_grads()
         self.optimizer_step()
+
+    # ---- learning-rate schedule, evaluated on the device from the optimizer's step counter --------------------
+    def set_schedule(self, name: str, num_warmup_steps: int = 0, num_training_steps: int = 0, num_cycles: float = 0.0,
+                     power: float = 1.0, lr_end: float = 1e-7, steps_per_step: int = 1) -> None:
+        """Install lambda(step) of diffusers' get_scheduler (train_svd.py:807-813) into opt_state[9..15] (include/svdx.h).
+        `steps_per_step`: scheduler steps per optimizer step (accelerate steps the wrapped scheduler num_processes times)."""
+        if name not in K.SCHED_KINDS:
+            raise ValueError(f"unknown lr schedule {name!r} (have {sorted(K.SCHED_KINDS)})")
+        vals = [float(K.SCHED_KINDS[name]), float(num_warmup_steps), float(num_training_steps), float(num_cycles), float(power),
+                float(lr_end) / float(self.lr), float(steps_per_step)]
+        self.opt_state[9:16] = torch.tensor(vals, dtype=torch.float32).to(self.dev)
+        self.schedule = dict(name=name, num_warmup_steps=num_warmup_steps, num_training_steps=num_training_steps,
+                             num_cycles=num_cycles, power=power, lr_end=lr_end, steps_per_step=steps_per_step)
+
+    def weights_changed(self) -> None:
+        """The float masters of the trainables were written by something other than `optimizer_step` (EMA copy_to / restore,
+        a loaded checkpoint): refresh the 16-bit copies the kernels read, including the transposed twins AdamW maintains."""
+        saved, self.rt.adam_writes_wt = self.rt.adam_writes_wt, False
+        try:
+            self.model.refresh_trainable(masters_changed_on_host=True)
+        finally:
+            self.rt.adam_writes_wt = saved
+
+    # ---- resume (`accelerator.save_state` / `load_state`, train_svd.py:698-729, 900-924, 1088-1090) -----------------
+    def save_state(self, output_dir: str, ema=None, scheduler=None) -> None:
+        from .checkpoint import save_state
+        save_state(self, output_dir, ema=ema, scheduler=scheduler)
+
+    def load_state(self, input_dir: str, ema=None, scheduler=None) -> None:
+        from .checkpoint import load_state
+        load_state(self, input_dir, ema=ema, scheduler=scheduler)
 
     def last_loss(self) -> torch.Tensor:
         """Mean (unscaled) loss over ranks/micro-batches of the last reduced step (device scalar; read it

@@ -780,6 +780,26 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         self.config = FrozenConfig({**self.config, **kwargs})
 
     @classmethod
+    def load_config(cls, path, return_unused_kwargs: bool = False, subfolder: Optional[str] = None, **unused):
+        """`config.json` of a diffusers model folder, split into constructor arguments and everything else (EMAModel keeps its
+        settings there, train_svd.py:699-700 / :710-711)."""
+        import json
+        import os
+        folder = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(folder, CONFIG_NAME)) as f:
+            raw = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        names = cls.__init__.__code__.co_varnames
+        cfg = {k: v for k, v in raw.items() if k in names}
+        rest = {k: v for k, v in raw.items() if k not in names}
+        return (cfg, rest) if return_unused_kwargs else cfg
+
+    @classmethod
+    def from_config(cls, config, **unused):
+        """A randomly initialised model from a config mapping (EMAModel.save_pretrained rebuilds the module tree this way)."""
+        names = cls.__init__.__code__.co_varnames
+        return cls(**{k: v for k, v in dict(config).items() if k in names and not k.startswith("_")})
+
+    @classmethod
     def from_pretrained(cls, path, subfolder: Optional[str] = None, variant: Optional[str] = None, torch_dtype=None,
                         **unused):
         """diffusers folder layout (train_svd.py:651-656, 721): `<path>/<subfolder>/config.json` +

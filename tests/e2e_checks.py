@@ -132,6 +132,79 @@ def graphed_vs_eager(dev=None, dtype=torch.float16, steps=3):
                 param_abs_max=float(e["p"].abs().max()), opt_steps=(e["state"][0], g["state"][0]), segments=g["segments"])
 
 
+def resume_vs_straight(tmpdir, dev=None, dtype=torch.float16, steps=4, cut=2):
+    """`steps` optimizer steps in one go vs `cut` steps, save_state, a fresh trainer from other weights, load_state, the rest:
+    weights, Adam moments, loss scale, the device-side lr schedule (graph-replayed steps after the resume) and the EMA."""
+    import os
+
+    from svd_xtend_amd.optimization import get_scheduler
+    from svd_xtend_amd.train import GraphedStep
+    from svd_xtend_amd.training_utils import EMAModel
+    dev = dev or torch.device("cuda")
+    cfg = TINY_CONFIG
+    b = make_synthetic_batch(1, 3, 16, 16, 78, cross_dim=cfg["cross_attention_dim"])
+    unet_in, ts, ehs, ids, noisy, _ = edm_inputs(b)
+    batch = {k: v.to(dev) for k, v in dict(unet_in=unet_in, timesteps=ts, ehs=ehs, added_time_ids=ids, noisy_latents=noisy,
+                                           target=b["latents"], sigmas=b["sigmas"]).items()}
+
+    def fresh(seed):
+        orc = UNetSpatioTemporalConditionOracle(**cfg)
+        scaled_init_(orc, seed)
+        m = UNetSpatioTemporalConditionModel(**cfg)
+        m.load_state_dict(orc.state_dict(), strict=True)
+        m.to(dev)
+        tr = Trainer(m, dtype=dtype, lr=1e-3)
+        sched = get_scheduler("cosine", optimizer=tr, num_warmup_steps=1, num_training_steps=steps + 2)
+        ema = EMAModel(m.parameters(), decay=0.8, model_cls=UNetSpatioTemporalConditionModel, model_config=m.config,
+                       on_weights_changed=tr.weights_changed)
+        return tr, sched, ema
+
+    a, sa, ema_a = fresh(6)
+    lrs_a = []
+    for _ in range(steps):
+        a.step(batch)
+        ema_a.step(a.model.parameters())
+        lrs_a.append(1e-3 * float(a.opt_state[8]))
+    c, sc, ema_c = fresh(6)
+    for _ in range(cut):
+        c.step(batch)
+        ema_c.step(c.model.parameters())
+    path = os.path.join(str(tmpdir), f"checkpoint-{cut}")
+    c.save_state(path, ema=ema_c, scheduler=sc)
+    d, sd_, ema_d = fresh(123)
+    d.load_state(path, ema=ema_d, scheduler=sd_)
+    gs = GraphedStep(d, batch)                   # its warm-up pass is one real step
+    ema_d.step(d.model.parameters())
+    lrs_d = [1e-3 * float(d.opt_state[8])]
+    for _ in range(steps - cut - 1):
+        gs()
+        ema_d.step(d.model.parameters())
+        lrs_d.append(1e-3 * float(d.opt_state[8]))
+    torch.cuda.synchronize()
+    n = a.n_flat
+    sh_a = torch.cat([t.reshape(-1) for t, p in zip(ema_a.shadow_params, a.model.parameters()) if p.requires_grad])
+    sh_d = torch.cat([t.reshape(-1) for t, p in zip(ema_d.shadow_params, d.model.parameters()) if p.requires_grad])
+    # EMA swap on the prepared model: predictions change, and come back after restore
+    with torch.no_grad():
+        y0 = d.model(batch["unet_in"], batch["timesteps"], batch["ehs"], batch["added_time_ids"]).sample.float().clone()
+        packed0 = (d.p_flat.clone(), d.rt.w16_flat.clone(), d.rt.wt16_flat[:d.rt.wt_pos].clone())
+        ema_d.store(d.model.parameters())
+        ema_d.copy_to(d.model.parameters())
+        y1 = d.model(batch["unet_in"], batch["timesteps"], batch["ehs"], batch["added_time_ids"]).sample.float().clone()
+        ema_d.restore(d.model.parameters())
+        y2 = d.model(batch["unet_in"], batch["timesteps"], batch["ehs"], batch["added_time_ids"]).sample.float().clone()
+        packed2 = (d.p_flat, d.rt.w16_flat, d.rt.wt16_flat[:d.rt.wt_pos])
+        restored = all(torch.equal(x, y) for x, y in zip(packed0, packed2))
+    return dict(weights_restored_exactly=restored, files=sorted(os.listdir(path)), opt_steps=(float(a.opt_state[0]), float(d.opt_state[0])),
+                scale=(float(a.opt_state[1]), float(d.opt_state[1])), lrs_straight=lrs_a[cut:], lrs_resumed=lrs_d,
+                param_max_diff=float((a.p_flat[:n] - d.p_flat[:n]).abs().max()),
+                param_mean_diff=float((a.p_flat[:n] - d.p_flat[:n]).abs().mean()),
+                m_rel=float((a.m_flat - d.m_flat).norm() / a.m_flat.norm()),
+                ema_max_diff=float((sh_a - sh_d).abs().max()), ema_vs_live=float((sh_d - d.p_flat[:n][:sh_d.numel()]).abs().max()) if sh_d.numel() == n else -1.0,
+                swap_changes_pred=float((y1 - y0).abs().max()), restore_pred_diff=float((y2 - y0).abs().max()),
+                ema_step=ema_d.optimization_step, segments=len(gs.graphs))
+
+
 def run_lora(verbose=False, dev=None, ranks=(64, 8)):
     """Config 5 on the tiny topology: LoRA adapters (train_svd_lora.py:659-674) through libsvdx vs the oracle's peft restatement."""
     dev = dev or torch.device("cuda")

@@ -449,10 +449,40 @@ class EmuBackend:
                 tracker += 1
                 if tracker >= interval:
                     scale, tracker = scale * growth, 0.0
+        st[8] = self._lr_lambda(st, step * max(1.0, float(st[15])))
         if not found:
             step += 1
-        st.copy_(torch.tensor([step, scale, tracker, 0.0, inv, 1 - beta1 ** step, 1 - beta2 ** step,
-                               1.0 if found else 0.0], dtype=torch.float32))
+        st[:8].copy_(torch.tensor([step, scale, tracker, 0.0, inv, 1 - beta1 ** step, 1 - beta2 ** step,
+                                   1.0 if found else 0.0], dtype=torch.float32))
+
+    @staticmethod
+    def _lr_lambda(st, n):
+        kind, warm, total, cycles, power, end_ratio = (float(x) for x in st[9:15])
+        kind = int(kind)
+        if kind == 0:
+            return 1.0
+        if kind == 5:
+            if n < warm:
+                return n / max(1.0, warm)
+            if n > total:
+                return end_ratio
+            return (1 - end_ratio) * (1 - (n - warm) / (total - warm)) ** power + end_ratio
+        if n < warm:
+            return n / max(1.0, warm)
+        if kind == 1:
+            return 1.0
+        if kind == 2:
+            return max(0.0, (total - n) / max(1.0, total - warm))
+        prog = (n - warm) / max(1.0, total - warm)
+        if kind == 3:
+            return max(0.0, 0.5 * (1 + math.cos(math.pi * cycles * 2 * prog)))
+        if prog >= 1:
+            return 0.0
+        return max(0.0, 0.5 * (1 + math.cos(math.pi * ((cycles * prog) % 1.0))))
+
+    def ema_lerp(self, shadow, p, n, one_minus_decay):
+        S, P = V1(shadow, n), V1(p, n)
+        S.sub_(one_minus_decay * (S - P))
 
     def zero_spans(self, base, spans, n_spans):
         for off, cnt in spans[:n_spans].view(-1, 2).tolist():
@@ -461,6 +491,7 @@ class EmuBackend:
     def adamw_tiled(self, p, g, m, v, tiles, n_tiles, lr, beta1, beta2, eps, wd, grad_mul, st, p_act, pt_act):
         if float(st[7]) > 0:
             return
+        lr = lr * float(st[8])
         gm, ss, bc2 = float(st[4]) * grad_mul, lr / float(st[5]), math.sqrt(float(st[6]))
         for off, ld, rows, cols, wt_off, ldwt in tiles[:n_tiles].view(-1, 6).tolist():
             def T2(t):
@@ -479,6 +510,7 @@ class EmuBackend:
     def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, grad_mul, st, p_act):
         if float(st[7]) > 0:
             return
+        lr = lr * float(st[8])
         P, G, Mm, Vv = V1(p, n), V1(g, n), V1(m, n), V1(v, n)
         gg = G * (float(st[4]) * grad_mul)
         P.mul_(1 - lr * wd)

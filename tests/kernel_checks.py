@@ -404,7 +404,7 @@ def check_optim(P, dt):
     pred = rnd((B * T * HW, C), dt, P.dev, g)
     noisy, target = rndf((B, T, C, HW), P.dev, g), rndf((B, T, C, HW), P.dev, g)
     sigma = torch.tensor([0.7, 3.1], device=P.dev)
-    st = torch.tensor([0, 1024.0, 0, 0, 1, 1, 1, 0], dtype=torch.float32, device=P.dev)
+    st = torch.tensor([0, 1024.0, 0, 0, 1, 1, 1, 0] + [1.0] + [0.0] * 7, dtype=torch.float32, device=P.dev)
     o1, o2 = P.run("edm_loss", lambda o: ((pred, C, noisy, target, sigma, o["loss"], o["d"], B, T, C, HW, st), {}),
                    dict(loss=torch.zeros(1, device=P.dev), d=torch.zeros(B * T * HW, 64, dtype=dt, device=P.dev)))
     res.append(("edm_loss loss", relerr(o1["loss"], o2["loss"]), 1e-4))
@@ -412,11 +412,15 @@ def check_optim(P, dt):
     n = 4 * 5000
     p, gr = rndf((n,), P.dev, g), rndf((n,), P.dev, g, 100.0)
     m, v = rndf((n,), P.dev, g, 0.1), rndf((n,), P.dev, g).abs()
-    for found in (False, True):
+    # (found_inf, schedule slots 9..15: kind, warmup, total, cycles, power, lr_end ratio, scheduler steps per step)
+    cases = [(False, [0, 0, 0, 0, 0, 0, 0]), (True, [0, 0, 0, 0, 0, 0, 0]), (False, [1, 10, 0, 0, 0, 0, 1]), (False, [2, 2, 40, 0, 0, 0, 2]),
+             (False, [3, 1, 20, 0.5, 0, 0, 1]), (False, [4, 1, 20, 3, 0, 0, 2]), (False, [5, 2, 30, 0, 2.0, 1e-2, 1]),
+             (False, [5, 1, 2, 0, 1.0, 1e-2, 1])]
+    for found, sched in cases:
         gg = gr.clone()
         if found:
             gg[1234] = float("inf")
-        st0 = torch.tensor([3, 1024.0, 5, 0, 1, 1, 1, 0], dtype=torch.float32, device=P.dev)
+        st0 = torch.tensor([3, 1024.0, 5, 0, 1, 1, 1, 0, 1.0] + sched, dtype=torch.float32, device=P.dev)
         outs = dict(st=st0, p=p.clone(), m=m.clone(), v=v.clone(), pa=torch.zeros(n, dtype=dt, device=P.dev))
 
         def seq(be, o):
@@ -429,10 +433,15 @@ def check_optim(P, dt):
         seq(P.ref, o2)
         if P.dev.type == "cuda":
             torch.cuda.synchronize()
-        res.append((f"optim found_inf={found} state", relerr(o1["st"], o2["st"]), 1e-5))
+        res.append((f"optim found_inf={found} sched={sched[0]} state", relerr(o1["st"], o2["st"]), 1e-5))
+        res.append((f"optim sched={sched[0]} lr multiplier", abs(float(o1["st"][8]) - float(o2["st"][8])), 5e-6))
         for nm in ("p", "m", "v"):
             res.append((f"adamw found_inf={found} {nm}", relerr(o1[nm], o2[nm]), 1e-5))
         res.append((f"adamw found_inf={found} p_act", relerr(o1["pa"], o2["pa"]), tol_for(dt)))
+    for n_e in (4 * 3000, 4 * 3000 + 3):
+        sh, w = rndf((n_e,), P.dev, g), rndf((n_e,), P.dev, g)
+        o1, o2 = P.run("ema_lerp", lambda o: ((o["s"], w, n_e, 0.013), {}), dict(s=sh))
+        res.append((f"ema_lerp n={n_e}", relerr(o1["s"], o2["s"]), 1e-6))
     # span zeroing and the float-store finalize (write-once weight gradients)
     buf = rndf((5000,), P.dev, g)
     spans = torch.tensor([[0, 64], [128, 4], [1000, 2048], [4996, 4]], dtype=torch.int32, device=P.dev)
@@ -458,7 +467,7 @@ def check_optim(P, dt):
     for q, o in zip(ps, offs):
         p0[o:o + q.numel()] = q.data.reshape(-1)
     gr, m, v = rndf((n,), P.dev, g, 10.0), rndf((n,), P.dev, g, 0.1), rndf((n,), P.dev, g).abs()
-    st = torch.tensor([3, 64.0, 5, 0, 1 / 64.0, 0.271, 0.003, 0], dtype=torch.float32, device=P.dev)
+    st = torch.tensor([3, 64.0, 5, 0, 1 / 64.0, 0.271, 0.003, 0, 0.37] + [0.0] * 7, dtype=torch.float32, device=P.dev)
     outs = dict(p=p0, m=m, v=v, pa=torch.zeros(n, dtype=dt, device=P.dev), pt=torch.zeros(64 + 192 * 196, dtype=dt, device=P.dev))
     o1, o2 = P.run("adamw_tiled", lambda o: ((o["p"], gr, o["m"], o["v"], tiles, tiles.shape[0], 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0.5, st,
                                               o["pa"], o["pt"]), {}), outs)

@@ -182,7 +182,7 @@ def test_adamw_and_scaler_match_torch():
     p_ref = torch.nn.Parameter(p0.clone())
     opt = torch.optim.AdamW([p_ref], lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
     p, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
-    st = torch.tensor([0, 8.0, 0, 0, 1, 1, 1, 0], dtype=torch.float32)
+    st = torch.tensor([0, 8.0, 0, 0, 1, 1, 1, 0, 1.0] + [0.0] * 7, dtype=torch.float32)
     for it in range(3):
         p_ref.grad = g.clone() * (it + 1)
         opt.step()
