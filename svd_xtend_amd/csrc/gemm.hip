@@ -35,6 +35,8 @@ struct GemmParams {
     int xcd_n, sub_m, sub_n;   // variant 4: the 8 XCDs form an (8/xcd_n) x xcd_n grid, each owning sub_m x sub_n tiles (0: balanced row-major split)
     int epi; const void* aux_in; void* aux_out; int aux_dim;   // fused GEGLU epilogues (variant 4)
     float* a_colsum;                                           // TN form: += column sums of A (the bias gradient), or null
+    // variant 4, second operand pair: acc += A2 [M, K2] B2^T [N, K2] after the main reduction (the LoRA term of a projection)
+    const void* A2; const void* B2; int K2, lda2, ldb2, a2_bytes, b2_bytes;
 };
 
 struct RowInfo { int a, b, base; };   // per gathered A row (meaning depends on gather mode)
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
 //  * Tried and dropped: a 5-stage / 4-stage LDS ring with counted vmcnt + raw s_barrier (no gain in
 //    situ, slower in isolation: the loop is not latency bound), direct 8-byte epilogue stores (worse DRAM efficiency).
 // ================================================================================================================
-template <typename T, int NB, int MB>
+template <typename T, int NB, int MB, bool DUAL>
 __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and LDS-DMA builtin only exist in the device pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -553,9 +555,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
     }
     const bool plain = p.g.mode == SVDX_GATHER_PLAIN;
     const int cin = plain ? p.K : p.g.cin;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // DUAL: after the K-tiles of (A, B) the same pipeline runs the K2 / KT tiles of the plain pair (A2, B2) into the same
+    // accumulators -- y = x W^T + (s x A^T) B^T in one launch instead of a second GEMM that re-reads and re-writes y
+    bool seg2 = false;
     int tap = plain ? 0 : (kt_begin * KT) / cin;
     int ci0 = kt_begin * KT - tap * cin;                // channel offset inside the tap (plain: k offset)
     auto set_tap = [&]() __attribute__((always_inline)) {
@@ -586,9 +591,29 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)dst, 16, vob[i], (tap * cin + ci0) * 2, 0, 0);
         }
     };
+    const int n_main = kt_end - kt_begin;                          // K-tiles of the main pair handled by this block
+    const int n_tiles = n_main + (DUAL ? p.K2 / KT : 0);
+    int issued = 0;
+    // called after a tile was issued: make the addressing state describe the next one
     auto advance_k = [&]() __attribute__((always_inline)) {
+        ++issued;
+        if (DUAL && issued == n_main) {                            // next tile is the first one of (A2, B2): plain addressing
+            seg2 = true;
+            ci0 = 0;
+            tap = 0;                                                   // B offset (tap * cin + ci0) becomes ci0
+            rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A2), 0, p.a2_bytes, 0x00020000);
+            rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B2), 0, p.b2_bytes, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) voa[i] = (min(m0 + i * RPP + ld_row, p.M - 1) * p.lda2 + lc * 8) * 2;
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) {
+                const int nl = i * RPP + ld_row;
+                vob[i] = nl < BN3 ? (brow(nl) * p.ldb2 + lc * 8) * 2 : (int)0x80000000;
+            }
+            return;
+        }
         ci0 += KT;
-        if (!plain && ci0 == cin) { ci0 = 0; ++tap; set_tap(); }
+        if (!plain && !(DUAL && seg2) && ci0 == cin) { ci0 = 0; ++tap; set_tap(); }
     };
     f32x4 acc[NB][MB];                                   // [n-block][m-block], transposed: rows = n, cols = m
 #pragma unroll
@@ -626,7 +651,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int cur = 0;
-        for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
+        for (int kt = 0; kt < n_tiles - 1; ++kt) {
             SVDX_V4_COMPUTE(cur, true);
             advance_k();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -970,7 +995,8 @@ int launch_gemm_v4(GemmParams p, hipStream_t st) {
     constexpr int LDS = 2 * (32 * MB + 32 * NB) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, MB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, MB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     p.tiles_m = cdiv(p.M, 32 * MB);
@@ -999,7 +1025,8 @@ int launch_gemm_v4(GemmParams p, hipStream_t st) {
         gx = 8 * p.sub_m * p.sub_n;
     }
     dim3 grid(gx, p.split_k);
-    hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB>), grid, dim3(NTHREADS), LDS, st, p);
+    if (p.K2 > 0) hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB, true>), grid, dim3(NTHREADS), LDS, st, p);
+    else hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB, false>), grid, dim3(NTHREADS), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm");
     return 0;
 }
@@ -1040,12 +1067,17 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
     DISPATCH_DTYPE(dtype, return launch_gemm_tn<T>(p, (hipStream_t)stream));
 }
 
-extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
-                         const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
-                         const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
-                         int out_mode, float alpha, int split_k, int variant, int epilogue, const void* aux_in, void* aux_out,
-                         int aux_dim, int dtype, void* stream) {
+static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                      const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
+                      const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
+                      int out_mode, float alpha, int split_k, int variant, int epilogue, const void* aux_in, void* aux_out,
+                      int aux_dim, const void* A2, const void* B2, int K2, int lda2, int ldb2, int dtype, void* stream) {
     SVDX_CHECK_ARG(A && B && C, "svdx_gemm: null operand");
+    if (K2 > 0) {
+        SVDX_CHECK_ARG(A2 && B2 && K2 % BK == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && lda2 >= K2 && ldb2 >= K2 &&
+                           (((uintptr_t)A2 | (uintptr_t)B2) & 15) == 0, "svdx_gemm_dual: second operand pair misaligned (K2=%d)", K2);
+        SVDX_CHECK_ARG(variant >= 2 && split_k == 1, "svdx_gemm_dual: needs variant 4 and split_k == 1");
+    }
     if (epilogue != SVDX_EPI_NONE) {
         SVDX_CHECK_ARG(variant >= 2 && out_mode == SVDX_OUT_ACT && split_k == 1 && !res && !rowvec && aux_dim > 0 && aux_dim % 64 == 0 &&
                            (!gather || gather->mode == SVDX_GATHER_PLAIN), "svdx_gemm: fused GEGLU epilogue needs variant 4, plain A, no split-K");
@@ -1068,6 +1100,7 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
     p.res = res; p.ldres = ldres; p.zero_page = zero_page;
     p.out_mode = out_mode; p.alpha = alpha; p.split_k = split_k; p.slab_stride = (long)M * ldc;
     p.epi = epilogue; p.aux_in = aux_in; p.aux_out = aux_out; p.aux_dim = aux_dim; p.a_colsum = nullptr;
+    p.A2 = A2; p.B2 = B2; p.K2 = K2 > 0 ? K2 : 0; p.lda2 = lda2; p.ldb2 = ldb2; p.a2_bytes = p.b2_bytes = 0;
     if (gather && gather->mode != SVDX_GATHER_PLAIN) {
         p.g = *gather;
         SVDX_CHECK_ARG(p.g.cin % BK == 0, "svdx_gemm: gather cin=%d must be a multiple of %d", p.g.cin, BK);
@@ -1107,6 +1140,12 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
     const int a_w = p.g.mode == SVDX_GATHER_PLAIN ? K : p.g.cin;
     long a_bytes = ((a_rows - 1) * a_ld + a_w) * 2, b_bytes = ((long)(N - 1) * ldb + K) * 2;
     if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) { a_bytes = 0; b_bytes = 0; }   // falls back to variant 1 (64-bit pointers)
+    if (p.K2 > 0) {
+        const long b_rows = epilogue == SVDX_EPI_GEGLU_FWD ? 2L * aux_dim : N;
+        const long a2 = ((long)(M - 1) * lda2 + K2) * 2, b2 = ((b_rows - 1) * ldb2 + K2) * 2;
+        if (a_bytes == 0 || a2 >= (1L << 31) || b2 >= (1L << 31)) { svdx_set_error("svdx_gemm_dual: operands too large for the buffer-addressed kernel"); return -2; }
+        p.a2_bytes = (int)a2; p.b2_bytes = (int)b2;
+    }
     DISPATCH_DTYPE(dtype, {
         if (variant >= 2 && a_bytes > 0 && b_bytes > 0) {
             p.a_bytes = (int)a_bytes; p.b_bytes = (int)b_bytes;
@@ -1123,6 +1162,25 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
         if (epilogue != SVDX_EPI_NONE) { svdx_set_error("svdx_gemm: fused epilogue unavailable (buffer too large for variant 4)"); return -2; }
         return variant == 0 ? launch_gemm<T, false>(p, st) : launch_gemm<T, true>(p, st);
     });
+}
+
+extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                         const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
+                         const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
+                         int out_mode, float alpha, int split_k, int variant, int epilogue, const void* aux_in, void* aux_out,
+                         int aux_dim, int dtype, void* stream) {
+    return gemm_entry(A, B, C, M, N, K, lda, ldb, ldc, bias, rowvec, rv_ld, rv_rows_per_group, rv_mod, res, ldres, gather, zero_page,
+                      out_mode, alpha, split_k, variant, epilogue, aux_in, aux_out, aux_dim, nullptr, nullptr, 0, 0, 0, dtype, stream);
+}
+
+extern "C" int svdx_gemm_dual(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                              const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
+                              const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
+                              int out_mode, float alpha, int variant, const void* A2, const void* B2, int K2, int lda2, int ldb2,
+                              int dtype, void* stream) {
+    SVDX_CHECK_ARG(K2 > 0, "svdx_gemm_dual: K2 must be positive");
+    return gemm_entry(A, B, C, M, N, K, lda, ldb, ldc, bias, rowvec, rv_ld, rv_rows_per_group, rv_mod, res, ldres, gather, zero_page,
+                      out_mode, alpha, 1, variant, SVDX_EPI_NONE, nullptr, nullptr, 0, A2, B2, K2, lda2, ldb2, dtype, stream);
 }
 
 extern "C" int svdx_small_linear(const float* X, const void* W, const float* bias, float* Y, int M, int N, int K,

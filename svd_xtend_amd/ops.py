@@ -9,6 +9,7 @@ temporal ops address rows with stride HW.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -54,6 +55,7 @@ class Runtime:
         self.gemm_variant = 4      # 0 register-staged reference, 1 global_load_lds, 4 production (lean buffer_load-lds loop, 128x160 tiles)
         self.split_k = True
         self.fuse_geglu = True
+        self.fuse_dual = os.environ.get("SVDX_LORA_FUSED", "1") != "0"   # developer knob for A/B runs: adapter term as its own launch
         self.tuner = None           # GemmTuner (Trainer.tune_gemms): measured tile / split-K per GEMM problem
         # transposed 16-bit twins ([K,N], operand of the data-grad GEMM) of the trainable nn.Linear weights live in one arena so
         # that the tiled AdamW kernel can write them (wt_map: id(weight) -> (element offset of W^T[0, n0], row pitch))
@@ -232,26 +234,32 @@ def _nt_candidates(M: int, N: int, Kd: int, splittable: bool):
 
 
 def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
-             res=None, ldres=0, gather=None) -> None:
+             res=None, ldres=0, gather=None, dual=None) -> None:
     """Activation-dtype GEMM.  Tile shape and split-K factor come from the GemmTuner table when the model was tuned
     (Trainer.tune_gemms), else from a formula: the 10x16 / 5x8 latent levels (M = 2240 / 560 rows against K up to 23040)
     cannot fill 256 CUs with output tiles alone, so the reduction is split across blocks -- partial sums go to float slabs
-    that a small epilogue kernel reduces, applying bias/row-vector/residual."""
+    that a small epilogue kernel reduces, applying bias/row-vector/residual.
+    dual = (A2, B2, K2, lda2, ldb2): out also gets A2 B2^T (the LoRA term) -- inside the same launch when the reduction is not
+    split, by a second accumulate launch when it is."""
     k = rt.k
     splittable = rt.split_k and N % 4 == 0 and ldc % 4 == 0
     key = ("nt", M, N, Kd, lda, ldc, 0 if gather is None else (gather.mode, gather.stride, gather.ups, gather.cin),
-           bias is not None, rowvec is not None, res is not None)
+           bias is not None, rowvec is not None, res is not None) + (() if dual is None else (("dual", dual[2]),))
 
     def run(cfg):
         split, variant = cfg
+        fused = dual if (split == 1 and rt.fuse_dual) else None
         if split == 1:
             k.gemm(A, B, out, M, N, Kd, lda, ldb, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod,
-                   res=res, ldres=ldres, gather=gather, variant=variant)
-            return
-        acc = rt.f32(split, M, N)
-        k.gemm(A, B, acc, M, N, Kd, lda, ldb, N, gather=gather, out_mode=K.OUT_F32_SLAB, split_k=split, variant=variant)
-        k.gemm_finalize(acc, split, M * N, out, M, N, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg,
-                        rv_mod=rv_mod, res=res, ldres=ldres)
+                   res=res, ldres=ldres, gather=gather, variant=variant, dual=fused)
+        else:
+            acc = rt.f32(split, M, N)
+            k.gemm(A, B, acc, M, N, Kd, lda, ldb, N, gather=gather, out_mode=K.OUT_F32_SLAB, split_k=split, variant=variant)
+            k.gemm_finalize(acc, split, M * N, out, M, N, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg,
+                            rv_mod=rv_mod, res=res, ldres=ldres)
+        if dual is not None and fused is None:
+            A2, B2, K2, lda2, ldb2 = dual
+            k.gemm(A2, B2, out, M, N, K2, lda2, ldb2, ldc, res=out, ldres=ldc, variant=rt.gemm_variant)
 
     tuned_call(rt, key, lambda: _nt_candidates(M, N, Kd, splittable), lambda: choose_cfg(rt, M, N, Kd, ldc), run)
 
@@ -347,16 +355,16 @@ class LinearOp:
     # ---- compute ----
     def fwd(self, rt: Runtime, x: torch.Tensor, M: int, res: Optional[torch.Tensor] = None,
             rowvec: Optional[torch.Tensor] = None, rv_ld: int = 0, rv_rpg: int = 0, rv_mod: int = 0,
-            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+            out: Optional[torch.Tensor] = None, dual=None) -> torch.Tensor:
         y = out if out is not None else rt.empty(M, self.N)
         gemm_act(rt, x, self.w, y, M, self.N, self.Kdim, self.Kdim, self.Kdim, self.N, bias=self.b,
                  rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod, res=res,
-                 ldres=self.N if res is not None else 0)
+                 ldres=self.N if res is not None else 0, dual=dual)
         return y
 
-    def bwd_dx(self, rt: Runtime, dy: torch.Tensor, M: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def bwd_dx(self, rt: Runtime, dy: torch.Tensor, M: int, out: Optional[torch.Tensor] = None, dual=None) -> torch.Tensor:
         dx = out if out is not None else rt.empty(M, self.Kdim)
-        gemm_act(rt, dy, self.wt, dx, M, self.Kdim, self.N, self.N, self.N, self.Kdim)
+        gemm_act(rt, dy, self.wt, dx, M, self.Kdim, self.N, self.N, self.N, self.Kdim, dual=dual)
         return dx
 
     def bwd_dw(self, rt: Runtime, dy: torch.Tensor, x: torch.Tensor, M: int) -> None:
@@ -460,10 +468,13 @@ class SmallLinearOp:
 # --------------------------------------------------------------------------------------------------
 class LoraOp:
     """Adapter branch of a (possibly fused) LinearOp: y[:, seg_j] += s * (x A_j^T) B_j^T for the J wrapped projections that
-    share the input x (J = 3 for fused q/k/v, 1 for to_out).  Two skinny NT GEMMs forward; backward is one skinny NT GEMM per
-    segment for d(xA^T) (scaled by s through the GEMM alpha), TN GEMMs for dB_j and dA_j, and one NT GEMM that adds
-    d(xA^T) A into dx.  The rank is zero-padded to a multiple of 64 (the GEMM K granule); packed 16-bit copies of the small
-    A / B matrices (stacked A, its transpose, B_j and B_j^T) are refreshed after every optimizer step."""
+    share the input x (J = 3 for fused q/k/v, 1 for to_out).
+
+    Forward: one skinny NT GEMM xs = s * x [A_1; ..; A_J]^T, then the adapter term rides on the base projection as its second
+    operand pair (xs, B_bd) -- B_bd [sum N_j, J*rp] is block-structured, segment j's rows hold B_j in columns j*rp.. -- so y is
+    written once.  Backward: one skinny NT GEMM per segment for d(xA^T) = s * dy_j B_j, TN GEMMs for dB_j and dA_j, and the term
+    d(xA^T) [A_1; ..; A_J] rides on the base data-grad GEMM the same way.  The rank is zero-padded to a multiple of 64 (the GEMM K
+    granule); the packed 16-bit copies of the small matrices are refreshed after every optimizer step."""
 
     def __init__(self, mods):
         self.mods = list(mods)
@@ -475,7 +486,7 @@ class LoraOp:
         self.outs = [m.out_features for m in self.mods]
         assert all(m.r == self.r and m.in_features == self.in_f and m.scaling == self.s for m in self.mods)
         self.trainable = any(m.A.requires_grad or m.B.requires_grad for m in self.mods)
-        self.A3 = self.A3T = None
+        self.A3 = self.A3T = self.Bbd = None
         self.Bp: List[torch.Tensor] = []
         self.BTp: List[torch.Tensor] = []
 
@@ -483,39 +494,44 @@ class LoraOp:
         J, rp = self.J, self.rp
         self.A3 = torch.zeros(J * rp, self.in_f, dtype=rt.dt, device=rt.dev)
         self.A3T = rt.empty(self.in_f, J * rp)
-        self.Bp = [torch.zeros(n, rp, dtype=rt.dt, device=rt.dev) for n in self.outs]
+        self.Bbd = torch.zeros(sum(self.outs), J * rp, dtype=rt.dt, device=rt.dev)
+        self.Bp, off = [], 0
+        for j, n in enumerate(self.outs):
+            self.Bp.append(self.Bbd[off:off + n, j * rp:(j + 1) * rp])          # view, row pitch J*rp
+            off += n
         self.BTp = [rt.empty(rp, n) for n in self.outs]
         if self.r == rp:
             rt.write_once.update(id(q) for m in self.mods for q in (m.A, m.B) if q.requires_grad)
         self.refresh(rt)
 
     def refresh(self, rt: Runtime) -> None:
-        k, r, rp = rt.k, self.r, self.rp
+        k, r, rp, J = rt.k, self.r, self.rp, self.J
         for j, m in enumerate(self.mods):
             if r == rp:
                 k.cast_from_f32(m.A.data, self.A3[j * rp:(j + 1) * rp], r * self.in_f)
-                k.cast_from_f32(m.B.data, self.Bp[j], self.outs[j] * r)
-            else:                                   # padded rank: strided re-layout of two tiny matrices
+            else:                                   # padded rank: strided re-layout of a tiny matrix
                 self.A3[j * rp:j * rp + r].copy_(m.A.data)
-                self.Bp[j][:, :r].copy_(m.B.data)
-            k.transpose(self.Bp[j], rp, self.BTp[j], self.outs[j], self.outs[j], rp)
-        k.transpose(self.A3, self.in_f, self.A3T, self.J * rp, self.J * rp, self.in_f)
+            if r == rp and J == 1:
+                k.cast_from_f32(m.B.data, self.Bbd, self.outs[j] * r)
+            else:
+                self.Bp[j][:, :r].copy_(m.B.data)       # strided block of B_bd
+            k.transpose(self.Bp[j], J * rp, self.BTp[j], self.outs[j], self.outs[j], rp)
+        k.transpose(self.A3, self.in_f, self.A3T, J * rp, J * rp, self.in_f)
 
-    def fwd(self, rt: Runtime, x: torch.Tensor, y: torch.Tensor, M: int, ldy: int) -> torch.Tensor:
-        """y (already holding the base projection) gets the adapter term added in place; returns xs = s * x A^T [M, J*rp]."""
-        k, rp, J = rt.k, self.rp, self.J
-        xs = rt.empty(M, J * rp)
-        k.gemm(x, self.A3, xs, M, J * rp, self.in_f, self.in_f, self.in_f, J * rp, alpha=self.s, variant=rt.gemm_variant)
-        off = 0
-        for j, n in enumerate(self.outs):
-            yj = y[:, off:off + n]
-            k.gemm(xs[:, j * rp:], self.Bp[j], yj, M, n, rp, J * rp, rp, ldy, res=yj, ldres=ldy, variant=rt.gemm_variant)
-            off += n
+    def fwd_xs(self, rt: Runtime, x: torch.Tensor, M: int) -> torch.Tensor:
+        """xs = s * x A^T [M, J*rp]; hand `self.fwd_dual(xs)` to the base projection's `fwd`."""
+        xs = rt.empty(M, self.J * self.rp)
+        rt.k.gemm(x, self.A3, xs, M, self.J * self.rp, self.in_f, self.in_f, self.in_f, self.J * self.rp, alpha=self.s,
+                  variant=rt.gemm_variant)
         return xs
 
-    def bwd(self, rt: Runtime, dy: torch.Tensor, lddy: int, x: torch.Tensor, xs: torch.Tensor, dx: Optional[torch.Tensor],
-            M: int) -> None:
-        """dy [M, sum N_j] (row pitch lddy); accumulates A_j.grad / B_j.grad and, when dx is given, dx += d(xA^T) A."""
+    def fwd_dual(self, xs: torch.Tensor):
+        w = self.J * self.rp
+        return (xs, self.Bbd, w, w, w)
+
+    def bwd(self, rt: Runtime, dy: torch.Tensor, lddy: int, x: torch.Tensor, xs: torch.Tensor, M: int) -> torch.Tensor:
+        """dy [M, sum N_j] (row pitch lddy); accumulates A_j.grad / B_j.grad and returns dxa = s * dy B [M, J*rp]; hand
+        `self.bwd_dual(dxa)` to the base projection's `bwd_dx` for the dx term."""
         k, r, rp, J = rt.k, self.r, self.rp, self.J
         dxa = rt.empty(M, J * rp)
         off = 0
@@ -539,9 +555,11 @@ class LoraOp:
                     tmp = rt.zeros_f32(rp, self.in_f)
                     gemm_tn_acc(rt, dxa[:, j * rp:], x, tmp, M, rp, self.in_f, J * rp, self.in_f)
                     m.A.grad.add_(tmp[:r])
-        if dx is not None:
-            k.gemm(dxa, self.A3T, dx, M, self.in_f, J * rp, J * rp, J * rp, self.in_f, res=dx, ldres=self.in_f,
-                   variant=rt.gemm_variant)
+        return dxa
+
+    def bwd_dual(self, dxa: torch.Tensor):
+        w = self.J * self.rp
+        return (dxa, self.A3T, w, w, w)
 
 
 class SmallLoraOp:

@@ -211,6 +211,23 @@ class _Attention(nn.Module):
             self.v_lora.bwd(rt, dv, ctx, va, Bn, need_dx=False)
 
 
+def _proj_fwd(rt, lin, lora, x, M, **kw):
+    """Projection with an optional LoRA adapter: the adapter term is the base GEMM's second operand pair.  Returns (y, xs)."""
+    if lora is None:
+        return lin.fwd(rt, x, M, **kw), None
+    xs = lora.fwd_xs(rt, x, M)
+    return lin.fwd(rt, x, M, dual=lora.fwd_dual(xs), **kw), xs
+
+
+def _proj_bwd_dx(rt, lin, lora, dy, lddy, x, xs, M, need_dx=True):
+    """Adapter gradients (when there is an adapter) and d(input) of the adapted projection, the adapter's share riding on the
+    base data-grad GEMM."""
+    dxa = lora.bwd(rt, dy, lddy, x, xs, M) if lora is not None else None
+    if not need_dx:
+        return None
+    return lin.bwd_dx(rt, dy, M, dual=lora.bwd_dual(dxa) if lora is not None else None)
+
+
 # ==================================================================================================
 # transformer blocks
 # ==================================================================================================
@@ -247,16 +264,14 @@ class BasicTransformerBlock(nn.Module):
     def fwd(self, rt: Runtime, h, g: Geom, ctx):
         k, C, M, S = rt.k, self.dim, g.M, g.HW
         n1, st1 = self.ln1.fwd(rt, h, M)
-        qkv = self.attn1.qkv.fwd(rt, n1, M)
-        xs_qkv = self.attn1.qkv_lora.fwd(rt, n1, qkv, M, 3 * C) if self.attn1.qkv_lora is not None else None
+        qkv, xs_qkv = _proj_fwd(rt, self.attn1.qkv, self.attn1.qkv_lora, n1, M)
         if not (self.attn1.qkv_lora is not None and self.attn1.qkv_lora.trainable):
             n1 = None
         o = rt.empty(M, C)
         lse = rt.f32(g.N * self.heads * S)
         k.attn_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], o, lse, g.N, self.heads, S, 3 * C, C, HEAD_DIM ** -0.5)
         cvec, cv = self.attn2.cross_vec(rt, ctx, g.B)
-        h2 = self.attn1.o.fwd(rt, o, M, res=h, rowvec=cvec, rv_ld=C, rv_rpg=g.T * g.HW)
-        xs_o = self.attn1.o_lora.fwd(rt, o, h2, M, C) if self.attn1.o_lora is not None else None
+        h2, xs_o = _proj_fwd(rt, self.attn1.o, self.attn1.o_lora, o, M, res=h, rowvec=cvec, rv_ld=C, rv_rpg=g.T * g.HW)
         n3, st3 = self.ln3.fwd(rt, h2, M)
         h3, pre, _ = self.ff.fwd(rt, n3, M, res=h2)
         self.sv = (h, st1, qkv, o, lse, h2, st3, pre, n1, xs_qkv, xs_o, cv, ctx)
@@ -273,9 +288,7 @@ class BasicTransformerBlock(nn.Module):
             dvec = rt.f32(g.B, C)
             k.colsum(dh2, dvec, M, C, C, g.B, g.T * g.HW, 0)
             self.attn2.cross_vec_bwd(rt, dvec, cv, ctx, g.B)
-        d_o = self.attn1.o.bwd_dx(rt, dh2, M)
-        if self.attn1.o_lora is not None and self.attn1.o_lora.trainable:
-            self.attn1.o_lora.bwd(rt, dh2, C, o, xs_o, d_o, M)
+        d_o = _proj_bwd_dx(rt, self.attn1.o, self.attn1.o_lora, dh2, C, o, xs_o, M)
         D = rt.f32(g.N * self.heads * S)
         k.attn_bwd_prep(o, d_o, D, g.N, self.heads, S, C)
         dqkv = rt.empty(M, 3 * C)
@@ -287,9 +300,7 @@ class BasicTransformerBlock(nn.Module):
         lora_q = self.attn1.qkv_lora is not None and self.attn1.qkv_lora.trainable
         if not need_dx and not lora_q:
             return None
-        dn1 = self.attn1.qkv.bwd_dx(rt, dqkv, M) if need_dx else None
-        if lora_q:
-            self.attn1.qkv_lora.bwd(rt, dqkv, 3 * C, n1, xs_qkv, dn1, M)
+        dn1 = _proj_bwd_dx(rt, self.attn1.qkv, self.attn1.qkv_lora, dqkv, 3 * C, n1, xs_qkv, M, need_dx=need_dx)
         del dqkv
         if not need_dx:
             return None
@@ -340,13 +351,11 @@ class TemporalBasicTransformerBlock(nn.Module):
         n0, st0 = self.ln0.fwd(rt, x, M)
         h, pre0, g0 = self.ff_in.fwd(rt, n0, M, res=x)
         n1, st1 = self.ln1.fwd(rt, h, M)
-        qkv = self.attn1.qkv.fwd(rt, n1, M)
-        xs_qkv = self.attn1.qkv_lora.fwd(rt, n1, qkv, M, 3 * C) if self.attn1.qkv_lora is not None else None
+        qkv, xs_qkv = _proj_fwd(rt, self.attn1.qkv, self.attn1.qkv_lora, n1, M)
         o = rt.empty(M, C)
         k.tattn_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], o, g.B, g.T, g.HW, self.heads, 3 * C, C, HEAD_DIM ** -0.5)
         cvec, cv = self.attn2.cross_vec(rt, tctx, g.B)
-        h1 = self.attn1.o.fwd(rt, o, M, res=h, rowvec=cvec, rv_ld=C, **self._rv(g))
-        xs_o = self.attn1.o_lora.fwd(rt, o, h1, M, C) if self.attn1.o_lora is not None else None
+        h1, xs_o = _proj_fwd(rt, self.attn1.o, self.attn1.o_lora, o, M, res=h, rowvec=cvec, rv_ld=C, **self._rv(g))
         n3, st3 = self.ln3.fwd(rt, h1, M)
         out, pre, gg = self.ff.fwd(rt, n3, M, res=h1)
         if not self.trainable:
@@ -369,20 +378,16 @@ class TemporalBasicTransformerBlock(nn.Module):
             dvec = rt.f32(g.B, C)
             k.colsum(dh1, dvec, M, C, C, g.B, rv["rv_rpg"], rv["rv_mod"])
             self.attn2.cross_vec_bwd(rt, dvec, cv, tctx, g.B)
-        d_o = self.attn1.o.bwd_dx(rt, dh1, M)
+        d_o = _proj_bwd_dx(rt, self.attn1.o, self.attn1.o_lora, dh1, C, o, xs_o, M)
         if self.attn1.o.trainable:
             self.attn1.o.bwd_dw(rt, dh1, o, M)
-        if self.attn1.o_lora is not None and self.attn1.o_lora.trainable:
-            self.attn1.o_lora.bwd(rt, dh1, C, o, xs_o, d_o, M)
         dqkv = rt.empty(M, 3 * C)
         k.tattn_bwd(qkv, qkv[:, C:], qkv[:, 2 * C:], d_o, dqkv, dqkv[:, C:], dqkv[:, 2 * C:], g.B, g.T, g.HW,
                     self.heads, 3 * C, C, 3 * C, HEAD_DIM ** -0.5)
         del d_o, qkv, o
-        dn1 = self.attn1.qkv.bwd_dx(rt, dqkv, M)
+        dn1 = _proj_bwd_dx(rt, self.attn1.qkv, self.attn1.qkv_lora, dqkv, 3 * C, n1, xs_qkv, M)
         if self.attn1.qkv.trainable:
             self.attn1.qkv.bwd_dw(rt, dqkv, n1, M)
-        if self.attn1.qkv_lora is not None and self.attn1.qkv_lora.trainable:
-            self.attn1.qkv_lora.bwd(rt, dqkv, 3 * C, n1, xs_qkv, dn1, M)
         del dqkv, n1
         dh = self.ln1.bwd(rt, dn1, h, st1, M, add=dh1)
         del dn1, dh1, h

@@ -86,7 +86,7 @@ class EmuBackend:
     # ---- GEMM family ----
     def gemm(self, A, B, C, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
              res=None, ldres=0, gather=None, out_mode=K.OUT_ACT, alpha=1.0, split_k=1, variant=0, epilogue=0, aux_in=None,
-             aux_out=None, aux_dim=0):
+             aux_out=None, aux_dim=0, dual=None):
         assert Kd % 64 == 0, "GEMM K must be a multiple of 64"
         if gather is None or gather.mode == K.GATHER_PLAIN:
             a = V(A, M, Kd, lda).float()
@@ -94,7 +94,12 @@ class EmuBackend:
             a = gather_rows(A, gather, M)
             assert a.shape[1] == Kd
         b = V(B, N, Kd, ldb).float()
-        v = alpha * (a @ b.t())
+        v = a @ b.t()
+        if dual is not None:
+            A2, B2, K2, lda2, ldb2 = dual
+            assert K2 % 64 == 0 and split_k == 1 and epilogue == K.EPI_NONE
+            v = v + V(A2, M, K2, lda2).float() @ V(B2, N, K2, ldb2).float().t()
+        v = alpha * v
         if bias is not None:
             v = v + V1(bias, N)[None]
         if rowvec is not None:

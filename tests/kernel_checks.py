@@ -78,6 +78,24 @@ def check_gemm_plain(P, dt, variant):
                 out = torch.ones(M, N, dtype=torch.float32, device=P.dev)
             o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, N, Kd, Kd, Kd, N), kw), dict(C=out))
             res.append((f"gemm v{variant} {M}x{N}x{Kd} {mode}", relerr(o1["C"], o2["C"]), tol_for(dt)))
+    # second operand pair (svdx_gemm_dual, the LoRA term): strided A2 / B2 inside wider buffers, K2 = 64 / 192, K = 64 (one main tile)
+    if variant >= 2:
+        for (M, N, Kd, K2, pa, pb) in [(200, 320, 320, 64, 64, 64), (300, 960, 320, 192, 192, 192), (130, 640, 64, 64, 192, 256),
+                                       (1000, 1280, 1280, 192, 192, 192), (70, 128, 128, 128, 128, 128)]:
+            A, B = rnd((M, Kd), dt, P.dev, g), rnd((N, Kd), dt, P.dev, g, Kd ** -0.5)
+            A2w, B2w = rnd((M, pa), dt, P.dev, g), rnd((N, pb), dt, P.dev, g, K2 ** -0.5)
+            A2, B2 = A2w[:, pa - K2:], B2w[:, pb - K2:]
+            bias, R, rv = rndf((N,), P.dev, g), rnd((M, N), dt, P.dev, g), rndf((4, N), P.dev, g)
+            for mode in ("plain", "bias_res_rowvec", "f32"):
+                kw = dict(variant=variant, dual=(A2, B2, K2, pa, pb))
+                out = torch.zeros(M, N, dtype=dt, device=P.dev)
+                if mode == "bias_res_rowvec":
+                    kw.update(bias=bias, res=R, ldres=N, rowvec=rv, rv_ld=N, rv_mod=4)
+                elif mode == "f32":
+                    kw.update(out_mode=K.OUT_F32, alpha=0.5)
+                    out = torch.zeros(M, N, dtype=torch.float32, device=P.dev)
+                o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, N, Kd, Kd, Kd, N), kw), dict(C=out))
+                res.append((f"gemm v{variant} dual {M}x{N}x{Kd}+{K2} {mode}", relerr(o1["C"], o2["C"]), tol_for(dt)))
     # split-K into a float scratch + finalize epilogue
     M, N, Kd = 200, 320, 1280
     A, B = rnd((M, Kd), dt, P.dev, g), rnd((N, Kd), dt, P.dev, g, Kd ** -0.5)
@@ -185,6 +203,11 @@ def check_gemm_gather(P, dt, variant):
         o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, co_, taps * ci_, ci_, taps * ci_, co_),
                                           dict(bias=bias, gather=ga, variant=variant)), dict(C=out))
         res.append((f"gemm v{variant} {label}", relerr(o1["C"], o2["C"]), tol_for(dt)))
+        if variant >= 2 and label in ("conv3x3 s1", "temporal3"):       # taps, then the plain second operand pair
+            A2, B2 = rnd((M, 64), dt, P.dev, g), rnd((co_, 64), dt, P.dev, g, 0.125)
+            o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, co_, taps * ci_, ci_, taps * ci_, co_),
+                                              dict(bias=bias, gather=ga, variant=variant, dual=(A2, B2, 64, 64, 64))), dict(C=out))
+            res.append((f"gemm v{variant} {label} + dual", relerr(o1["C"], o2["C"]), tol_for(dt)))
     # stride-1 3x3 convolutions at the image widths of every UNet level: several channel slices, tiles that straddle image / batch
     # borders, residual epilogue, and split-K into float slabs
     for (n_, h_, w_, ci_, co_) in [(2, 20, 64, 192, 320), (3, 9, 16, 128, 160), (1, 5, 8, 64, 320), (2, 7, 32, 320, 160)]:
