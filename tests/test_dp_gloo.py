@@ -60,6 +60,14 @@ def _worker(rank, world, port, out):
         res[overlap] = dict(p=tr.p_flat.clone(), loss=tr.last_loss().clone())
     assert torch.equal(res[True]["p"], res[False]["p"]) and torch.equal(res[True]["loss"], res[False]["loss"])
     torch.save(res[True], os.path.join(out, f"r{rank}.pt"))
+    # checkpoint-N under two ranks: every rank writes its RNG states, rank 0 the replicated rest; the scheduler takes
+    # accelerate's "num_processes scheduler steps per optimizer step" from the process group
+    from svd_xtend_amd.optimization import get_scheduler
+    sched = get_scheduler("linear", optimizer=tr, num_warmup_steps=2 * world, num_training_steps=10 * world)
+    assert tr.schedule["steps_per_step"] == world and sched.last_epoch == 2 * world
+    assert abs(sched.get_last_lr()[0] - 1e-3 * (10 * world - 2 * world) / (10 * world - 2 * world)) < 1e-12   # warmup just ended
+    tr.save_state(os.path.join(out, "checkpoint-2"), scheduler=sched)
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -71,6 +79,9 @@ def test_two_rank_allreduce_equals_grad_accumulation(tmp_path):
     r1 = torch.load(tmp_path / "r1.pt")
     assert torch.equal(r0["p"], r1["p"])                  # replicas identical after the reduced steps
     assert torch.equal(r0["loss"], r1["loss"])            # the loss rides in the same buffer
+    assert sorted(os.listdir(tmp_path / "checkpoint-2")) == ["optimizer.bin", "random_states_0.pkl", "random_states_1.pkl",
+                                                              "scheduler.bin", "unet"]
+    assert torch.load(tmp_path / "checkpoint-2" / "scheduler.bin", weights_only=False)["last_epoch"] == 4
     _setup()
     from svd_xtend_amd.train import Trainer
     tr = Trainer(_make(0), dtype=torch.float32, lr=1e-3, grad_accum=2)

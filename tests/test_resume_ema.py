@@ -246,6 +246,36 @@ def test_resume_continues_the_same_trajectory(emu_backend, tmp_path, dtype):
         assert torch.equal(p.data, q.data), n
 
 
+def test_resume_with_lora_adapters(emu_backend, tmp_path):
+    """train_svd_lora.py uses the same save / load hooks (:693-715): the unet/ folder then carries peft's key names."""
+    from svd_xtend_amd.lora import LoraConfig
+    cfg = LoraConfig(r=8, lora_alpha=8, init_lora_weights="gaussian", target_modules=["to_k", "to_q", "to_v", "to_out.0"])
+
+    def fresh(seed):
+        m = build(seed)
+        for p in m.parameters():
+            p.requires_grad_(False)
+        torch.manual_seed(seed)
+        m.add_adapter(cfg)
+        return Trainer(m, dtype=torch.float32, lr=1e-2)
+    batches = [batch_of(30 + i) for i in range(3)]
+    a = fresh(7)
+    for b in batches:
+        a.step(b)
+    c = fresh(7)
+    for b in batches[:2]:
+        c.step(b)
+    path = str(tmp_path / "checkpoint-2")
+    c.save_state(path)
+    from safetensors.torch import load_file
+    keys = set(load_file(os.path.join(path, "unet", "diffusion_pytorch_model.safetensors")))
+    assert any(k.endswith("to_q.lora_A.default.weight") for k in keys) and any(k.endswith("to_q.base_layer.weight") for k in keys)
+    d = fresh(8)
+    d.load_state(path)
+    d.step(batches[2])
+    assert torch.equal(d.p_flat, a.p_flat) and torch.equal(d.m_flat, a.m_flat) and float(d.opt_state[0]) == 3.0
+
+
 def test_optimizer_bin_is_a_torch_adamw_state_dict(emu_backend, tmp_path):
     """optimizer.bin written here loads into torch.optim.AdamW over the same parameter list, and one written by torch loads here."""
     tr = Trainer(build(5), dtype=torch.float32, lr=1e-3)
