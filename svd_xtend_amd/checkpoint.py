@@ -81,12 +81,11 @@ def load_optimizer_state_dict(trainer, sd: dict) -> None:
     if len(order) != len(trainer.params):
         raise ValueError(f"optimizer state holds {len(order)} parameters, the trainer has {len(trainer.params)} trainables")
     g0 = groups[0]
-    base_lr = float(g0.get("initial_lr", g0["lr"]))
-    mine = (trainer.lr, tuple(trainer.betas), trainer.eps, trainer.wd)
-    theirs = (base_lr, tuple(float(b) for b in g0["betas"]), float(g0["eps"]), float(g0["weight_decay"]))
-    if any(abs(a - b) > 1e-12 * max(1.0, abs(a)) for a, b in zip((mine[0], *mine[1], mine[2], mine[3]),
-                                                                  (theirs[0], *theirs[1], theirs[2], theirs[3]))):
-        raise ValueError(f"optimizer hyper-parameters differ: checkpoint (lr, betas, eps, wd) = {theirs}, trainer = {mine}")
+    theirs = [float(g0.get("initial_lr", g0["lr"])), float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]),
+              float(g0["weight_decay"])]
+    mine = [trainer.lr, trainer.betas[0], trainer.betas[1], trainer.eps, trainer.wd]
+    if any(abs(a - b) > 1e-12 * max(1.0, abs(a)) for a, b in zip(mine, theirs)):
+        raise ValueError(f"optimizer hyper-parameters differ: checkpoint (lr, beta1, beta2, eps, wd) = {theirs}, trainer = {mine}")
     steps = set()
     trainer.m_flat.zero_()
     trainer.v_flat.zero_()
