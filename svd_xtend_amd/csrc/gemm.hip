@@ -890,25 +890,32 @@ __global__ __launch_bounds__(256) void small_linear_nt(const float* __restrict__
     }
 }
 
-// trans = 1: Y[m,k] += sum_n X[m,n] W[n,k]; thread = (8 consecutive k, slice of 32 n), partial sums by atomicAdd
-constexpr int NN_SLICE = 32;
+// trans = 1: Y[m,k] += sum_n X[m,n] W[n,k]; thread = (8 consecutive k, slice of 8 n), partial sums by atomicAdd.  The op is a
+// GEMV over a matrix of a few MB: it is latency-shaped, so a thread issues all of its 16-byte row loads before the first FMA and
+// the slices are short enough for ~100 blocks at N = K = 1280 (32-row slices with dependent loads ran at 160 GB/s).
+constexpr int NN_SLICE = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void small_linear_nn(const float* X, const T* W, float* Y, int M, int N, int K, int ldw) {
     const int k8n = K / 8;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int k8 = idx % k8n, ns = idx / k8n;
     const int m = blockIdx.y;
-    const int n0 = ns * NN_SLICE, n1 = min(N, n0 + NN_SLICE);
+    const int n0 = ns * NN_SLICE;
     if (n0 >= N) return;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const float* x = X + (size_t)m * N;
-    for (int n = n0; n < n1; ++n) {
-        float wv[8];
-        load8<T>(W + (size_t)n * ldw + k8 * 8, wv);
-        const float xv = x[n];
+    Vec8<T> w[NN_SLICE];
+    float xv[NN_SLICE];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += xv * wv[j];
+    for (int i = 0; i < NN_SLICE; ++i) {
+        const int n = min(n0 + i, N - 1);
+        w[i] = *reinterpret_cast<const Vec8<T>*>(W + (size_t)n * ldw + k8 * 8);
+        xv[i] = n0 + i < N ? x[n] : 0.f;
     }
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NN_SLICE; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += xv[i] * to_f<T>(w[i].v[j]);
     float* y = Y + (size_t)m * K + k8 * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) atomicAdd(y + j, acc[j]);
