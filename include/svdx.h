@@ -78,12 +78,15 @@ int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int ld
  *   C = alpha * (gather(A) B^T + A2 B2^T) (+ bias + rowvec + res),  A2 [M, K2] row pitch lda2, B2 [N, K2] row pitch ldb2.
  * One launch computes a LoRA-adapted projection y = x W^T + (s x A^T) B^T (train_svd_lora.py:659-674, peft's Linear.forward)
  * instead of a second GEMM that re-reads and re-writes y.  Variant-4 kernels only (variant >= 2), no split-K, no fused epilogue;
- * K2 a multiple of 64, both pitches multiples of 8 elements, 16-byte aligned bases. */
+ * K2 a multiple of 64, both pitches multiples of 8 elements, 16-byte aligned bases.
+ * a2_seg_n > 0 (fused q/k/v adapters): output columns [j*a2_seg_n, (j+1)*a2_seg_n) pair with A2 columns [j*K2, (j+1)*K2), so A2 is
+ * [M, (N / a2_seg_n) * K2] and B2 stays [N, K2]; a2_seg_n must divide N and be a multiple of the kernel's tile width (160 when
+ * N % 160 == 0 and variant != 8, else 128). */
 int svdx_gemm_dual(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                    const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
                    const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
                    int out_mode, float alpha, int variant, const void* A2, const void* B2, int K2, int lda2, int ldb2,
-                   int dtype, void* stream);
+                   int a2_seg_n, int dtype, void* stream);
 
 /* Weight-gradient GEMM in TN form: C[n*ldc + k] (+)= sum_r A[r*lda + n] * B[r*ldb + k]  (A = dY [R,N], B = X [R,K], float C).
  * Replaces the dW part of autograd's Linear backward (train_svd.py:1044) without materialising transposes.

@@ -37,6 +37,7 @@ struct GemmParams {
     float* a_colsum;                                           // TN form: += column sums of A (the bias gradient), or null
     // variant 4, second operand pair: acc += A2 [M, K2] B2^T [N, K2] after the main reduction (the LoRA term of a projection)
     const void* A2; const void* B2; int K2, lda2, ldb2, a2_bytes, b2_bytes;
+    int a2_seg;   // > 0: output columns [j * a2_seg, (j + 1) * a2_seg) read A2 columns [j * K2, (j + 1) * K2) (fused q/k/v adapters)
 };
 
 struct RowInfo { int a, b, base; };   // per gathered A row (meaning depends on gather mode)
@@ -603,8 +604,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
             tap = 0;                                                   // B offset (tap * cin + ci0) becomes ci0
             rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A2), 0, p.a2_bytes, 0x00020000);
             rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B2), 0, p.b2_bytes, 0x00020000);
+            const int a2_col = p.a2_seg > 0 ? (n0 / p.a2_seg) * p.K2 : 0;
 #pragma unroll
-            for (int i = 0; i < NLA; ++i) voa[i] = (min(m0 + i * RPP + ld_row, p.M - 1) * p.lda2 + lc * 8) * 2;
+            for (int i = 0; i < NLA; ++i) voa[i] = (min(m0 + i * RPP + ld_row, p.M - 1) * p.lda2 + a2_col + lc * 8) * 2;
 #pragma unroll
             for (int i = 0; i < NLB; ++i) {
                 const int nl = i * RPP + ld_row;
@@ -1078,12 +1080,15 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
                       const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
                       const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
                       int out_mode, float alpha, int split_k, int variant, int epilogue, const void* aux_in, void* aux_out,
-                      int aux_dim, const void* A2, const void* B2, int K2, int lda2, int ldb2, int dtype, void* stream) {
+                      int aux_dim, const void* A2, const void* B2, int K2, int lda2, int ldb2, int a2_seg, int dtype, void* stream) {
     SVDX_CHECK_ARG(A && B && C, "svdx_gemm: null operand");
     if (K2 > 0) {
         SVDX_CHECK_ARG(A2 && B2 && K2 % BK == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && lda2 >= K2 && ldb2 >= K2 &&
                            (((uintptr_t)A2 | (uintptr_t)B2) & 15) == 0, "svdx_gemm_dual: second operand pair misaligned (K2=%d)", K2);
         SVDX_CHECK_ARG(variant >= 2 && split_k == 1, "svdx_gemm_dual: needs variant 4 and split_k == 1");
+        const int bn = (variant != 8 && N % 160 == 0) ? 160 : 128;           // tile width the dispatch below will pick
+        SVDX_CHECK_ARG(a2_seg == 0 || (a2_seg > 0 && N % a2_seg == 0 && a2_seg % bn == 0 && lda2 >= (N / a2_seg) * K2),
+                       "svdx_gemm_dual: a2_seg_n=%d must divide N=%d, be a multiple of the %d-column tile, and fit lda2", a2_seg, N, bn);
     }
     if (epilogue != SVDX_EPI_NONE) {
         SVDX_CHECK_ARG(variant >= 2 && out_mode == SVDX_OUT_ACT && split_k == 1 && !res && !rowvec && aux_dim > 0 && aux_dim % 64 == 0 &&
@@ -1107,7 +1112,7 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
     p.res = res; p.ldres = ldres; p.zero_page = zero_page;
     p.out_mode = out_mode; p.alpha = alpha; p.split_k = split_k; p.slab_stride = (long)M * ldc;
     p.epi = epilogue; p.aux_in = aux_in; p.aux_out = aux_out; p.aux_dim = aux_dim; p.a_colsum = nullptr;
-    p.A2 = A2; p.B2 = B2; p.K2 = K2 > 0 ? K2 : 0; p.lda2 = lda2; p.ldb2 = ldb2; p.a2_bytes = p.b2_bytes = 0;
+    p.A2 = A2; p.B2 = B2; p.K2 = K2 > 0 ? K2 : 0; p.lda2 = lda2; p.ldb2 = ldb2; p.a2_bytes = p.b2_bytes = 0; p.a2_seg = K2 > 0 ? a2_seg : 0;
     if (gather && gather->mode != SVDX_GATHER_PLAIN) {
         p.g = *gather;
         SVDX_CHECK_ARG(p.g.cin % BK == 0, "svdx_gemm: gather cin=%d must be a multiple of %d", p.g.cin, BK);
@@ -1149,7 +1154,7 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
     if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) { a_bytes = 0; b_bytes = 0; }   // falls back to variant 1 (64-bit pointers)
     if (p.K2 > 0) {
         const long b_rows = epilogue == SVDX_EPI_GEGLU_FWD ? 2L * aux_dim : N;
-        const long a2 = ((long)(M - 1) * lda2 + K2) * 2, b2 = ((b_rows - 1) * ldb2 + K2) * 2;
+        const long a2 = ((long)(M - 1) * lda2 + (long)(a2_seg > 0 ? N / a2_seg : 1) * K2) * 2, b2 = ((b_rows - 1) * ldb2 + K2) * 2;
         if (a_bytes == 0 || a2 >= (1L << 31) || b2 >= (1L << 31)) { svdx_set_error("svdx_gemm_dual: operands too large for the buffer-addressed kernel"); return -2; }
         p.a2_bytes = (int)a2; p.b2_bytes = (int)b2;
     }
@@ -1177,17 +1182,17 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
                          int out_mode, float alpha, int split_k, int variant, int epilogue, const void* aux_in, void* aux_out,
                          int aux_dim, int dtype, void* stream) {
     return gemm_entry(A, B, C, M, N, K, lda, ldb, ldc, bias, rowvec, rv_ld, rv_rows_per_group, rv_mod, res, ldres, gather, zero_page,
-                      out_mode, alpha, split_k, variant, epilogue, aux_in, aux_out, aux_dim, nullptr, nullptr, 0, 0, 0, dtype, stream);
+                      out_mode, alpha, split_k, variant, epilogue, aux_in, aux_out, aux_dim, nullptr, nullptr, 0, 0, 0, 0, dtype, stream);
 }
 
 extern "C" int svdx_gemm_dual(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                               const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
                               const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
                               int out_mode, float alpha, int variant, const void* A2, const void* B2, int K2, int lda2, int ldb2,
-                              int dtype, void* stream) {
+                              int a2_seg_n, int dtype, void* stream) {
     SVDX_CHECK_ARG(K2 > 0, "svdx_gemm_dual: K2 must be positive");
     return gemm_entry(A, B, C, M, N, K, lda, ldb, ldc, bias, rowvec, rv_ld, rv_rows_per_group, rv_mod, res, ldres, gather, zero_page,
-                      out_mode, alpha, 1, variant, SVDX_EPI_NONE, nullptr, nullptr, 0, A2, B2, K2, lda2, ldb2, dtype, stream);
+                      out_mode, alpha, 1, variant, SVDX_EPI_NONE, nullptr, nullptr, 0, A2, B2, K2, lda2, ldb2, a2_seg_n, dtype, stream);
 }
 
 extern "C" int svdx_small_linear(const float* X, const void* W, const float* bias, float* Y, int M, int N, int K,

@@ -62,7 +62,7 @@ class Gather:
 # signature table: p void*, i int, f float, l int64, z size_t
 _SIGS = {
     "svdx_gemm": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifii" "ippi" "ip",
-    "svdx_gemm_dual": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifi" "pp" "iii" "ip",
+    "svdx_gemm_dual": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifi" "pp" "iiii" "ip",
     "svdx_gemm_tn": "ppp" "iiiiii" "pp" "ii" "ip",
     "svdx_gemm_finalize": "pil" "pi" "iii" "pp" "iii" "pi" "ip",
     "svdx_small_linear": "pppp" "iiii" "iii" "ip",
@@ -173,15 +173,16 @@ class HipBackend:
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
              res=None, ldres=0, gather: Optional[Gather] = None, out_mode=OUT_ACT, alpha=1.0, split_k=1,
              variant=0, epilogue=EPI_NONE, aux_in=None, aux_out=None, aux_dim=0, dual=None):
-        """dual = (A2, B2, K2, lda2, ldb2): second operand pair reduced into the same accumulators (svdx_gemm_dual)."""
+        """dual = (A2, B2, K2, lda2, ldb2[, a2_seg_n]): second operand pair reduced into the same accumulators (svdx_gemm_dual)."""
         g = gather.to_c() if gather is not None else None
         if dual is not None:
-            A2, B2, K2, lda2, ldb2 = dual
+            A2, B2, K2, lda2, ldb2 = dual[:5]
+            seg = dual[5] if len(dual) > 5 else 0
             assert split_k == 1 and epilogue == EPI_NONE and A2.dtype == A.dtype == B2.dtype
             self._call("svdx_gemm_dual", _p(A), _p(B), _p(C), M, N, K, lda, ldb, ldc, _f32(bias),
                        _f32(rowvec), rv_ld, rv_rpg, rv_mod, _p(res), ldres,
                        ctypes.cast(ctypes.pointer(g), ctypes.c_void_p) if g is not None else None,
-                       _p(self._zero_page), out_mode, float(alpha), variant, _p(A2), _p(B2), K2, lda2, ldb2, _dt(A), self._stream())
+                       _p(self._zero_page), out_mode, float(alpha), variant, _p(A2), _p(B2), K2, lda2, ldb2, seg, _dt(A), self._stream())
             return
         self._call("svdx_gemm", _p(A), _p(B), _p(C), M, N, K, lda, ldb, ldc, _f32(bias),
                    _f32(rowvec), rv_ld, rv_rpg, rv_mod, _p(res), ldres,

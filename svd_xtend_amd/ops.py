@@ -24,17 +24,33 @@ def rup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+def _layout_order(names: List[str]) -> List[int]:
+    """Order in which the trainables are laid out in the flat buffer.  named_parameters() order, except that the LoRA factors
+    of one attention module are regrouped as A_q, A_k, A_v, A_out, B_q, B_k, B_v, B_out: the stacked q/k/v factors are then
+    contiguous blocks whose 16-bit twins (written by AdamW) are GEMM operands as they stand -- no per-step re-packing."""
+    first, keys = {}, []
+    for i, n in enumerate(names):
+        if ".lora_A." in n or ".lora_B." in n:
+            g = first.setdefault(n.split(".to_")[0], i)
+            keys.append((g, 0 if ".lora_A." in n else 1, i))
+        else:
+            keys.append((i, 0, i))
+    return sorted(range(len(names)), key=lambda i: keys[i])
+
+
 def flatten_trainables(model: "nn.Module", align: int = 64):
-    """Re-home every trainable parameter (and its .grad) as a view of one flat float buffer, in named_parameters()
-    order -- adjacent q/k/v weights then form one [3C, C] block for the fused weight-grad GEMM, and the whole set is
-    one all-reduce / one AdamW launch.  Returns (params, offsets, n_flat, p_flat, g_flat); the buffers carry one extra
-    aligned slot at the tail (the loss rides there through the gradient all-reduce)."""
-    params = [p for _, p in model.named_parameters() if p.requires_grad]
+    """Re-home every trainable parameter (and its .grad) as a view of one flat float buffer -- adjacent q/k/v weights then form
+    one [3C, C] block for the fused weight-grad GEMM, and the whole set is one all-reduce / one AdamW launch.  Returns
+    (params, offsets, n_flat, p_flat, g_flat) with params in named_parameters() order (the order of the reference's optimizer
+    parameter list) and offsets following `_layout_order`; the buffers carry one extra aligned slot at the tail (the loss rides
+    there through the gradient all-reduce)."""
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    params = [p for _, p in named]
     dev = params[0].device if params else next(model.parameters()).device
-    offs, off = [], 0
-    for p in params:
-        offs.append(off)
-        off = rup(off + p.numel(), align)
+    offs, off = [0] * len(params), 0
+    for i in _layout_order([n for n, _ in named]):
+        offs[i] = off
+        off = rup(off + params[i].numel(), align)
     p_flat = torch.zeros(off + align, dtype=torch.float32, device=dev)
     g_flat = torch.zeros(off + align, dtype=torch.float32, device=dev)
     for p, o in zip(params, offs):
@@ -258,8 +274,11 @@ def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowve
             k.gemm_finalize(acc, split, M * N, out, M, N, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg,
                             rv_mod=rv_mod, res=res, ldres=ldres)
         if dual is not None and fused is None:
-            A2, B2, K2, lda2, ldb2 = dual
-            k.gemm(A2, B2, out, M, N, K2, lda2, ldb2, ldc, res=out, ldres=ldc, variant=rt.gemm_variant)
+            A2, B2, K2, lda2, ldb2 = dual[:5]
+            seg = dual[5] if len(dual) > 5 and dual[5] else N
+            for j in range(N // seg):            # the adapter term as its own accumulate launch (per q/k/v segment)
+                oj = out[:, j * seg:]
+                k.gemm(A2[:, j * K2:], B2[j * seg:], oj, M, seg, K2, lda2, ldb2, ldc, res=oj, ldres=ldc, variant=rt.gemm_variant)
 
     tuned_call(rt, key, lambda: _nt_candidates(M, N, Kd, splittable), lambda: choose_cfg(rt, M, N, Kd, ldc), run)
 
@@ -486,26 +505,73 @@ class LoraOp:
         self.outs = [m.out_features for m in self.mods]
         assert all(m.r == self.r and m.in_features == self.in_f and m.scaling == self.s for m in self.mods)
         self.trainable = any(m.A.requires_grad or m.B.requires_grad for m in self.mods)
-        self.A3 = self.A3T = self.Bbd = None
+        self.A3 = self.A3T = self.Bbd = self.Bst = None
+        self.fast = self.seg_ok = False
         self.Bp: List[torch.Tensor] = []
         self.BTp: List[torch.Tensor] = []
 
     def pack(self, rt: Runtime) -> None:
         J, rp = self.J, self.rp
-        self.A3 = torch.zeros(J * rp, self.in_f, dtype=rt.dt, device=rt.dev)
-        self.A3T = rt.empty(self.in_f, J * rp)
-        self.Bbd = torch.zeros(sum(self.outs), J * rp, dtype=rt.dt, device=rt.dev)
-        self.Bp, off = [], 0
-        for j, n in enumerate(self.outs):
-            self.Bp.append(self.Bbd[off:off + n, j * rp:(j + 1) * rp])          # view, row pitch J*rp
-            off += n
-        self.BTp = [rt.empty(rp, n) for n in self.outs]
+        n_sum = sum(self.outs)
         if self.r == rp:
             rt.write_once.update(id(q) for m in self.mods for q in (m.A, m.B) if q.requires_grad)
-        self.refresh(rt)
+        # Fast layout: the flat buffer holds A_1..A_J and B_1..B_J as two contiguous blocks (ops._layout_order), so their 16-bit
+        # twins ARE the stacked operands, and the transposed copies live in the arena the tiled AdamW writes: nothing to re-pack.
+        a_tw = rt.act_view(LinearOp._flat_view([m.A.data for m in self.mods])) if self.r == rp else None
+        b_tw = rt.act_view(LinearOp._flat_view([m.B.data for m in self.mods])) if self.r == rp else None
+        n_wt = self.in_f * J * rp + sum(rp * n for n in self.outs)
+        self.fast = (a_tw is not None and b_tw is not None and rt.wt16_flat is not None
+                     and rt.wt_pos + n_wt + 64 * (J + 1) <= rt.wt16_flat.numel())
+        n0 = self.outs[0]
+        # one B2 [sum N, r] with per-segment A2 columns needs segments that are whole tiles of the dual kernel (include/svdx.h)
+        self.seg_ok = J == 1 or (all(n == n0 for n in self.outs) and (n_sum % 160 != 0 or n0 % 160 == 0)
+                                 and (n0 % 128 == 0 or (n_sum % 160 == 0 and n_sum % 128 != 0)))
+        if self.fast:
+            self.A3 = a_tw.view(J * rp, self.in_f)
+            self.Bst = b_tw.view(n_sum, rp)
 
-    def refresh(self, rt: Runtime) -> None:
+            def arena(n_el):
+                off = rt.wt_pos
+                rt.wt_pos += rup(n_el, 64)
+                return off
+            off = arena(self.in_f * J * rp)
+            self.A3T = rt.wt16_flat[off:off + self.in_f * J * rp].view(self.in_f, J * rp)
+            for j, m in enumerate(self.mods):
+                rt.wt_map[id(m.A)] = (off + j * rp, J * rp)         # A_j^T is the column block j of A3T
+            self.BTp = []
+            for m, n in zip(self.mods, self.outs):
+                off = arena(rp * n)
+                self.BTp.append(rt.wt16_flat[off:off + rp * n].view(rp, n))
+                rt.wt_map[id(m.B)] = (off, n)
+        else:
+            self.A3 = torch.zeros(J * rp, self.in_f, dtype=rt.dt, device=rt.dev)
+            self.A3T = rt.empty(self.in_f, J * rp)
+            self.BTp = [rt.empty(rp, n) for n in self.outs]
+            self.Bst = None
+        if not (self.fast and self.seg_ok):
+            self.Bbd = torch.zeros(n_sum, J * rp, dtype=rt.dt, device=rt.dev)
+            self.Bp, off = [], 0
+            for j, n in enumerate(self.outs):
+                self.Bp.append(self.Bbd[off:off + n, j * rp:(j + 1) * rp])          # view, row pitch J*rp
+                off += n
+        self.refresh(rt, force=True)
+
+    def refresh(self, rt: Runtime, force: bool = False) -> None:
         k, r, rp, J = rt.k, self.r, self.rp, self.J
+        if self.fast:
+            if self.Bbd is not None:                 # segments that are not whole tiles: block-structured B for the dual launch
+                off = 0
+                for j, n in enumerate(self.outs):
+                    self.Bp[j].copy_(self.Bst[off:off + n])
+                    off += n
+            if rt.adam_writes_wt and not force:
+                return                               # AdamW wrote the twins and their transposes
+            off = 0
+            for j, n in enumerate(self.outs):
+                k.transpose(self.Bst[off:off + n], rp, self.BTp[j], n, n, rp)
+                off += n
+            k.transpose(self.A3, self.in_f, self.A3T, J * rp, J * rp, self.in_f)
+            return
         for j, m in enumerate(self.mods):
             if r == rp:
                 k.cast_from_f32(m.A.data, self.A3[j * rp:(j + 1) * rp], r * self.in_f)
@@ -527,6 +593,8 @@ class LoraOp:
 
     def fwd_dual(self, xs: torch.Tensor):
         w = self.J * self.rp
+        if self.fast and self.seg_ok:                # B2 = the stacked B twins [sum N, r]; segment j reads xs[:, j*r:(j+1)*r]
+            return (xs, self.Bst, self.rp, w, self.rp, self.outs[0] if self.J > 1 else 0)
         return (xs, self.Bbd, w, w, w)
 
     def bwd(self, rt: Runtime, dy: torch.Tensor, lddy: int, x: torch.Tensor, xs: torch.Tensor, M: int) -> torch.Tensor:

@@ -115,7 +115,7 @@ class Trainer:
         # with atomics (biases, LayerNorm, skinny cross-attention weights, alignment gaps, the loss slot) are cleared, by one
         # span-table launch.  Saves a 1.6 GB memset and a 1.6 GB read per step.
         spans, pos = [], 0
-        for p, off in zip(self.params, self.offsets):
+        for off, p in sorted(zip(self.offsets, self.params), key=lambda t: t[0]):    # layout order (ops._layout_order)
             if id(p) in self.rt.write_once:
                 if off > pos:
                     spans.append((pos, off))

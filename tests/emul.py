@@ -96,9 +96,16 @@ class EmuBackend:
         b = V(B, N, Kd, ldb).float()
         v = a @ b.t()
         if dual is not None:
-            A2, B2, K2, lda2, ldb2 = dual
+            A2, B2, K2, lda2, ldb2 = dual[:5]
+            seg = dual[5] if len(dual) > 5 else 0
             assert K2 % 64 == 0 and split_k == 1 and epilogue == K.EPI_NONE
-            v = v + V(A2, M, K2, lda2).float() @ V(B2, N, K2, ldb2).float().t()
+            b2 = V(B2, N, K2, ldb2).float()
+            if seg:
+                assert N % seg == 0 and seg % 128 == 0 or seg % 160 == 0
+                a2 = V(A2, M, (N // seg) * K2, lda2).float()
+                v = v + torch.cat([a2[:, j * K2:(j + 1) * K2] @ b2[j * seg:(j + 1) * seg].t() for j in range(N // seg)], 1)
+            else:
+                v = v + V(A2, M, K2, lda2).float() @ b2.t()
         v = alpha * v
         if bias is not None:
             v = v + V1(bias, N)[None]

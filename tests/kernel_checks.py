@@ -96,6 +96,15 @@ def check_gemm_plain(P, dt, variant):
                     out = torch.zeros(M, N, dtype=torch.float32, device=P.dev)
                 o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, N, Kd, Kd, Kd, N), kw), dict(C=out))
                 res.append((f"gemm v{variant} dual {M}x{N}x{Kd}+{K2} {mode}", relerr(o1["C"], o2["C"]), tol_for(dt)))
+        # segmented A2 (fused q/k/v adapters): 3 segments of 320 (160-wide tiles) / 128 and 256 (128-wide tiles, variants 4 and 8)
+        for (M, N, Kd, seg, var) in [(300, 960, 320, 320, variant), (200, 384, 128, 128, variant), (150, 768, 256, 256, 8)]:
+            nseg = N // seg
+            A, B = rnd((M, Kd), dt, P.dev, g), rnd((N, Kd), dt, P.dev, g, Kd ** -0.5)
+            A2, B2 = rnd((M, nseg * 64), dt, P.dev, g), rnd((N, 64), dt, P.dev, g, 0.125)
+            R = rnd((M, N), dt, P.dev, g)
+            kw = dict(variant=var, dual=(A2, B2, 64, nseg * 64, 64, seg), res=R, ldres=N)
+            o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, N, Kd, Kd, Kd, N), kw), dict(C=torch.zeros(M, N, dtype=dt, device=P.dev)))
+            res.append((f"gemm v{var} dual segmented {M}x{N}x{Kd} seg={seg}", relerr(o1["C"], o2["C"]), tol_for(dt)))
     # split-K into a float scratch + finalize epilogue
     M, N, Kd = 200, 320, 1280
     A, B = rnd((M, Kd), dt, P.dev, g), rnd((N, Kd), dt, P.dev, g, Kd ** -0.5)

@@ -207,6 +207,25 @@ def test_lora_fp32_train_step_matches_oracle(emu_backend, r):
     tr.zero_grad()
     tr.forward_backward(unet_in, ts, ehs, ids, noisy, batch["latents"], batch["sigmas"])
     assert float(tr.last_loss()) < float(loss)          # one lr = 1e-3 step on the same batch lowers the loss
+    # packed adapter copies: at r = 64 the flat layout regroups the factors (A_q A_k A_v A_out B_q ...) so that the stacked operands
+    # are views of the 16-bit twin and AdamW maintains their transposes; the padded rank keeps the re-packing path
+    from svd_xtend_amd.ops import LoraOp
+    ops_ = [l for kind, mod in m.steps if kind == "attn" for blk in list(mod.transformer_blocks) + list(mod.temporal_transformer_blocks)
+            for l in blk.attn1.loras if isinstance(l, LoraOp)]
+    assert ops_
+    if r == 64:
+        assert all(l.fast for l in ops_)
+        assert any(l.J == 3 and l.seg_ok for l in ops_) and any(l.J == 3 and not l.seg_ok for l in ops_)     # C = 128 / C = 64 levels
+        for l in ops_:
+            assert l.A3.data_ptr() == tr.rt.act_view(l.mods[0].A.data).data_ptr()
+            for j, mod in enumerate(l.mods):            # after the optimizer step: twins and transposes written by AdamW are current
+                a16 = mod.A.data.to(tr.rt.dt)
+                assert torch.equal(l.A3[j * l.rp:(j + 1) * l.rp], a16) and torch.equal(l.A3T[:, j * l.rp:(j + 1) * l.rp], a16.t())
+                assert torch.equal(l.BTp[j], mod.B.data.to(tr.rt.dt).t())
+        offs = sorted(zip(tr.offsets, tr.params), key=lambda t: t[0])
+        assert [o for o, _ in offs] != tr.offsets          # layout order differs from the optimizer's parameter order
+    else:
+        assert not any(l.fast for l in ops_)
 
 
 def test_to_dtype_keeps_float_masters(emu_backend):

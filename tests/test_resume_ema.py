@@ -249,7 +249,8 @@ def test_resume_continues_the_same_trajectory(emu_backend, tmp_path, dtype):
 def test_resume_with_lora_adapters(emu_backend, tmp_path):
     """train_svd_lora.py uses the same save / load hooks (:693-715): the unet/ folder then carries peft's key names."""
     from svd_xtend_amd.lora import LoraConfig
-    cfg = LoraConfig(r=8, lora_alpha=8, init_lora_weights="gaussian", target_modules=["to_k", "to_q", "to_v", "to_out.0"])
+    # r = 64: the flat layout regroups the adapter factors, optimizer.bin keeps the optimizer's (named_parameters) order
+    cfg = LoraConfig(r=64, lora_alpha=64, init_lora_weights="gaussian", target_modules=["to_k", "to_q", "to_v", "to_out.0"])
 
     def fresh(seed):
         m = build(seed)
@@ -270,6 +271,9 @@ def test_resume_with_lora_adapters(emu_backend, tmp_path):
     from safetensors.torch import load_file
     keys = set(load_file(os.path.join(path, "unet", "diffusion_pytorch_model.safetensors")))
     assert any(k.endswith("to_q.lora_A.default.weight") for k in keys) and any(k.endswith("to_q.base_layer.weight") for k in keys)
+    osd = torch.load(os.path.join(path, "optimizer.bin"), weights_only=False)
+    names = [n for n, p in c.model.named_parameters() if p.requires_grad]
+    assert all(tuple(osd["state"][i]["exp_avg"].shape) == tuple(dict(c.model.named_parameters())[n].shape) for i, n in enumerate(names))
     d = fresh(8)
     d.load_state(path)
     d.step(batches[2])
