@@ -1,7 +1,10 @@
 """CPU oracle: the training-step math of /root/reference/train_svd.py:941-1049 on latents.
 
-TEST INFRASTRUCTURE ONLY (see oracle/unet.py header).  PARITY UNPINNED: the reference holds no
-golden vectors for this path; these functions restate the reference lines they cite.
+TEST INFRASTRUCTURE ONLY (see oracle/unet.py header).  PINNED for the arithmetic that lives in the reference file itself:
+`rand_log_normal`, the EDM noising, the conditioning dropout + channel concat and the weighted-MSE loss are checked against
+values computed by the reference's own statements (tests/golden/make_golden_step_math.py and make_golden_resize.py lift them out of
+/root/reference/train_svd.py and execute them in this container; tests/test_oracle_step_math.py).  The UNet call in the middle is
+oracle/unet.py (parity unpinned, see its header).
 """
 from __future__ import annotations
 
@@ -51,6 +54,17 @@ def edm_inputs(batch: Dict[str, torch.Tensor]):
     cond = batch["cond_latents"].unsqueeze(1).repeat(1, T, 1, 1, 1)                     # :1014-1015
     unet_in = torch.cat([inp_noisy, cond], dim=2)                                       # :1016-1017
     return unet_in, timesteps, batch["ehs"], added_time_ids, noisy_latents, sigmas
+
+
+def conditioning_dropout(random_p: torch.Tensor, encoder_hidden_states: torch.Tensor, conditional_latents: torch.Tensor, prob: float):
+    """train_svd.py:992-1011 (classifier-free-guidance dropout): with p = random_p per sample, the image embedding [B, D] is zeroed
+    (and gains its sequence axis, [B, 1, D]) where p < 2 prob, the conditioning latents where prob <= p < 3 prob."""
+    bsz = random_p.shape[0]
+    prompt_mask = (random_p < 2 * prob).reshape(bsz, 1, 1)
+    ehs = torch.where(prompt_mask, torch.zeros_like(encoder_hidden_states).unsqueeze(1), encoder_hidden_states.unsqueeze(1))
+    dt = conditional_latents.dtype
+    image_mask = 1 - ((random_p >= prob).to(dt) * (random_p < 3 * prob).to(dt))
+    return ehs, image_mask.reshape(bsz, 1, 1, 1) * conditional_latents
 
 
 def edm_loss(model_pred: torch.Tensor, noisy_latents: torch.Tensor, target: torch.Tensor,

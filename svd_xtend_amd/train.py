@@ -381,3 +381,12 @@ def edm_prepare(latents, noise, cond_latents, sigmas):
     inp = noisy / ((s ** 2 + 1) ** 0.5)
     cond = cond_latents.unsqueeze(1).repeat(1, T, 1, 1, 1)
     return torch.cat([inp, cond], dim=2), timesteps, noisy
+
+
+def conditioning_dropout(random_p, encoder_hidden_states, conditional_latents, prob: float):
+    """Classifier-free-guidance dropout of train_svd.py:992-1011 (host-side data prep, plain tensor ops): `random_p` [B] uniform in
+    [0, 1); the image embedding [B, D] -> [B, 1, D], zeroed where p < 2 prob; the conditioning latents zeroed where prob <= p < 3 prob."""
+    bsz = random_p.shape[0]
+    ehs = encoder_hidden_states.unsqueeze(1) * (random_p >= 2 * prob).to(encoder_hidden_states.dtype).reshape(bsz, 1, 1)
+    keep = 1 - ((random_p >= prob) & (random_p < 3 * prob)).to(conditional_latents.dtype)
+    return ehs, keep.reshape(bsz, 1, 1, 1) * conditional_latents

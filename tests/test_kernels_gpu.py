@@ -41,3 +41,40 @@ def test_extension_is_loaded_and_native():
     from svd_xtend_amd import kernels as K
     be = K.backend()
     assert isinstance(be, K.HipBackend) and be.lib.svdx_device_ok() == 1
+
+
+@gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_edm_loss_kernel_matches_reference_statements(dt):
+    """svdx_edm_loss against the loss computed by the reference's own statements (tests/golden/step_math.safetensors, made by
+    tests/golden/make_golden_step_math.py from train_svd.py:1025-1036); the prediction is rounded to the activation dtype first."""
+    import os
+    import sys
+
+    from safetensors.torch import load_file
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    from make_golden_step_math import CASES, case_inputs
+    from svd_xtend_amd import kernels as K
+    k, dev = K.backend(), torch.device("cuda")
+    g = load_file(os.path.join(here, "golden", "step_math.safetensors"))
+    for i, (bsz, T, h, w, D, prob, seed) in enumerate(CASES):
+        inp = case_inputs(bsz, T, h, w, D, seed)
+        C = 4
+        pred16 = inp["model_pred"].permute(0, 1, 3, 4, 2).reshape(bsz * T * h * w, C).to(dt)
+        sig5 = g[f"case{i}.sigmas"]
+        # the reference loss on the SAME rounded prediction (the golden value itself uses the float prediction)
+        pr = pred16.float().view(bsz, T, h, w, C).permute(0, 1, 4, 2, 3)
+        c_out, c_skip = -sig5 / ((sig5 ** 2 + 1) ** 0.5), 1 / (sig5 ** 2 + 1)
+        wgt = (1 + sig5 ** 2) * (sig5 ** -2.0)
+        want = (wgt * (pr * c_out + c_skip * g[f"case{i}.noisy_latents"] - inp["latents"]) ** 2).reshape(bsz, -1).mean(1).mean()
+        st = torch.zeros(K.OPT_STATE_FLOATS, device=dev)
+        st[1] = 1.0
+        loss = torch.zeros(1, device=dev)
+        dpred = torch.zeros(bsz * T * h * w, 64, dtype=dt, device=dev)
+        k.edm_loss(pred16.to(dev).contiguous(), C, g[f"case{i}.noisy_latents"].to(dev).contiguous(), inp["latents"].to(dev).contiguous(),
+                   sig5.reshape(-1).to(dev).contiguous(), loss, dpred, bsz, T, C, h * w, st)
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(want)) <= 1e-5 * float(want), (i, float(loss), float(want))
+        # and within the rounding of the prediction of the golden loss itself
+        assert abs(float(loss) - float(g[f"case{i}.loss"])) <= (2e-2 if dt == torch.bfloat16 else 3e-3) * float(g[f"case{i}.loss"]), i

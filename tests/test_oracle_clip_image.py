@@ -24,6 +24,16 @@ def test_resize_matches_reference_outputs():
         assert float((y - ref).abs().max()) <= 1e-6, name            # same torch ops in the same order: bit-equal in practice
 
 
+def test_rand_log_normal_matches_reference_outputs():
+    """oracle.step.rand_log_normal (the sigma sampler of train_svd.py:63-66, used at :954 / :964) against the reference's function."""
+    from make_golden_resize import SIGMA_CASES
+    from oracle.step import rand_log_normal
+    g = load_file(os.path.join(HERE, "golden", "resize_antialias.safetensors"))
+    for j, (loc, scale) in enumerate(SIGMA_CASES):
+        torch.manual_seed(200 + j)
+        assert torch.equal(rand_log_normal([8], loc=loc, scale=scale), g[f"rand_log_normal.{j}"]), (loc, scale)
+
+
 def test_blur_parameters():
     assert blur_taps(320 / 224) == (3, (320 / 224 - 1) / 2)           # c2 height: sigma 0.214, minimum window
     assert blur_taps(512 / 224) == (3, (512 / 224 - 1) / 2)           # c2 width: sigma 0.643 -> int(2.57) = 2 -> max(.., 3)
