@@ -14,6 +14,12 @@ following the reference's own call sites, and is self-pinned only by structural 
 (tests/test_oracle.py): parameter count == 1,524,623,082, trainable-by-name count == 397,620,480,
 the diffusers state-dict key set, LoRA r=64 delta == 26,558,464.
 
+The TOP LEVEL is pinned to the reference's own code: tests/golden/make_golden_unet_toplevel.py executes
+/root/reference/src/unet_spatio_temporal_condition.py unmodified in this container with diffusers' block factories standing in as
+the blocks of this file, loads these weights into it (strict: same key layout) and stores its outputs;
+`UNetSpatioTemporalConditionOracle` reproduces them bit for bit (tests/test_oracle_toplevel.py), and the reference's own
+constructor at its default configuration yields the two parameter counts above.  The blocks below that level remain unpinned.
+
 Every class cites the reference line that instantiates it and the diffusers module it restates.
 Module / parameter names are exactly diffusers' so `state_dict()` keys match a real SVD checkpoint.
 """

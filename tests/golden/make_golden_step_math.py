@@ -56,6 +56,18 @@ def main():
         exec(code["loss"], ns)
         for k in ("sigmas", "noisy_latents", "timesteps", "inp_noisy_latents", "encoder_hidden_states", "loss"):
             out[f"case{i}.{k}"] = ns[k].detach().clone().contiguous()
+    # `_get_add_time_ids` (:878-898), a function nested in main(): executed with a stand-in for the two model attributes it reads
+    nested = [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "_get_add_time_ids"]
+    ns = {"torch": torch, "unet": SimpleNamespace(config=SimpleNamespace(addition_time_embed_dim=256),
+                                                  add_embedding=SimpleNamespace(linear_1=SimpleNamespace(in_features=768)))}
+    exec(compile(ast.Module(body=nested, type_ignores=[]), REF, "exec"), ns)
+    out["add_time_ids"] = ns["_get_add_time_ids"](7, 127, torch.tensor(0.0625), torch.float32, 3)     # call site :981-987
+    ns["unet"].add_embedding.linear_1.in_features = 512
+    try:
+        ns["_get_add_time_ids"](7, 127, 0.02, torch.float32, 1)
+        raise SystemExit("the reference's config check did not fire")
+    except ValueError:
+        pass
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "step_math.safetensors")
     save_file(out, path)
     print("wrote", path, os.path.getsize(path), "bytes;", {k: tuple(v.shape) for k, v in out.items() if k.startswith("case1.")})

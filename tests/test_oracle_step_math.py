@@ -42,6 +42,13 @@ def test_oracle_step_math_matches_reference_statements():
     assert n_masked >= 4            # the seeded cases exercise both masks
 
 
+def test_add_time_ids_match_reference_function():
+    from oracle.step import get_add_time_ids
+    g = load_file(os.path.join(HERE, "golden", "step_math.safetensors"))
+    assert torch.equal(get_add_time_ids(7, 127, torch.tensor(0.0625), torch.float32, 3), g["add_time_ids"])
+    assert g["add_time_ids"].tolist() == [[7.0, 127.0, 0.0625]] * 3
+
+
 def test_product_data_prep_matches_reference_statements():
     from svd_xtend_amd.train import conditioning_dropout as product_dropout
     from svd_xtend_amd.train import edm_prepare
