@@ -113,6 +113,20 @@ def main():
             yo = orc(x, t, ehs, added_time_ids=ids).sample
             print(f"case {i}: reference top level vs oracle top level max |diff| = {float((y - yo).abs().max()):.3e}")
             out[f"case{i}.sample"] = y.contiguous()
+    # the trainable-set selection + optimizer construction of train_svd.py:758-773, executed as written on the reference class instance
+    import ast
+    tsrc = "/root/reference/train_svd.py"
+    tree = ast.parse(open(tsrc).read())
+    stmts = [n for n in ast.walk(tree) if isinstance(n, ast.stmt) and 758 <= n.lineno and n.end_lineno <= 773]
+    top = sorted([n for n in stmts if not any(m is not n and any(c is n for c in ast.walk(m)) for m in stmts)], key=lambda n: n.lineno)
+    args = SimpleNamespace(learning_rate=1e-4, adam_beta1=0.9, adam_beta2=0.999, adam_weight_decay=1e-2, adam_epsilon=1e-8)
+    ns = dict(unet=ref, torch=torch, args=args, optimizer_cls=torch.optim.AdamW)
+    exec(compile(ast.Module(body=top, type_ignores=[]), tsrc, "exec"), ns)
+    chosen = [n for n, p in ref.named_parameters() if p.requires_grad]
+    assert len(ns["parameters_list"]) == len(chosen) and isinstance(ns["optimizer"], torch.optim.AdamW)
+    with open(os.path.join(HERE, "unet_toplevel_trainable_names.txt"), "w") as f:
+        f.write("\n".join(chosen) + "\n")
+    print("reference selection loop on the tiny model:", len(chosen), "trainable tensors")
     # the full-size constructor: the reference's own channel plumbing yields the published parameter count
     with torch.device("meta"):
         full = Ref()

@@ -36,6 +36,20 @@ def test_reference_constructor_counts():
     assert _gold()["full_counts"].tolist() == [1_524_623_082, 397_620_480]
 
 
+def test_trainable_selection_equals_reference_loop():
+    """select_trainable (product) and trainable_names (oracle) against the parameter list the reference's own loop
+    (train_svd.py:758-766, executed on the reference class instance by the golden script) put into its optimizer."""
+    from oracle.unet import trainable_names
+    from svd_xtend_amd.train import select_trainable
+    from svd_xtend_amd.unet import UNetSpatioTemporalConditionModel
+    want = open(os.path.join(HERE, "golden", "unet_toplevel_trainable_names.txt")).read().split()
+    assert len(want) > 100 and all("temporal_transformer_block" in n for n in want)
+    assert list(trainable_names(UNetSpatioTemporalConditionOracle(**TINY_CONFIG))) == want
+    m = UNetSpatioTemporalConditionModel(**TINY_CONFIG)
+    assert select_trainable(m) == want
+    assert [n for n, p in m.named_parameters() if p.requires_grad] == want
+
+
 def test_product_forward_equals_reference_class_output(emu_backend):
     from make_golden_unet_toplevel import CASES, toplevel_inputs
     from svd_xtend_amd.unet import UNetSpatioTemporalConditionModel
