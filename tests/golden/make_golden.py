@@ -1,8 +1,10 @@
 """Generates tests/golden/tiny_step.safetensors: one seeded train step of the CPU oracle (oracle/) on the tiny topology.
 
-The reference holds no golden vectors, tests or fixtures (parity unpinned) and diffusers/peft cannot be imported
-in the build container, so this fixture freezes the ORACLE, not the reference: it guards the restatement against accidental
-drift (tests/test_oracle.py re-derives it on CPU) and gives the GPU parity test a second, committed anchor.
+The reference holds no golden vectors, tests or fixtures and diffusers/peft cannot be imported in the build
+container, so this fixture freezes the ORACLE: it guards the restatement against accidental drift (tests/test_oracle.py re-derives
+it on CPU) and gives the GPU parity test a second, committed anchor.  Its "full" half is tied to the reference's own code by
+tests/golden/make_golden_unet_toplevel.py, which assembles the same step from the reference's UNet class (over the oracle's blocks)
+and the reference's loop-body statements and finds it bit-equal (tests/test_oracle_toplevel.py).
 Contents: the inputs are re-generated from the seeds (make_synthetic_batch is deterministic); stored are the prediction, the
 loss and the L2 norm of every trainable gradient, for the full-parameter (config 2) and the LoRA r = 8 (config 5) step.
 usage: python tests/golden/make_golden.py"""

@@ -97,6 +97,66 @@ def reference_class():
     return mod.UNetSpatioTemporalConditionModel
 
 
+def lift(tree, lo, hi, filename):
+    """Outermost statements lying entirely inside lines [lo, hi], compiled for exec."""
+    import ast
+    inside = [n for n in ast.walk(tree) if isinstance(n, ast.stmt) and n.lineno >= lo and n.end_lineno <= hi]
+    top = sorted([n for n in inside if not any(m is not n and any(c is n for c in ast.walk(m)) for m in inside)], key=lambda n: n.lineno)
+    return compile(ast.Module(body=top, type_ignores=[]), filename, "exec")
+
+
+def reference_assembled_step(Ref, tree):
+    """One whole optimizer step put together from the reference's own pieces, on the inputs of tests/golden/make_golden.py
+    (SPEC there): the reference top-level class (over oracle blocks), its trainable-set loop and AdamW construction (:758-773), its
+    nested `_get_add_time_ids` (:878-898), and the loop-body statements as written -- noising (:964-972; `rand_log_normal` is
+    handed the batch's sigmas), concat (:992-1017, dropout off), the UNet call (:1020-1022), the loss (:1025-1036), backward (:1044),
+    optimizer / scheduler / zero_grad (:1047-1049).  Compared against the oracle's step and stored."""
+    import ast
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle.step import make_synthetic_batch
+    from oracle.unet import TINY_CONFIG, UNetSpatioTemporalConditionOracle, scaled_init_
+    B, T, h, w, seed, lr = 1, 4, 16, 16, 3, 1e-4                      # make_golden.py SPEC
+    tsrc = "/root/reference/train_svd.py"
+    orc = UNetSpatioTemporalConditionOracle(**TINY_CONFIG)
+    scaled_init_(orc, seed)
+    unet = Ref(**TINY_CONFIG)
+    unet.load_state_dict(orc.state_dict(), strict=True)
+    batch = make_synthetic_batch(B, T, h, w, seed + 1, cross_dim=TINY_CONFIG["cross_attention_dim"])
+    ns = dict(torch=torch, unet=unet, optimizer_cls=torch.optim.AdamW, bsz=B, train_loss=0.0,
+              args=SimpleNamespace(learning_rate=lr, adam_beta1=0.9, adam_beta2=0.999, adam_weight_decay=1e-2, adam_epsilon=1e-8,
+                                   conditioning_dropout_prob=None, per_gpu_batch_size=B, gradient_accumulation_steps=1),
+              accelerator=SimpleNamespace(device=torch.device("cpu"), backward=lambda loss: loss.backward(), gather=lambda t: t),
+              lr_scheduler=SimpleNamespace(step=lambda: None), generator=None,
+              rand_log_normal=lambda shape, loc, scale: batch["sigmas"].clone(),
+              latents=batch["latents"], noise=batch["noise"], conditional_latents=batch["cond_latents"],
+              encoder_hidden_states=batch["ehs"])
+    exec(lift(tree, 758, 773, tsrc), ns)                                  # trainable set + optimizer
+    nested = [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "_get_add_time_ids"]
+    exec(compile(ast.Module(body=nested, type_ignores=[]), tsrc, "exec"), ns)
+    ns["added_time_ids"] = ns["_get_add_time_ids"](7, 127, batch["cond_sigmas"][0], torch.float32, B)      # call site :981-987
+    for lo, hi in ((964, 972), (992, 1017), (1020, 1022), (1025, 1036), (1039, 1041), (1044, 1044)):
+        exec(lift(tree, lo, hi, tsrc), ns)
+    grads = {n: p.grad.clone() for n, p in unet.named_parameters() if p.grad is not None}
+    exec(lift(tree, 1047, 1049, tsrc), ns)
+    after = {n: p.detach().clone() for n, p in unet.named_parameters() if p.requires_grad}
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in unet.parameters())           # zero_grad ran
+
+    import e2e_checks
+    o = e2e_checks.oracle_step(TINY_CONFIG, B, T, h, w, seed=seed, lr=lr, cross_dim=TINY_CONFIG["cross_attention_dim"])
+    d_loss = abs(float(ns["loss"]) - o["loss"])
+    d_pred = float((ns["model_pred"].detach() - o["pred"]).abs().max())
+    d_grad = max(float((grads[n] - o["grads"][n]).abs().max()) for n in o["grads"])
+    d_after = max(float((after[n] - o["params_after"][n]).abs().max()) for n in after)
+    print(f"reference-assembled step vs oracle step: |d loss| {d_loss:.2e}, |d pred| {d_pred:.2e}, |d grad| {d_grad:.2e}, "
+          f"|d params after AdamW| {d_after:.2e}; loss {float(ns['loss']):.7f}, train_loss {ns['train_loss']:.7f}")
+    assert set(grads) == set(o["grads"]) and d_loss == 0.0 and d_pred == 0.0 and d_grad == 0.0 and d_after == 0.0
+    names = sorted(grads)
+    return {"step.loss": torch.tensor([float(ns["loss"])], dtype=torch.float64), "step.pred": ns["model_pred"].detach().contiguous(),
+            "step.grad_norms": torch.tensor([float(grads[n].double().norm()) for n in names], dtype=torch.float64),
+            "step.param_delta_norm": torch.tensor([float(sum((after[n] - orc.state_dict()[n]).double().pow(2).sum() for n in after)) ** 0.5],
+                                                  dtype=torch.float64)}
+
+
 def main():
     from oracle.unet import TINY_CONFIG, UNetSpatioTemporalConditionOracle, scaled_init_
     Ref = reference_class()
@@ -127,6 +187,7 @@ def main():
     with open(os.path.join(HERE, "unet_toplevel_trainable_names.txt"), "w") as f:
         f.write("\n".join(chosen) + "\n")
     print("reference selection loop on the tiny model:", len(chosen), "trainable tensors")
+    out.update(reference_assembled_step(Ref, tree))
     # the full-size constructor: the reference's own channel plumbing yields the published parameter count
     with torch.device("meta"):
         full = Ref()

@@ -36,6 +36,18 @@ def test_reference_constructor_counts():
     assert _gold()["full_counts"].tolist() == [1_524_623_082, 397_620_480]
 
 
+def test_reference_assembled_step_equals_the_e2e_anchor():
+    """A whole optimizer step put together by the golden script from the reference's own pieces (its UNet class over oracle blocks,
+    its trainable-set loop and AdamW construction, its loop-body statements from the noising to optimizer.zero_grad()) equalled the
+    oracle's step bit for bit when the fixture was made; here its stored loss / prediction / gradient norms must equal
+    tests/golden/tiny_step.safetensors -- the committed anchor the GPU parity test (test_e2e_gpu.py) and smoke() compare with."""
+    g, anchor = _gold(), load_file(os.path.join(HERE, "golden", "tiny_step.safetensors"))
+    assert float(g["step.loss"]) == float(anchor["full.loss"])
+    assert torch.equal(g["step.pred"], anchor["full.pred"])
+    assert torch.equal(g["step.grad_norms"], anchor["full.grad_norms"])
+    assert float(g["step.param_delta_norm"]) > 0
+
+
 def test_trainable_selection_equals_reference_loop():
     """select_trainable (product) and trainable_names (oracle) against the parameter list the reference's own loop
     (train_svd.py:758-766, executed on the reference class instance by the golden script) put into its optimizer."""
