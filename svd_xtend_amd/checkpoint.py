@@ -43,6 +43,13 @@ def global_step_of(name: str) -> int:
     return int(name.split("-")[1])
 
 
+def resume_position(global_step: int, num_update_steps_per_epoch: int, gradient_accumulation_steps: int):
+    """train_svd.py:921-925: (first_epoch, resume_step) -- the epoch to restart in and how many of its micro-batches to skip."""
+    resume_global_step = global_step * gradient_accumulation_steps
+    return (global_step // num_update_steps_per_epoch,
+            resume_global_step % (num_update_steps_per_epoch * gradient_accumulation_steps))
+
+
 def rotate_checkpoints(output_dir: str, total_limit: Optional[int]) -> List[str]:
     """train_svd.py:1062-1082, run BEFORE saving a new checkpoint: keep at most `total_limit - 1` of the existing ones (oldest
     removed first).  Returns the removed folder names."""

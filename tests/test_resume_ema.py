@@ -202,6 +202,27 @@ def test_checkpoint_directory_rules(tmp_path):
     assert sorted(os.listdir(out)) == ["checkpoint-10000", "checkpoint-1500", "logs"]
 
 
+def test_checkpoint_rules_match_reference_statements(tmp_path):
+    """Decisions recorded from the reference's own resume (:901-925) and rotation (:1062-1090) statements
+    (tests/golden/make_golden_checkpoint_rules.py) on six directory layouts."""
+    import json
+    rules = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checkpoint_rules.json")))
+    assert len(rules) == 6
+    for i, r in enumerate(rules):
+        root = str(tmp_path / f"case{i}")
+        for d in r["dirs"]:
+            os.makedirs(os.path.join(root, d))
+        name = ckpt.latest_checkpoint(root, r["resume_from_checkpoint"])
+        assert ([name] if name else []) == r["loaded"], r
+        if name:
+            step = ckpt.global_step_of(name)
+            assert step == r["global_step"]
+            assert ckpt.resume_position(step, 300, 2) == (r["first_epoch"], r["resume_step"])
+        assert ckpt.rotate_checkpoints(root, r["checkpoints_total_limit"]) == r["removed"], r
+        os.makedirs(os.path.join(root, f"checkpoint-{r['save_at_step']}"))
+        assert sorted(os.listdir(root)) == sorted(set(r["dirs"]) - set(r["removed"]) | set(r["created"]))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_resume_continues_the_same_trajectory(emu_backend, tmp_path, dtype):
     """5 steps straight == 3 steps, save_state, fresh process state, load_state, 2 steps (weights, moments, loss scale, lr)."""
