@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE (CPU oracle) -- PARITY UNPINNED, like the rest of oracle/.
+"""TEST INFRASTRUCTURE (CPU oracle) -- PARITY UNPINNED (peft is absent), like the diffusers blocks of oracle/unet.py.
 
 LoRA as the reference uses it (config 5): /root/reference/train_svd_lora.py:659-674 builds
 `LoraConfig(r=rank, lora_alpha=rank, init_lora_weights="gaussian", target_modules=["to_k","to_q","to_v","to_out.0"])` and calls

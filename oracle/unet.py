@@ -4,7 +4,8 @@ TEST INFRASTRUCTURE ONLY.  Nothing in the product package (`svd_xtend_amd/`) may
 module; only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg use it, and
 only as the checker.
 
-PARITY UNPINNED.  The arithmetic of this path lives in `diffusers` (un-vendored, un-pinned:
+PARITY UNPINNED BELOW THE TOP LEVEL (the top level is pinned to the reference's own class, see the end of this header).  The
+arithmetic of the blocks lives in `diffusers` (un-vendored, un-pinned:
 `check_min_version("0.24.0.dev0")` /root/reference/train_svd.py:59, `"0.29.1"`
 /root/reference/train_svd_lora.py:63; import path `diffusers.models.unets.unet_3d_blocks`
 /root/reference/src/unet_spatio_temporal_condition.py:13 implies >= 0.26) which is NOT installed here
