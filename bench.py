@@ -240,7 +240,9 @@ def main():
 
     # ---- roofline of the dominant kernel (one instrumented eager step; events on the launch stream) ---------
     roof = None
-    if not args.no_roofline and rank == 0:
+    # Every rank runs the instrumented step (same collectives on all ranks -- a rank-0-only step would leave its all-reduces without
+    # peers); only rank 0 installs the timing hooks and reports.
+    if not args.no_roofline:
         k = trainer.rt.k
         orig, orig_tn = k.gemm, k.gemm_tn
         recs, recs_bytes = [], []
@@ -263,47 +265,50 @@ def main():
             e1.record()
             recs.append((e0, e1, 2.0 * R * N * Kd, ("tn", N, Kd, R, 0, kw.get("split_k", 1))))
             recs_bytes.append((0, 0, 0, 2.0 * R * N + 2.0 * R * Kd + 4.0 * N * Kd * max(2, kw.get("split_k", 1))))
-        k.gemm, k.gemm_tn = timed_gemm, timed_gemm_tn
+        if rank == 0:
+            k.gemm, k.gemm_tn = timed_gemm, timed_gemm_tn
         try:
             fwd_bwd()
             torch.cuda.synchronize()
         finally:
             k.gemm, k.gemm_tn = orig, orig_tn
+        trainer.allreduce_grads()
         opt_step()
         torch.cuda.synchronize()
-        if args.gemm_table:
-            agg = {}
-            for a, b, f, key in recs:
-                e = agg.setdefault(key, [0, 0.0, 0.0])
-                e[0] += 1
-                e[1] += a.elapsed_time(b)
-                e[2] += f
-            rows = sorted(([list(kk) + [v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12] for kk, v in agg.items()]), key=lambda r: -r[7])
-            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "gemm_table.json"), "w") as f:
-                json.dump(rows, f)
-            tn = trainer.rt.tuner
-            if tn is not None:
-                with open(os.path.join(ROOT, "gpurun_out", "gemm_tuned.json"), "w") as f:
-                    json.dump([[repr(kk), repr(tn.table.get(kk)), [[c if not isinstance(c, tuple) else list(c), (st[0] / st[1]) if st[1] else None]
-                                                                  for c, st in zip(tn.cands[kk], tn.stats[kk])]] for kk in tn.cands], f)
-        recs = [(a, b, f) for a, b, f, _ in recs]
-        t_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-        fl = sum(f for _, _, f in recs)
-        ach = fl / (t_ms * 1e-3) / 1e12
-        # HBM-side bytes per launch of the same kernel family: rocprofv3 FETCH_SIZE / WRITE_SIZE passes over this exact command
-        # (tools/pmc_traffic.py, gfx950 FETCH_SIZE x2 correction), committed under profiles/ -- bench.py cannot run a profiler
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if (not args.tiny) and (T, h, w) == (14, 40, 64) and args.dtype == "fp16" and not args.lora_rank and os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath))["gemm"]["bytes_per_launch"]
-            except Exception:  # noqa: BLE001
-                traffic = None
-        roof = {"bound": "mfma", "kernel": "MFMA GEMM family (NT + implicit conv, TN weight-grad)", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "launches": len(recs),
-                "flops_per_step": fl, "kernel_ms_per_step": t_ms,
-                "algorithmic_bytes_per_launch": sum(b for _, _, _, b in recs_bytes) / max(len(recs_bytes), 1)}
+        if rank == 0:
+            if args.gemm_table:
+                agg = {}
+                for a, b, f, key in recs:
+                    e = agg.setdefault(key, [0, 0.0, 0.0])
+                    e[0] += 1
+                    e[1] += a.elapsed_time(b)
+                    e[2] += f
+                rows = sorted(([list(kk) + [v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12] for kk, v in agg.items()]), key=lambda r: -r[7])
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "gemm_table.json"), "w") as f:
+                    json.dump(rows, f)
+                tn = trainer.rt.tuner
+                if tn is not None:
+                    with open(os.path.join(ROOT, "gpurun_out", "gemm_tuned.json"), "w") as f:
+                        json.dump([[repr(kk), repr(tn.table.get(kk)), [[c if not isinstance(c, tuple) else list(c), (st[0] / st[1]) if st[1] else None]
+                                                                      for c, st in zip(tn.cands[kk], tn.stats[kk])]] for kk in tn.cands], f)
+            recs = [(a, b, f) for a, b, f, _ in recs]
+            t_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            ach = fl / (t_ms * 1e-3) / 1e12
+            # HBM-side bytes per launch of the same kernel family: rocprofv3 FETCH_SIZE / WRITE_SIZE passes over this exact command
+            # (tools/pmc_traffic.py, gfx950 FETCH_SIZE x2 correction), committed under profiles/ -- bench.py cannot run a profiler
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if (not args.tiny) and (T, h, w) == (14, 40, 64) and args.dtype == "fp16" and not args.lora_rank and os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath))["gemm"]["bytes_per_launch"]
+                except Exception:  # noqa: BLE001
+                    traffic = None
+            roof = {"bound": "mfma", "kernel": "MFMA GEMM family (NT + implicit conv, TN weight-grad)", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "launches": len(recs),
+                    "flops_per_step": fl, "kernel_ms_per_step": t_ms,
+                    "algorithmic_bytes_per_launch": sum(b for _, _, _, b in recs_bytes) / max(len(recs_bytes), 1)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
