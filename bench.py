@@ -70,11 +70,14 @@ def make_batch(B, T, h, w, cross_dim, seed, dev):
                 noisy_latents=noisy.to(dev), target=latents.to(dev), sigmas=sigmas.to(dev))
 
 
-def cpu_baseline(dev=None, dtype=torch.float16):
+def cpu_baseline(dev=None, dtype=torch.float16, c2=True):
     """The oracle (kind 'port': pure-PyTorch restatement; diffusers is not installed) on the host cores.
-    Sample: c1' = one 8-frame 256x192 clip, fp32, full SVD UNet, fwd + loss + bwd + AdamW, 1 step.
-    The same weights and batch then go through the HIP path once (`parity_full_model`): the checker role of the oracle at the
-    FULL 1.52 B-parameter topology, beside the tiny-topology parity tests."""
+    Sample: c1' = one 8-frame 256x192 clip, fp32, full SVD UNet, fwd + loss + bwd + AdamW: 1 warm-up step, then the median of 3.
+    When the host has the cores and the memory, ONE step of the benched shape itself (c2, 14 x 512x320) follows on the same model.
+    Each oracle batch also goes through the HIP path on the oracle's weights (`parity_full_model`, `parity_c2`): the checker role of
+    the oracle at the FULL 1.52 B-parameter topology, beside the parity tests of tests/."""
+    import statistics
+
     from oracle.step import edm_inputs, make_optimizer, make_synthetic_batch, train_step
     from oracle.unet import SVD_CONFIG, UNetSpatioTemporalConditionOracle, scaled_init_
     torch.manual_seed(0)
@@ -82,13 +85,13 @@ def cpu_baseline(dev=None, dtype=torch.float16):
     t0 = time.time()
     orc = UNetSpatioTemporalConditionOracle(**SVD_CONFIG)
     scaled_init_(orc, 0)                            # O(1) activations through all 4 levels: the prediction matters in the loss
-    opt = make_optimizer(orc, lr=1e-5)
-    batch = make_synthetic_batch(1, 8, 24, 32, 1)
+    opt = make_optimizer(orc, lr=0.0)               # lr 0: the timed steps do the full AdamW arithmetic but leave the weights where
+    batch = make_synthetic_batch(1, 8, 24, 32, 1)   # the HIP model copied them, so every step is the same step
     t_build = time.time() - t0
-    parity = None
     prod = None
+    perr = None
     if dev is not None:
-        try:                                       # copy the oracle's initial weights before its optimizer step changes them
+        try:
             from svd_xtend_amd.train import Trainer
             from svd_xtend_amd.unet import UNetSpatioTemporalConditionModel
             with torch.device(dev):
@@ -96,27 +99,56 @@ def cpu_baseline(dev=None, dtype=torch.float16):
             pm.load_state_dict(orc.state_dict(), strict=True)
             prod = Trainer(pm, dtype=dtype, lr=1e-5)
         except Exception as e:  # noqa: BLE001
-            parity = {"error": repr(e)[:200]}
-    t1 = time.time()
-    loss, _ = train_step(orc, batch, opt)
-    dt = time.time() - t1
-    if prod is not None:
+            perr = {"error": repr(e)[:200]}
+
+    def hip_loss(b, loss_ref, pred_ref):
+        if prod is None:
+            return perr
         try:
-            unet_in, ts, ehs, ids, noisy, _ = edm_inputs(batch)
+            unet_in, ts, ehs, ids, noisy, _ = edm_inputs(b)
+            with torch.no_grad():
+                pred = prod.model(unet_in.to(dev), ts.to(dev), ehs.to(dev), ids.to(dev)).sample.float().cpu()
             prod.zero_grad()
-            prod.forward_backward(unet_in.to(dev), ts.to(dev), ehs.to(dev), ids.to(dev), noisy.to(dev), batch["latents"].to(dev),
-                                  batch["sigmas"].to(dev))
+            prod.forward_backward(unet_in.to(dev), ts.to(dev), ehs.to(dev), ids.to(dev), noisy.to(dev), b["latents"].to(dev),
+                                  b["sigmas"].to(dev))
             lg = float(prod.last_loss())
-            parity = {"loss_oracle_fp32": float(loss), "loss_hip": lg, "loss_rel_err": abs(lg - float(loss)) / abs(float(loss)),
-                      "tolerance": 1e-3 if dtype == torch.float16 else 8e-3, "dtype": str(dtype).split(".")[-1]}
+            return {"loss_oracle_fp32": float(loss_ref), "loss_hip": lg, "loss_rel_err": abs(lg - float(loss_ref)) / abs(float(loss_ref)),
+                    "pred_rel_l2": float((pred - pred_ref).norm() / pred_ref.norm()),
+                    "tolerance": 1e-3 if dtype == torch.float16 else 8e-3, "dtype": str(dtype).split(".")[-1]}
         except Exception as e:  # noqa: BLE001
-            parity = {"error": repr(e)[:200]}
-        del prod
+            return {"error": repr(e)[:200]}
+
+    times = []
+    for i in range(4):                              # step 0 = warm-up (allocator, thread pools), then 3 timed
+        t1 = time.time()
+        loss, pred = train_step(orc, batch, opt)
+        times.append(time.time() - t1)
+    dt = statistics.median(times[1:])
+    parity = hip_loss(batch, loss, pred)
+    out = {"value": 1.0 / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": "c1': the full SVD UNet on one 8-frame 256x192 clip (latent 24x32), fp32, fwd+loss+bwd+AdamW; 1 warm-up step "
+                     f"({times[0]:.1f}s) + median of 3 ({dt:.1f}s; +{t_build:.1f}s model build); 4.1 TFLOP/step",
+           "seconds": dt, "seconds_all": times, "loss": float(loss), "parity_full_model": parity}
+    # one step at the benched shape (c2) when the host can afford it: ~25 TFLOP of fp32 work and ~60 GB of saved activations
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available / 2 ** 30
+    except Exception:  # noqa: BLE001
+        avail = 0.0
+    if c2 and cores >= 32 and avail >= 110.0 and dt <= 45.0:
+        b2 = make_synthetic_batch(1, 14, 40, 64, 2)
+        t1 = time.time()
+        loss2, pred2 = train_step(orc, b2, opt)
+        t2 = time.time() - t1
+        out["c2"] = {"value": 1.0 / t2, "unit": "samples/s", "seconds": t2, "loss": float(loss2),
+                     "sample": "c2: ONE un-warmed step of the benched shape (14 frames 512x320, latent 40x64), same model, fp32; 24.8 TFLOP",
+                     "parity_c2": hip_loss(b2, loss2, pred2)}
+    else:
+        out["c2"] = {"skipped": f"needs >= 32 cores, >= 110 GB free RAM and a c1' step <= 45 s (have {cores} cores, {avail:.0f} GB, {dt:.1f} s)"}
+    del prod
+    if dev is not None:
         torch.cuda.empty_cache()
-    return {"value": 1.0 / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "c1': 1 step of the full SVD UNet on one 8-frame 256x192 clip (latent 24x32), fp32, "
-                      f"fwd+loss+bwd+AdamW, {dt:.1f}s (+{t_build:.1f}s model build); 4.1 TFLOP/step",
-            "seconds": dt, "loss": float(loss), "parity_full_model": parity}
+    return out
 
 
 def main():
@@ -140,7 +172,29 @@ def main():
                          "than the built-in formula once the step is power-limited: off by default)")
     ap.add_argument("--gemm-table", action="store_true", help="dump per-shape GEMM timings of one step")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny topology instead of the SVD config")
+    ap.add_argument("--grad-accum", type=int, default=1,
+                    help="micro-batches per optimizer step (reference config 4 runs gradient_accumulation_steps = 2); gradients are "
+                         "reduced over ranks on the last one only")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: ONE all-reduce of the flat gradient buffer after the backward sweep instead of one per transformer "
+                         "block started during it (A/B switch for the scaling runs)")
+    ap.add_argument("--no-cpu-c2", action="store_true", help="skip the single CPU-oracle step at the benched shape")
+    ap.add_argument("--with-vae", action="store_true",
+                    help="also time the step with the VAE encode of the next micro-batch (train_svd.py:948, 957-960) on a second "
+                         "stream; reported as a second field, the headline metric stays UNet-only")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher the driver contract describes -- one rank per GPU under
+        # torch.distributed.run on this node (127.0.0.1 rendezvous), same arguments
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -157,7 +211,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     from svd_xtend_amd.train import GraphedStep, Trainer
     from svd_xtend_amd.unet import UNetSpatioTemporalConditionModel
@@ -175,17 +230,21 @@ def main():
             p.requires_grad_(False)
         with torch.device(dev):
             model.add_adapter(LoraConfig(r=args.lora_rank, lora_alpha=args.lora_rank, init_lora_weights="gaussian"))
-    trainer = Trainer(model, dtype=dt, lr=1e-5)
+    trainer = Trainer(model, dtype=dt, lr=1e-5, grad_accum=args.grad_accum)
     trainer.rt.gemm_variant = args.gemm_variant
+    trainer.overlap = not args.no_overlap
     n_params = sum(p.numel() for p in model.parameters())
     n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
     B, T, h, w = 1, args.frames, args.height // 8, args.width // 8
     cross = model.config.cross_attention_dim
-    batch = make_batch(B, T, h, w, cross, seed=123 + rank, dev=dev)       # rank-distinct data
+    # rank-distinct data, one clip per micro-batch
+    batches = [make_batch(B, T, h, w, cross, seed=123 + rank + 1000 * i, dev=dev) for i in range(args.grad_accum)]
+    batch = batches[0]
 
     def fwd_bwd():
         trainer.zero_grad()
-        trainer.forward_backward(**batch)
+        for b in batches:
+            trainer.forward_backward(**b)
 
     def opt_step():
         trainer.optimizer_step()
@@ -208,7 +267,7 @@ def main():
         try:
             # chain of graph segments cut at the transformer blocks: each block's gradient slice starts its all-reduce
             # (eager RCCL call between two replays) while the rest of the backward sweep runs -- svd_xtend_amd.train.GraphedStep
-            step_graph = GraphedStep(trainer, batch)
+            step_graph = GraphedStep(trainer, batches)
             step_graph()
             torch.cuda.synchronize()
             step = step_graph
@@ -236,7 +295,25 @@ def main():
     loss = float(trainer.last_loss())
     state = trainer.opt_state.cpu().tolist()
     ms = elapsed / args.steps * 1e3
-    value = world * B * args.steps / elapsed
+    value = world * B * args.grad_accum * args.steps / elapsed
+
+    # ---- what RCCL saw: ranks (an all-reduce of ones) and the cost of the gradient exchange on its own -------------------------
+    ranks_seen, allreduce_ms = 1, None
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        gbuf = torch.zeros_like(trainer.g_flat)
+        for _ in range(2):
+            dist.all_reduce(gbuf)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(gbuf)
+        torch.cuda.synchronize()
+        allreduce_ms = (time.perf_counter() - t1) / 5 * 1e3
+        del gbuf
 
     # ---- roofline of the dominant kernel (one instrumented eager step; events on the launch stream) ---------
     roof = None
@@ -298,22 +375,25 @@ def main():
             ach = fl / (t_ms * 1e-3) / 1e12
             # HBM-side bytes per launch of the same kernel family: rocprofv3 FETCH_SIZE / WRITE_SIZE passes over this exact command
             # (tools/pmc_traffic.py, gfx950 FETCH_SIZE x2 correction), committed under profiles/ -- bench.py cannot run a profiler
-            traffic = None
+            traffic, traffic_source = None, None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if (not args.tiny) and (T, h, w) == (14, 40, 64) and args.dtype == "fp16" and not args.lora_rank and os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath))["gemm"]["bytes_per_launch"]
+                    tj = json.load(open(tpath))
+                    traffic = tj["gemm"]["bytes_per_launch"]
+                    traffic_source = f"profiles/pmc_traffic.json@{tj.get('commit', 'unknown')} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes " \
+                                     "of this command, tools/pmc_traffic.py; NOT a counter of this run)"
                 except Exception:  # noqa: BLE001
                     traffic = None
             roof = {"bound": "mfma", "kernel": "MFMA GEMM family (NT + implicit conv, TN weight-grad)", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "launches": len(recs),
+                    "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "launches": len(recs),
                     "flops_per_step": fl, "kernel_ms_per_step": t_ms,
                     "algorithmic_bytes_per_launch": sum(b for _, _, _, b in recs_bytes) / max(len(recs_bytes), 1)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(dev, dt)
+            cpu = cpu_baseline(dev, dt, c2=not args.no_cpu_c2 and not args.tiny)
         except Exception as e:  # noqa: BLE001
             cpu = {"error": repr(e)[:200]}
 
@@ -325,14 +405,19 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic latents/CLIP embed, random-init weights (no checkpoints offline)",
-            "config": {"workload": f"SVD UNet train step, {T} frames {args.width}x{args.height}, batch 1/GPU, "
+            "config": {"workload": f"SVD UNet train step, {T} frames {args.width}x{args.height}, batch 1/GPU"
+                                   f"{' x %d micro-batches' % args.grad_accum if args.grad_accum > 1 else ''}, "
                                    f"{n_params} params ({n_train} trainable: "
                                    f"{'LoRA r=%d adapters on to_q/to_k/to_v/to_out.0' % args.lora_rank if args.lora_rank else 'temporal_transformer_block*'}), "
                                    "fwd + EDM loss + bwd + grad all-reduce + AdamW",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "exec": exec_mode, "gemm_tuning_sweeps": tune_sweeps,
+                       "global_batch": world * B * args.grad_accum, "grad_accum": args.grad_accum, "parallelism": f"dp{world}",
+                       "grad_allreduce": ("none" if world == 1 else "one collective after backward" if args.no_overlap else
+                                          "per-transformer-block buckets overlapped with the backward sweep"),
+                       "ranks_seen": ranks_seen, "allreduce_ms": allreduce_ms, "allreduce_bytes": trainer.n_total * 4,
+                       "exec": exec_mode, "gemm_tuning_sweeps": tune_sweeps,
                        "gemm_variant": args.gemm_variant, "loss": loss, "loss_scale": state[1], "opt_steps": state[0],
-                       "step_tflops_per_gpu": (STEP_TFLOP_C2 / (ms * 1e-3) if full else None),
-                       "step_frac_of_mfma_peak": (STEP_TFLOP_C2 / (ms * 1e-3) / MFMA_PEAK_TFLOPS if full else None)},
+                       "step_tflops_per_gpu": (STEP_TFLOP_C2 * args.grad_accum / (ms * 1e-3) if full else None),
+                       "step_frac_of_mfma_peak": (STEP_TFLOP_C2 * args.grad_accum / (ms * 1e-3) / MFMA_PEAK_TFLOPS if full else None)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

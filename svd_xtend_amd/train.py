@@ -39,12 +39,14 @@ def build_adam_tiles(params, offsets, wt_map, device) -> torch.Tensor:
     carry its location so the optimizer kernel writes it.  int32 [n_tiles, 6] = off, ld, rows, cols, wt_off, ldwt."""
     rows_out = []
     for p, off in zip(params, offsets):
-        if p.ndim == 2:
-            R, C = p.shape
-        else:
-            R, C = 1, p.numel()
-        assert C % 4 == 0 and off % 4 == 0, "parameters must be multiples of 4 elements (16-byte vector access)"
         wt = wt_map.get(id(p))
+        if p.ndim == 2 and (wt is not None or p.shape[1] % 4 == 0):
+            R, C = p.shape
+        else:                            # vectors, and matrices whose rows are not 16-byte multiples (a LoRA factor [out, r] with
+            R, C = 1, p.numel()          # r = 1, 2, 3, ...: train_svd_lora.py accepts any --rank): one flat row, no transposed twin
+        if C % 4 or off % 4:
+            raise ValueError(f"trainable parameter of shape {tuple(p.shape)} at flat offset {off}: the optimizer kernel needs "
+                             "16-byte multiples (every SVD / LoRA parameter is, or flattens to one)")
         r0 = torch.arange(0, R, 64)
         c0 = torch.arange(0, C, 64)
         rr, cc = torch.meshgrid(r0, c0, indexing="ij")
@@ -57,7 +59,8 @@ def build_adam_tiles(params, offsets, wt_map, device) -> torch.Tensor:
         if wt is None:
             t[:, 4], t[:, 5] = -1, 0
         else:
-            assert R % 4 == 0 and wt[0] % 4 == 0 and wt[1] % 4 == 0
+            if R % 4 or wt[0] % 4 or wt[1] % 4:
+                raise ValueError(f"transposed twin of a {tuple(p.shape)} weight is not 16-byte aligned")
             t[:, 4] = wt[0] + cc * wt[1] + rr
             t[:, 5] = wt[1]
         rows_out.append(t)
@@ -99,13 +102,23 @@ class Trainer:
         self.schedule = dict(name="constant", num_warmup_steps=0, num_training_steps=0, num_cycles=0.0, power=1.0, lr_end=1e-7,
                              steps_per_step=1)
         self._build_runtime()
+        if self.world > 1:
+            # DistributedDataParallel's constructor broadcast (train_svd.py:815 through accelerate.prepare): the replicas start from
+            # rank 0's trainables whatever each rank drew locally (peft's gaussian LoRA init uses the process-global generator)
+            dist.broadcast(self.p_flat, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                           group=process_group)
+            self.weights_changed()
 
     def _build_runtime(self) -> None:
         """Pack the model for the kernels and derive every table that depends on the packed layout (also after `load_state`
         replaced the weights)."""
         model, dtype, dev = self.model, self.dtype, self.dev
+        old = getattr(self, "rt", None)
         model.prepare(dtype)
         self.rt = model.rt
+        if old is not None:              # a rebuild after load_state: keep what the caller tuned / set on the previous runtime
+            for knob in ("tuner", "gemm_variant", "split_k", "fuse_geglu", "fuse_dual"):
+                setattr(self.rt, knob, getattr(old, knob))
         # AdamW walks a tile table so that it can also emit the transposed 16-bit twins the data-grad GEMMs read
         tiled = bool(self.params) and os.environ.get("SVDX_ADAM_TILED", "1") != "0"      # developer knob for A/B runs
         self.adam_tiles = build_adam_tiles(self.params, self.offsets, self.rt.wt_map, dev) if tiled else None
@@ -133,7 +146,7 @@ class Trainer:
         # gradient buckets for overlapping the all-reduce with the backward sweep: one contiguous slice of g_flat per transformer
         # block (its trainables are adjacent in named_parameters order), reduced as soon as backward_rows leaves the block
         self.overlap = True
-        self._pending = []
+        self._pending = []              # (span, work) of the all-reduces started during THIS step's backward sweep (zero_grad clears)
         self._buckets = {}
         off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
         for kind, m in model.steps:
@@ -203,7 +216,9 @@ class Trainer:
         n = 0
         while n < max_steps:
             self.zero_grad()
-            self.forward_backward(**batch)
+            self.forward_loss(**batch)
+            self.backward(on_block=lambda m: None)      # no gradient all-reduce here: these sweeps are measurements, not steps
+            self.micro = 0
             n += 1
             if self.rt.tuner.end_step():
                 break
@@ -216,6 +231,9 @@ class Trainer:
     def zero_grad(self):
         """After this call the next backward behaves as if every gradient were zero.  (Write-once gradients keep their stale
         values until that backward stores over them -- do not read `.grad` in between.)"""
+        for _, w in self._pending:        # collectives of a step that was abandoned before allreduce_grads(): finish them first
+            w.wait()
+        self._pending = []
         if self.zero_spans is None:
             self.rt.k.zero(self.g_flat)
         else:
@@ -309,27 +327,41 @@ class Trainer:
 
 
 class GraphedStep:
-    """One optimizer step (grad_accum == 1) replayed from hipGraphs, with the gradient all-reduce overlapped.
+    """One optimizer step (all `grad_accum` micro-batches) replayed from hipGraphs, with the gradient all-reduce overlapped.
 
-    The step is captured once, on fixed input tensors, as a CHAIN of graphs sharing one memory pool: the first holds zero_grad,
-    the forward sweep, the loss and the backward sweep down to the first transformer block; every later one holds the backward
-    sweep between two transformer blocks; the last holds the rest of it; one more holds the optimizer.  Replaying them in order
-    is the whole step, and between two replays -- outside any graph, so RCCL is never captured -- the slice of the flat gradient
-    buffer that the previous segment completed starts its all-reduce (async: it runs beside the next segments' kernels).
-    On one rank the collectives vanish and the chain is just the step."""
+    The step is captured once, on fixed input tensors (one dict per micro-batch), as a CHAIN of graphs sharing one memory pool: the
+    first holds zero_grad, the whole forward + backward of every micro-batch but the last, then the last one's forward sweep, loss
+    and backward sweep down to the first transformer block; every later graph holds the backward sweep between two transformer
+    blocks; one more holds the optimizer.  Replaying them in order is the whole step, and between two replays -- outside any graph,
+    so RCCL is never captured -- the slice of the flat gradient buffer that the previous segment completed starts its all-reduce
+    (async: it runs beside the next segments' kernels).  Gradients are only reduced on the last micro-batch, as with
+    `accelerator.accumulate` (train_svd.py:941).  On one rank the collectives vanish and the chain is just the step."""
 
-    def __init__(self, trainer: "Trainer", batch: Dict[str, torch.Tensor]):
-        assert trainer.grad_accum == 1, "GraphedStep captures a whole step: use grad_accum == 1"
+    def __init__(self, trainer: "Trainer", batch, cut_blocks: Optional[bool] = None):
+        """cut_blocks: cut the chain at every transformer block (None: only when there is a collective to interleave, i.e. on
+        several ranks with `trainer.overlap`; True lets one rank rehearse the multi-rank chain)."""
+        batches = [batch] if isinstance(batch, dict) else list(batch)
+        if cut_blocks is None:
+            cut_blocks = trainer.world > 1 and trainer.overlap
+        if len(batches) != trainer.grad_accum:
+            raise ValueError(f"expected {trainer.grad_accum} micro-batch(es), got {len(batches)}")
         self.tr = trainer
         self.graphs: List[torch.cuda.CUDAGraph] = []
         self.spans: List[Optional[tuple]] = []
         tr = trainer
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):                       # warm-up on the capture stream (allocator, lazy module state)
+
+        def sweep(on_last_block):
             tr.zero_grad()
-            tr.forward_loss(**batch)
-            tr.backward(on_block=lambda m: None)
+            for b in batches[:-1]:
+                tr.forward_loss(**b)
+                tr.backward(on_block=lambda m: None)
+            tr.forward_loss(**batches[-1])
+            tr.backward(on_block=on_last_block)
+
+        with torch.cuda.stream(s):                       # warm-up on the capture stream (allocator, lazy module state)
+            sweep(lambda m: None)
             tr.allreduce_grads()                         # the warm-up pass is a real step: keep the replicas identical
             tr.optimizer_step()
             torch.cuda.synchronize()
@@ -340,14 +372,14 @@ class GraphedStep:
             self.graphs.append(g)
             try:
                 def cut(module):
+                    if not cut_blocks:
+                        return                           # nothing to interleave: the whole sweep stays one graph
                     self.graphs[-1].capture_end()
                     self.spans.append(tr._buckets.get(id(module)))
                     g2 = torch.cuda.CUDAGraph()
                     g2.capture_begin(pool=pool, capture_error_mode="thread_local")
                     self.graphs.append(g2)
-                tr.zero_grad()
-                tr.forward_loss(**batch)
-                tr.backward(on_block=cut)
+                sweep(cut)
             finally:
                 self.graphs[-1].capture_end()
             self.g_opt = torch.cuda.CUDAGraph()

@@ -1009,8 +1009,9 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         k = rt.k
         rt.begin_pass(0)
         B, T, Cin, h, w = sample.shape
-        if h % 8 or w % 8:
-            raise ValueError("latent height/width must be multiples of 8 (3 stride-2 levels; SURVEY.md 0.8)")
+        mult = 2 ** sum(1 for kind, _ in self.steps if kind == "down")
+        if h % mult or w % mult:
+            raise ValueError(f"latent height/width must be multiples of {mult} ({mult.bit_length() - 1} stride-2 levels; SURVEY.md 0.8)")
         g = Geom(B, T, h, w)
         dev = rt.dev
         # 1. time + added-id embeddings (float, skinny path)  src/unet_spatio_temporal_condition.py:386-416

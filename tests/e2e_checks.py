@@ -16,9 +16,10 @@ def cosine(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-def oracle_step(cfg, B, T, h, w, seed, lr, cross_dim, lora_r=0):
-    orc = UNetSpatioTemporalConditionOracle(**cfg)
-    scaled_init_(orc, seed)
+def oracle_step(cfg, B, T, h, w, seed, lr, cross_dim, lora_r=0, orc=None):
+    if orc is None:
+        orc = UNetSpatioTemporalConditionOracle(**cfg)
+        scaled_init_(orc, seed)
     if lora_r:                                   # config 5: adapters are the trainable set (B randomised so dA is non-zero)
         from oracle.lora import add_adapter
         for p in orc.parameters():
@@ -39,7 +40,10 @@ def oracle_step(cfg, B, T, h, w, seed, lr, cross_dim, lora_r=0):
     loss.backward()
     grads = {n: p.grad.clone() for n, p in orc.named_parameters() if p.grad is not None}
     opt.step()
-    return dict(sd0=sd0, batch=batch, inputs=(unet_in, ts, ehs, ids, noisy), loss=float(loss), pred=pred.detach(),
+    with torch.no_grad():                        # the prediction of the UPDATED weights (checks the optimizer step end to end)
+        pred_after = orc(unet_in, ts, ehs, added_time_ids=ids).sample
+    return dict(sd0=sd0, batch=batch, inputs=(unet_in, ts, ehs, ids, noisy), loss=float(loss.detach()), pred=pred.detach(),
+                pred_after=pred_after, lr=lr,
                 grads=grads, params_after={n: p.detach().clone() for n, p in orc.named_parameters() if p.requires_grad})
 
 
@@ -53,6 +57,8 @@ def product_step(ref, cfg, dtype, dev, lr, lora_r=0):
     tr = Trainer(m, dtype=dtype, lr=lr)
     unet_in, ts, ehs, ids, noisy = (t.to(dev) for t in ref["inputs"])
     b = ref["batch"]
+    with torch.no_grad():
+        pred0 = m(unet_in, ts, ehs, ids).sample.float().cpu()
     tr.zero_grad()
     tr.forward_backward(unet_in, ts, ehs, ids, noisy, b["latents"].to(dev), b["sigmas"].to(dev))
     loss = float(tr.last_loss())
@@ -62,7 +68,7 @@ def product_step(ref, cfg, dtype, dev, lr, lora_r=0):
     params = {n: p.detach().float().cpu() for n, p in m.named_parameters() if p.requires_grad}
     with torch.no_grad():
         pred = m(unet_in, ts, ehs, ids).sample.float().cpu()
-    return dict(loss=loss, grads=grads, params_after=params, pred_after=pred, state=tr.opt_state.cpu().tolist())
+    return dict(loss=loss, grads=grads, params_after=params, pred=pred0, pred_after=pred, state=tr.opt_state.cpu().tolist())
 
 
 def compare(ref, got):
@@ -73,9 +79,35 @@ def compare(ref, got):
     gn_ref = sum(float(g.double().pow(2).sum()) for g in ref["grads"].values()) ** 0.5
     gn = sum(float(g.double().pow(2).sum()) for g in got["grads"].values()) ** 0.5
     out["grad_norm_rel"] = abs(gn - gn_ref) / gn_ref
+    out["n_grads"] = len(cos)
     out["param_max_diff"] = max(float((got["params_after"][n] - p).abs().max()) for n, p in ref["params_after"].items())
+    n_el = sum(p.numel() for p in ref["params_after"].values())
+    out["param_mean_diff"] = sum(float((got["params_after"][n] - p).abs().sum()) for n, p in ref["params_after"].items()) / n_el
+    out["lr"] = ref.get("lr")
+    out["pred_rel_l2"] = rel_l2(got["pred"], ref["pred"]) if "pred" in got else None
+    out["pred_after_rel_l2"] = rel_l2(got["pred_after"], ref["pred_after"]) if "pred_after" in ref else None
     out["opt_state"] = got["state"]
     return out
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def assert_parity(key, r, bf16=None):
+    """The acceptance bar of every oracle comparison (north_star: noise-prediction MSE within 1e-3 relative at fp16; bf16 carries
+    8x less mantissa).  One AdamW step moves a weight by at most ~lr, and where the gradient is at rounding level its sign -- and
+    with it the whole update -- may differ: the worst weight is bounded by 2.5 lr, the mean weight must agree far below lr."""
+    assert "error" not in r, f"{key}: {r}"
+    bf16 = ("bfloat16" in key) if bf16 is None else bf16          # NB: "float16" is a substring of "bfloat16"
+    assert r["loss_rel"] <= (8e-3 if bf16 else 1e-3), f"{key}: loss rel err {r['loss_rel']:.3e}"
+    assert r["grad_cos_min"] >= (0.95 if bf16 else 0.99), f"{key}: {r}"
+    assert r["pred_rel_l2"] is None or r["pred_rel_l2"] <= (4e-2 if bf16 else 5e-3), f"{key}: {r}"
+    assert r["pred_after_rel_l2"] is None or r["pred_after_rel_l2"] <= (4e-2 if bf16 else 5e-3), f"{key}: {r}"
+    if r.get("lr"):
+        assert r["param_max_diff"] <= 2.5 * r["lr"], f"{key}: {r}"
+        assert r["param_mean_diff"] <= (0.2 if bf16 else 0.05) * r["lr"], f"{key}: {r}"
 
 
 def run_all(verbose=False, dev=None):
@@ -120,7 +152,7 @@ def graphed_vs_eager(dev=None, dtype=torch.float16, steps=3):
                 tr.step(batch)
             segs = 0
         else:
-            gs = GraphedStep(tr, batch)              # its warm-up pass is one real step
+            gs = GraphedStep(tr, batch, cut_blocks=True)   # its warm-up pass is one real step; one rank rehearses the multi-rank chain
             for _ in range(steps - 1):
                 gs()
             segs = len(gs.graphs)
@@ -173,7 +205,7 @@ def resume_vs_straight(tmpdir, dev=None, dtype=torch.float16, steps=4, cut=2):
     c.save_state(path, ema=ema_c, scheduler=sc)
     d, sd_, ema_d = fresh(123)
     d.load_state(path, ema=ema_d, scheduler=sd_)
-    gs = GraphedStep(d, batch)                   # its warm-up pass is one real step
+    gs = GraphedStep(d, batch, cut_blocks=True)  # its warm-up pass is one real step
     ema_d.step(d.model.parameters())
     lrs_d = [1e-3 * float(d.opt_state[8])]
     for _ in range(steps - cut - 1):
@@ -223,3 +255,111 @@ def run_lora(verbose=False, dev=None, ranks=(64, 8)):
             if verbose:
                 print(key, res[key], flush=True)
     return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Real widths.  One-level UNets whose every block has the channel width, head count, frame count and pixel count of ONE resolution
+# level of the benched configuration (c2: 14 frames, latent 40x64): the same GEMM problems (M = 35840 / 8960 / 2240 / 560 rows,
+# N and K multiples of 320), hence the same tile / split-K choices of `ops.choose_cfg`, the T = 14 -> 16 padding of the temporal
+# attention, spatial sequences of 2560 / 640 / 160 / 40, the 2C -> C resnets behind a skip concat with their 1x1 shortcut.
+# layers_per_block = 1 keeps the CPU oracle at seconds per case.
+# ----------------------------------------------------------------------------------------------------------------------
+def level_config(C, heads, cross_dim=1024, layers=1):
+    return dict(in_channels=8, out_channels=4, down_block_types=("CrossAttnDownBlockSpatioTemporal",),
+                up_block_types=("CrossAttnUpBlockSpatioTemporal",), block_out_channels=(C,), addition_time_embed_dim=256,
+                projection_class_embeddings_input_dim=768, layers_per_block=layers, cross_attention_dim=cross_dim,
+                transformer_layers_per_block=1, num_attention_heads=(heads,), num_frames=14)
+
+
+C2_LEVELS = {           # name: (C, heads, h, w) at T = 14
+    "L0 320ch 40x64": (320, 5, 40, 64),
+    "L1 640ch 20x32": (640, 10, 20, 32),
+    "L2 1280ch 10x16": (1280, 20, 10, 16),
+    "L3 1280ch 5x8": (1280, 20, 5, 8),
+}
+
+
+def run_levels(levels=None, dtypes=(torch.float16,), T=14, lora_r=0, verbose=False, dev=None, seed=11):
+    dev = dev or torch.device("cuda")
+    res = {}
+    for name, (C, heads, h, w) in C2_LEVELS.items():
+        if levels is not None and name.split()[0] not in levels:
+            continue
+        cfg = level_config(C, heads)
+        t0 = time.time()
+        ref = oracle_step(cfg, 1, T, h, w, seed=seed, lr=1e-4, cross_dim=cfg["cross_attention_dim"], lora_r=lora_r)
+        t_or = time.time() - t0
+        for dt in dtypes:
+            key = f"{name} T={T} {'lora r=%d ' % lora_r if lora_r else ''}{str(dt).split('.')[-1]}"
+            try:
+                res[key] = compare(ref, product_step(ref, cfg, dt, dev, 1e-4, lora_r=lora_r))
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                res[key] = {"error": repr(e)[:400]}
+            if verbose:
+                print(key, res[key], f"oracle {t_or:.1f}s total {time.time() - t0:.1f}s", flush=True)
+        del ref
+    return res
+
+
+def run_full_c1(dtypes=(torch.float16, torch.bfloat16), verbose=False, dev=None):
+    """c1' (SURVEY.md 8d): the FULL 1,524,623,082-parameter topology on one 8-frame 256x192 clip (latent 24x32), the oracle's
+    weights through the HIP path: loss, every trainable tensor's gradient, prediction, updated weights."""
+    from oracle.unet import SVD_CONFIG
+    dev = dev or torch.device("cuda")
+    t0 = time.time()
+    ref = oracle_step(SVD_CONFIG, 1, 8, 24, 32, seed=0, lr=1e-4, cross_dim=1024)
+    t_or = time.time() - t0
+    res = {}
+    for dt in dtypes:
+        key = f"c1' full topology 8x24x32 {str(dt).split('.')[-1]}"
+        try:
+            res[key] = compare(ref, product_step(ref, SVD_CONFIG, dt, dev, 1e-4))
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            res[key] = {"error": repr(e)[:400]}
+        if verbose:
+            print(key, res[key], f"oracle {t_or:.1f}s total {time.time() - t0:.1f}s", flush=True)
+        torch.cuda.empty_cache() if dev.type == "cuda" else None
+    return res
+
+
+def autograd_route(dev=None, dtype=torch.float16, cfg=None, shape=(1, 4, 16, 16), lr=1e-4):
+    """The minimal-change route INTEGRATION.md shows first: the host script keeps `loss.backward()` and its own
+    `torch.optim.AdamW`; `unet(...).sample` goes through `_UNetFn`, whose backward runs on autograd's worker thread (with that
+    thread's current stream) -- SURVEY.md 8(b).  Compared with the oracle's step on the same weights."""
+    dev = dev or torch.device("cuda")
+    cfg = cfg or TINY_CONFIG
+    B, T, h, w = shape
+    ref = oracle_step(cfg, B, T, h, w, seed=9, lr=lr, cross_dim=cfg["cross_attention_dim"])
+    m = UNetSpatioTemporalConditionModel(**cfg)
+    m.load_state_dict(ref["sd0"], strict=True)
+    m.to(dev)
+    for n, p in m.named_parameters():                          # train_svd.py:761-766
+        p.requires_grad_("temporal_transformer_block" in n)
+    m.prepare(dtype)
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=lr, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    unet_in, ts, ehs, ids, noisy = (t.to(dev) for t in ref["inputs"])
+    b = ref["batch"]
+    sig = b["sigmas"].to(dev)[:, None, None, None, None]
+    scale = 1024.0 if dtype == torch.float16 else 1.0          # a GradScaler-style constant loss scale on the host side
+    with torch.no_grad():
+        pred0 = m(unet_in, ts, ehs, ids).sample.float().cpu()
+    pred = m(unet_in, ts, ehs, ids).sample                     # train_svd.py:1021
+    loss = edm_loss(pred, noisy, b["latents"].to(dev), sig)    # :1025-1036 (the oracle's statement-level restatement)
+    opt.zero_grad(set_to_none=False)
+    (loss * scale).backward()                                  # :1044
+    torch.cuda.synchronize() if dev.type == "cuda" else None
+    grads = {n: (p.grad.detach().float().cpu() / scale) for n, p in m.named_parameters() if p.requires_grad}
+    for p in m.parameters():
+        if p.requires_grad:
+            p.grad.div_(scale)
+    opt.step()                                                 # :1047
+    m.refresh_trainable()
+    params = {n: p.detach().float().cpu() for n, p in m.named_parameters() if p.requires_grad}
+    with torch.no_grad():
+        pred1 = m(unet_in, ts, ehs, ids).sample.float().cpu()
+    got = dict(loss=float(loss.detach()), grads=grads, params_after=params, pred=pred0, pred_after=pred1, state=[])
+    return compare(ref, got)
