@@ -42,6 +42,8 @@ extern "C" {
 #define SVDX_GATHER_CONV3X3 1     /* 3x3, pad 1, stride 1|2, optional nearest x2 upsampled source */
 #define SVDX_GATHER_CONV3X3_DGRAD2 2 /* data-gradient of the stride-2 3x3 conv (transposed conv) */
 #define SVDX_GATHER_TEMPORAL3 3   /* Conv3d kernel (3,1,1) pad (1,0,0) over the frame axis */
+#define SVDX_GATHER_CONV3X3_PAD0 4 /* 3x3 stride 2 over F.pad(x, (0,1,0,1)): the VAE encoder's Downsample2D(padding=0) -- zeros only
+                                    * below / right of the image (diffusers vae.Encoder, reached from train_svd.py:283-291) */
 
 /* Implicit-GEMM A-operand addressing: row m of the GEMM is an output pixel, K = taps*cin,
  * k = tap*cin + ci.  Replaces cuDNN/MIOpen conv2d/conv3d reached from diffusers ResnetBlock2D /
@@ -187,6 +189,34 @@ int svdx_cast_transpose_from_f32(const float* in, void* out, int R, int Ccols, i
 int svdx_nchw_to_rows(const float* in, void* out, int n_img, int C, int H, int W, int ld, float mul, int dtype, void* stream);
 int svdx_rows_to_nchw(const void* in, float* out, int n_img, int C, int H, int W, int ld, int dtype, void* stream);
 int svdx_zero(void* p, size_t bytes, void* stream);
+
+/* ---- fused temporal self-attention forward (csrc/tsa.hip): norm1 -> attn1 -> residual of diffusers' TemporalBasicTransformerBlock
+ * (the block built at /root/reference/src/unet_spatio_temporal_condition.py:170-192) in ONE launch,
+ *   n   = LayerNorm(x; gamma, beta, eps)                                   [M, C]   (also stored, with stats[M,2] = mean, rstd)
+ *   qkv = n wqkv^T                                                        [M, 3C]  (stored: the backward needs q, k, v)
+ *   o   = softmax over the T frames of each (clip, pixel, head) of q k^T * scale, times v      [M, C] (stored)
+ *   h1  = o wo^T + bo + cvec[group(row)] + x                               [M, C]
+ * rows are (b, t, pixel) ordered, M = B*T*HW; wqkv [3C, C] and wo [C, C] row-major in the activation dtype; cvec (float, may be NULL)
+ * is indexed like svdx_gemm's rowvec.  Needs T <= 16, C = 64*heads <= 320.  A workgroup owns svdx_tsa_pixels_per_band(T, HW) pixels
+ * (the largest divisor of HW with at most 144 rows) of one clip. */
+int svdx_tsa_pixels_per_band(int T, int HW);
+int svdx_tsa_fwd(const void* x, const float* gamma, const float* beta, float eps, const void* wqkv, const void* wo, const float* bo,
+                 const float* cvec, int rv_ld, int rv_rows_per_group, int rv_mod, void* n1, float* stats, void* qkv, void* o, void* h1,
+                 int B, int T, int HW, int C, int heads, float scale, int dtype, void* stream);
+
+/* ---- frozen conditioners either side of the step (csrc/encoders.hip) --------------------------------------
+ * svdx_patch_rows: im2col of a few-channel NCHW float image into GEMM rows,
+ *   out[(n*ho + y)*wo + x][(c*kh + dy)*kw + dx] = mul * in[n][c][y*stride + dy - pad][x*stride + dx - pad]   (0 outside, 0 for k >= C*kh*kw up to ldk)
+ *   -- the k order of a flattened torch conv weight [Cout, C, kh, kw].  Replaces the first convolution of diffusers' vae.Encoder
+ *   (`conv_in`, reached from train_svd.py:286) and CLIPVisionEmbeddings.patch_embedding (train_svd.py:872).
+ * svdx_softmax_rows: out[r][c] = softmax_c(scale * in[r][c]) for c < cols, 0 for cols <= c < cols_out (fp32 inside): the attention of
+ *   a head dimension other than 64 is GEMM -> this -> GEMM (VAE mid-block attention, CLIP self-attention).
+ * svdx_act_rows: out = gelu_erf(in) (act 0) or in * sigmoid(1.702 in) (act 1, quick_gelu). */
+int svdx_patch_rows(const float* in, void* out, int n_img, int C, int H, int W, int kh, int kw, int stride, int pad, int ho, int wo,
+                    int ldk, float mul, int dtype, void* stream);
+int svdx_softmax_rows(const void* in, void* out, int rows, int cols, int cols_out, int64_t ld_in, int64_t ld_out, float scale,
+                      int dtype, void* stream);
+int svdx_act_rows(const void* in, void* out, int64_t n, int act, int dtype, void* stream);
 /* base[off .. off+cnt) = 0 for each (off, cnt) pair of `spans` (int pairs; off and cnt multiples of 4): ONE launch for the scattered
  * gradient slots that are accumulated with atomics and so must start from zero (biases, LayerNorm, skinny cross-attention weights). */
 int svdx_zero_spans(float* base, const int* spans, int n_spans, void* stream);

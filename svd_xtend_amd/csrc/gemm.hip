@@ -50,7 +50,7 @@ __device__ __forceinline__ const T* a_row_ptr(const GemmParams& p, const RowInfo
     valid = true;
     if (g.mode == SVDX_GATHER_PLAIN) return A + (size_t)m_clamped * p.lda + k0;
     int src;
-    if (g.mode == SVDX_GATHER_CONV3X3) {
+    if (g.mode == SVDX_GATHER_CONV3X3 || g.mode == SVDX_GATHER_CONV3X3_PAD0) {
         int dy = tap / 3, dx = tap - dy * 3;
         int ys = ri.a + dy, xs = ri.b + dx;
         valid = (ys >= 0) & (ys < g.hi) & (xs >= 0) & (xs < g.wi);
@@ -71,11 +71,12 @@ __device__ __forceinline__ const T* a_row_ptr(const GemmParams& p, const RowInfo
 
 __device__ __forceinline__ RowInfo decode_row(const svdx_gather& g, int m) {
     RowInfo ri{0, 0, 0};
-    if (g.mode == SVDX_GATHER_CONV3X3) {
+    if (g.mode == SVDX_GATHER_CONV3X3 || g.mode == SVDX_GATHER_CONV3X3_PAD0) {
         int x = m % g.wo, t = m / g.wo;
         int y = t % g.ho, n = t / g.ho;
-        ri.a = y * g.stride - 1;
-        ri.b = x * g.stride - 1;
+        const int pad = g.mode == SVDX_GATHER_CONV3X3 ? 1 : 0;      // PAD0: the zero row / column sit below / right of the image only
+        ri.a = y * g.stride - pad;
+        ri.b = x * g.stride - pad;
         ri.base = n * (g.hi >> g.ups) * (g.wi >> g.ups);
     } else if (g.mode == SVDX_GATHER_CONV3X3_DGRAD2) {
         int x = m % g.wo, t = m / g.wo;
@@ -1120,8 +1121,9 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
         SVDX_CHECK_ARG(zero_page && ((uintptr_t)zero_page & 15) == 0, "svdx_gemm: gather needs an aligned zero page");
         const int taps = p.g.mode == SVDX_GATHER_TEMPORAL3 ? 3 : 9;
         SVDX_CHECK_ARG(K == taps * p.g.cin, "svdx_gemm: K=%d != taps*cin=%d", K, taps * p.g.cin);
-        if (p.g.mode == SVDX_GATHER_CONV3X3) {
+        if (p.g.mode == SVDX_GATHER_CONV3X3 || p.g.mode == SVDX_GATHER_CONV3X3_PAD0) {
             SVDX_CHECK_ARG(M == p.g.n_img * p.g.ho * p.g.wo, "svdx_gemm: conv rows mismatch");
+            SVDX_CHECK_ARG(p.g.mode == SVDX_GATHER_CONV3X3 || (p.g.stride == 2 && !p.g.ups), "svdx_gemm: the pad-0 gather is the stride-2 downsample");
             SVDX_CHECK_ARG(p.g.stride == 1 || p.g.stride == 2, "svdx_gemm: conv stride");
             SVDX_CHECK_ARG(!p.g.ups || (p.g.hi % 2 == 0 && p.g.wi % 2 == 0), "svdx_gemm: upsampled dims must be even");
         } else if (p.g.mode == SVDX_GATHER_CONV3X3_DGRAD2) {
@@ -1145,7 +1147,7 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
     hipStream_t st = (hipStream_t)stream;
     // extents of the A / B buffers for the bounds-checked buffer loads of variant 4 (must stay below 2 GiB)
     long a_rows = M;
-    if (p.g.mode == SVDX_GATHER_CONV3X3) a_rows = (long)p.g.n_img * (p.g.hi >> p.g.ups) * (p.g.wi >> p.g.ups);
+    if (p.g.mode == SVDX_GATHER_CONV3X3 || p.g.mode == SVDX_GATHER_CONV3X3_PAD0) a_rows = (long)p.g.n_img * (p.g.hi >> p.g.ups) * (p.g.wi >> p.g.ups);
     else if (p.g.mode == SVDX_GATHER_CONV3X3_DGRAD2) a_rows = (long)p.g.n_img * p.g.hi * p.g.wi;
     else if (p.g.mode == SVDX_GATHER_TEMPORAL3) a_rows = (long)p.g.n_img * p.g.t * p.g.hw;
     const int a_ld = p.g.mode == SVDX_GATHER_PLAIN ? lda : p.g.lda;

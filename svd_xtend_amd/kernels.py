@@ -24,7 +24,7 @@ OUT_ACT, OUT_F32, OUT_F32_ATOMIC, OUT_F32_SLAB, OUT_F32_ADD = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GEGLU_FWD, EPI_GEGLU_BWD = 0, 1, 2
 LN_PARTIAL_ROWS = 512
 GN_REPLICAS = 8
-GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3 = 0, 1, 2, 3
+GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3, GATHER_CONV3X3_PAD0 = 0, 1, 2, 3, 4
 OPT_STATE_FLOATS = 16          # include/svdx.h: layout of the optimizer / loss-scale / schedule state
 SCHED_KINDS = {"constant": 0, "constant_with_warmup": 1, "linear": 2, "cosine": 3, "cosine_with_restarts": 4, "polynomial": 5}
 
@@ -80,6 +80,7 @@ _SIGS = {
     "svdx_attn_bwd_dq": "ppppppp" "iiiiii" "f" "ip",
     "svdx_tattn_fwd": "pppp" "iiii" "ii" "f" "ip",
     "svdx_tattn_bwd": "ppppppp" "iiii" "iii" "f" "ip",
+    "svdx_tsa_fwd": "ppp" "f" "ppp" "piii" "ppppp" "iiiii" "f" "ip",
     "svdx_geglu_fwd": "pp" "ii" "ip",
     "svdx_geglu_bwd": "ppp" "ii" "ip",
     "svdx_add": "ppp" "l" "ip",
@@ -96,6 +97,9 @@ _SIGS = {
     "svdx_nchw_to_rows": "pp" "iiiii" "f" "ip",
     "svdx_rows_to_nchw": "pp" "iiiii" "ip",
     "svdx_zero": "pzp",
+    "svdx_patch_rows": "pp" "iiiiiiiiii" "i" "f" "ip",
+    "svdx_softmax_rows": "pp" "iii" "ll" "f" "ip",
+    "svdx_act_rows": "pp" "l" "i" "ip",
     "svdx_zero_spans": "pp" "ip",
     "svdx_edm_loss": "pi" "ppppp" "iiii" "p" "ip",
     "svdx_check_finite": "plpp",
@@ -106,7 +110,15 @@ _SIGS = {
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "l": ctypes.c_int64, "z": ctypes.c_size_t}
 
-EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_version", "svdx_last_error", "svdx_device_ok")
+EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band")
+TSA_MAX_C, TSA_MAX_T, TSA_BAND_ROWS = 320, 16, 144
+
+
+def tsa_pixels_per_band(T: int, HW: int) -> int:
+    """include/svdx.h svdx_tsa_pixels_per_band: the largest divisor of HW with at most 144 band rows (0: unsupported T)."""
+    if T <= 0 or T > TSA_MAX_T or HW <= 0:
+        return 0
+    return max((P for P in range(1, min(HW, TSA_BAND_ROWS // T) + 1) if HW % P == 0), default=0)
 
 
 def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
@@ -119,6 +131,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = [_CT[c] for c in sig]
         fn.restype = ctypes.c_int
+    lib.svdx_tsa_pixels_per_band.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.svdx_tsa_pixels_per_band.restype = ctypes.c_int
     lib.svdx_version.restype = ctypes.c_int
     lib.svdx_device_ok.restype = ctypes.c_int
     lib.svdx_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
@@ -260,6 +274,10 @@ class HipBackend:
         self._call("svdx_tattn_bwd", _p(q), _p(k), _p(v), _p(d_o), _p(dq), _p(dk), _p(dv), B, T, HW, heads,
                    ld, ld_o, ld_d, float(scale), _dt(q), self._stream())
 
+    def tsa_fwd(self, x, gamma, beta, eps, wqkv, wo, bo, cvec, rv_ld, rv_rpg, rv_mod, n1, stats, qkv, o, h1, B, T, HW, C, heads, scale):
+        self._call("svdx_tsa_fwd", _p(x), _f32(gamma), _f32(beta), float(eps), _p(wqkv), _p(wo), _f32(bo), _f32(cvec), rv_ld, rv_rpg,
+                   rv_mod, _p(n1), _f32(stats), _p(qkv), _p(o), _p(h1), B, T, HW, C, heads, float(scale), _dt(x), self._stream())
+
     # ---- elementwise ------------------------------------------------------------------------------
     def geglu_fwd(self, pre, out, M, F):
         self._call("svdx_geglu_fwd", _p(pre), _p(out), M, F, _dt(pre), self._stream())
@@ -309,6 +327,17 @@ class HipBackend:
 
     def zero(self, t):
         self._call("svdx_zero", _p(t), t.numel() * t.element_size(), self._stream())
+
+    # ---- frozen conditioners (VAE encoder, CLIP image tower) --------------------------------------
+    def patch_rows(self, inp, out, n_img, C, H, W, kh, kw, stride, pad, ho, wo, ldk, mul=1.0):
+        self._call("svdx_patch_rows", _f32(inp), _p(out), n_img, C, H, W, kh, kw, stride, pad, ho, wo, ldk, float(mul), _dt(out),
+                   self._stream())
+
+    def softmax_rows(self, inp, out, rows, cols, cols_out, ld_in, ld_out, scale):
+        self._call("svdx_softmax_rows", _p(inp), _p(out), rows, cols, cols_out, ld_in, ld_out, float(scale), _dt(inp), self._stream())
+
+    def act_rows(self, inp, out, n, act=0):
+        self._call("svdx_act_rows", _p(inp), _p(out), n, int(act), _dt(inp), self._stream())
 
     # ---- loss / optimizer -------------------------------------------------------------------------
     def edm_loss(self, pred, ld, noisy, target, sigma, loss, dpred, B, T, C, HW, opt_state):

@@ -71,6 +71,9 @@ class Runtime:
         self.gemm_variant = 4      # 0 register-staged reference, 1 global_load_lds, 4 production (lean buffer_load-lds loop, 128x160 tiles)
         self.split_k = True
         self.fuse_geglu = True
+        # temporal self-attention op (norm1 -> q/k/v -> attention over frames -> out-projection + residual) as one launch when
+        # the level qualifies (csrc/tsa.hip); SVDX_FUSE_TSA=0: developer knob for A/B runs
+        self.fuse_tsa = os.environ.get("SVDX_FUSE_TSA", "1") != "0"
         self.fuse_dual = os.environ.get("SVDX_LORA_FUSED", "1") != "0"   # developer knob for A/B runs: adapter term as its own launch
         self.tuner = None           # GemmTuner (Trainer.tune_gemms): measured tile / split-K per GEMM problem
         # transposed 16-bit twins ([K,N], operand of the data-grad GEMM) of the trainable nn.Linear weights live in one arena so
@@ -250,7 +253,7 @@ def _nt_candidates(M: int, N: int, Kd: int, splittable: bool):
 
 
 def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
-             res=None, ldres=0, gather=None, dual=None) -> None:
+             res=None, ldres=0, gather=None, dual=None, alpha: float = 1.0) -> None:
     """Activation-dtype GEMM.  Tile shape and split-K factor come from the GemmTuner table when the model was tuned
     (Trainer.tune_gemms), else from a formula: the 10x16 / 5x8 latent levels (M = 2240 / 560 rows against K up to 23040)
     cannot fill 256 CUs with output tiles alone, so the reduction is split across blocks -- partial sums go to float slabs
@@ -261,16 +264,17 @@ def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowve
     splittable = rt.split_k and N % 4 == 0 and ldc % 4 == 0
     key = ("nt", M, N, Kd, lda, ldc, 0 if gather is None else (gather.mode, gather.stride, gather.ups, gather.cin),
            bias is not None, rowvec is not None, res is not None) + (() if dual is None else (("dual", dual[2]),))
+    assert alpha == 1.0 or dual is None
 
     def run(cfg):
         split, variant = cfg
         fused = dual if (split == 1 and rt.fuse_dual) else None
         if split == 1:
             k.gemm(A, B, out, M, N, Kd, lda, ldb, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod,
-                   res=res, ldres=ldres, gather=gather, variant=variant, dual=fused)
+                   res=res, ldres=ldres, gather=gather, variant=variant, dual=fused, alpha=alpha)
         else:
             acc = rt.f32(split, M, N)
-            k.gemm(A, B, acc, M, N, Kd, lda, ldb, N, gather=gather, out_mode=K.OUT_F32_SLAB, split_k=split, variant=variant)
+            k.gemm(A, B, acc, M, N, Kd, lda, ldb, N, gather=gather, out_mode=K.OUT_F32_SLAB, split_k=split, variant=variant, alpha=alpha)
             k.gemm_finalize(acc, split, M * N, out, M, N, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg,
                             rv_mod=rv_mod, res=res, ldres=ldres)
         if dual is not None and fused is None:
@@ -672,9 +676,11 @@ class ConvOp:
     (train_svd.py:761-766 trains only temporal transformer blocks), so only fwd + data-grad exist."""
 
     def __init__(self, weight: nn.Parameter, bias: Optional[nn.Parameter], kind: str, stride: int = 1,
-                 ups: bool = False, cin_pad: Optional[int] = None, cout_pad: Optional[int] = None):
+                 ups: bool = False, cin_pad: Optional[int] = None, cout_pad: Optional[int] = None, pad0: bool = False):
+        """pad0: the VAE encoder's Downsample2D(padding=0) -- stride 2 over F.pad(x, (0, 1, 0, 1)); forward only."""
         assert kind in ("3x3", "1x1", "t3")
-        self.weight, self.bias, self.kind, self.stride, self.ups = weight, bias, kind, stride, ups
+        assert not pad0 or (kind == "3x3" and stride == 2 and not ups)
+        self.weight, self.bias, self.kind, self.stride, self.ups, self.pad0 = weight, bias, kind, stride, ups, pad0
         self.cout, self.cin = weight.shape[0], weight.shape[1]
         self.cin_p = cin_pad or self.cin
         self.cout_p = cout_pad or self.cout     # padded channel count of the *incoming gradient* rows
@@ -707,6 +713,10 @@ class ConvOp:
             return None
         if self.kind == "t3":
             return K.Gather(K.GATHER_TEMPORAL3, n_img=n_img, cin=cin, t=T, hw=hw, lda=lda)
+        if self.pad0:
+            if dgrad:
+                raise NotImplementedError("the pad-0 downsample exists on the frozen VAE encoder only (no data-grad)")
+            return K.Gather(K.GATHER_CONV3X3_PAD0, n_img=n_img, hi=hi, wi=wi, ho=ho, wo=wo, cin=cin, stride=2, lda=lda)
         if dgrad and self.stride == 2:
             return K.Gather(K.GATHER_CONV3X3_DGRAD2, n_img=n_img, hi=hi, wi=wi, ho=ho, wo=wo, cin=cin, lda=lda)
         return K.Gather(K.GATHER_CONV3X3, n_img=n_img, hi=hi, wi=wi, ho=ho, wo=wo, cin=cin,
@@ -715,6 +725,8 @@ class ConvOp:
     def out_hw(self, h: int, w: int):
         if self.ups:
             return 2 * h, 2 * w
+        if self.pad0:
+            return (h - 2) // 2 + 1, (w - 2) // 2 + 1
         if self.stride == 2:
             return (h - 1) // 2 + 1, (w - 1) // 2 + 1
         return h, w

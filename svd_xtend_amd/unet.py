@@ -346,16 +346,33 @@ class TemporalBasicTransformerBlock(nn.Module):
         assert g.HW % g.B == 0, "time_context ordering quirk needs HW % B == 0"
         return dict(rv_rpg=0, rv_mod=g.B)
 
+    def _tsa_fused(self, rt: Runtime, g: Geom) -> bool:
+        """norm1 -> attn1 -> residual as ONE launch (csrc/tsa.hip): needs T <= 16, C <= 320, no adapters on attn1, and pays when a
+        band of pixels fills most of the kernel's 144-row tile (the 64x40 level of the benched shape: 10 pixels x 14 frames)."""
+        if not (rt.fuse_tsa and hasattr(rt.k, "tsa_fwd") and self.attn1.qkv_lora is None and self.attn1.o_lora is None):
+            return False
+        if self.dim > K.TSA_MAX_C or self.dim % 64 or g.T > K.TSA_MAX_T:
+            return False
+        return K.tsa_pixels_per_band(g.T, g.HW) * g.T >= 96
+
     def fwd(self, rt: Runtime, x, g: Geom, tctx):
         k, C, M = rt.k, self.dim, g.M
         n0, st0 = self.ln0.fwd(rt, x, M)
         h, pre0, g0 = self.ff_in.fwd(rt, n0, M, res=x)
-        n1, st1 = self.ln1.fwd(rt, h, M)
-        qkv, xs_qkv = _proj_fwd(rt, self.attn1.qkv, self.attn1.qkv_lora, n1, M)
-        o = rt.empty(M, C)
-        k.tattn_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], o, g.B, g.T, g.HW, self.heads, 3 * C, C, HEAD_DIM ** -0.5)
         cvec, cv = self.attn2.cross_vec(rt, tctx, g.B)
-        h1, xs_o = _proj_fwd(rt, self.attn1.o, self.attn1.o_lora, o, M, res=h, rowvec=cvec, rv_ld=C, **self._rv(g))
+        if self._tsa_fused(rt, g):
+            n1 = rt.empty(M, C) if self.trainable else None
+            st1, qkv, o, h1 = rt.f32(M, 2), rt.empty(M, 3 * C), rt.empty(M, C), rt.empty(M, C)
+            rv = self._rv(g)
+            k.tsa_fwd(h, self.norm1.weight.data, self.norm1.bias.data, self.norm1.eps, self.attn1.qkv.w, self.attn1.o.w, self.attn1.o.b,
+                      cvec, C, rv["rv_rpg"], rv["rv_mod"], n1, st1, qkv, o, h1, g.B, g.T, g.HW, C, self.heads, HEAD_DIM ** -0.5)
+            xs_qkv = xs_o = None
+        else:
+            n1, st1 = self.ln1.fwd(rt, h, M)
+            qkv, xs_qkv = _proj_fwd(rt, self.attn1.qkv, self.attn1.qkv_lora, n1, M)
+            o = rt.empty(M, C)
+            k.tattn_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], o, g.B, g.T, g.HW, self.heads, 3 * C, C, HEAD_DIM ** -0.5)
+            h1, xs_o = _proj_fwd(rt, self.attn1.o, self.attn1.o_lora, o, M, res=h, rowvec=cvec, rv_ld=C, **self._rv(g))
         n3, st3 = self.ln3.fwd(rt, h1, M)
         out, pre, gg = self.ff.fwd(rt, n3, M, res=h1)
         if not self.trainable:

@@ -44,14 +44,15 @@ def gather_rows(A, g: K.Gather, M):
     dev = A.device
     m = torch.arange(M, device=dev)
     cols = []
-    if g.mode in (K.GATHER_CONV3X3, K.GATHER_CONV3X3_DGRAD2):
+    if g.mode in (K.GATHER_CONV3X3, K.GATHER_CONV3X3_DGRAD2, K.GATHER_CONV3X3_PAD0):
         x = m % g.wo
         y = (m // g.wo) % g.ho
         n = m // (g.wo * g.ho)
         for dy in range(3):
             for dx in range(3):
-                if g.mode == K.GATHER_CONV3X3:
-                    ys, xs = y * g.stride + dy - 1, x * g.stride + dx - 1
+                if g.mode in (K.GATHER_CONV3X3, K.GATHER_CONV3X3_PAD0):
+                    pad = 1 if g.mode == K.GATHER_CONV3X3 else 0
+                    ys, xs = y * g.stride + dy - pad, x * g.stride + dx - pad
                     valid = (ys >= 0) & (ys < g.hi) & (xs >= 0) & (xs < g.wi)
                     if g.ups:
                         row = (n * (g.hi // 2) + ys.clamp(min=0) // 2) * (g.wi // 2) + xs.clamp(min=0) // 2
@@ -430,6 +431,47 @@ class EmuBackend:
 
     def zero(self, t):
         t.zero_()
+
+    def tsa_fwd(self, x, gamma, beta, eps, wqkv, wo, bo, cvec, rv_ld, rv_rpg, rv_mod, n1, stats, qkv, o, h1, B, T, HW, C, heads, scale):
+        """The four launches the fused op replaces, with their roundings (n, qkv, o are stored in the activation dtype and re-read)."""
+        M = B * T * HW
+        dt = x.dtype
+        xf = V(x, M, C, C).float()
+        mean = xf.mean(1, keepdim=True)
+        var = ((xf - mean) ** 2).mean(1, keepdim=True)
+        rstd = torch.rsqrt(var + eps)
+        V(stats, M, 2, 2).copy_(torch.cat([mean, rstd], 1))
+        n = ((xf - mean) * rstd * V1(gamma, C) + V1(beta, C)).to(dt)
+        if n1 is not None:
+            V(n1, M, C, C).copy_(n)
+        q3 = (n.float() @ V(wqkv, 3 * C, C, C).float().t()).to(dt)
+        V(qkv, M, 3 * C, 3 * C).copy_(q3)
+        self.tattn_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], o, B, T, HW, heads, 3 * C, C, scale)
+        v = V(o, M, C, C).float() @ V(wo, C, C, C).float().t() + V1(bo, C)[None]
+        if cvec is not None:
+            m = torch.arange(M, device=x.device)
+            gi = (m % rv_mod) if rv_mod else (m // rv_rpg)
+            v = v + V(cvec, int(gi.max()) + 1, C, rv_ld)[gi]
+        V(h1, M, C, C).copy_((v + xf).to(dt))
+
+    # ---- frozen conditioners ----
+    def patch_rows(self, inp, out, n_img, C, H, W, kh, kw, stride, pad, ho, wo, ldk, mul=1.0):
+        import torch.nn.functional as F
+        x = V1(inp, n_img * C * H * W).view(n_img, C, H, W) * mul
+        cols = F.unfold(x, (kh, kw), padding=pad, stride=stride)                  # [n, C*kh*kw, ho*wo], k = (c*kh + dy)*kw + dx
+        o = V(out, n_img * ho * wo, ldk, ldk)
+        o.zero_()
+        o[:, :C * kh * kw] = cols.permute(0, 2, 1).reshape(n_img * ho * wo, C * kh * kw).to(out.dtype)
+
+    def softmax_rows(self, inp, out, rows, cols, cols_out, ld_in, ld_out, scale):
+        x = V(inp, rows, cols, ld_in).float() * scale
+        o = V(out, rows, cols_out, ld_out)
+        o.zero_()
+        o[:, :cols] = torch.softmax(x, -1).to(out.dtype)
+
+    def act_rows(self, inp, out, n, act=0):
+        x = V1(inp, n).float()
+        V1(out, n).copy_((gelu(x) if act == 0 else x * torch.sigmoid(1.702 * x)).to(out.dtype))
 
     # ---- loss / optimizer ----
     def edm_loss(self, pred, ld, noisy, target, sigma, loss, dpred, B, T, C, HW, opt_state):

@@ -387,6 +387,75 @@ def check_temporal_attention(P, dt):
     return res
 
 
+def check_tsa(P, dt):
+    """svdx_tsa_fwd (LayerNorm -> q/k/v -> attention over frames -> out-projection + bias + row vector + residual in one launch)
+    against the emulation of the four launches it replaces.  Shapes: the benched 64x40 level (T = 14, HW = 2560, C = 320: 10 pixels
+    per band, 256 bands), partial bands, T = 16 / 3 / 1, B = 2 with the rv_mod grouping, every C the kernel admits."""
+    g = torch.Generator().manual_seed(17)
+    res = []
+    for (B, T, HW, heads, mod) in [(1, 14, 2560, 5, 0), (2, 14, 36, 5, 2), (1, 16, 9, 1, 0), (1, 3, 48, 2, 0), (2, 5, 7, 4, 0), (1, 1, 16, 3, 0)]:
+        C = heads * 64
+        M = B * T * HW
+        x = rnd((M, C), dt, P.dev, g)
+        x[:, :8] += 3.0                                     # a mean the LayerNorm has to remove
+        gamma, beta = 1.0 + 0.1 * rndf((C,), P.dev, g), 0.1 * rndf((C,), P.dev, g)
+        wqkv, wo = rnd((3 * C, C), dt, P.dev, g, C ** -0.5), rnd((C, C), dt, P.dev, g, C ** -0.5)
+        wqkv[:C] *= 2.0                                     # peaked softmax rows
+        bo, cvec = 0.1 * rndf((C,), P.dev, g), rndf((B, C), P.dev, g)
+        rpg = 0 if mod else T * HW
+        outs = dict(n1=torch.zeros(M, C, dtype=dt, device=P.dev), st=torch.zeros(M, 2, device=P.dev),
+                    qkv=torch.zeros(M, 3 * C, dtype=dt, device=P.dev), o=torch.zeros(M, C, dtype=dt, device=P.dev),
+                    h1=torch.zeros(M, C, dtype=dt, device=P.dev))
+        o1, o2 = P.run("tsa_fwd", lambda o: ((x, gamma, beta, 1e-5, wqkv, wo, bo, cvec, C, rpg, mod, o["n1"], o["st"], o["qkv"], o["o"],
+                                              o["h1"], B, T, HW, C, heads, 0.125), {}), outs)
+        tag = f"tsa_fwd B={B} T={T} HW={HW} C={C}"
+        res.append((f"{tag} n1", relerr(o1["n1"], o2["n1"]), tol_for(dt)))
+        res.append((f"{tag} stats", relerr(o1["st"], o2["st"]), 1e-4))
+        res.append((f"{tag} qkv", relerr(o1["qkv"], o2["qkv"]), tol_for(dt, 2)))
+        res.append((f"{tag} o", relerr(o1["o"], o2["o"]), tol_for(dt, 2)))
+        res.append((f"{tag} h1", relerr(o1["h1"], o2["h1"]), tol_for(dt, 2)))
+        res.append((f"{tag} h1 1-cos(rows)", 1.0 - cos_rows_min(o1["h1"], o2["h1"]), 1e-4 if dt == torch.float16 else 2e-3))
+    return res
+
+
+def check_encoders(P, dt):
+    """svdx_patch_rows / svdx_softmax_rows / svdx_act_rows (csrc/encoders.hip) and the pad-0 stride-2 gather of the VAE downsample."""
+    g = torch.Generator().manual_seed(18)
+    res = []
+    for (n, C, H, W, kh, st, pad, ldk) in [(2, 3, 16, 24, 3, 1, 1, 64), (1, 3, 28, 42, 14, 14, 0, 640), (3, 3, 9, 7, 3, 1, 1, 32)]:
+        ho, wo = (H + 2 * pad - kh) // st + 1, (W + 2 * pad - kh) // st + 1
+        img = rndf((n, C, H, W), P.dev, g)
+        o1, o2 = P.run("patch_rows", lambda o: ((img, o["y"], n, C, H, W, kh, kh, st, pad, ho, wo, ldk, 0.5), {}),
+                       dict(y=torch.ones(n * ho * wo, ldk, dtype=dt, device=P.dev)))
+        res.append((f"patch_rows {n}x{C}x{H}x{W} k{kh} s{st}", relerr(o1["y"], o2["y"]), tol_for(dt, 0.5)))
+    for (rows, cols, cols_out) in [(5, 2560, 2560), (7, 257, 320), (3, 15, 64), (2, 8, 8)]:
+        x = rnd((rows, cols_out), dt, P.dev, g, 3.0)
+        o1, o2 = P.run("softmax_rows", lambda o: ((x, o["y"], rows, cols, cols_out, cols_out, cols_out, 0.7), {}),
+                       dict(y=torch.ones(rows, cols_out, dtype=dt, device=P.dev)))
+        res.append((f"softmax_rows {rows}x{cols}->{cols_out}", relerr(o1["y"], o2["y"]), tol_for(dt)))
+    x = rnd((8 * 333,), dt, P.dev, g, 2.0)
+    for act in (0, 1):
+        o1, o2 = P.run("act_rows", lambda o: ((x, o["y"], x.numel(), act), {}), dict(y=torch.zeros_like(x)))
+        res.append((f"act_rows act={act}", relerr(o1["y"], o2["y"]), tol_for(dt)))
+    # Downsample2D(padding=0): stride 2 over F.pad(x, (0, 1, 0, 1))
+    for (n, h, w, cin, cout) in [(2, 8, 12, 64, 64), (1, 6, 6, 128, 192)]:
+        ho, wo = h // 2, w // 2
+        x = rnd((n * h * w, cin), dt, P.dev, g)
+        wt = rnd((cout, 9 * cin), dt, P.dev, g, (9 * cin) ** -0.5)
+        ga = K.Gather(K.GATHER_CONV3X3_PAD0, n_img=n, hi=h, wi=w, ho=ho, wo=wo, cin=cin, stride=2, lda=cin)
+        M = n * ho * wo
+        o1, o2 = P.run("gemm", lambda o: ((x, wt, o["C"], M, cout, 9 * cin, cin, 9 * cin, cout), dict(gather=ga, variant=4)),
+                       dict(C=torch.zeros(M, cout, dtype=dt, device=P.dev)))
+        res.append((f"gemm pad0-gather {n}x{h}x{w} {cin}->{cout}", relerr(o1["C"], o2["C"]), tol_for(dt)))
+        # and the emulated gather against torch's own padded convolution
+        import torch.nn.functional as F
+        xi = x.float().view(n, h, w, cin).permute(0, 3, 1, 2)
+        w4 = wt.float().view(cout, 9, cin).permute(0, 2, 1).reshape(cout, cin, 3, 3)
+        want = F.conv2d(F.pad(xi, (0, 1, 0, 1)), w4, stride=2).permute(0, 2, 3, 1).reshape(M, cout)
+        res.append((f"pad0-gather emulation vs F.conv2d {cin}->{cout}", relerr(o2["C"].float(), want), tol_for(dt)))
+    return res
+
+
 def check_elementwise(P, dt):
     g = torch.Generator().manual_seed(8)
     res = []
@@ -543,7 +612,8 @@ def run_all(impl, dev, dtypes=DTYPES, verbose=True):
                   ("gemm_tn", lambda: check_gemm_tn(P, dt)), ("gemm_geglu", lambda: check_gemm_geglu(P, dt)), ("gemm_gather_v0", lambda: check_gemm_gather(P, dt, 0)), ("gemm_gather_v1", lambda: check_gemm_gather(P, dt, 1)),
                   ("small", lambda: check_small(P, dt)), ("groupnorm", lambda: check_groupnorm(P, dt)),
                   ("layernorm", lambda: check_layernorm(P, dt)), ("attention", lambda: check_attention(P, dt)),
-                  ("temporal_attention", lambda: check_temporal_attention(P, dt)), ("elementwise", lambda: check_elementwise(P, dt)),
+                  ("temporal_attention", lambda: check_temporal_attention(P, dt)), ("tsa", lambda: check_tsa(P, dt)),
+                  ("encoders", lambda: check_encoders(P, dt)), ("elementwise", lambda: check_elementwise(P, dt)),
                   ("optim", lambda: check_optim(P, dt))]
         for name, fn in checks:
             try:
