@@ -297,6 +297,57 @@ def main():
     ms = elapsed / args.steps * 1e3
     value = world * B * args.grad_accum * args.steps / elapsed
 
+    # ---- the same step with the VAE encode of the NEXT micro-batch running beside it (train_svd.py:948, 957-960) ----------------
+    vae_info = None
+    if args.with_vae:
+        from svd_xtend_amd.vae import AutoencoderKLTemporalDecoder
+        with torch.device(dev):
+            vae = AutoencoderKLTemporalDecoder() if not args.tiny else AutoencoderKLTemporalDecoder(block_out_channels=(64, 128, 128, 128), layers_per_block=1)
+        init_weights_(vae, seed=4321)
+        vae.prepare(dt)
+        frames = B * (T + 1)                            # the clip's T frames + its noised conditioning frame
+        pix = torch.rand(frames, 3, args.height, args.width, device=dev) * 2 - 1
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                z = vae.encode(pix).latent_dist.sample() * vae.config.scaling_factor
+            torch.cuda.synchronize()
+            gv = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gv, stream=side):
+                z = vae.encode(pix).latent_dist.sample() * vae.config.scaling_factor
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(side):
+            e0.record()
+            for _ in range(5):
+                gv.replay()
+            e1.record()
+        torch.cuda.synchronize()
+        vae_alone = e0.elapsed_time(e1) / 5
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            with torch.cuda.stream(side):
+                gv.replay()                              # frozen, no dependency on the update: free to run under the all-reduce / AdamW
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el2 = time.perf_counter() - t1
+        if world > 1:
+            te = torch.tensor([el2], device=dev, dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el2 = float(te)
+        vae_info = {"ms_per_step": el2 / args.steps * 1e3, "value": world * B * args.grad_accum * args.steps / el2, "unit": "samples/s",
+                    "vae_ms_alone": vae_alone, "frames_encoded_per_step": frames,
+                    "what": "UNet step + AutoencoderKLTemporalDecoder.encode of the next clip (T + 1 frames, pixels resident in HBM) on a second "
+                            "HIP stream, both replayed from hipGraphs; the headline `value` above is the UNet step alone",
+                    "latent_mean_abs": float(z.abs().mean())}
+        del vae, gv, pix
+
     # ---- what RCCL saw: ranks (an all-reduce of ones) and the cost of the gradient exchange on its own -------------------------
     ranks_seen, allreduce_ms = 1, None
     if world > 1:
@@ -418,7 +469,7 @@ def main():
                        "gemm_variant": args.gemm_variant, "loss": loss, "loss_scale": state[1], "opt_steps": state[0],
                        "step_tflops_per_gpu": (STEP_TFLOP_C2 * args.grad_accum / (ms * 1e-3) if full else None),
                        "step_frac_of_mfma_peak": (STEP_TFLOP_C2 * args.grad_accum / (ms * 1e-3) / MFMA_PEAK_TFLOPS if full else None)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "with_vae": vae_info,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
