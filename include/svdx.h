@@ -217,6 +217,20 @@ int svdx_patch_rows(const float* in, void* out, int n_img, int C, int H, int W, 
 int svdx_softmax_rows(const void* in, void* out, int rows, int cols, int cols_out, int64_t ld_in, int64_t ld_out, float scale,
                       int dtype, void* stream);
 int svdx_act_rows(const void* in, void* out, int64_t n, int act, int dtype, void* stream);
+/* The anti-aliased resize in front of the CLIP tower (`_resize_with_antialiasing`, train_svd.py:140-248), float NCHW planes:
+ * svdx_blur_axis: one pass of the separable Gaussian blur (`_filter2d` with F.pad(mode="reflect")) along x (axis 0) or y (axis 1);
+ *   `taps` (device floats, odd count) is the normalised window of `_gaussian`.
+ * svdx_bicubic_affine: F.interpolate(mode="bicubic", align_corners=True) to (ho, wo), then out = scale[c] * v + shift[c] -- the
+ *   un-normalisation (x + 1) / 2 and CLIP's mean / std normalisation of train_svd.py:861-871 in one affine map per channel. */
+int svdx_blur_axis(const float* in, float* out, int planes, int H, int W, const float* taps, int ntaps, int axis, void* stream);
+int svdx_bicubic_affine(const float* in, float* out, int n_img, int C, int H, int W, int ho, int wo, const float* scale,
+                        const float* shift, void* stream);
+/* Self-attention over a short sequence with any head dimension (CLIP ViT-H/14: 257 tokens, 16 heads of 80; transformers
+ * CLIPAttention reached from train_svd.py:875).  qkv rows [n_img*S, ld]; head h: q at column h*dp, k at (heads + h)*dp, v at
+ * (2*heads + h)*dp, d real channels out of the dp the packed projection gives every head; out rows [n_img*S, ld_o], head h at h*dp
+ * (channels d..dp written as zeros).  S <= 384, dp <= 128. */
+int svdx_attn_small_fwd(const void* qkv, void* out, int n_img, int S, int heads, int d, int dp, int64_t ld, int64_t ld_o, float scale,
+                        int dtype, void* stream);
 /* base[off .. off+cnt) = 0 for each (off, cnt) pair of `spans` (int pairs; off and cnt multiples of 4): ONE launch for the scattered
  * gradient slots that are accumulated with atomics and so must start from zero (biases, LayerNorm, skinny cross-attention weights). */
 int svdx_zero_spans(float* base, const int* spans, int n_spans, void* stream);

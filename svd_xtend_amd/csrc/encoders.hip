@@ -99,6 +99,155 @@ __global__ void act_rows_kernel(const T* __restrict__ in, T* __restrict__ out, l
     }
 }
 
+
+// ---- anti-aliased resize of encode_image (train_svd.py:140-248): separable Gaussian blur with reflect padding, then bicubic ----
+// axis 0: along x (W), axis 1: along y (H); planes = n * C images of H x W floats; taps odd (the reference makes them odd)
+__global__ void blur_axis_kernel(const float* __restrict__ in, float* __restrict__ out, long total, int H, int W, const float* __restrict__ taps,
+                                 int nt, int axis) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const long t = i / W;
+        const int y = (int)(t % H);
+        const long pl = t / H;
+        const float* src = in + pl * (long)H * W;
+        const int half = (nt - 1) / 2;
+        float acc = 0.f;
+        for (int k = 0; k < nt; ++k) {
+            int xs = x, ys = y;
+            if (axis == 0) { xs = x + k - half; if (xs < 0) xs = -xs; if (xs >= W) xs = 2 * (W - 1) - xs; }
+            else { ys = y + k - half; if (ys < 0) ys = -ys; if (ys >= H) ys = 2 * (H - 1) - ys; }
+            acc += taps[k] * src[(long)ys * W + xs];
+        }
+        out[i] = acc;
+    }
+}
+
+__device__ __forceinline__ void cubic_weights(float t, float (&w)[4]) {      // torch's upsample_bicubic2d, A = -0.75
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x3 = 2.f - t, x2 = 1.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+// out[n][c][yo][xo] = scale[c] * bicubic(in[n][c])(yo, xo; align_corners = True) + shift[c]
+__global__ void bicubic_affine_kernel(const float* __restrict__ in, float* __restrict__ out, long total, int C, int H, int W, int ho, int wo,
+                                      float ry, float rx, const float* __restrict__ scale, const float* __restrict__ shift) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % wo);
+        const long t = i / wo;
+        const int yo = (int)(t % ho);
+        const long pl = t / ho;
+        const int c = (int)(pl % C);
+        const float* src = in + pl * (long)H * W;
+        const float fy = ry * yo, fx = rx * xo;
+        const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+        float wy[4], wx[4];
+        cubic_weights(fy - iy, wy);
+        cubic_weights(fx - ix, wx);
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int ys = min(max(iy - 1 + a, 0), H - 1);
+            float row = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) row += wx[b] * src[(long)ys * W + min(max(ix - 1 + b, 0), W - 1)];
+            acc += wy[a] * row;
+        }
+        out[i] = acc * scale[c] + shift[c];
+    }
+}
+
+// ---- self-attention of a short sequence with an arbitrary head dimension (CLIP ViT-H: 257 tokens, 16 heads of 80) ----------------
+// qkv rows [n*S, ld]: head h of q at column h*dp, of k at (heads + h)*dp, of v at (2 heads + h)*dp; d <= dp real channels (the rest of
+// a head's dp columns is padding).  Block = (32 queries, head, image): K and V of the head live in LDS; a wave takes 8 queries, its
+// lanes split the keys for the scores and the channels for the output.  10 GFLOP over the whole tower: VALU work, latency-shaped.
+constexpr int AS_QT = 32, AS_MAXS = 384, AS_MAXD = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void attn_small_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int S, int heads, int d, int dp,
+                                                             long ld, long ld_o, float sl2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dr = (d + 7) / 8 * 8;                 // staged channels per row (multiple of 8)
+    const int pitch = (dr + 8) * 2;                 // bytes; +16 B keeps 16-byte row reads of consecutive keys on distinct banks
+    char* Ks = smem;
+    char* Vs = smem + (size_t)S * pitch;
+    float* Pw = reinterpret_cast<float*>(smem + 2 * (size_t)S * pitch);      // [4 waves][AS_MAXS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y, n = blockIdx.z, q0 = blockIdx.x * AS_QT;
+    const T* base = qkv + (size_t)n * S * ld;
+    const int c8 = dr / 8;
+    for (int i = tid; i < S * c8; i += 256) {
+        const int r = i / c8, c = i - r * c8;
+        *reinterpret_cast<uint4*>(Ks + r * pitch + c * 16) = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + (heads + h) * dp + c * 8);
+        *reinterpret_cast<uint4*>(Vs + r * pitch + c * 16) = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + (2 * heads + h) * dp + c * 8);
+    }
+    __syncthreads();
+    float* P = Pw + wave * AS_MAXS;
+    for (int qi = 0; qi < AS_QT / 4; ++qi) {
+        const int q = q0 + wave * (AS_QT / 4) + qi;
+        if (q >= S) break;                                           // wave-uniform
+        float qv[AS_MAXD];
+#pragma unroll
+        for (int c = 0; c < AS_MAXD / 8; ++c) {
+            if (c < c8) {
+                float t8[8];
+                load8<T>(base + (size_t)q * ld + h * dp + c * 8, t8);        // same address in every lane: one broadcast transaction
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qv[c * 8 + e] = t8[e];
+            }
+        }
+        float sc[AS_MAXS / 64];
+        float mx = -1e30f;
+#pragma unroll
+        for (int j = 0; j < AS_MAXS / 64; ++j) {
+            const int ki = lane + 64 * j;
+            float a = -1e30f;
+            if (ki < S) {
+                a = 0.f;
+#pragma unroll
+                for (int c = 0; c < AS_MAXD / 8; ++c) {
+                    if (c < c8) {
+                        float k8[8];
+                        load8<T>(reinterpret_cast<const T*>(Ks + ki * pitch + c * 16), k8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a += qv[c * 8 + e] * k8[e];
+                    }
+                }
+                a *= sl2;
+            }
+            sc[j] = a;
+            mx = fmaxf(mx, a);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < AS_MAXS / 64; ++j) {
+            const float pv = (lane + 64 * j) < S ? __builtin_amdgcn_exp2f(sc[j] - mx) : 0.f;
+            sc[j] = pv;
+            sum += pv;
+        }
+        const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+        for (int j = 0; j < AS_MAXS / 64; ++j)
+            if (lane + 64 * j < S) P[lane + 64 * j] = sc[j] * inv;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // output channels lane and lane + 64
+        float o0 = 0.f, o1 = 0.f;
+        const bool two = lane + 64 < dr;
+        for (int k = 0; k < S; ++k) {
+            const float pk = P[k];
+            const T* vr = reinterpret_cast<const T*>(Vs + k * pitch);
+            if (lane < dr) o0 += pk * to_f<T>(vr[lane]);
+            if (two) o1 += pk * to_f<T>(vr[lane + 64]);
+        }
+        T* op = out + ((size_t)n * S + q) * ld_o + h * dp;
+        for (int c = lane; c < dp; c += 64) op[c] = from_f<T>(c < d ? (c < 64 ? o0 : o1) : 0.f);     // padding channels of the head: zeros
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
 
 extern "C" int svdx_patch_rows(const float* in, void* out, int n_img, int C, int H, int W, int kh, int kw, int stride, int pad,
@@ -129,5 +278,49 @@ extern "C" int svdx_act_rows(const void* in, void* out, int64_t n, int act, int 
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((act_rows_kernel<T>), dim3((int)std::min<long>((n / 8 + 255) / 256, 4096)), dim3(256), 0,
                                              (hipStream_t)stream, (const T*)in, (T*)out, (long)(n / 8), act));
     SVDX_LAUNCH_CHECK("svdx_act_rows");
+    return 0;
+}
+
+extern "C" int svdx_blur_axis(const float* in, float* out, int planes, int H, int W, const float* taps, int ntaps, int axis, void* stream) {
+    SVDX_CHECK_ARG(in && out && taps && planes > 0 && H > 0 && W > 0 && ntaps > 0 && ntaps % 2 == 1 && (axis == 0 || axis == 1),
+                   "svdx_blur_axis: bad args (odd tap count, axis 0 = x / 1 = y)");
+    SVDX_CHECK_ARG((ntaps - 1) / 2 < (axis == 0 ? W : H), "svdx_blur_axis: reflect padding needs (taps - 1) / 2 < extent");
+    const long total = (long)planes * H * W;
+    hipLaunchKernelGGL(blur_axis_kernel, dim3((int)std::min<long>((total + 255) / 256, 65536)), dim3(256), 0, (hipStream_t)stream, in, out,
+                       total, H, W, taps, ntaps, axis);
+    SVDX_LAUNCH_CHECK("svdx_blur_axis");
+    return 0;
+}
+
+extern "C" int svdx_bicubic_affine(const float* in, float* out, int n_img, int C, int H, int W, int ho, int wo, const float* scale,
+                                   const float* shift, void* stream) {
+    SVDX_CHECK_ARG(in && out && scale && shift && n_img > 0 && C > 0 && H > 0 && W > 0 && ho > 0 && wo > 0, "svdx_bicubic_affine: bad args");
+    const float ry = ho > 1 ? (float)(H - 1) / (float)(ho - 1) : 0.f, rx = wo > 1 ? (float)(W - 1) / (float)(wo - 1) : 0.f;
+    const long total = (long)n_img * C * ho * wo;
+    hipLaunchKernelGGL(bicubic_affine_kernel, dim3((int)std::min<long>((total + 255) / 256, 65536)), dim3(256), 0, (hipStream_t)stream, in, out,
+                       total, C, H, W, ho, wo, ry, rx, scale, shift);
+    SVDX_LAUNCH_CHECK("svdx_bicubic_affine");
+    return 0;
+}
+
+extern "C" int svdx_attn_small_fwd(const void* qkv, void* out, int n_img, int S, int heads, int d, int dp, int64_t ld, int64_t ld_o, float scale,
+                                   int dtype, void* stream) {
+    SVDX_CHECK_ARG(qkv && out && n_img > 0 && S > 0 && S <= AS_MAXS && heads > 0 && d > 0 && d <= dp && dp <= AS_MAXD && dp % 8 == 0,
+                   "svdx_attn_small_fwd: needs S <= %d, d <= dp <= %d, dp %% 8 == 0 (got S=%d d=%d dp=%d)", AS_MAXS, AS_MAXD, S, d, dp);
+    SVDX_CHECK_ARG(ld % 8 == 0 && ld >= 3L * heads * dp && ld_o >= (long)heads * dp && (((uintptr_t)qkv) & 15) == 0, "svdx_attn_small_fwd: alignment");
+    const int dr = (d + 7) / 8 * 8;
+    const size_t lds = 2 * (size_t)S * (dr + 8) * 2 + 4 * AS_MAXS * sizeof(float);
+    SVDX_CHECK_ARG(lds <= 160 * 1024, "svdx_attn_small_fwd: K/V of one head do not fit LDS");
+    dim3 grid((S + AS_QT - 1) / AS_QT, heads, n_img);
+    DISPATCH_DTYPE(dtype, {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((attn_small_fwd_kernel<T>), grid, dim3(256), lds, (hipStream_t)stream, (const T*)qkv, (T*)out, S, heads, d, dp,
+                           (long)ld, (long)ld_o, scale * 1.4426950408889634f);
+    });
+    SVDX_LAUNCH_CHECK("svdx_attn_small_fwd");
     return 0;
 }

@@ -100,6 +100,9 @@ _SIGS = {
     "svdx_patch_rows": "pp" "iiiiiiiiii" "i" "f" "ip",
     "svdx_softmax_rows": "pp" "iii" "ll" "f" "ip",
     "svdx_act_rows": "pp" "l" "i" "ip",
+    "svdx_blur_axis": "pp" "iii" "p" "ii" "p",
+    "svdx_bicubic_affine": "pp" "iiiiii" "pp" "p",
+    "svdx_attn_small_fwd": "pp" "iiiii" "ll" "f" "ip",
     "svdx_zero_spans": "pp" "ip",
     "svdx_edm_loss": "pi" "ppppp" "iiii" "p" "ip",
     "svdx_check_finite": "plpp",
@@ -338,6 +341,15 @@ class HipBackend:
 
     def act_rows(self, inp, out, n, act=0):
         self._call("svdx_act_rows", _p(inp), _p(out), n, int(act), _dt(inp), self._stream())
+
+    def blur_axis(self, inp, out, planes, H, W, taps, axis):
+        self._call("svdx_blur_axis", _f32(inp), _f32(out), planes, H, W, _f32(taps), taps.numel(), int(axis), self._stream())
+
+    def bicubic_affine(self, inp, out, n_img, C, H, W, ho, wo, scale, shift):
+        self._call("svdx_bicubic_affine", _f32(inp), _f32(out), n_img, C, H, W, ho, wo, _f32(scale), _f32(shift), self._stream())
+
+    def attn_small_fwd(self, qkv, out, n_img, S, heads, d, dp, ld, ld_o, scale):
+        self._call("svdx_attn_small_fwd", _p(qkv), _p(out), n_img, S, heads, d, dp, ld, ld_o, float(scale), _dt(qkv), self._stream())
 
     # ---- loss / optimizer -------------------------------------------------------------------------
     def edm_loss(self, pred, ld, noisy, target, sigma, loss, dpred, B, T, C, HW, opt_state):

@@ -469,6 +469,30 @@ class EmuBackend:
         o.zero_()
         o[:, :cols] = torch.softmax(x, -1).to(out.dtype)
 
+    def blur_axis(self, inp, out, planes, H, W, taps, axis):
+        import torch.nn.functional as F
+        x = V1(inp, planes * H * W).view(planes, 1, H, W)
+        half = (taps.numel() - 1) // 2
+        if axis == 0:
+            y = F.conv2d(F.pad(x, (half, half, 0, 0), mode="reflect"), taps.view(1, 1, 1, -1))
+        else:
+            y = F.conv2d(F.pad(x, (0, 0, half, half), mode="reflect"), taps.view(1, 1, -1, 1))
+        V1(out, planes * H * W).copy_(y.reshape(-1))
+
+    def bicubic_affine(self, inp, out, n_img, C, H, W, ho, wo, scale, shift):
+        import torch.nn.functional as F
+        x = V1(inp, n_img * C * H * W).view(n_img, C, H, W)
+        y = F.interpolate(x, size=(ho, wo), mode="bicubic", align_corners=True)
+        V1(out, n_img * C * ho * wo).copy_((y * scale.view(1, C, 1, 1) + shift.view(1, C, 1, 1)).reshape(-1))
+
+    def attn_small_fwd(self, qkv, out, n_img, S, heads, d, dp, ld, ld_o, scale):
+        x = V(qkv, n_img * S, 3 * heads * dp, ld).float().view(n_img, S, 3, heads, dp)
+        q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))                  # [n, heads, S, dp]; channels >= d are padding
+        p = torch.softmax((q[..., :d] @ k[..., :d].transpose(-1, -2)) * scale, -1)
+        o = torch.zeros(n_img, heads, S, dp, device=qkv.device)
+        o[..., :d] = p @ v[..., :d]
+        V(out, n_img * S, heads * dp, ld_o).copy_(o.permute(0, 2, 1, 3).reshape(n_img * S, heads * dp).to(out.dtype))
+
     def act_rows(self, inp, out, n, act=0):
         x = V1(inp, n).float()
         V1(out, n).copy_((gelu(x) if act == 0 else x * torch.sigmoid(1.702 * x)).to(out.dtype))
