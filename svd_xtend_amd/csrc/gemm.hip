@@ -893,35 +893,55 @@ __global__ __launch_bounds__(256) void small_linear_nt(const float* __restrict__
     }
 }
 
-// trans = 1: Y[m,k] += sum_n X[m,n] W[n,k]; thread = (8 consecutive k, slice of 8 n), partial sums by atomicAdd.  The op is a
-// GEMV over a matrix of a few MB: it is latency-shaped, so a thread issues all of its 16-byte row loads before the first FMA and
-// the slices are short enough for ~100 blocks at N = K = 1280 (32-row slices with dependent loads ran at 160 GB/s).
-constexpr int NN_SLICE = 8;
+// trans = 1: Y[m,k] (+)= sum_n X[m,n] W[n,k].  The op is a GEMV over a matrix of a few MB: latency-shaped.  A block owns 64
+// output columns (8 chunks of 8) x 32 row lanes; a thread walks the rows n = nl, nl + 32, ... with four 16-byte loads in flight and
+// the 32 partial sums of a column are then added in a fixed order -- no atomics, so the result is run-to-run identical (the
+// gradient of the cross-attention value path depends on it).
 template <typename T>
-__global__ __launch_bounds__(256) void small_linear_nn(const float* X, const T* W, float* Y, int M, int N, int K, int ldw) {
-    const int k8n = K / 8;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int k8 = idx % k8n, ns = idx / k8n;
+__global__ __launch_bounds__(256) void small_linear_nn(const float* X, const T* W, float* Y, int M, int N, int K, int ldw, int accumulate) {
+    __shared__ float part[32][65];
+    const int kc = threadIdx.x & 7, nl = threadIdx.x >> 3;
+    const int k8 = blockIdx.x * 8 + kc;
     const int m = blockIdx.y;
-    const int n0 = ns * NN_SLICE;
-    if (n0 >= N) return;
-    const float* x = X + (size_t)m * N;
-    Vec8<T> w[NN_SLICE];
-    float xv[NN_SLICE];
-#pragma unroll
-    for (int i = 0; i < NN_SLICE; ++i) {
-        const int n = min(n0 + i, N - 1);
-        w[i] = *reinterpret_cast<const Vec8<T>*>(W + (size_t)n * ldw + k8 * 8);
-        xv[i] = n0 + i < N ? x[n] : 0.f;
-    }
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (k8 * 8 < K) {
+        const float* x = X + (size_t)m * N;
+        const T* wp = W + k8 * 8;
+        int n = nl;
+        for (; n + 96 < N; n += 128) {
+            const Vec8<T> w0 = *reinterpret_cast<const Vec8<T>*>(wp + (size_t)n * ldw);
+            const Vec8<T> w1 = *reinterpret_cast<const Vec8<T>*>(wp + (size_t)(n + 32) * ldw);
+            const Vec8<T> w2 = *reinterpret_cast<const Vec8<T>*>(wp + (size_t)(n + 64) * ldw);
+            const Vec8<T> w3 = *reinterpret_cast<const Vec8<T>*>(wp + (size_t)(n + 96) * ldw);
+            const float x0 = x[n], x1 = x[n + 32], x2 = x[n + 64], x3 = x[n + 96];
 #pragma unroll
-    for (int i = 0; i < NN_SLICE; ++i)
+            for (int j = 0; j < 8; ++j) {
+                acc[j] += x0 * to_f<T>(w0.v[j]);
+                acc[j] += x1 * to_f<T>(w1.v[j]);
+                acc[j] += x2 * to_f<T>(w2.v[j]);
+                acc[j] += x3 * to_f<T>(w3.v[j]);
+            }
+        }
+        for (; n < N; n += 32) {
+            const Vec8<T> w0 = *reinterpret_cast<const Vec8<T>*>(wp + (size_t)n * ldw);
+            const float x0 = x[n];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += xv[i] * to_f<T>(w[i].v[j]);
-    float* y = Y + (size_t)m * K + k8 * 8;
+            for (int j = 0; j < 8; ++j) acc[j] += x0 * to_f<T>(w0.v[j]);
+        }
+    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(y + j, acc[j]);
+    for (int j = 0; j < 8; ++j) part[nl][kc * 8 + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int k = blockIdx.x * 64 + threadIdx.x;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) sum += part[r][threadIdx.x];
+        if (k < K) {
+            float* y = Y + (size_t)m * K + k;
+            *y = accumulate ? *y + sum : sum;
+        }
+    }
 }
 
 // split-K epilogue: v = sum over `nsplit` float slabs (+ bias + rowvec + res);  C = (dtype)v, or Cf += v (weight grads)
@@ -1216,9 +1236,7 @@ extern "C" int svdx_small_linear(const float* X, const void* W, const float* bia
                                    silu_in, accumulate);
         } else {
             SVDX_CHECK_ARG(!bias && !silu_in, "svdx_small_linear: trans=1 takes no bias/activation");
-            if (!accumulate) (void)hipMemsetAsync(Y, 0, sizeof(float) * (size_t)M * K, st);
-            hipLaunchKernelGGL((small_linear_nn<T>), dim3(cdiv((long)(K / 8) * cdiv(N, NN_SLICE), 256), M), dim3(256), 0, st, X,
-                               (const T*)W, Y, M, N, K, ldw);
+            hipLaunchKernelGGL((small_linear_nn<T>), dim3(cdiv(K / 8, 8), M), dim3(256), 0, st, X, (const T*)W, Y, M, N, K, ldw, accumulate);
         }
     });
     SVDX_LAUNCH_CHECK("svdx_small_linear");

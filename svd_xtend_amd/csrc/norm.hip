@@ -333,18 +333,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         }
     }
     if (affine) {
+        // the four waves add their column partials one after the other: a fixed summation order (float atomics would leave the
+        // gradient of the affine parameters run-to-run different in its last bits)
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; ++i) {
-            const int j = lane + i * 64;
-            if (j < cc) {
+                for (int i = 0; i < LN_MAXCH; ++i) {
+                    const int j = lane + i * 64;
+                    if (j < cc) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    atomicAdd(&red[j * 8 + e], pg[i][e]);
-                    atomicAdd(&red[C + j * 8 + e], pb[i][e]);
+                        for (int e = 0; e < 8; ++e) {
+                            red[j * 8 + e] += pg[i][e];
+                            red[C + j * 8 + e] += pb[i][e];
+                        }
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
         if (partial) {
             for (int i = threadIdx.x; i < 2 * C; i += 256) partial[(size_t)blockIdx.x * 2 * C + i] = red[i];
         } else {

@@ -39,7 +39,16 @@ struct TsaParams {
     void* n1; float* stats; void* qkv; void* o; void* h1;
     int B, T, HW, C, heads, P; float sl2;
     int x_bytes, wqkv_bytes, wo_bytes;
+#ifdef TSA_STAMPS
+    unsigned long long* stamps;      // tools/probes/tsa_probe.hip: [block][16] shader-clock stamps of wave 0
+#endif
 };
+
+#ifdef TSA_STAMPS
+#define TSA_STAMP(i) do { if (tid == 0) p.stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TSA_STAMP(i) do { } while (0)
+#endif
 
 typedef short tsa_v4s __attribute__((ext_vector_type(4)));
 typedef short tsa_v8s __attribute__((ext_vector_type(8)));
@@ -56,14 +65,26 @@ __device__ __forceinline__ typename TT<T>::v8 tsa_frag_tr(const char* lds, int d
     return __builtin_bit_cast(typename TT<T>::v8, r);
 }
 
-// acc[j][i] (+)= IMG[rows i*16.., K] * Bmat[N, K]^T for the wave's 48 columns of every 192-column pass; `epi(pass, acc)` runs when a
-// pass has seen all of K.  Ends with every wave past the last barrier (LDS stages free, this wave's global stores issued).
+// sum over the 16 lanes of a DPP row, result in every lane: row_mirror, row_half_mirror, then the two quad permutes -- four VALU
+// instructions instead of four ds_bpermute round trips (the LayerNorm phase was a chain of those)
+__device__ __forceinline__ float tsa_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // lane i + lane 15 - i
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // + mirror inside each half
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    return v;
+}
+
+// acc[j][i] = IMG[rows i*16.., K] * Bmat[N, K]^T for the wave's 48 columns of every 192-column pass; `epi(pass, acc)` runs when a
+// pass has seen all of K (the loop body is gemm_v4's: fragments of one 32-deep half step in registers, then its 27 MFMAs).  The first
+// stage of the next pass is already travelling when the epilogue runs.  Ends with every wave past a barrier and its stores complete.
 template <typename T, typename Epi>
-__device__ __forceinline__ void tsa_band_gemm(const char* IMG, char* BST, const void* Bmat, int b_bytes, int N, int Kd, int tid, Epi&& epi) {
+__device__ __forceinline__ void tsa_band_gemm(const char* IMG, char* BST, const void* Bmat, int b_bytes, int N, int Kd, int tid, Epi&& epi,
+                                              unsigned long long* wait_cycles = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef typename TT<T>::v8 v8;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
-    const int KS = Kd / 64, npass = (N + TSA_PW - 1) / TSA_PW, total = npass * KS;
+    const int KS = Kd / 64, npass = (N + TSA_PW - 1) / TSA_PW;
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Bmat), 0, b_bytes, 0x00020000);
     int vob[TSA_NPC];
     auto set_pass = [&](int pass) __attribute__((always_inline)) {
@@ -81,58 +102,61 @@ __device__ __forceinline__ void tsa_band_gemm(const char* IMG, char* BST, const 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(BST + stage * TSA_BST + (i * 4 + wave) * 1024), 16,
                                                      vob[i], ks * 128, 0, 0);
     };
-    f32x4 acc[TSA_NB][TSA_MB];
-#pragma unroll
-    for (int j = 0; j < TSA_NB; ++j)
-#pragma unroll
-        for (int i = 0; i < TSA_MB; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     set_pass(0);
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int cur = 0, pass = 0, ks = 0;
-    for (int s = 0; s < total; ++s) {
-        int nks = ks + 1, np = pass;
-        if (nks == KS) { nks = 0; np = pass + 1; }
-        if (s + 1 < total) {
-            if (nks == 0) set_pass(np);
-            issue(cur ^ 1, nks);
-        }
-        if (pass * TSA_PW + wave * TSA_WN < N) {                 // a wave whose 48 columns lie beyond N idles through the pass
-            const char* As = IMG + ks * (TSA_RP * 128);
-            const char* Bs = BST + cur * TSA_BST;
+    int cur = 0;
+    for (int pass = 0; pass < npass; ++pass) {
+        f32x4 acc[TSA_NB][TSA_MB];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int chunk = ((kk * 4 + fg) ^ (fr & 7)) * 16;
-                v8 bf[TSA_NB];
+        for (int j = 0; j < TSA_NB; ++j)
 #pragma unroll
-                for (int j = 0; j < TSA_NB; ++j) bf[j] = *reinterpret_cast<const v8*>(Bs + (wave * TSA_WN + j * 16 + fr) * 128 + chunk);
+            for (int i = 0; i < TSA_MB; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool live = pass * TSA_PW + wave * TSA_WN < N;     // a wave whose 48 columns lie beyond N idles through the pass
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+                issue(cur ^ 1, ks + 1);
+            } else if (pass + 1 < npass) {
+                set_pass(pass + 1);
+                issue(cur ^ 1, 0);
+            }
+            if (live) {
+                const char* As = IMG + ks * (TSA_RP * 128);
+                const char* Bs = BST + cur * TSA_BST;
 #pragma unroll
-                for (int i = 0; i < TSA_MB; ++i) {
-                    const v8 af = *reinterpret_cast<const v8*>(As + (i * 16 + fr) * 128 + chunk);
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int chunk = ((kk * 4 + fg) ^ (fr & 7)) * 16;
+                    v8 af[TSA_MB], bf[TSA_NB];
 #pragma unroll
-                    for (int j = 0; j < TSA_NB; ++j) acc[j][i] = TT<T>::mfma(bf[j], af, acc[j][i]);
+                    for (int i = 0; i < TSA_MB; ++i) af[i] = *reinterpret_cast<const v8*>(As + (i * 16 + fr) * 128 + chunk);
+#pragma unroll
+                    for (int j = 0; j < TSA_NB; ++j) bf[j] = *reinterpret_cast<const v8*>(Bs + (wave * TSA_WN + j * 16 + fr) * 128 + chunk);
+#pragma unroll
+                    for (int i = 0; i < TSA_MB; ++i)
+#pragma unroll
+                        for (int j = 0; j < TSA_NB; ++j) acc[j][i] = TT<T>::mfma(bf[j], af[i], acc[j][i]);
                 }
             }
-            if (ks == KS - 1) {
-                epi(pass, acc);
-#pragma unroll
-                for (int j = 0; j < TSA_NB; ++j)
-#pragma unroll
-                    for (int i = 0; i < TSA_MB; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+#ifdef TSA_STAMPS
+            const unsigned long long w0 = __builtin_readcyclecounter();
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#ifdef TSA_STAMPS
+            if (wait_cycles) *wait_cycles += __builtin_readcyclecounter() - w0;
+#endif
+            cur ^= 1;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
-        ks = nks;
-        pass = np;
+        if (live) epi(pass, acc);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #endif
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 1) void tsa_fwd_kernel(TsaParams p) {
+__global__ __launch_bounds__(256, 2) void tsa_fwd_kernel(TsaParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
@@ -146,6 +170,15 @@ __global__ __launch_bounds__(256, 1) void tsa_fwd_kernel(TsaParams p) {
     const int row0 = b * Tn * HW + p0;                 // global row of (pixel p0, frame 0); frame t of pixel pi: row0 + t*HW + pi
     auto grow = [&](int lr) __attribute__((always_inline)) { const int pi = lr / Tn; return row0 + (lr - pi * Tn) * HW + pi; };
     const T* X = reinterpret_cast<const T*>(p.x);
+    TSA_STAMP(0);
+#ifdef TSA_STAMPS
+    unsigned long long wait2 = 0, wait4 = 0;
+#define TSA_WAIT2 , &wait2
+#define TSA_WAIT4 , &wait4
+#else
+#define TSA_WAIT2
+#define TSA_WAIT4
+#endif
 
     // ---- phase 1a: band rows -> LDS image (one DMA piece = 8 rows x 128 B of one 64-channel block) --------------------------------
     {
@@ -160,66 +193,79 @@ __global__ __launch_bounds__(256, 1) void tsa_fwd_kernel(TsaParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    // ---- phase 1b: LayerNorm in place; 16 lanes per row, 4 rows per wave per iteration ----------------------------------------------
+    TSA_STAMP(1);
+    // ---- phase 1b: LayerNorm in place; 16 lanes per row, 4 rows per wave per step, 3 independent steps in flight -----------------------
     {
         const int l16 = lane & 15;
         constexpr int NCH = (TSA_MAXC / 8 + 15) / 16;       // 16-byte chunks per lane (3 at C = 320)
+        constexpr int G = 3;                                // row groups in flight
         float gm[NCH][8], bt[NCH][8];
+        bool cv[NCH];
+        int cl[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = l16 + 16 * j;
+            cv[j] = c < C8;
+            cl[j] = min(c, C8 - 1);                         // invalid chunks read a valid address and are masked to zero
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                gm[j][e] = c < C8 ? p.gamma[c * 8 + e] : 0.f;
-                bt[j][e] = c < C8 ? p.beta[c * 8 + e] : 0.f;
+                gm[j][e] = p.gamma[cl[j] * 8 + e];
+                bt[j][e] = p.beta[cl[j] * 8 + e];
             }
         }
         T* N1 = reinterpret_cast<T*>(p.n1);
         const float invC = 1.f / (float)C;
-        for (int it = 0; it < TSA_RP / 16; ++it) {
-            const int row = wave * (TSA_RP / 4) + it * 4 + (lane >> 4);
-            float v[NCH][8];
-            float s = 0.f;
+        for (int it0 = 0; it0 < TSA_RP / 16; it0 += G) {
+            float v[G][NCH][8], mean[G], rstd[G];
+            int row[G];
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int c = l16 + 16 * j;
-                if (c < C8) {
-                    load8<T>(reinterpret_cast<const T*>(IMG + (c >> 3) * (TSA_RP * 128) + row * 128 + (((c & 7) ^ (row & 7)) * 16)), v[j]);
+            for (int g = 0; g < G; ++g) {
+                row[g] = wave * (TSA_RP / 4) + (it0 + g) * 4 + (lane >> 4);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) s += v[j][e];
+                for (int j = 0; j < NCH; ++j) {
+                    load8<T>(reinterpret_cast<const T*>(IMG + (cl[j] >> 3) * (TSA_RP * 128) + row[g] * 128 + (((cl[j] & 7) ^ (row[g] & 7)) * 16)), v[g][j]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[g][j][e] = cv[j] ? v[g][j][e] : 0.f;
                 }
             }
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
-            const float mean = s * invC;
-            float ss = 0.f;
+            for (int g = 0; g < G; ++g) {
+                float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                if (l16 + 16 * j < C8) {
+                for (int j = 0; j < NCH; ++j)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mean; ss += d * d; }
-                }
+                    for (int e = 0; e < 8; ++e) s += v[g][j][e];
+                mean[g] = tsa_row16_sum(s) * invC;
             }
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) ss += __shfl_xor(ss, off, 64);
-            const float rstd = rsqrtf(ss * invC + p.eps);
-            const bool real = row < R;
-            const int gr = real ? grow(row) : 0;
-            if (real && l16 == 0) { p.stats[(size_t)gr * 2] = mean; p.stats[(size_t)gr * 2 + 1] = rstd; }
+            for (int g = 0; g < G; ++g) {
+                float ss = 0.f;
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int c = l16 + 16 * j;
-                if (c < C8) {
+                for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = cv[j] ? v[g][j][e] - mean[g] : 0.f; ss += d * d; }
+                rstd[g] = rsqrtf(tsa_row16_sum(ss) * invC + p.eps);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const bool real = row[g] < R;
+                const int gr = real ? grow(row[g]) : 0;
+                if (real && l16 == 0) *reinterpret_cast<float2*>(p.stats + (size_t)gr * 2) = float2{mean[g], rstd[g]};
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
                     float o[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = real ? (v[j][e] - mean) * rstd * gm[j][e] + bt[j][e] : 0.f;
-                    store8<T>(reinterpret_cast<T*>(IMG + (c >> 3) * (TSA_RP * 128) + row * 128 + (((c & 7) ^ (row & 7)) * 16)), o);
-                    if (real && N1) store8<T>(N1 + (size_t)gr * C + c * 8, o);
+                    for (int e = 0; e < 8; ++e) o[e] = real ? (v[g][j][e] - mean[g]) * rstd[g] * gm[j][e] + bt[j][e] : 0.f;
+                    if (cv[j]) {
+                        store8<T>(reinterpret_cast<T*>(IMG + (cl[j] >> 3) * (TSA_RP * 128) + row[g] * 128 + (((cl[j] & 7) ^ (row[g] & 7)) * 16)), o);
+                        if (real && N1) store8<T>(N1 + (size_t)gr * C + cl[j] * 8, o);
+                    }
                 }
             }
         }
         __syncthreads();
     }
+    TSA_STAMP(2);
     // rows this lane owns in the accumulator layout: block i, row i*16 + fr
     int growr[TSA_MB];
 #pragma unroll
@@ -230,6 +276,9 @@ __global__ __launch_bounds__(256, 1) void tsa_fwd_kernel(TsaParams p) {
     const int N3 = 3 * C;
     tsa_band_gemm<T>(IMG, BST, p.wqkv, p.wqkv_bytes, N3, C, tid, [&](int pass, f32x4 (&acc)[TSA_NB][TSA_MB]) __attribute__((always_inline)) {
         const int nb = pass * TSA_PW + wave * TSA_WN + fg * 4;
+#ifdef TSA_SKIP_QKV_STORE
+        if (p.T > 0) return;
+#endif
 #pragma unroll
         for (int i = 0; i < TSA_MB; ++i) {
             if (growr[i] < 0) continue;
@@ -244,18 +293,21 @@ __global__ __launch_bounds__(256, 1) void tsa_fwd_kernel(TsaParams p) {
                 }
             }
         }
-    });
+    } TSA_WAIT2);
+    TSA_STAMP(3);
     // every wave's q/k/v stores are complete (vmcnt(0) before the last barrier) and visible to the other waves of this CU
 
-    // ---- phase 3: attention over the frames of each (pixel, head) --------------------------------------------------------------------
+    // ---- phase 3: attention over the frames of each (pixel, head); two problems per wave in flight, the next two being fetched ---------
     {
         T* Og = reinterpret_cast<T*>(p.o);
-        char* Vs = BST + wave * 2048;
+        char* VsA = BST + wave * 4096;
+        char* VsB = VsA + 2048;
         const int nprob = p.P * p.heads;
         const int tq = min(fr, Tn - 1);
         struct Loaded { v8 q0, q1, k0, k1; uint4 va, vb; };
         auto load_prob = [&](int pr) __attribute__((always_inline)) {
             Loaded L;
+            pr = min(pr, nprob - 1);
             const int pi = pr / p.heads, hd = pr - pi * p.heads;
             const T* base = QKV + (size_t)(row0 + pi) * N3 + hd * 64;
             const T* qr = base + (size_t)tq * HW * N3;
@@ -263,26 +315,23 @@ __global__ __launch_bounds__(256, 1) void tsa_fwd_kernel(TsaParams p) {
             L.q1 = *reinterpret_cast<const v8*>(qr + 32 + fg * 8);
             L.k0 = *reinterpret_cast<const v8*>(qr + C + fg * 8);
             L.k1 = *reinterpret_cast<const v8*>(qr + C + 32 + fg * 8);
-            {
-                const int r = lane >> 3, pc = lane & 7, lc = pc ^ (r & 7);
-                L.va = *reinterpret_cast<const uint4*>(base + (size_t)min(r, Tn - 1) * HW * N3 + 2 * C + lc * 8);
-                L.vb = *reinterpret_cast<const uint4*>(base + (size_t)min(r + 8, Tn - 1) * HW * N3 + 2 * C + lc * 8);   // (r + 8) & 7 == r & 7
-            }
+            const int r = lane >> 3, lc = (lane & 7) ^ (r & 7);
+            L.va = *reinterpret_cast<const uint4*>(base + (size_t)min(r, Tn - 1) * HW * N3 + 2 * C + lc * 8);
+            L.vb = *reinterpret_cast<const uint4*>(base + (size_t)min(r + 8, Tn - 1) * HW * N3 + 2 * C + lc * 8);   // (r + 8) & 7 == r & 7
             return L;
         };
-        Loaded cur = load_prob(min(wave, nprob - 1));
-        for (int pr = wave; pr < nprob; pr += 4) {
-            const Loaded nxt = load_prob(min(pr + 4, nprob - 1));       // next problem's operands travel while this one is computed
-            const int pi = pr / p.heads, hd = pr - pi * p.heads;
-            *reinterpret_cast<uint4*>(Vs + (lane >> 3) * 128 + (lane & 7) * 16) = cur.va;
-            *reinterpret_cast<uint4*>(Vs + ((lane >> 3) + 8) * 128 + (lane & 7) * 16) = cur.vb;
+        auto stage_v = [&](const Loaded& L, char* Vs) __attribute__((always_inline)) {
+            *reinterpret_cast<uint4*>(Vs + (lane >> 3) * 128 + (lane & 7) * 16) = L.va;
+            *reinterpret_cast<uint4*>(Vs + ((lane >> 3) + 8) * 128 + (lane & 7) * 16) = L.vb;
+        };
+        auto scores = [&](const Loaded& L) __attribute__((always_inline)) {
             f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-            s = TT<T>::mfma(cur.k0, cur.q0, s);
-            s = TT<T>::mfma(cur.k1, cur.q1, s);                         // s[e] = <q_fr, k_(4 fg + e)>
+            s = TT<T>::mfma(L.k0, L.q0, s);
+            s = TT<T>::mfma(L.k1, L.q1, s);                          // s[e] = <q_fr, k_(4 fg + e)>
             float mx = -1e30f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (fg * 4 + e >= Tn) s[e] = -1e30f;                    // padded frames carry no weight
+                if (fg * 4 + e >= Tn) s[e] = -1e30f;                 // padded frames carry no weight
                 mx = fmaxf(mx, s[e]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -296,8 +345,10 @@ __global__ __launch_bounds__(256, 1) void tsa_fwd_kernel(TsaParams p) {
             v8 pf;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { pf[e] = from_f<T>(s[e] * inv); pf[4 + e] = from_f<T>(0.f); }
-            __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0): this wave's V tile is in LDS
-            __builtin_amdgcn_wave_barrier();
+            return pf;
+        };
+        auto output = [&](int pr, const v8& pf, const char* Vs) __attribute__((always_inline)) {
+            const int pi = pr / p.heads, hd = pr - pi * p.heads;
             const int lr = pi * Tn + fr;
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
@@ -312,16 +363,42 @@ __global__ __launch_bounds__(256, 1) void tsa_fwd_kernel(TsaParams p) {
                     *reinterpret_cast<Vec4<T>*>(Og + (size_t)(row0 + pi + fr * HW) * C + hd * 64 + db * 16 + fg * 4) = o;
                 }
             }
+        };
+        Loaded ca = load_prob(wave), cb = load_prob(wave + 4);
+        for (int pr = wave; pr < nprob; pr += 8) {
+            const Loaded na = load_prob(pr + 8), nb = load_prob(pr + 12);      // the next two problems travel while these are computed
+            const bool has_b = pr + 4 < nprob;
+            stage_v(ca, VsA);
+            if (has_b) stage_v(cb, VsB);
+            const v8 pa = scores(ca);
+            const v8 pb = scores(cb);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's V tiles are in LDS
             __builtin_amdgcn_wave_barrier();
-            cur = nxt;
+            output(pr, pa, VsA);
+            if (has_b) output(pr + 4, pb, VsB);
+            __builtin_amdgcn_wave_barrier();
+            ca = na;
+            cb = nb;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    TSA_STAMP(4);
 
     // ---- phase 4: h1 = o W_o^T + b_o + cvec + h ----------------------------------------------------------------------------------
     T* H1 = reinterpret_cast<T*>(p.h1);
     tsa_band_gemm<T>(IMG, BST, p.wo, p.wo_bytes, C, C, tid, [&](int pass, f32x4 (&acc)[TSA_NB][TSA_MB]) __attribute__((always_inline)) {
         const int nb = pass * TSA_PW + wave * TSA_WN + fg * 4;
+        // residual rows first: the compiler cannot know that h1 does not alias h, and a load issued between two stores costs a memory
+        // round trip (27 of them in a chain: 61 k cycles in the first version of this epilogue)
+        Vec4<T> r4[TSA_NB][TSA_MB];
+#pragma unroll
+        for (int j = 0; j < TSA_NB; ++j)
+#pragma unroll
+            for (int i = 0; i < TSA_MB; ++i) {
+                const bool ok = growr[i] >= 0 && nb + j * 16 < C;
+                r4[j][i] = *reinterpret_cast<const Vec4<T>*>(X + (size_t)(ok ? growr[i] : row0) * C + (ok ? nb + j * 16 : 0));
+            }
         float bb[TSA_NB][4];
 #pragma unroll
         for (int j = 0; j < TSA_NB; ++j)
@@ -336,15 +413,18 @@ __global__ __launch_bounds__(256, 1) void tsa_fwd_kernel(TsaParams p) {
             for (int j = 0; j < TSA_NB; ++j) {
                 const int n = nb + j * 16;
                 if (n < C) {
-                    const Vec4<T> r4 = *reinterpret_cast<const Vec4<T>*>(X + (size_t)gr * C + n);
                     Vec4<T> o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(acc[j][i][e] + bb[j][e] + (rv ? rv[n + e] : 0.f) + to_f<T>(r4.v[e]));
+                    for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(acc[j][i][e] + bb[j][e] + (rv ? rv[n + e] : 0.f) + to_f<T>(r4[j][i].v[e]));
                     *reinterpret_cast<Vec4<T>*>(H1 + (size_t)gr * C + n) = o;
                 }
             }
         }
-    });
+    } TSA_WAIT4);
+    TSA_STAMP(5);
+#ifdef TSA_STAMPS
+    if (tid == 0) { p.stamps[blockIdx.x * 16 + 6] = wait2; p.stamps[blockIdx.x * 16 + 7] = wait4; }
+#endif
 #endif
 }
 
