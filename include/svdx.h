@@ -93,17 +93,20 @@ int svdx_gemm_dual(const void* A, const void* B, void* C, int M, int N, int K, i
 /* Weight-gradient GEMM in TN form: C[n*ldc + k] (+)= sum_r A[r*lda + n] * B[r*ldb + k]  (A = dY [R,N], B = X [R,K], float C).
  * Replaces the dW part of autograd's Linear backward (train_svd.py:1044) without materialising transposes.
  * out_mode: F32 (store), F32_ADD (+=), F32_SLAB (split z -> C + z*N*ldc), F32_ATOMIC.
- * a_colsum (may be NULL): a_colsum[n] += sum_r A[r*lda + n] -- the Linear bias gradient, computed on the MFMA pipe from the dY
- * tiles the GEMM stages anyway (float atomics, one per column per split). */
+ * a_colsum (may be NULL): the column sums of A -- the Linear bias gradient, computed on the MFMA pipe from the dY tiles the GEMM stages
+ * anyway.  Unsplit (split_k == 1): a_colsum[n] += sum_r A[r*lda + n] (one owner per column, no atomics).  SVDX_OUT_F32_SLAB:
+ * a_colsum is float[split_k][N] and slice z STORES its partial into row z; svdx_gemm_finalize(colsum_slabs = a_colsum, ...) adds
+ * the rows in order -- a fixed summation order, so the bias gradient is run-to-run identical. */
 int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
                  float* a_colsum, const void* zero_page, int out_mode, int split_k, int dtype, void* stream);
 
 /* Epilogue of a split-K GEMM run with SVDX_OUT_F32_SLAB: v = sum_z acc[z*slab_stride + m*N + n] + bias + rowvec + res (same operand
  * meaning as svdx_gemm); c_is_f32_accumulate: 0 -> C[m*ldc+n] = (dtype)v, 1 -> ((float*)C)[m*ldc+n] += v, 2 -> ((float*)C)[m*ldc+n] = v
- * (a weight gradient that is written exactly once per step needs neither a zeroed destination nor the read of it). */
+ * (a weight gradient that is written exactly once per step needs neither a zeroed destination nor the read of it).
+ * colsum_slabs (may be NULL): float[nsplit][colsum_n] partial column sums left by svdx_gemm_tn; colsum_out[n] += their sum. */
 int svdx_gemm_finalize(const float* acc, int nsplit, int64_t slab_stride, void* C, int c_is_f32_accumulate, int M, int N, int ldc,
                        const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
-                       const void* res, int ldres, int dtype, void* stream);
+                       const void* res, int ldres, const float* colsum_slabs, float* colsum_out, int colsum_n, int dtype, void* stream);
 
 /* Skinny linears (M <= 64): time/added-id embedding MLPs, time_emb_proj, time_pos_embed, the KV-length-1
  * cross-attention.  X, Y float; W in dtype.
@@ -117,10 +120,13 @@ int svdx_outer_acc(const float* dY, const float* X, float* dW, int M, int N, int
 int svdx_timestep_embed(const float* t, float* out, int n, int dim, void* stream);
 
 /* ---- GroupNorm(32) (+SiLU) over n_s samples of `rows` rows x C channels (2-D: sample = frame;
- *      3-D: sample = clip, rows = T*HW).  stats / bstats are float[SVDX_GN_REPLICAS][n_s][G][2] partial (sum, sumsq):
- *      blocks spread their atomics over the replicas, readers add them.  The kernels zero the buffer first unless
- *      `prezeroed` (the host zeroes one arena per pass instead of ~200 tiny memsets). ------------------------------- */
+ *      3-D: sample = clip, rows = T*HW).  stats / bstats are OPAQUE buffers of SVDX_GN_STAT_FLOATS * SVDX_GN_REPLICAS * n_s * G
+ *      floats (8-byte aligned): int64[SVDX_GN_REPLICAS][n_s][G][2] partial sums in 64-bit fixed point (sum, sum of squares; backward:
+ *      sum dz*gamma, sum dz*gamma*xhat).  Blocks spread their atomics over the replicas, readers add them; integer addition is
+ *      associative, so the statistics are run-to-run identical.  The kernels zero the buffer first unless `prezeroed` (the host
+ *      zeroes one arena per pass instead of ~200 tiny memsets). ------------------------------------------------------------ */
 #define SVDX_GN_REPLICAS 8
+#define SVDX_GN_STAT_FLOATS 4   /* floats of storage per (replica, sample, group): two int64 */
 int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int C, int G, int prezeroed, int dtype, void* stream);
 int svdx_gn_apply(const void* x, const float* stats, const float* gamma, const float* beta, void* y,
                   int n_s, int rows, int C, int G, float eps, int silu, int dtype, void* stream);
@@ -173,9 +179,12 @@ int svdx_blend(const void* a, const void* b, const float* mix_factor, void* out,
 int svdx_blend_bwd(const void* dy, const float* mix_factor, void* da, void* db, int64_t n, int dtype, void* stream);
 int svdx_add_rowvec(const void* x, const float* vec, void* out, int rows, int C, int rv_ld,
                     int rows_per_group, int mod, int dtype, void* stream);
-/* out[g, c] (+)= sum over rows of group g (float; zeroed first unless accumulate) */
+/* out[g, c] (+)= sum over rows of group g (float; zeroed first unless accumulate).  scratch (may be NULL): float[nslab][n_groups][C]
+ * with nslab = ceil(rows of the largest group / SVDX_COLSUM_SLAB) -- row slabs then leave partial sums there and a second launch adds
+ * them in slab order (run-to-run identical); without it the slabs add with float atomics. */
+#define SVDX_COLSUM_SLAB 512
 int svdx_colsum(const void* x, float* out, int rows, int C, int ldx, int n_groups, int rows_per_group, int mod,
-                int accumulate, int dtype, void* stream);
+                int accumulate, float* scratch, int dtype, void* stream);
 /* out[c*ld_out + r] = in[r*ld_in + c]; columns r in [rows, ld_out) zero-filled */
 int svdx_transpose(const void* in, int ld_in, void* out, int ld_out, int rows, int cols, int dtype, void* stream);
 int svdx_concat2(const void* a, int Ca, const void* b, int Cb, void* out, int rows, int dtype, void* stream);

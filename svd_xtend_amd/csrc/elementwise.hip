@@ -91,7 +91,8 @@ constexpr int CS_SLAB = 512;
 // thread streams 64 rows with 4 loads in flight, the 8 row lanes are reduced through LDS and one atomicAdd per column per
 // block goes out (float atomics are the scarce resource: ~15/ns chip-wide).
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* out, int rows, int C, int ldx, int rpg, int mod) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* out, int rows, int C, int ldx, int rpg, int mod,
+                                                     float* partial) {
     __shared__ float red[8][32 * 8 + 8];
     const int g = blockIdx.x, slab = blockIdx.y;
     const int cnt = mod ? (rows - g + mod - 1) / mod : min(rpg, rows - g * rpg);
@@ -128,7 +129,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 #pragma unroll
     for (int r = 0; r < 8; ++r) s += red[r][c];
     const int col = blockIdx.z * 256 + c;
-    if (col < C && i0 < i1) atomicAdd(out + (size_t)g * C + col, s);
+    if (partial) {                  // deterministic form: slab `slab` of group g leaves its sums in partial[slab][g][C] (zeros when empty)
+        if (col < C) partial[((size_t)slab * gridDim.x + g) * C + col] = i0 < i1 ? s : 0.f;
+    } else if (col < C && i0 < i1) {
+        atomicAdd(out + (size_t)g * C + col, s);
+    }
+}
+
+// out[i] (+)= sum over the row slabs, in slab order
+__global__ void colsum_reduce_kernel(const float* __restrict__ partial, float* out, int nslab, long n, int accumulate) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float t = 0.f;
+        for (int sl = 0; sl < nslab; ++sl) t += partial[(size_t)sl * n + i];
+        out[i] = accumulate ? out[i] + t : t;
+    }
 }
 
 // batched tiled transpose: out[b][c*ld_out + r] = in[b][r*ld_in + c], r in [0, ld_out) zero-filled beyond rows.
@@ -300,15 +314,21 @@ extern "C" int svdx_add_rowvec(const void* x, const float* vec, void* out, int r
 }
 
 extern "C" int svdx_colsum(const void* x, float* out, int rows, int C, int ldx, int n_groups, int rows_per_group, int mod,
-                           int accumulate, int dtype, void* stream) {
+                           int accumulate, float* scratch, int dtype, void* stream) {
     EW_ALIGN_CHECK("svdx_colsum", C % 8 == 0 && ldx % 8 == 0 && al16(x) && (mod > 0 || rows_per_group > 0));
     hipStream_t st = (hipStream_t)stream;
-    if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * n_groups * C, st);
     const int maxcnt = mod ? cdiv(rows, mod) : std::min(rows_per_group, rows);
-    dim3 grid(n_groups, cdiv(maxcnt, CS_SLAB), cdiv(C, 256));
+    const int nslab = cdiv(maxcnt, CS_SLAB);
+    if (!scratch && !accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * n_groups * C, st);
+    dim3 grid(n_groups, nslab, cdiv(C, 256));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, out, rows, C, ldx,
-                                             rows_per_group, mod));
+                                             rows_per_group, mod, scratch));
     SVDX_LAUNCH_CHECK("svdx_colsum");
+    if (scratch) {
+        const long n = (long)n_groups * C;
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, scratch, out, nslab, n, accumulate);
+        SVDX_LAUNCH_CHECK("svdx_colsum(reduce)");
+    }
     return 0;
 }
 

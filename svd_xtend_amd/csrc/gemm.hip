@@ -463,7 +463,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + e;
-                if (n < p.M) atomicAdd(p.a_colsum + n, accb[i][e]);
+                if (n >= p.M) continue;
+                // one owner per (row slice z, column n): a split reduction leaves its partial in slab z of a_colsum (summed in a fixed
+                // order by svdx_gemm_finalize), an unsplit one adds to the running bias gradient -- no atomics, reproducible bits
+                if (p.out_mode == SVDX_OUT_F32_SLAB) p.a_colsum[(size_t)z * p.M + n] = accb[i][e];
+                else p.a_colsum[n] += accb[i][e];
             }
     }
     gemm_epilogue<T>(p, acc, smem, m0, n0, z, tid, lane, wm, wn);
@@ -949,7 +953,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void gemm_finalize_kernel(const float* __restrict__ acc, int nsplit, long slab_stride, T* __restrict__ C,
                                                             float* __restrict__ Cf, int f32_store, int M, int N, int ldc,
                                                             const float* __restrict__ bias, const float* __restrict__ rowvec,
-                                                            int rv_ld, int rv_rpg, int rv_mod, const T* __restrict__ res, int ldres) {
+                                                            int rv_ld, int rv_rpg, int rv_mod, const T* __restrict__ res, int ldres,
+                                                            const float* __restrict__ cs_slabs, float* cs_out, int cs_n) {
+    if (cs_slabs && blockIdx.x == 0) {         // bias gradient: the row slices' column sums, added in slice order
+        for (int n = threadIdx.x; n < cs_n; n += blockDim.x) {
+            float t = 0.f;
+            for (int z = 0; z < nsplit; ++z) t += cs_slabs[(size_t)z * cs_n + n];
+            cs_out[n] += t;
+        }
+    }
     const long total4 = (long)M * N / 4;       // N % 4 == 0
     for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
         const long i = i4 * 4;
@@ -1245,7 +1257,9 @@ extern "C" int svdx_small_linear(const float* X, const void* W, const float* bia
 
 extern "C" int svdx_gemm_finalize(const float* acc, int nsplit, int64_t slab_stride, void* C, int c_is_f32_accumulate, int M, int N,
                                   int ldc, const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
-                                  const void* res, int ldres, int dtype, void* stream) {
+                                  const void* res, int ldres, const float* colsum_slabs, float* colsum_out, int colsum_n, int dtype,
+                                  void* stream) {
+    SVDX_CHECK_ARG(!colsum_slabs || (colsum_out && colsum_n > 0), "svdx_gemm_finalize: colsum_slabs needs colsum_out / colsum_n");
     SVDX_CHECK_ARG(acc && C && M > 0 && N > 0 && nsplit >= 1, "svdx_gemm_finalize: bad args");
     SVDX_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && slab_stride % 4 == 0 && (!res || ldres % 4 == 0) && (!rowvec || rv_ld % 4 == 0),
                    "svdx_gemm_finalize: N/ld must be multiples of 4");
@@ -1254,7 +1268,7 @@ extern "C" int svdx_gemm_finalize(const float* acc, int nsplit, int64_t slab_str
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_finalize_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, nsplit,
                                              (long)slab_stride, c_is_f32_accumulate ? (T*)nullptr : (T*)C,
                                              c_is_f32_accumulate ? (float*)C : (float*)nullptr, c_is_f32_accumulate == 2, M, N, ldc, bias, rowvec, rv_ld,
-                                             rv_rows_per_group, rv_mod, (const T*)res, ldres));
+                                             rv_rows_per_group, rv_mod, (const T*)res, ldres, colsum_slabs, colsum_out, colsum_n));
     SVDX_LAUNCH_CHECK("svdx_gemm_finalize");
     return 0;
 }

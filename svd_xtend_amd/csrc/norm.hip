@@ -16,19 +16,33 @@ struct GnGeom {
 };
 
 // Group sums live in SVDX_GN_REPLICAS partial copies ([rep][n_s][G][2]): blocks spread their atomics over the copies (a clip-wide
-// temporal norm has only 64 distinct addresses and >1000 blocks: same-address float atomics serialise), readers add them up.
-__device__ __forceinline__ void group_sums(const float* stats, int n_s, int n, int G, int g, float& s, float& ss) {
-    s = 0.f; ss = 0.f;
+// temporal norm has only 64 distinct addresses and >1000 blocks: same-address atomics serialise), readers add them up.
+// The sums are 64-bit FIXED-POINT integers: integer addition is associative, so the result does not depend on the order in which
+// the blocks' atomics land -- the statistics (and with them the whole step) are run-to-run identical, which float atomics are not.
+// Scale 2^k per (kind, count): k = 62 - (bits of the largest term) - ceil(log2(count)), so that no sum can leave 63 bits while
+// |x| <= 2^16 (the fp16 range), |dz gamma| <= 2^18, |xhat| <= 2^8; a block's float partial converts exactly (24 significant bits).
+__host__ __device__ __forceinline__ void gn_fixed_scales(long cnt, int mode, int& k0, int& k1) {
+    int lg = 0;
+    while ((1L << lg) < cnt) ++lg;
+    const int b0 = mode == 0 ? 16 : 18, b1 = mode == 0 ? 32 : 26;
+    k0 = 62 - b0 - lg; k1 = 62 - b1 - lg;
+    k0 = k0 < 0 ? 0 : (k0 > 40 ? 40 : k0);
+    k1 = k1 < 0 ? 0 : (k1 > 40 ? 40 : k1);
+}
+__device__ __forceinline__ void group_sums(const float* stats, int n_s, int n, int G, int g, float i0, float i1, float& s, float& ss) {
+    long long a = 0, b = 0;
+    const long long* st = reinterpret_cast<const long long*>(stats);
 #pragma unroll
     for (int r = 0; r < SVDX_GN_REPLICAS; ++r) {
-        const float2 v = *reinterpret_cast<const float2*>(stats + (((size_t)r * n_s + n) * G + g) * 2);
-        s += v.x; ss += v.y;
+        const size_t o = (((size_t)r * n_s + n) * G + g) * 2;
+        a += st[o]; b += st[o + 1];
     }
+    s = (float)a * i0; ss = (float)b * i1;
 }
-__device__ __forceinline__ void group_mean_rstd(const float* stats, int n_s, int n, int G, int g, float cnt, float eps,
+__device__ __forceinline__ void group_mean_rstd(const float* stats, int n_s, int n, int G, int g, float cnt, float eps, float i0, float i1,
                                                 float& mean, float& rstd) {
     float s, ss;
-    group_sums(stats, n_s, n, G, g, s, ss);
+    group_sums(stats, n_s, n, G, g, i0, i1, s, ss);
     mean = s / cnt;
     const float var = fmaxf(ss / cnt - mean * mean, 0.f);
     rstd = rsqrtf(var + eps);
@@ -39,10 +53,14 @@ template <typename T, int MODE>
 __global__ void gn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ stats,
                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* out,
                                  GnGeom q, float eps, int silu) {
-    __shared__ float gacc[64];
+    __shared__ unsigned long long gacc[64];
     const int t = threadIdx.x;
-    if (t < 64) gacc[t] = 0.f;
+    if (t < 64) gacc[t] = 0ull;
     __syncthreads();
+    int fk0, fk1, sk0, sk1;
+    gn_fixed_scales((long)q.rows * q.cg, 0, fk0, fk1);               // scales of the forward statistics (read in MODE 1)
+    gn_fixed_scales((long)q.rows * q.cg, MODE, sk0, sk1);            // scales of the sums this launch produces
+    const float fi0 = exp2f((float)-fk0), fi1 = exp2f((float)-fk1), m0 = exp2f((float)sk0), m1 = exp2f((float)sk1);
     const int n = blockIdx.x, slab = blockIdx.y;
     const int j = t % q.cc, ry = t / q.cc;
     const int r0 = slab * q.slab, r1 = min(q.rows, r0 + q.slab);
@@ -54,13 +72,13 @@ __global__ void gn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ 
         const float cnt = (float)q.rows * q.cg;
         const int gA = (j * 8) / q.cg, gB = min((j * 8 + 7) / q.cg, q.G - 1);   // a chunk of 8 channels touches <= 2 groups when cg >= 8
         float meanA, rstdA, meanB, rstdB;
-        group_mean_rstd(stats, q.n_s, n, q.G, gA, cnt, eps, meanA, rstdA);
-        group_mean_rstd(stats, q.n_s, n, q.G, gB, cnt, eps, meanB, rstdB);
+        group_mean_rstd(stats, q.n_s, n, q.G, gA, cnt, eps, fi0, fi1, meanA, rstdA);
+        group_mean_rstd(stats, q.n_s, n, q.G, gB, cnt, eps, fi0, fi1, meanB, rstdB);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = j * 8 + e, g = c / q.cg;
             float mean = g == gA ? meanA : meanB, rstd = g == gA ? rstdA : rstdB;
-            if (g != gA && g != gB) group_mean_rstd(stats, q.n_s, n, q.G, g, cnt, eps, mean, rstd);
+            if (g != gA && g != gB) group_mean_rstd(stats, q.n_s, n, q.G, g, cnt, eps, fi0, fi1, mean, rstd);
             mu[e] = mean; rs[e] = rstd; gm[e] = gamma[c];
             sc[e] = rstd * gm[e];
             sh[e] = beta[c] - mean * sc[e];
@@ -108,17 +126,18 @@ __global__ void gn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ 
         for (int e = 0; e < 8; ++e) {
             const int g = (j * 8 + e) / q.cg;
             if (g != cur) {
-                atomicAdd(&gacc[cur * 2], s0);
-                atomicAdd(&gacc[cur * 2 + 1], s1);
+                atomicAdd(&gacc[cur * 2], (unsigned long long)__float2ll_rn(s0 * m0));
+                atomicAdd(&gacc[cur * 2 + 1], (unsigned long long)__float2ll_rn(s1 * m1));
                 cur = g; s0 = 0.f; s1 = 0.f;
             }
             s0 += a0[e]; s1 += a1[e];
         }
-        atomicAdd(&gacc[cur * 2], s0);
-        atomicAdd(&gacc[cur * 2 + 1], s1);
+        atomicAdd(&gacc[cur * 2], (unsigned long long)__float2ll_rn(s0 * m0));
+        atomicAdd(&gacc[cur * 2 + 1], (unsigned long long)__float2ll_rn(s1 * m1));
     }
     __syncthreads();
-    if (t < 2 * q.G) atomicAdd(out + ((size_t)(slab % SVDX_GN_REPLICAS) * q.n_s + n) * q.G * 2 + t, gacc[t]);
+    if (t < 2 * q.G)
+        atomicAdd(reinterpret_cast<unsigned long long*>(out) + ((size_t)(slab % SVDX_GN_REPLICAS) * q.n_s + n) * q.G * 2 + t, gacc[t]);
 }
 
 // MODE 0: y = act(xhat*gamma+beta).  MODE 1: dx = rstd*(dz*gamma - (s1 + xhat*s2)/cnt) (+ add).
@@ -136,11 +155,15 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ d
     float sc[8], sh[8], gm[8], mu[8], rs[8], b1[8], b2[8];
     const int gA = (j * 8) / q.cg, gB = min((j * 8 + 7) / q.cg, q.G - 1);
     float meanA, rstdA, meanB, rstdB, b1A = 0.f, b2A = 0.f, b1B = 0.f, b2B = 0.f;
-    group_mean_rstd(stats, q.n_s, n, q.G, gA, cnt, eps, meanA, rstdA);
-    group_mean_rstd(stats, q.n_s, n, q.G, gB, cnt, eps, meanB, rstdB);
+    int fk0, fk1, bk0, bk1;
+    gn_fixed_scales((long)q.rows * q.cg, 0, fk0, fk1);
+    gn_fixed_scales((long)q.rows * q.cg, 1, bk0, bk1);
+    const float fi0 = exp2f((float)-fk0), fi1 = exp2f((float)-fk1), bi0 = exp2f((float)-bk0), bi1 = exp2f((float)-bk1);
+    group_mean_rstd(stats, q.n_s, n, q.G, gA, cnt, eps, fi0, fi1, meanA, rstdA);
+    group_mean_rstd(stats, q.n_s, n, q.G, gB, cnt, eps, fi0, fi1, meanB, rstdB);
     if (MODE == 1) {
-        group_sums(bstats, q.n_s, n, q.G, gA, b1A, b2A);
-        group_sums(bstats, q.n_s, n, q.G, gB, b1B, b2B);
+        group_sums(bstats, q.n_s, n, q.G, gA, bi0, bi1, b1A, b2A);
+        group_sums(bstats, q.n_s, n, q.G, gB, bi0, bi1, b1B, b2B);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -148,8 +171,8 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ d
         float mean = g == gA ? meanA : meanB, rstd = g == gA ? rstdA : rstdB;
         float s1 = g == gA ? b1A : b1B, s2 = g == gA ? b2A : b2B;
         if (g != gA && g != gB) {                    // cg < 4: more than two groups per chunk (not an SVD shape; kept correct)
-            group_mean_rstd(stats, q.n_s, n, q.G, g, cnt, eps, mean, rstd);
-            if (MODE == 1) group_sums(bstats, q.n_s, n, q.G, g, s1, s2);
+            group_mean_rstd(stats, q.n_s, n, q.G, g, cnt, eps, fi0, fi1, mean, rstd);
+            if (MODE == 1) group_sums(bstats, q.n_s, n, q.G, g, bi0, bi1, s1, s2);
         }
         mu[e] = mean; rs[e] = rstd; gm[e] = gamma[c];
         sc[e] = rstd * gm[e];
@@ -389,7 +412,7 @@ extern "C" int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int
     GnGeom q; int threads;
     if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (!prezeroed) (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * n_s * G * SVDX_GN_REPLICAS, st);
+    if (!prezeroed) (void)hipMemsetAsync(stats, 0, sizeof(long long) * 2 * n_s * G * SVDX_GN_REPLICAS, st);
     dim3 grid(n_s, cdiv(rows, q.slab));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_reduce_kernel<T, 0>), grid, dim3(threads), 0, st, (const T*)x,
                                              (const T*)nullptr, (const float*)nullptr, (const float*)nullptr,
@@ -416,7 +439,7 @@ extern "C" int svdx_gn_bwd_stats(const void* dy, const void* x, const float* sta
     GnGeom q; int threads;
     if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (!prezeroed) (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * n_s * G * SVDX_GN_REPLICAS, st);
+    if (!prezeroed) (void)hipMemsetAsync(bstats, 0, sizeof(long long) * 2 * n_s * G * SVDX_GN_REPLICAS, st);
     dim3 grid(n_s, cdiv(rows, q.slab));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_reduce_kernel<T, 1>), grid, dim3(threads), 0, st, (const T*)x,
                                              (const T*)dy, stats, gamma, beta, bstats, q, eps, silu));

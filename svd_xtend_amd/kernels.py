@@ -24,6 +24,7 @@ OUT_ACT, OUT_F32, OUT_F32_ATOMIC, OUT_F32_SLAB, OUT_F32_ADD = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GEGLU_FWD, EPI_GEGLU_BWD = 0, 1, 2
 LN_PARTIAL_ROWS = 512
 GN_REPLICAS = 8
+GN_STAT_FLOATS = 4             # floats of storage per (replica, sample, group) of a GroupNorm statistics buffer: two int64
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3, GATHER_CONV3X3_PAD0 = 0, 1, 2, 3, 4
 OPT_STATE_FLOATS = 16          # include/svdx.h: layout of the optimizer / loss-scale / schedule state
 SCHED_KINDS = {"constant": 0, "constant_with_warmup": 1, "linear": 2, "cosine": 3, "cosine_with_restarts": 4, "polynomial": 5}
@@ -64,7 +65,7 @@ _SIGS = {
     "svdx_gemm": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifii" "ippi" "ip",
     "svdx_gemm_dual": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifi" "pp" "iiii" "ip",
     "svdx_gemm_tn": "ppp" "iiiiii" "pp" "ii" "ip",
-    "svdx_gemm_finalize": "pil" "pi" "iii" "pp" "iii" "pi" "ip",
+    "svdx_gemm_finalize": "pil" "pi" "iii" "pp" "iii" "pi" "ppi" "ip",
     "svdx_small_linear": "pppp" "iiii" "iii" "ip",
     "svdx_outer_acc": "ppp" "iii" "f" "p",
     "svdx_timestep_embed": "pp" "ii" "p",
@@ -87,7 +88,7 @@ _SIGS = {
     "svdx_blend": "pppp" "l" "ip",
     "svdx_blend_bwd": "pppp" "l" "ip",
     "svdx_add_rowvec": "ppp" "iiiii" "ip",
-    "svdx_colsum": "pp" "iiiiiii" "ip",
+    "svdx_colsum": "pp" "iiiiiii" "p" "ip",
     "svdx_transpose": "pi" "pi" "ii" "ip",
     "svdx_concat2": "pi" "pi" "p" "i" "ip",
     "svdx_split2": "p" "pi" "pi" "i" "ip",
@@ -115,6 +116,15 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "l": ctypes
 
 EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band")
 TSA_MAX_C, TSA_MAX_T, TSA_BAND_ROWS = 320, 16, 144
+
+
+COLSUM_SLAB = 512
+
+
+def colsum_slabs(rows: int, rpg: int, mod: int) -> int:
+    """Row slabs of svdx_colsum (its deterministic form wants float[slabs][n_groups][C] of scratch)."""
+    maxcnt = -(-rows // mod) if mod else min(rpg, rows)
+    return -(-maxcnt // COLSUM_SLAB)
 
 
 def tsa_pixels_per_band(T: int, HW: int) -> int:
@@ -212,10 +222,11 @@ class HipBackend:
                    _dt(A), self._stream())
 
     def gemm_finalize(self, acc, nsplit, slab_stride, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
-                      res=None, ldres=0, accumulate_f32=False, dtype=None):
+                      res=None, ldres=0, accumulate_f32=False, dtype=None, colsum_slabs=None, colsum_out=None):
         dt = F16 if dtype == torch.float16 else BF16 if dtype == torch.bfloat16 else _dt(C)
         self._call("svdx_gemm_finalize", _f32(acc), nsplit, slab_stride, _p(C), int(accumulate_f32), M, N, ldc, _f32(bias),
-                   _f32(rowvec), rv_ld, rv_rpg, rv_mod, _p(res), ldres, dt, self._stream())
+                   _f32(rowvec), rv_ld, rv_rpg, rv_mod, _p(res), ldres, _f32(colsum_slabs), _f32(colsum_out),
+                   colsum_out.numel() if colsum_out is not None else 0, dt, self._stream())
 
     def small_linear(self, X, W, bias, Y, M, N, K, ldw, trans=0, silu_in=0, accumulate=0):
         self._call("svdx_small_linear", _f32(X), _p(W), _f32(bias), _f32(Y), M, N, K, ldw, trans, silu_in,
@@ -300,8 +311,10 @@ class HipBackend:
     def add_rowvec(self, x, vec, out, rows, C, rv_ld, rpg, mod):
         self._call("svdx_add_rowvec", _p(x), _f32(vec), _p(out), rows, C, rv_ld, rpg, mod, _dt(x), self._stream())
 
-    def colsum(self, x, out, rows, C, ldx, n_groups, rpg, mod, accumulate=0):
-        self._call("svdx_colsum", _p(x), _f32(out), rows, C, ldx, n_groups, rpg, mod, int(accumulate), _dt(x),
+    def colsum(self, x, out, rows, C, ldx, n_groups, rpg, mod, accumulate=0, scratch=None):
+        if scratch is not None:
+            assert scratch.numel() >= colsum_slabs(rows, rpg, mod) * n_groups * C
+        self._call("svdx_colsum", _p(x), _f32(out), rows, C, ldx, n_groups, rpg, mod, int(accumulate), _f32(scratch), _dt(x),
                    self._stream())
 
     def transpose(self, inp, ld_in, out, ld_out, rows, cols):

@@ -413,8 +413,10 @@ def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tenso
             k.gemm_tn(dy, x, dst, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32 if store else K.OUT_F32_ADD, a_colsum=a_colsum)
         else:
             slabs = rt.f32(sk, N, Kd)
-            k.gemm_tn(dy, x, slabs, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32_SLAB, split_k=sk, a_colsum=a_colsum)
-            k.gemm_finalize(slabs, sk, N * Kd, dst, N, Kd, Kd, accumulate_f32=2 if store else 1, dtype=rt.dt)
+            cs = rt.f32(sk, N) if a_colsum is not None else None       # per-slice column sums, added in slice order by the finalize
+            k.gemm_tn(dy, x, slabs, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32_SLAB, split_k=sk, a_colsum=cs)
+            k.gemm_finalize(slabs, sk, N * Kd, dst, N, Kd, Kd, accumulate_f32=2 if store else 1, dtype=rt.dt, colsum_slabs=cs,
+                            colsum_out=a_colsum)
 
     tiles = ((N + 127) // 128) * ((Kd + 127) // 128)
 
@@ -788,7 +790,7 @@ class GroupNormOp:
             raise NotImplementedError("GroupNorm affine grads are outside this round's trainable set")
 
     def fwd(self, rt: Runtime, x: torch.Tensor, n_s: int, rows: int):
-        stats, pz = rt.take_zeroed(K.GN_REPLICAS * n_s * GN_GROUPS * 2)
+        stats, pz = rt.take_zeroed(K.GN_REPLICAS * n_s * GN_GROUPS * K.GN_STAT_FLOATS)
         y = rt.empty(n_s * rows, self.C)
         rt.k.gn_stats(x, stats, n_s, rows, self.C, GN_GROUPS, prezeroed=pz)
         rt.k.gn_apply(x, stats, self.mod.weight.data, self.mod.bias.data, y, n_s, rows, self.C, GN_GROUPS,
@@ -796,7 +798,7 @@ class GroupNormOp:
         return y, stats
 
     def bwd(self, rt: Runtime, dy, x, stats, n_s: int, rows: int, add: Optional[torch.Tensor] = None):
-        bst, pz = rt.take_zeroed(K.GN_REPLICAS * n_s * GN_GROUPS * 2)
+        bst, pz = rt.take_zeroed(K.GN_REPLICAS * n_s * GN_GROUPS * K.GN_STAT_FLOATS)
         dx = rt.empty(n_s * rows, self.C)
         g, b = self.mod.weight.data, self.mod.bias.data
         rt.k.gn_bwd_stats(dy, x, stats, g, b, bst, n_s, rows, self.C, GN_GROUPS, self.eps, self.silu, prezeroed=pz)

@@ -286,7 +286,7 @@ class BasicTransformerBlock(nn.Module):
         del dn3, pre, h2
         if self.attn2.cross_trainable:               # adapters on the cross-attention's to_v / to_out (per-clip vectors)
             dvec = rt.f32(g.B, C)
-            k.colsum(dh2, dvec, M, C, C, g.B, g.T * g.HW, 0)
+            k.colsum(dh2, dvec, M, C, C, g.B, g.T * g.HW, 0, scratch=rt.f32(K.colsum_slabs(M, g.T * g.HW, 0) * g.B * C))
             self.attn2.cross_vec_bwd(rt, dvec, cv, ctx, g.B)
         d_o = _proj_bwd_dx(rt, self.attn1.o, self.attn1.o_lora, dh2, C, o, xs_o, M)
         D = rt.f32(g.N * self.heads * S)
@@ -393,7 +393,8 @@ class TemporalBasicTransformerBlock(nn.Module):
         if self.attn2.cross_trainable:
             rv = self._rv(g)
             dvec = rt.f32(g.B, C)
-            k.colsum(dh1, dvec, M, C, C, g.B, rv["rv_rpg"], rv["rv_mod"])
+            k.colsum(dh1, dvec, M, C, C, g.B, rv["rv_rpg"], rv["rv_mod"],
+                     scratch=rt.f32(K.colsum_slabs(M, rv["rv_rpg"], rv["rv_mod"]) * g.B * C))
             self.attn2.cross_vec_bwd(rt, dvec, cv, tctx, g.B)
         d_o = _proj_bwd_dx(rt, self.attn1.o, self.attn1.o_lora, dh1, C, o, xs_o, M)
         if self.attn1.o.trainable:

@@ -164,6 +164,27 @@ def graphed_vs_eager(dev=None, dtype=torch.float16, steps=3):
                 param_abs_max=float(e["p"].abs().max()), opt_steps=(e["state"][0], g["state"][0]), segments=g["segments"])
 
 
+def run_steps(dev=None, dtype=torch.float16, steps=3, seed=5):
+    """`steps` eager optimizer steps of the tiny topology from seeded weights on a seeded batch; returns the final state."""
+    dev = dev or torch.device("cuda")
+    cfg = TINY_CONFIG
+    orc = UNetSpatioTemporalConditionOracle(**cfg)
+    scaled_init_(orc, seed)
+    b = make_synthetic_batch(1, 3, 16, 16, 77, cross_dim=cfg["cross_attention_dim"])
+    unet_in, ts, ehs, ids, noisy, _ = edm_inputs(b)
+    batch = {k: v.to(dev) for k, v in dict(unet_in=unet_in, timesteps=ts, ehs=ehs, added_time_ids=ids, noisy_latents=noisy,
+                                           target=b["latents"], sigmas=b["sigmas"]).items()}
+    m = UNetSpatioTemporalConditionModel(**cfg)
+    m.load_state_dict(orc.state_dict(), strict=True)
+    m.to(dev)
+    tr = Trainer(m, dtype=dtype, lr=1e-3)
+    for _ in range(steps):
+        tr.step(batch)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    return dict(p=tr.p_flat.clone(), m=tr.m_flat.clone(), v=tr.v_flat.clone(), loss=float(tr.last_loss()))
+
+
 def resume_vs_straight(tmpdir, dev=None, dtype=torch.float16, steps=4, cut=2):
     """`steps` optimizer steps in one go vs `cut` steps, save_state, a fresh trainer from other weights, load_state, the rest:
     weights, Adam moments, loss scale, the device-side lr schedule (graph-replayed steps after the resume) and the EMA."""

@@ -83,6 +83,33 @@ def gather_rows(A, g: K.Gather, M):
     return torch.cat(out, 1)
 
 
+def gn_fixed_scales(cnt: int, mode: int):
+    """include/svdx.h GroupNorm statistics: 64-bit fixed point, scale 2^k per (kind, count) -- csrc/norm.hip gn_fixed_scales."""
+    lg = 0
+    while (1 << lg) < cnt:
+        lg += 1
+    b0, b1 = (16, 32) if mode == 0 else (18, 26)
+    return min(max(62 - b0 - lg, 0), 40), min(max(62 - b1 - lg, 0), 40)
+
+
+def gn_view(stats, n_s, G):
+    """int64 [replicas, n_s, G, 2] view of a statistics buffer (a float tensor of K.GN_STAT_FLOATS floats per entry)."""
+    return V1(stats, GN_REPLICAS * n_s * G * K.GN_STAT_FLOATS).view(torch.int64).view(GN_REPLICAS, n_s, G, 2)
+
+
+def gn_decode(stats, n_s, G, cnt, mode):
+    k0, k1 = gn_fixed_scales(cnt, mode)
+    tot = gn_view(stats, n_s, G).sum(0)
+    return torch.stack([tot[..., 0].double() * 2.0 ** -k0, tot[..., 1].double() * 2.0 ** -k1], -1).float()
+
+
+def gn_encode_add(stats, n_s, G, cnt, mode, s0, s1):
+    k0, k1 = gn_fixed_scales(cnt, mode)
+    v = gn_view(stats, n_s, G)
+    v[0, ..., 0] += torch.round(s0.double() * 2.0 ** k0).to(torch.int64)
+    v[0, ..., 1] += torch.round(s1.double() * 2.0 ** k1).to(torch.int64)
+
+
 class EmuBackend:
     # ---- GEMM family ----
     def gemm(self, A, B, C, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
@@ -149,7 +176,7 @@ class EmuBackend:
 
     def gemm_tn(self, A, B, C, R, N, Kd, lda, ldb, ldc, out_mode=K.OUT_F32_ADD, split_k=1, a_colsum=None):
         a, b = V(A, R, N, lda).float(), V(B, R, Kd, ldb).float()
-        if a_colsum is not None:
+        if a_colsum is not None and out_mode != K.OUT_F32_SLAB:
             V1(a_colsum, N).add_(a.sum(0))
         if out_mode == K.OUT_F32_SLAB:
             assert ldc == Kd
@@ -158,6 +185,8 @@ class EmuBackend:
             for z in range(split_k):
                 sl = torch.as_strided(C, (N, Kd), (Kd, 1), C.storage_offset() + z * N * Kd)
                 sl.copy_(a[z * per:(z + 1) * per].t() @ b[z * per:(z + 1) * per])
+                if a_colsum is not None:                  # float[split_k][N]: slice z stores its partial column sums
+                    V(a_colsum, split_k, N, N)[z].copy_(a[z * per:(z + 1) * per].sum(0))
             return
         v = a.t() @ b
         c = V(C, N, Kd, ldc)
@@ -167,7 +196,10 @@ class EmuBackend:
             c += v
 
     def gemm_finalize(self, acc, nsplit, slab_stride, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
-                      res=None, ldres=0, accumulate_f32=False, dtype=None):
+                      res=None, ldres=0, accumulate_f32=False, dtype=None, colsum_slabs=None, colsum_out=None):
+        if colsum_slabs is not None:
+            n = colsum_out.numel()
+            V1(colsum_out, n).add_(V(colsum_slabs, nsplit, n, n).sum(0))
         v = torch.zeros(M, N, device=acc.device)
         for z in range(nsplit):
             v = v + torch.as_strided(acc, (M, N), (N, 1), acc.storage_offset() + z * slab_stride)
@@ -216,7 +248,7 @@ class EmuBackend:
     def _gn_parts(x, stats, n_s, rows, C, G, eps):
         xf = V(x, n_s * rows, C, C).float().view(n_s, rows, G, C // G)
         cnt = rows * (C // G)
-        st = V(stats, GN_REPLICAS * n_s * G, 2, 2).view(GN_REPLICAS, n_s, G, 2).sum(0)
+        st = gn_decode(stats, n_s, G, cnt, 0)
         mean = st[..., 0] / cnt
         var = (st[..., 1] / cnt - mean * mean).clamp(min=0)
         rstd = torch.rsqrt(var + eps)
@@ -224,11 +256,10 @@ class EmuBackend:
 
     def gn_stats(self, x, stats, n_s, rows, C, G, prezeroed=0):
         xf = V(x, n_s * rows, C, C).float().view(n_s, rows, G, C // G)
-        st = V(stats, GN_REPLICAS * n_s * G, 2, 2).view(GN_REPLICAS, n_s, G, 2)
         if not prezeroed:
-            st.zero_()
-        st[0, ..., 0] += xf.sum((1, 3))          # the replica split is the kernel's business; only the sum is specified
-        st[0, ..., 1] += (xf * xf).sum((1, 3))
+            gn_view(stats, n_s, G).zero_()
+        # the replica split is the kernel's business; only the (fixed-point) sum is specified
+        gn_encode_add(stats, n_s, G, rows * (C // G), 0, xf.sum((1, 3)), (xf * xf).sum((1, 3)))
 
     def gn_apply(self, x, stats, gamma, beta, y, n_s, rows, C, G, eps, silu_):
         xf, mean, rstd, _ = self._gn_parts(x, stats, n_s, rows, C, G, eps)
@@ -249,15 +280,13 @@ class EmuBackend:
 
     def gn_bwd_stats(self, dy, x, stats, gamma, beta, bstats, n_s, rows, C, G, eps, silu_, prezeroed=0):
         xhat, dzg, _, _ = self._gn_dz(dy, x, stats, gamma, beta, n_s, rows, C, G, eps, silu_)
-        bs = V(bstats, GN_REPLICAS * n_s * G, 2, 2).view(GN_REPLICAS, n_s, G, 2)
         if not prezeroed:
-            bs.zero_()
-        bs[0, ..., 0] += dzg.sum((1, 3))
-        bs[0, ..., 1] += (dzg * xhat).sum((1, 3))
+            gn_view(bstats, n_s, G).zero_()
+        gn_encode_add(bstats, n_s, G, rows * (C // G), 1, dzg.sum((1, 3)), (dzg * xhat).sum((1, 3)))
 
     def gn_bwd_apply(self, dy, x, stats, bstats, gamma, beta, add, dx, n_s, rows, C, G, eps, silu_):
         xhat, dzg, rstd, cnt = self._gn_dz(dy, x, stats, gamma, beta, n_s, rows, C, G, eps, silu_)
-        bs = V(bstats, GN_REPLICAS * n_s * G, 2, 2).view(GN_REPLICAS, n_s, G, 2).sum(0)
+        bs = gn_decode(bstats, n_s, G, cnt, 1)
         s1 = bs[..., 0][:, None, :, None]
         s2 = bs[..., 1][:, None, :, None]
         d = rstd * (dzg - (s1 + xhat * s2) / cnt)
@@ -387,7 +416,7 @@ class EmuBackend:
         v = V(vec, int(gi.max()) + 1, C, rv_ld)
         V(out, rows, C, C).copy_((V(x, rows, C, C).float() + v[gi]).to(out.dtype))
 
-    def colsum(self, x, out, rows, C, ldx, n_groups, rpg, mod, accumulate=0):
+    def colsum(self, x, out, rows, C, ldx, n_groups, rpg, mod, accumulate=0, scratch=None):
         gi = self._gidx(rows, rpg, mod, x.device)
         o = V(out, n_groups, C, C)
         if not accumulate:

@@ -166,11 +166,18 @@ def check_gemm_tn(P, dt):
                 outs = dict(C=torch.zeros(3, N, Kd, device=P.dev))
             else:
                 outs = dict(C=torch.ones(N, Kd, device=P.dev))
-            outs["cs"] = torch.ones(N, device=P.dev)
+            # column sums of A: a running total when the reduction is not split, one stored row per slice when it is
+            outs["cs"] = torch.ones(N, device=P.dev) if mode != K.OUT_F32_SLAB else torch.full((3, N), 7.0, device=P.dev)
             o1, o2 = P.run("gemm_tn", lambda o: ((A, B, o["C"], R, N, Kd, N, Kd, Kd),
                                                  dict(out_mode=mode, split_k=sk, a_colsum=o["cs"])), outs)
             res.append((f"gemm_tn {R}x{N}x{Kd} mode={mode}", relerr(o1["C"], o2["C"]), tol_for(dt)))
             res.append((f"gemm_tn {R}x{N}x{Kd} mode={mode} colsum(A)", relerr(o1["cs"], o2["cs"]), 2e-3))
+            if mode == K.OUT_F32_SLAB:
+                slabs, cs = o2["C"], o2["cs"]
+                o1, o2 = P.run("gemm_finalize", lambda o: ((slabs, 3, N * Kd, o["W"], N, Kd, Kd),
+                                                           dict(accumulate_f32=2, dtype=dt, colsum_slabs=cs, colsum_out=o["b"])),
+                               dict(W=torch.ones(N, Kd, device=P.dev), b=torch.ones(N, device=P.dev)))
+                res.append((f"gemm_finalize {N}x{Kd} of 3 slabs + colsum rows", max(relerr(o1["W"], o2["W"]), relerr(o1["b"], o2["b"])), 1e-5))
     big = rnd((300, 3 * 128), dt, P.dev, g)
     X = rnd((300, 64), dt, P.dev, g)
     o1, o2 = P.run("gemm_tn", lambda o: ((big[:, 128:], X, o["C"], 300, 128, 64, 384, 64, 64), dict(out_mode=K.OUT_F32)),
@@ -286,17 +293,20 @@ def check_groupnorm(P, dt):
         dy = rnd((n_s * rows, C), dt, P.dev, g)
         add = rnd((n_s * rows, C), dt, P.dev, g)
         gamma, beta = 1 + 0.1 * rndf((C,), P.dev, g), 0.1 * rndf((C,), P.dev, g)
-        st = torch.zeros(K.GN_REPLICAS, n_s, 32, 2, device=P.dev)
+        cnt = rows * (C // 32)
+        st = torch.zeros(K.GN_REPLICAS, n_s, 32, K.GN_STAT_FLOATS, device=P.dev)
         o1, o2 = P.run("gn_stats", lambda o: ((x, o["st"], n_s, rows, C, 32), {}), dict(st=st))
-        res.append((f"gn_stats {n_s}x{rows}x{C}", relerr(o1["st"].sum(0), o2["st"].sum(0)), 1e-4))
+        res.append((f"gn_stats {n_s}x{rows}x{C}", relerr(emul.gn_decode(o1["st"], n_s, 32, cnt, 0).view(-1, 2),
+                                                          emul.gn_decode(o2["st"], n_s, 32, cnt, 0).view(-1, 2)), 1e-4))
         stats = o2["st"]
         for silu in (0, 1):
             o1, o2 = P.run("gn_apply", lambda o: ((x, stats, gamma, beta, o["y"], n_s, rows, C, 32, 1e-5, silu), {}),
                            dict(y=torch.zeros_like(x)))
             res.append((f"gn_apply {n_s}x{rows}x{C} silu={silu}", relerr(o1["y"], o2["y"]), tol_for(dt)))
             o1, o2 = P.run("gn_bwd_stats", lambda o: ((dy, x, stats, gamma, beta, o["b"], n_s, rows, C, 32, 1e-5, silu), {}),
-                           dict(b=torch.zeros(K.GN_REPLICAS, n_s, 32, 2, device=P.dev)))
-            res.append((f"gn_bwd_stats {n_s}x{rows}x{C} silu={silu}", relerr(o1["b"].sum(0), o2["b"].sum(0)), 2e-3))
+                           dict(b=torch.zeros(K.GN_REPLICAS, n_s, 32, K.GN_STAT_FLOATS, device=P.dev)))
+            res.append((f"gn_bwd_stats {n_s}x{rows}x{C} silu={silu}", relerr(emul.gn_decode(o1["b"], n_s, 32, cnt, 1).view(-1, 2),
+                                                                            emul.gn_decode(o2["b"], n_s, 32, cnt, 1).view(-1, 2)), 2e-3))
             bst = o2["b"]
             for ad in (None, add):
                 o1, o2 = P.run("gn_bwd_apply", lambda o: ((dy, x, stats, bst, gamma, beta, ad, o["dx"], n_s, rows, C, 32, 1e-5, silu), {}),
@@ -486,6 +496,15 @@ def check_elementwise(P, dt):
             o1, o2 = P.run("colsum", lambda o: ((x, o["s"], rows, C, C, 5, rpg, mod), dict(accumulate=acc)),
                            dict(s=torch.ones(5, C, device=P.dev)))
             res.append((f"colsum rpg={rpg} mod={mod} acc={acc}", relerr(o1["s"], o2["s"]), 1e-3))
+            scr = torch.full((K.colsum_slabs(rows, rpg, mod) * 5 * C,), float("nan"), device=P.dev)      # deterministic (slab) form
+            o1, o2 = P.run("colsum", lambda o: ((x, o["s"], rows, C, C, 5, rpg, mod), dict(accumulate=acc, scratch=scr)),
+                           dict(s=torch.ones(5, C, device=P.dev)))
+            res.append((f"colsum rpg={rpg} mod={mod} acc={acc} slabs", relerr(o1["s"], o2["s"]), 1e-3))
+    tall = rnd((3000, 320), dt, P.dev, g)                   # several row slabs per group, the last one ragged, one group shorter
+    for rpg, mod, ng in ((1400, 0, 3), (0, 2, 2)):
+        scr = torch.full((K.colsum_slabs(3000, rpg, mod) * ng * 320,), float("nan"), device=P.dev)
+        o1, o2 = P.run("colsum", lambda o: ((tall, o["s"], 3000, 320, 320, ng, rpg, mod), dict(scratch=scr)), dict(s=torch.ones(ng, 320, device=P.dev)))
+        res.append((f"colsum 3000 rows rpg={rpg} mod={mod} slabs", relerr(o1["s"], o2["s"]), 1e-3))
     big = rnd((700, 3 * 320), dt, P.dev, g)
     o1, o2 = P.run("colsum", lambda o: ((big[:, 320:], o["s"], 700, 320, 960, 1, 700, 0), {}), dict(s=torch.zeros(1, 320, device=P.dev)))
     res.append(("colsum strided 1 group", relerr(o1["s"], o2["s"]), 1e-3))

@@ -92,13 +92,13 @@ def test_groupnorm_fwd_bwd_2d_and_3d():
         if silu:
             y_ref = F.silu(y_ref)
         xf = x.detach().reshape(-1, C).contiguous()
-        st, y = torch.zeros(8, n_s, 32, 2), torch.zeros(n_s * rws, C)
+        st, y = torch.zeros(8, n_s, 32, 4), torch.zeros(n_s * rws, C)
         E.gn_stats(xf, st, n_s, rws, C, 32)
         E.gn_apply(xf, st, gamma, beta, y, n_s, rws, C, 32, 1e-5, silu)
         assert torch.allclose(y.view(n_s, rws, C), y_ref, atol=1e-4)
         dy = torch.randn(n_s, rws, C)
         (dx_ref,) = torch.autograd.grad(y_ref, x, dy)
-        bs, dx = torch.zeros(8, n_s, 32, 2), torch.zeros(n_s * rws, C)
+        bs, dx = torch.zeros(8, n_s, 32, 4), torch.zeros(n_s * rws, C)
         add = torch.randn(n_s * rws, C)
         E.gn_bwd_stats(dy.reshape(-1, C), xf, st, gamma, beta, bs, n_s, rws, C, 32, 1e-5, silu)
         E.gn_bwd_apply(dy.reshape(-1, C), xf, st, bs, gamma, beta, add, dx, n_s, rws, C, 32, 1e-5, silu)
