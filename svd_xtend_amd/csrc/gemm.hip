@@ -382,7 +382,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
     const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
     const int kt_begin = z * kt_per;
     const int kt_end = min(kt_total, kt_begin + kt_per);
-    if (kt_begin >= kt_end) return;
+    if (kt_begin >= kt_end) {               // a slice without rows (the host never asks for one): its column-sum row is all zeros
+        if (p.a_colsum && p.out_mode == SVDX_OUT_F32_SLAB && pid_n == 0 && tid < BM && m0 + tid < p.M) p.a_colsum[(size_t)z * p.M + m0 + tid] = 0.f;
+        return;
+    }
 
     // staging: tile = 64 rows x 16 chunks (16 B); thread handles 4 rows, one fixed physical chunk
     const int pc = tid & 15, ld_row = tid >> 4;          // ld_row 0..15; rows ld_row + 16*i

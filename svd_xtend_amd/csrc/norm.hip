@@ -48,76 +48,107 @@ __device__ __forceinline__ void group_mean_rstd(const float* stats, int n_s, int
     rstd = rsqrtf(var + eps);
 }
 
+// Per-block statistics: thread g < G adds the replicas of group g once and leaves (mean, rstd) [and the backward sums / cnt] in LDS.
+// (Every thread doing this for its own 2-3 groups was 48 tiny loads per thread against 5 rows of data: the prologue, not the
+// streaming, set the kernel time -- 19 us where the rows alone take 12.)
+template <bool BWD>
+__device__ __forceinline__ void gn_block_stats(const float* stats, const float* bstats, const GnGeom& q, int n, float eps, float* sm) {
+    const int g = threadIdx.x;
+    if (g < q.G) {
+        int fk0, fk1, bk0, bk1;
+        gn_fixed_scales((long)q.rows * q.cg, 0, fk0, fk1);
+        const float cnt = (float)q.rows * q.cg;
+        float mean, rstd;
+        group_mean_rstd(stats, q.n_s, n, q.G, g, cnt, eps, exp2f((float)-fk0), exp2f((float)-fk1), mean, rstd);
+        sm[g * 4] = mean; sm[g * 4 + 1] = rstd;
+        if (BWD) {
+            gn_fixed_scales((long)q.rows * q.cg, 1, bk0, bk1);
+            float s1, s2;
+            group_sums(bstats, q.n_s, n, q.G, g, exp2f((float)-bk0), exp2f((float)-bk1), s1, s2);
+            sm[g * 4 + 2] = s1 / cnt; sm[g * 4 + 3] = s2 / cnt;
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void gn_load8f(const float* p, float (&o)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+
 // MODE 0: stats of x.  MODE 1: backward stats (sum dz*gamma, sum dz*gamma*xhat).
 template <typename T, int MODE>
 __global__ void gn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ stats,
                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* out,
                                  GnGeom q, float eps, int silu) {
     __shared__ unsigned long long gacc[64];
+    __shared__ float sm[32 * 4];
     const int t = threadIdx.x;
     if (t < 64) gacc[t] = 0ull;
-    __syncthreads();
-    int fk0, fk1, sk0, sk1;
-    gn_fixed_scales((long)q.rows * q.cg, 0, fk0, fk1);               // scales of the forward statistics (read in MODE 1)
+    int sk0, sk1;
     gn_fixed_scales((long)q.rows * q.cg, MODE, sk0, sk1);            // scales of the sums this launch produces
-    const float fi0 = exp2f((float)-fk0), fi1 = exp2f((float)-fk1), m0 = exp2f((float)sk0), m1 = exp2f((float)sk1);
+    const float m0 = exp2f((float)sk0), m1 = exp2f((float)sk1);
     const int n = blockIdx.x, slab = blockIdx.y;
     const int j = t % q.cc, ry = t / q.cc;
+    const bool worker = ry < q.rpi;
     const int r0 = slab * q.slab, r1 = min(q.rows, r0 + q.slab);
+    // U rows per batch, the next batch already travelling while this one is accumulated
+    constexpr int U = MODE == 0 ? 4 : 2;
+    const size_t base = (size_t)n * q.rows * q.C + j * 8;
+    Vec8<T> xb[U], db[U], xn[U], dn[U];
+    auto fetch = [&](int r, Vec8<T> (&xo)[U], Vec8<T> (&dd)[U]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = min(r + u * q.rpi, q.rows - 1);          // rows past the slab are loaded (in range) and ignored
+            xo[u] = *reinterpret_cast<const Vec8<T>*>(x + base + (size_t)rr * q.C);
+            if (MODE == 1) dd[u] = *reinterpret_cast<const Vec8<T>*>(dy + base + (size_t)rr * q.C);
+        }
+    };
+    int r = r0 + ry;
+    if (worker && r < r1) fetch(r, xb, db);                         // the first rows travel while the statistics are put together
     float a0[8], a1[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
     float sc[8], sh[8], gm[8], mu[8], rs[8];
     if (MODE == 1) {
-        const float cnt = (float)q.rows * q.cg;
-        const int gA = (j * 8) / q.cg, gB = min((j * 8 + 7) / q.cg, q.G - 1);   // a chunk of 8 channels touches <= 2 groups when cg >= 8
-        float meanA, rstdA, meanB, rstdB;
-        group_mean_rstd(stats, q.n_s, n, q.G, gA, cnt, eps, fi0, fi1, meanA, rstdA);
-        group_mean_rstd(stats, q.n_s, n, q.G, gB, cnt, eps, fi0, fi1, meanB, rstdB);
+        gn_block_stats<false>(stats, nullptr, q, n, eps, sm);
+        float bt[8];
+        gn_load8f(gamma + j * 8, gm);
+        gn_load8f(beta + j * 8, bt);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int c = j * 8 + e, g = c / q.cg;
-            float mean = g == gA ? meanA : meanB, rstd = g == gA ? rstdA : rstdB;
-            if (g != gA && g != gB) group_mean_rstd(stats, q.n_s, n, q.G, g, cnt, eps, fi0, fi1, mean, rstd);
-            mu[e] = mean; rs[e] = rstd; gm[e] = gamma[c];
-            sc[e] = rstd * gm[e];
-            sh[e] = beta[c] - mean * sc[e];
+            const int g = (j * 8 + e) / q.cg;
+            mu[e] = sm[g * 4]; rs[e] = sm[g * 4 + 1];
+            sc[e] = rs[e] * gm[e];
+            sh[e] = bt[e] - mu[e] * sc[e];
         }
+    } else {
+        __syncthreads();                                             // gacc is zero
     }
-    if (ry < q.rpi) {
-        auto accum = [&](const float (&xv)[8], const float (&dv)[8]) __attribute__((always_inline)) {
-            if (MODE == 0) {
+    if (worker) {
+        for (; r < r1; r += U * q.rpi) {
+            const int rn = r + U * q.rpi;
+            if (rn < r1) fetch(rn, xn, dn);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { a0[e] += xv[e]; a1[e] += xv[e] * xv[e]; }
-            } else {
+            for (int u = 0; u < U; ++u) {
+                if (r + u * q.rpi < r1) {
+                    if (MODE == 0) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float dz = dv[e];
-                    if (silu) dz *= silu_gradf_(xv[e] * sc[e] + sh[e]);
-                    const float dzg = dz * gm[e];
-                    a0[e] += dzg;
-                    a1[e] += dzg * (xv[e] - mu[e]) * rs[e];
+                        for (int e = 0; e < 8; ++e) { const float xv = to_f<T>(xb[u].v[e]); a0[e] += xv; a1[e] += xv * xv; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float xv = to_f<T>(xb[u].v[e]);
+                            float dz = to_f<T>(db[u].v[e]);
+                            if (silu) dz *= silu_gradf_(xv * sc[e] + sh[e]);
+                            const float dzg = dz * gm[e];
+                            a0[e] += dzg;
+                            a1[e] += dzg * (xv - mu[e]) * rs[e];
+                        }
+                    }
                 }
             }
-        };
-        const size_t base = (size_t)n * q.rows * q.C + j * 8;
-        int r = r0 + ry;
-        for (; r + q.rpi < r1; r += 2 * q.rpi) {          // two independent rows in flight
-            float x0[8], x1[8], d0[8], d1[8];
-            load8<T>(x + base + (size_t)r * q.C, x0);
-            load8<T>(x + base + (size_t)(r + q.rpi) * q.C, x1);
-            if (MODE == 1) {
-                load8<T>(dy + base + (size_t)r * q.C, d0);
-                load8<T>(dy + base + (size_t)(r + q.rpi) * q.C, d1);
-            }
-            accum(x0, d0);
-            accum(x1, d1);
-        }
-        if (r < r1) {
-            float x0[8], d0[8];
-            load8<T>(x + base + (size_t)r * q.C, x0);
-            if (MODE == 1) load8<T>(dy + base + (size_t)r * q.C, d0);
-            accum(x0, d0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { xb[u] = xn[u]; if (MODE == 1) db[u] = dn[u]; }
         }
         // merge the 8 channels into their groups (runs of equal group id), then one LDS atomic per run
         int cur = (j * 8) / q.cg;
@@ -146,79 +177,92 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ d
                                 const float* __restrict__ bstats, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const T* __restrict__ add, T* __restrict__ out,
                                 GnGeom q, float eps, int silu) {
+    __shared__ float sm[32 * 4];
     const int t = threadIdx.x;
     const int n = blockIdx.x, slab = blockIdx.y;
     const int j = t % q.cc, ry = t / q.cc;
-    if (ry >= q.rpi) return;
+    const bool worker = ry < q.rpi;
     const int r0 = slab * q.slab, r1 = min(q.rows, r0 + q.slab);
-    const float cnt = (float)q.rows * q.cg;
-    float sc[8], sh[8], gm[8], mu[8], rs[8], b1[8], b2[8];
-    const int gA = (j * 8) / q.cg, gB = min((j * 8 + 7) / q.cg, q.G - 1);
-    float meanA, rstdA, meanB, rstdB, b1A = 0.f, b2A = 0.f, b1B = 0.f, b2B = 0.f;
-    int fk0, fk1, bk0, bk1;
-    gn_fixed_scales((long)q.rows * q.cg, 0, fk0, fk1);
-    gn_fixed_scales((long)q.rows * q.cg, 1, bk0, bk1);
-    const float fi0 = exp2f((float)-fk0), fi1 = exp2f((float)-fk1), bi0 = exp2f((float)-bk0), bi1 = exp2f((float)-bk1);
-    group_mean_rstd(stats, q.n_s, n, q.G, gA, cnt, eps, fi0, fi1, meanA, rstdA);
-    group_mean_rstd(stats, q.n_s, n, q.G, gB, cnt, eps, fi0, fi1, meanB, rstdB);
-    if (MODE == 1) {
-        group_sums(bstats, q.n_s, n, q.G, gA, bi0, bi1, b1A, b2A);
-        group_sums(bstats, q.n_s, n, q.G, gB, bi0, bi1, b1B, b2B);
-    }
+    // batches of U rows, next batch prefetched (see gn_reduce_kernel)
+    constexpr int U = MODE == 0 ? 4 : 2;
+    const size_t base = (size_t)n * q.rows * q.C + j * 8;
+    Vec8<T> xb[U], db[U], ab[U], xn[U], dn[U], an[U];
+    auto fetch = [&](int r, Vec8<T> (&xo)[U], Vec8<T> (&dd)[U], Vec8<T> (&aa)[U]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t off = base + (size_t)min(r + u * q.rpi, q.rows - 1) * q.C;
+            xo[u] = *reinterpret_cast<const Vec8<T>*>(x + off);
+            if (MODE == 1) {
+                dd[u] = *reinterpret_cast<const Vec8<T>*>(dy + off);
+                if (add) aa[u] = *reinterpret_cast<const Vec8<T>*>(add + off);
+            }
+        }
+    };
+    int r = r0 + ry;
+    if (worker && r < r1) fetch(r, xb, db, ab);                     // the first rows travel while the statistics are put together
+    gn_block_stats<MODE == 1>(stats, bstats, q, n, eps, sm);
+    if (!worker) return;
+    float sc[8], sh[8], gm[8], mu[8], rs[8], b1[8], b2[8], bt[8];
+    gn_load8f(gamma + j * 8, gm);
+    gn_load8f(beta + j * 8, bt);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int c = j * 8 + e, g = c / q.cg;
-        float mean = g == gA ? meanA : meanB, rstd = g == gA ? rstdA : rstdB;
-        float s1 = g == gA ? b1A : b1B, s2 = g == gA ? b2A : b2B;
-        if (g != gA && g != gB) {                    // cg < 4: more than two groups per chunk (not an SVD shape; kept correct)
-            group_mean_rstd(stats, q.n_s, n, q.G, g, cnt, eps, fi0, fi1, mean, rstd);
-            if (MODE == 1) group_sums(bstats, q.n_s, n, q.G, g, bi0, bi1, s1, s2);
-        }
-        mu[e] = mean; rs[e] = rstd; gm[e] = gamma[c];
-        sc[e] = rstd * gm[e];
-        sh[e] = beta[c] - mean * sc[e];
-        if (MODE == 1) { b1[e] = s1 / cnt; b2[e] = s2 / cnt; }
+        const int g = (j * 8 + e) / q.cg;
+        mu[e] = sm[g * 4]; rs[e] = sm[g * 4 + 1];
+        sc[e] = rs[e] * gm[e];
+        sh[e] = bt[e] - mu[e] * sc[e];
+        if (MODE == 1) { b1[e] = sm[g * 4 + 2]; b2[e] = sm[g * 4 + 3]; }
     }
-#pragma unroll 2
-    for (int r = r0 + ry; r < r1; r += q.rpi) {
-        const size_t off = ((size_t)n * q.rows + r) * q.C + j * 8;
-        float xv[8], o[8];
-        load8<T>(x + off, xv);
+    for (; r < r1; r += U * q.rpi) {
+        const int rn = r + U * q.rpi;
+        // forward: the next batch travels while this one is normalised; backward (three operands per row): one batch at a time --
+        // a second register set halved the occupancy and cost more than the prefetch gave (39 vs 31 us at the 64x40 level)
+        if (MODE == 0 && rn < r1) fetch(rn, xn, dn, an);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * q.rpi;
+            if (rr < r1) {
+                float o[8];
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float z = to_f<T>(xb[u].v[e]) * sc[e] + sh[e];
+                        o[e] = silu ? siluf_(z) : z;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xv = to_f<T>(xb[u].v[e]);
+                        float dz = to_f<T>(db[u].v[e]);
+                        if (silu) dz *= silu_gradf_(xv * sc[e] + sh[e]);
+                        const float xhat = (xv - mu[e]) * rs[e];
+                        o[e] = rs[e] * (dz * gm[e] - (b1[e] + xhat * b2[e]));
+                        if (add) o[e] += to_f<T>(ab[u].v[e]);
+                    }
+                }
+                store8<T>(out + base + (size_t)rr * q.C, o);
+            }
+        }
         if (MODE == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float z = xv[e] * sc[e] + sh[e];
-                o[e] = silu ? siluf_(z) : z;
-            }
-        } else {
-            float dv[8];
-            load8<T>(dy + off, dv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float dz = dv[e];
-                if (silu) dz *= silu_gradf_(xv[e] * sc[e] + sh[e]);
-                const float xhat = (xv[e] - mu[e]) * rs[e];
-                o[e] = rs[e] * (dz * gm[e] - (b1[e] + xhat * b2[e]));
-            }
-            if (add) {
-                float av[8];
-                load8<T>(add + off, av);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] += av[e];
-            }
+            for (int u = 0; u < U; ++u) xb[u] = xn[u];
+        } else if (rn < r1) {
+            fetch(rn, xb, db, ab);
         }
-        store8<T>(out + off, o);
     }
 }
 
-int gn_geom(GnGeom& q, int n_s, int rows, int C, int G, int& threads) {
+int gn_geom(GnGeom& q, int n_s, int rows, int C, int G, int& threads, bool reduce = false) {
     SVDX_CHECK_ARG(n_s > 0 && rows > 0 && C > 0 && G > 0 && G <= 32, "groupnorm: bad sizes");
     SVDX_CHECK_ARG(C % G == 0 && C % 8 == 0 && C / 8 <= 1024, "groupnorm: C=%d must be a multiple of 8 and of G", C);
     q.n_s = n_s; q.rows = rows; q.C = C; q.G = G; q.cg = C / G; q.cc = C / 8;
     q.rpi = q.cc >= 256 ? 1 : 256 / q.cc;
     threads = q.cc * q.rpi;
-    int slab = 32;
-    while (slab > 2 * q.rpi && slab > 2 && (long)n_s * ((rows + slab - 1) / slab) < 1024) slab >>= 1;
+    // a statistics launch ends with 2G 64-bit atomics per block (the chip retires ~15 per ns): 64-row slabs while that still leaves
+    // >= 512 blocks; the apply kernels want >= 1024 blocks of 32 rows
+    int slab = reduce ? 64 : 32;
+    const long want = reduce ? 512 : 1024;
+    while (slab > 2 * q.rpi && slab > 2 && (long)n_s * ((rows + slab - 1) / slab) < want) slab >>= 1;
     q.slab = slab;
     return 0;
 }
@@ -226,44 +270,61 @@ int gn_geom(GnGeom& q, int n_s, int rows, int C, int G, int& threads) {
 // ---- LayerNorm: one wave per row, whole row in registers (C <= 2048) ------------------------------------------
 constexpr int LN_MAXCH_LIMIT = 4;
 
-template <typename T, int LN_MAXCH>
+// R rows per wave in flight: a C = 320 row is ONE 640-byte load, and a wave with a single load outstanding cannot keep HBM busy
+// (one row at a time ran at 3.1 TB/s where a plain copy reaches 5).
+template <typename T, int LN_MAXCH, int R>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ stats, int rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int cc = C / 8;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
-    for (int row = wid; row < rows; row += nw) {
-        float v[LN_MAXCH][8];
-        float s = 0.f;
+    const float invC = 1.f / (float)C;
+    for (int row0 = wid * R; row0 < rows; row0 += nw * R) {
+        Vec8<T> raw[R][LN_MAXCH];
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; ++i) {
-            const int j = lane + i * 64;
-            if (j < cc) {
-                load8<T>(x + (size_t)row * C + j * 8, v[i]);
+        for (int k = 0; k < R; ++k) {
+            const int row = min(row0 + k, rows - 1);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += v[i][e];
+            for (int i = 0; i < LN_MAXCH; ++i) {
+                const int j = lane + i * 64;
+                if (j < cc) raw[k][i] = *reinterpret_cast<const Vec8<T>*>(x + (size_t)row * C + j * 8);
             }
         }
-        const float mean = wave_sum(s) / C;
-        float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; ++i) {
-            if (lane + i * 64 < cc) {
+        for (int k = 0; k < R; ++k) {
+            const int row = row0 + k;
+            float v[LN_MAXCH][8];
+            float s = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+            for (int i = 0; i < LN_MAXCH; ++i) {
+                if (lane + i * 64 < cc) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v[i][e] = to_f<T>(raw[k][i].v[e]); s += v[i][e]; }
+                }
             }
-        }
-        const float rstd = rsqrtf(wave_sum(ss) / C + eps);
-        if (lane == 0) { stats[(size_t)row * 2] = mean; stats[(size_t)row * 2 + 1] = rstd; }
+            const float mean = wave_sum(s) * invC;
+            float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXCH; ++i) {
-            const int j = lane + i * 64;
-            if (j < cc) {
-                float o[8];
+            for (int i = 0; i < LN_MAXCH; ++i) {
+                if (lane + i * 64 < cc) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * gamma[j * 8 + e] + beta[j * 8 + e];
-                store8<T>(y + (size_t)row * C + j * 8, o);
+                    for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+                }
+            }
+            const float rstd = rsqrtf(wave_sum(ss) * invC + eps);
+            if (row < rows) {
+                if (lane == 0) { stats[(size_t)row * 2] = mean; stats[(size_t)row * 2 + 1] = rstd; }
+#pragma unroll
+                for (int i = 0; i < LN_MAXCH; ++i) {
+                    const int j = lane + i * 64;
+                    if (j < cc) {
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * gamma[j * 8 + e] + beta[j * 8 + e];
+                        store8<T>(y + (size_t)row * C + j * 8, o);
+                    }
+                }
             }
         }
     }
@@ -385,6 +446,153 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
+// ---- LayerNorm, 16 lanes per row (C <= 640): a wave normalises FOUR rows per step, the row sums are DPP reductions inside the
+// 16-lane group (no LDS crossbar), every lane keeps the affine parameters of its NCH chunks.  One wave per row spent a full wave of
+// instruction issue on 640 bytes: the kernels were issue / latency bound at 2.9-3.1 TB/s.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd16_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       T* __restrict__ y, float* __restrict__ stats, int rows, int C, float eps) {
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int cc = C / 8;
+    float gm[NCH][8], bt[NCH][8];
+    bool cv[NCH];
+    int cl[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = l16 + 16 * j;
+        cv[j] = c < cc;
+        cl[j] = min(c, cc - 1);
+        gn_load8f(gamma + cl[j] * 8, gm[j]);
+        gn_load8f(beta + cl[j] * 8, bt[j]);
+    }
+    const float invC = 1.f / (float)C;
+    constexpr int R = 2;                                  // rows in flight per 16-lane group
+    for (int row0 = (blockIdx.x * 16 + grp) * R; row0 < rows; row0 += gridDim.x * 16 * R) {
+        Vec8<T> raw[R][NCH];
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) raw[k][j] = *reinterpret_cast<const Vec8<T>*>(x + (size_t)min(row0 + k, rows - 1) * C + cl[j] * 8);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int row = row0 + k;
+            float v[NCH][8];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[j][e] = cv[j] ? to_f<T>(raw[k][j].v[e]) : 0.f; s += v[j][e]; }
+            const float mean = row16_sum(s) * invC;
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = cv[j] ? v[j][e] - mean : 0.f; ss += d * d; }
+            const float rstd = rsqrtf(row16_sum(ss) * invC + eps);
+            if (row < rows) {
+                if (l16 == 0) *reinterpret_cast<float2*>(stats + (size_t)row * 2) = float2{mean, rstd};
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    if (cv[j]) {
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (v[j][e] - mean) * rstd * gm[j][e] + bt[j][e];
+                        store8<T>(y + (size_t)row * C + cl[j] * 8, o);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd16_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const T* __restrict__ add, const T* __restrict__ add2,
+                                                       float add2_scale, T* __restrict__ dx, float* dgamma, float* dbeta, float* partial, int rows,
+                                                       int C) {
+    extern __shared__ float red[];   // [16 row groups][C] when affine grads are requested
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int cc = C / 8;
+    const bool affine = dgamma != nullptr;
+    float gm[NCH][8], pg[NCH][8], pb[NCH][8];
+    bool cv[NCH];
+    int cl[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = l16 + 16 * j;
+        cv[j] = c < cc;
+        cl[j] = min(c, cc - 1);
+        gn_load8f(gamma + cl[j] * 8, gm[j]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pg[j][e] = pb[j][e] = 0.f;
+    }
+    const float invC = 1.f / (float)C;
+    for (int row = blockIdx.x * 16 + grp; row < rows; row += gridDim.x * 16) {
+        Vec8<T> xr[NCH], dr[NCH], ar[NCH], a2r[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const size_t off = (size_t)row * C + cl[j] * 8;
+            xr[j] = *reinterpret_cast<const Vec8<T>*>(x + off);
+            dr[j] = *reinterpret_cast<const Vec8<T>*>(dy + off);
+            if (add) ar[j] = *reinterpret_cast<const Vec8<T>*>(add + off);
+            if (add2) a2r[j] = *reinterpret_cast<const Vec8<T>*>(add2 + off);
+        }
+        const float2 mr = *reinterpret_cast<const float2*>(stats + (size_t)row * 2);
+        float xh[NCH][8], dg[NCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = cv[j] ? to_f<T>(dr[j].v[e]) : 0.f;
+                xh[j][e] = cv[j] ? (to_f<T>(xr[j].v[e]) - mr.x) * mr.y : 0.f;
+                dg[j][e] = d * gm[j][e];
+                s1 += dg[j][e];
+                s2 += dg[j][e] * xh[j][e];
+                pg[j][e] += d * xh[j][e];
+                pb[j][e] += d;
+            }
+        const float m1 = row16_sum(s1) * invC, m2 = row16_sum(s2) * invC;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (cv[j]) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = mr.y * (dg[j][e] - m1 - xh[j][e] * m2);
+                    if (add) o[e] += to_f<T>(ar[j].v[e]);
+                    if (add2) o[e] += add2_scale * to_f<T>(a2r[j].v[e]);
+                }
+                store8<T>(dx + (size_t)row * C + cl[j] * 8, o);
+            }
+        }
+    }
+    if (affine) {
+        // column partials: every 16-lane group parks its own in LDS, then each thread adds the 16 groups of its columns in order;
+        // gamma and beta gradients take turns in the same [16][C] slab (40 KiB at C = 640: three workgroups per CU)
+        float* mine = red + (size_t)grp * C;
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                if (cv[j]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) mine[cl[j] * 8 + e] = which == 0 ? pg[j][e] : pb[j][e];
+                }
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < C; i += 256) {
+                float t = 0.f;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) t += red[(size_t)g * C + i];
+                if (partial) partial[(size_t)blockIdx.x * 2 * C + which * C + i] = t;
+                else atomicAdd((which == 0 ? dgamma : dbeta) + i, t);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // dgamma[c] += sum_b partial[b][c], dbeta[c] += sum_b partial[b][C + c]: 64 columns x 16 row groups per block.
 __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partial, int nblk, int C,
                                                                float* dgamma, float* dbeta) {
@@ -410,7 +618,7 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
 
 extern "C" int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int C, int G, int prezeroed, int dtype, void* stream) {
     GnGeom q; int threads;
-    if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
+    if (int rc = gn_geom(q, n_s, rows, C, G, threads, true)) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (!prezeroed) (void)hipMemsetAsync(stats, 0, sizeof(long long) * 2 * n_s * G * SVDX_GN_REPLICAS, st);
     dim3 grid(n_s, cdiv(rows, q.slab));
@@ -437,7 +645,7 @@ extern "C" int svdx_gn_bwd_stats(const void* dy, const void* x, const float* sta
                                  const float* beta, float* bstats, int n_s, int rows, int C, int G, float eps,
                                  int silu, int prezeroed, int dtype, void* stream) {
     GnGeom q; int threads;
-    if (int rc = gn_geom(q, n_s, rows, C, G, threads)) return rc;
+    if (int rc = gn_geom(q, n_s, rows, C, G, threads, true)) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (!prezeroed) (void)hipMemsetAsync(bstats, 0, sizeof(long long) * 2 * n_s * G * SVDX_GN_REPLICAS, st);
     dim3 grid(n_s, cdiv(rows, q.slab));
@@ -463,11 +671,22 @@ extern "C" int svdx_gn_bwd_apply(const void* dy, const void* x, const float* sta
 extern "C" int svdx_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows,
                            int C, float eps, int dtype, void* stream) {
     SVDX_CHECK_ARG(rows > 0 && C % 8 == 0 && C / 8 <= 64 * LN_MAXCH_LIMIT, "svdx_ln_fwd: C=%d unsupported", C);
-    const int blocks = min(cdiv(rows, 4), 2048);
+    const int nch16 = (C / 8 + 15) / 16;
+    if (nch16 <= 5) {                       // C <= 640: 16 lanes per row
+        const int blocks16 = min(cdiv(rows, 32), 2048);
+#define LN_FWD16(NCH) hipLaunchKernelGGL((ln_fwd16_kernel<T, NCH>), dim3(blocks16), dim3(256), 0, (hipStream_t)stream, (const T*)x, gamma, beta, \
+                                         (T*)y, stats, rows, C, eps)
+        DISPATCH_DTYPE(dtype, { if (nch16 == 1) LN_FWD16(1); else if (nch16 == 2) LN_FWD16(2); else if (nch16 == 3) LN_FWD16(3); else LN_FWD16(5); });
+#undef LN_FWD16
+        SVDX_LAUNCH_CHECK("svdx_ln_fwd");
+        return 0;
+    }
     const int nch = (C / 8 + 63) / 64;
-#define LN_FWD(NCH) hipLaunchKernelGGL((ln_fwd_kernel<T, NCH>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, gamma, \
-                                       beta, (T*)y, stats, rows, C, eps)
-    DISPATCH_DTYPE(dtype, { if (nch == 1) LN_FWD(1); else if (nch == 2) LN_FWD(2); else if (nch == 3) LN_FWD(3); else LN_FWD(4); });
+    const int R = nch == 1 ? 4 : (nch == 2 ? 2 : 1);
+    const int blocks = min(cdiv(rows, 4 * R), 4096);
+#define LN_FWD(NCH, RR) hipLaunchKernelGGL((ln_fwd_kernel<T, NCH, RR>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, gamma, \
+                                           beta, (T*)y, stats, rows, C, eps)
+    DISPATCH_DTYPE(dtype, { if (nch == 1) LN_FWD(1, 4); else if (nch == 2) LN_FWD(2, 2); else if (nch == 3) LN_FWD(3, 1); else LN_FWD(4, 1); });
 #undef LN_FWD
     SVDX_LAUNCH_CHECK("svdx_ln_fwd");
     return 0;
@@ -483,9 +702,35 @@ extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, co
     // affine grads: with scratch, up to SVDX_LN_PARTIAL_ROWS blocks each leave one [2C] partial row (>= 4 iterations per wave);
     // without, every block ends with 2*C float atomics, so keep one block per CU there
     int blocks = min(cdiv(rows, 4 * R), 2048);
-    if (dgamma) blocks = scratch ? max(1, min(cdiv(rows, 16 * R), SVDX_LN_PARTIAL_ROWS)) : min(blocks, 256);
+    if (dgamma) blocks = scratch ? max(1, min(cdiv(rows, 4 * R), SVDX_LN_PARTIAL_ROWS)) : min(blocks, 256);
     const size_t sh = dgamma ? sizeof(float) * 2 * C : 0;
     hipStream_t st = (hipStream_t)stream;
+    const int nch16 = (C / 8 + 15) / 16;
+    if (nch16 <= 5) {                       // C <= 640: 16 lanes per row, 16 rows per block per step
+        blocks = min(cdiv(rows, 16), 2048);
+        if (dgamma) blocks = scratch ? max(1, min(cdiv(rows, 32), SVDX_LN_PARTIAL_ROWS)) : min(blocks, 256);
+        const size_t sh16 = dgamma ? sizeof(float) * 16 * C : 0;
+        DISPATCH_DTYPE(dtype, {
+            static bool attr_set = false;                // once per dtype: the [16][2C] float slab is 80 KiB at C = 640
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd16_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd16_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd16_kernel<T, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd16_kernel<T, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                attr_set = true;
+            }
+        });
+#define LN_BWD16(NCH) hipLaunchKernelGGL((ln_bwd16_kernel<T, NCH>), dim3(blocks), dim3(256), sh16, st, (const T*)dy, (const T*)x, stats, gamma, \
+                                         (const T*)add, (const T*)add2, add2_scale, (T*)dx, dgamma, dbeta, scratch, rows, C)
+        DISPATCH_DTYPE(dtype, { if (nch16 == 1) LN_BWD16(1); else if (nch16 == 2) LN_BWD16(2); else if (nch16 == 3) LN_BWD16(3); else LN_BWD16(5); });
+#undef LN_BWD16
+        SVDX_LAUNCH_CHECK("svdx_ln_bwd");
+        if (dgamma && scratch) {
+            hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, st, scratch, blocks, C, dgamma, dbeta);
+            SVDX_LAUNCH_CHECK("svdx_ln_bwd(param reduce)");
+        }
+        return 0;
+    }
 #define LN_BWD(NCH, RR) hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, RR>), dim3(blocks), dim3(256), sh, st, (const T*)dy, \
                                            (const T*)x, stats, gamma, (const T*)add, (const T*)add2, add2_scale, (T*)dx, dgamma, dbeta, scratch, rows, C)
     DISPATCH_DTYPE(dtype, { if (nch == 1) LN_BWD(1, 4); else if (nch == 2) LN_BWD(2, 2); else if (nch == 3) LN_BWD(3, 1); else LN_BWD(4, 1); });

@@ -65,16 +65,6 @@ __device__ __forceinline__ typename TT<T>::v8 tsa_frag_tr(const char* lds, int d
     return __builtin_bit_cast(typename TT<T>::v8, r);
 }
 
-// sum over the 16 lanes of a DPP row, result in every lane: row_mirror, row_half_mirror, then the two quad permutes -- four VALU
-// instructions instead of four ds_bpermute round trips (the LayerNorm phase was a chain of those)
-__device__ __forceinline__ float tsa_row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // lane i + lane 15 - i
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // + mirror inside each half
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-    return v;
-}
-
 // acc[j][i] = IMG[rows i*16.., K] * Bmat[N, K]^T for the wave's 48 columns of every 192-column pass; `epi(pass, acc)` runs when a
 // pass has seen all of K (the loop body is gemm_v4's: fragments of one 32-deep half step in registers, then its 27 MFMAs).  The first
 // stage of the next pass is already travelling when the epilogue runs.  Ends with every wave past a barrier and its stores complete.
@@ -235,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void tsa_fwd_kernel(TsaParams p) {
                 for (int j = 0; j < NCH; ++j)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) s += v[g][j][e];
-                mean[g] = tsa_row16_sum(s) * invC;
+                mean[g] = row16_sum(s) * invC;
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -244,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void tsa_fwd_kernel(TsaParams p) {
                 for (int j = 0; j < NCH; ++j)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { const float d = cv[j] ? v[g][j][e] - mean[g] : 0.f; ss += d * d; }
-                rstd[g] = rsqrtf(tsa_row16_sum(ss) * invC + p.eps);
+                rstd[g] = rsqrtf(row16_sum(ss) * invC + p.eps);
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {

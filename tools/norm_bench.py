@@ -1,0 +1,93 @@
+"""HBM-bound kernel families at the level shapes of the benched configuration: GroupNorm (2-D per frame / 3-D per clip), LayerNorm,
+elementwise.  Prints achieved GB/s against the bytes each launch has to move (algorithmic: every operand once).
+    python tools/norm_bench.py [--iters 20]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from svd_xtend_amd import kernels as K  # noqa: E402
+
+
+def timeit(fn, iters):
+    """us per call with the calls replayed from one hipGraph (no host launch cost; includes the ~1.5 us kernel boundary)."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+    torch.cuda.current_stream().wait_stream(s)
+    return e0.elapsed_time(e1) / (2 * iters) * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    dt, dev = torch.float16, torch.device("cuda")
+    k = K.backend()
+    out = []
+    T = 14
+    for name, HW, C in (("L0", 2560, 320), ("L0cat", 2560, 640), ("L1", 640, 640), ("L2", 160, 1280), ("L3", 40, 1280)):
+        M = T * HW
+        # rotate over several buffer sets so the operands do not sit in the 256 MB Infinity Cache from the previous launch
+        nset = max(2, int(600e6 // (M * C * 2 * 4)))
+        xs = [torch.randn(M, C, device=dev).to(dt) for _ in range(nset)]
+        dys = [torch.randn(M, C, device=dev).to(dt) for _ in range(nset)]
+        ys = [torch.empty(M, C, dtype=dt, device=dev) for _ in range(nset)]
+        gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        B1 = M * C * 2
+        it = [0]
+
+        def nxt():
+            it[0] = (it[0] + 1) % nset
+            return it[0]
+        for kind, n_s, rows in (("2d", T, HW), ("3d", 1, M)):
+            st = torch.zeros(K.GN_REPLICAS * n_s * 32 * K.GN_STAT_FLOATS, device=dev)
+            bst = torch.zeros_like(st)
+            k.gn_stats(xs[0], st, n_s, rows, C, 32)
+            k.gn_bwd_stats(dys[0], xs[0], st, gamma, beta, bst, n_s, rows, C, 32, 1e-5, 1)
+            cases = {
+                "gn_stats": (lambda: k.gn_stats(xs[nxt()], st, n_s, rows, C, 32, prezeroed=1), 1),
+                "gn_apply": (lambda: (lambda i: k.gn_apply(xs[i], st, gamma, beta, ys[i], n_s, rows, C, 32, 1e-5, 1))(nxt()), 2),
+                "gn_bwd_stats": (lambda: (lambda i: k.gn_bwd_stats(dys[i], xs[i], st, gamma, beta, bst, n_s, rows, C, 32, 1e-5, 1, prezeroed=1))(nxt()), 2),
+                "gn_bwd_apply": (lambda: (lambda i: k.gn_bwd_apply(dys[i], xs[i], st, bst, gamma, beta, None, ys[i], n_s, rows, C, 32, 1e-5, 1))(nxt()), 3),
+            }
+            for nm, (fn, units) in cases.items():
+                us = timeit(fn, args.iters)
+                out.append(dict(level=name, kernel=f"{nm}_{kind}", us=round(us, 2), gbps=round(units * B1 / us / 1e3, 0)))
+        lst = torch.empty(M, 2, device=dev)
+        k.ln_fwd(xs[0], gamma, beta, ys[0], lst, M, C, 1e-5)
+        scr = torch.empty(K.LN_PARTIAL_ROWS * 2 * C, device=dev)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        cases = {
+            "ln_fwd": (lambda: (lambda i: k.ln_fwd(xs[i], gamma, beta, ys[i], lst, M, C, 1e-5))(nxt()), 2),
+            "ln_bwd": (lambda: (lambda i: k.ln_bwd(dys[i], xs[i], lst, gamma, None, ys[i], None, None, M, C))(nxt()), 3),
+            "ln_bwd_affine_add": (lambda: (lambda i: k.ln_bwd(dys[i], xs[i], lst, gamma, dys[(i + 1) % nset], ys[i], dg, db, M, C, scratch=scr))(nxt()), 4),
+            "add": (lambda: (lambda i: k.add(xs[i], dys[i], ys[i], M * C))(nxt()), 3),
+        }
+        for nm, (fn, units) in cases.items():
+            us = timeit(fn, args.iters)
+            out.append(dict(level=name, kernel=nm, us=round(us, 2), gbps=round(units * B1 / us / 1e3, 0)))
+    for r in out:
+        print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()
