@@ -246,9 +246,11 @@ int svdx_zero_spans(float* base, const int* spans, int n_spans, void* stream);
 
 /* ---- EDM loss (train_svd.py:1025-1036) fused with its gradient.  pred rows [B*T*HW, ld]; noisy/target
  *      float NCHW-per-frame [B,T,4,H,W]; sigma[B].  loss (float, accumulated; zero it first) and
- *      dpred rows = loss_scale * dLoss/dpred, loss_scale read from opt_state[1]. ----------------------- */
+ *      dpred rows = loss_scale * dLoss/dpred, loss_scale read from opt_state[1].  scratch: SVDX_EDM_LOSS_SCRATCH floats
+ *      (per-workgroup partial sums, added in a fixed order by a second launch: the loss is run-to-run identical). --- */
+#define SVDX_EDM_LOSS_SCRATCH 1024
 int svdx_edm_loss(const void* pred, int ld, const float* noisy, const float* target, const float* sigma,
-                  float* loss, void* dpred, int B, int T, int C, int HW, const float* opt_state,
+                  float* loss, void* dpred, int B, int T, int C, int HW, const float* opt_state, float* scratch,
                   int dtype, void* stream);
 
 /* ---- optimizer: AdamW (train_svd.py:767-773) + GradScaler semantics (accelerate fp16) + the learning-rate schedule

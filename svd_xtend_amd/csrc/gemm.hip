@@ -958,8 +958,8 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const float* __restr
                                                             const float* __restrict__ bias, const float* __restrict__ rowvec,
                                                             int rv_ld, int rv_rpg, int rv_mod, const T* __restrict__ res, int ldres,
                                                             const float* __restrict__ cs_slabs, float* cs_out, int cs_n) {
-    if (cs_slabs && blockIdx.x == 0) {         // bias gradient: the row slices' column sums, added in slice order
-        for (int n = threadIdx.x; n < cs_n; n += blockDim.x) {
+    if (cs_slabs) {                            // bias gradient: the row slices' column sums, added in slice order (spread over the grid)
+        for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < cs_n; n += gridDim.x * blockDim.x) {
             float t = 0.f;
             for (int z = 0; z < nsplit; ++z) t += cs_slabs[(size_t)z * cs_n + n];
             cs_out[n] += t;

@@ -7,21 +7,20 @@
 
 namespace {
 
-// ONE workgroup of 1024 threads: the loss is a single number, and a fixed reduction tree (thread-strided partial sums, wave
-// reduction, 16 wave totals added in order) makes it run-to-run identical -- per-block float atomics did not.  The tensors are a few
-// hundred thousand elements (latent resolution x 4 channels x frames): a latency-shaped 30 us, once per micro-batch.
+// The loss is a single number: every workgroup leaves its partial sum in `partial[block]` and a second, tiny launch adds them in
+// block order -- a fixed reduction tree, run-to-run identical (per-block float atomics were not; one 1024-thread workgroup over the
+// whole tensor was, but took 240 us).
 template <typename T>
-__global__ __launch_bounds__(1024) void edm_loss_kernel(const T* __restrict__ pred, int ld, const float* __restrict__ noisy,
-                                                        const float* __restrict__ target, const float* __restrict__ sigma,
-                                                        float* loss, T* __restrict__ dpred, int ld_d, int B, int T_, int C,
-                                                        int HW, const float* __restrict__ opt_state) {
-    __shared__ float red[16];
+__global__ __launch_bounds__(256) void edm_loss_kernel(const T* __restrict__ pred, int ld, const float* __restrict__ noisy,
+                                                       const float* __restrict__ target, const float* __restrict__ sigma,
+                                                       float* __restrict__ partial, T* __restrict__ dpred, int ld_d, int B, int T_, int C,
+                                                       int HW, const float* __restrict__ opt_state) {
+    __shared__ float red[4];
     const long n = (long)B * T_ * C * HW;
     const float norm = 1.f / (float)n;
     const float lscale = opt_state[1];
     float acc = 0.f;
-#pragma unroll 4
-    for (long i = threadIdx.x; i < n; i += 1024) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         // i indexes the NCHW-per-frame float tensors: ((b*T + t)*C + c)*HW + p
         const int p = (int)(i % HW);
         const long t1 = i / HW;
@@ -42,12 +41,14 @@ __global__ __launch_bounds__(1024) void edm_loss_kernel(const T* __restrict__ pr
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += red[i];
-        *loss += t * norm;
-    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * norm;
+}
+
+__global__ __launch_bounds__(64) void edm_loss_reduce_kernel(const float* __restrict__ partial, int n, float* loss) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) acc += partial[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) *loss += acc;
 }
 
 __global__ void check_finite_kernel(const float* __restrict__ g, long n, float* opt_state) {
@@ -225,14 +226,17 @@ __global__ __launch_bounds__(256) void adamw_tiled_kernel(float* __restrict__ p,
 }  // namespace
 
 extern "C" int svdx_edm_loss(const void* pred, int ld, const float* noisy, const float* target, const float* sigma,
-                             float* loss, void* dpred, int B, int T_, int C, int HW, const float* opt_state, int dtype,
+                             float* loss, void* dpred, int B, int T_, int C, int HW, const float* opt_state, float* scratch, int dtype,
                              void* stream) {
-    SVDX_CHECK_ARG(pred && noisy && target && sigma && loss && dpred && opt_state, "svdx_edm_loss: null argument");
+    SVDX_CHECK_ARG(pred && noisy && target && sigma && loss && dpred && opt_state && scratch, "svdx_edm_loss: null argument");
     const long n = (long)B * T_ * C * HW;
     const int ld_d = ((C + 63) / 64) * 64;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((edm_loss_kernel<T>), dim3(1), dim3(1024), 0, (hipStream_t)stream, (const T*)pred,
-                                             ld, noisy, target, sigma, loss, (T*)dpred, ld_d, B, T_, C, HW, opt_state));
+    const int blocks = (int)std::min<long>((n + 255) / 256, SVDX_EDM_LOSS_SCRATCH);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((edm_loss_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)pred,
+                                             ld, noisy, target, sigma, scratch, (T*)dpred, ld_d, B, T_, C, HW, opt_state));
     SVDX_LAUNCH_CHECK("svdx_edm_loss");
+    hipLaunchKernelGGL(edm_loss_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, blocks, loss);
+    SVDX_LAUNCH_CHECK("svdx_edm_loss(reduce)");
     return 0;
 }
 

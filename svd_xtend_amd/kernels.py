@@ -105,7 +105,7 @@ _SIGS = {
     "svdx_bicubic_affine": "pp" "iiiiii" "pp" "p",
     "svdx_attn_small_fwd": "pp" "iiiii" "ll" "f" "ip",
     "svdx_zero_spans": "pp" "ip",
-    "svdx_edm_loss": "pi" "ppppp" "iiii" "p" "ip",
+    "svdx_edm_loss": "pi" "ppppp" "iiii" "pp" "ip",
     "svdx_check_finite": "plpp",
     "svdx_optim_prep": "p" "ffff" "ii" "p",
     "svdx_adamw": "pppp" "l" "ffffff" "pp" "ip",
@@ -119,6 +119,7 @@ TSA_MAX_C, TSA_MAX_T, TSA_BAND_ROWS = 320, 16, 144
 
 
 COLSUM_SLAB = 512
+EDM_LOSS_SCRATCH = 1024        # floats of scratch svdx_edm_loss wants (per-workgroup partial sums)
 
 
 def colsum_slabs(rows: int, rpg: int, mod: int) -> int:
@@ -365,9 +366,12 @@ class HipBackend:
         self._call("svdx_attn_small_fwd", _p(qkv), _p(out), n_img, S, heads, d, dp, ld, ld_o, float(scale), _dt(qkv), self._stream())
 
     # ---- loss / optimizer -------------------------------------------------------------------------
-    def edm_loss(self, pred, ld, noisy, target, sigma, loss, dpred, B, T, C, HW, opt_state):
+    def edm_loss(self, pred, ld, noisy, target, sigma, loss, dpred, B, T, C, HW, opt_state, scratch=None):
+        if scratch is None:
+            scratch = torch.empty(EDM_LOSS_SCRATCH, dtype=torch.float32, device=pred.device)
+        assert scratch.numel() >= EDM_LOSS_SCRATCH
         self._call("svdx_edm_loss", _p(pred), ld, _f32(noisy), _f32(target), _f32(sigma), _f32(loss),
-                   _p(dpred), B, T, C, HW, _f32(opt_state), _dt(pred), self._stream())
+                   _p(dpred), B, T, C, HW, _f32(opt_state), _f32(scratch), _dt(pred), self._stream())
 
     def check_finite(self, g, n, opt_state):
         self._call("svdx_check_finite", _f32(g), n, _f32(opt_state), self._stream())

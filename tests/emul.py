@@ -527,7 +527,7 @@ class EmuBackend:
         V1(out, n).copy_((gelu(x) if act == 0 else x * torch.sigmoid(1.702 * x)).to(out.dtype))
 
     # ---- loss / optimizer ----
-    def edm_loss(self, pred, ld, noisy, target, sigma, loss, dpred, B, T, C, HW, opt_state):
+    def edm_loss(self, pred, ld, noisy, target, sigma, loss, dpred, B, T, C, HW, opt_state, scratch=None):
         p = V(pred, B * T * HW, C, ld).float().view(B, T, HW, C).permute(0, 1, 3, 2)
         nz = V1(noisy, B * T * C * HW).view(B, T, C, HW)
         tg = V1(target, B * T * C * HW).view(B, T, C, HW)
