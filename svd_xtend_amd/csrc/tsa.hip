@@ -11,8 +11,9 @@
 //            layer-normalised IN PLACE (16 lanes per row, fp32 statistics); n and (mean, rstd) also go to HBM -- the weight-gradient
 //            GEMM dW_qkv = dqkv^T n and the LayerNorm backward need them
 //   phase 2  qkv = n W_qkv^T on v_mfma_f32_16x16x32: the image is the resident A operand, W_qkv streams through a double-buffered
-//            LDS stage (lean buffer_load ... lds pieces, as gemm_v4); 4 waves x 48 columns per pass, 9 x 3 accumulator blocks per wave;
-//            q, k, v go to HBM (saved for the backward) and are read back by phase 3 from L2
+//            LDS stage (lean buffer_load ... lds pieces, as gemm_v4); 8 waves = 2 row halves x 4 column groups of 48, so every SIMD
+//            holds two waves and one's LDS latency hides under the other's MFMAs; q, k, v go to HBM (saved for the backward) with
+//            their stores drained under the next pass's MFMAs, and are read back by phase 3 from L2
 //   phase 3  per (pixel, head): S^T = K Q^T (2 MFMAs, T padded to 16 and masked), softmax over the 4 lanes that share a query,
 //            O^T = V^T P^T (4 MFMAs, V^T fragments by ds_read_b64_tr_b16 from a per-wave 2 KiB tile); O overwrites the image (the
 //            out-projection's A operand) and goes to HBM (dW_o = dh1^T o needs it)
@@ -25,11 +26,14 @@ namespace {
 constexpr float TSA_LOG2E = 1.4426950408889634f;
 constexpr int TSA_MB = 9;                      // 16-row blocks per band (up to 144 rows)
 constexpr int TSA_RP = TSA_MB * 16;
-constexpr int TSA_NB = 3;                      // 16-column blocks per wave per pass
-constexpr int TSA_WN = 16 * TSA_NB;            // 48 columns per wave
-constexpr int TSA_PW = 4 * TSA_WN;             // 192 columns per pass
-constexpr int TSA_BST = TSA_PW * 128;          // bytes of one B stage (K extent 64)
-constexpr int TSA_NPC = TSA_BST / 1024 / 4;    // DMA pieces per wave per stage (6)
+constexpr int TSA_WAVES = 8;
+constexpr int TSA_MBW = 5;                     // row blocks per wave: waves 0-3 own blocks 0-4, waves 4-7 blocks 5-8
+constexpr int TSA_NG = 2;                      // 32-column groups per wave per pass: groups cw and cw + 4 of the pass's eight
+constexpr int TSA_PW = 4 * TSA_NG * 32;        // 256 columns per pass
+constexpr int TSA_BST = TSA_PW * 128;          // bytes of one B stage (K extent 64): 32 KiB
+constexpr int TSA_NPC = TSA_BST / 1024 / TSA_WAVES;   // DMA pieces per wave per stage (4)
+constexpr int TSA_NSTG = 2;
+constexpr int TSA_ITEMS = TSA_NG * TSA_MBW;    // 16-byte output stores per lane per pass (10)
 constexpr int TSA_MAXC = 320;
 
 struct TsaParams {
@@ -46,8 +50,11 @@ struct TsaParams {
 
 #ifdef TSA_STAMPS
 #define TSA_STAMP(i) do { if (tid == 0) p.stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+// phase 3 of wave 0: cycles between consecutive marks of the problem loop, summed into stamps[8 + i]
+#define TSA_ACC(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if ((i) > 0) acc3[(i)] += now_ - last3; last3 = now_; } while (0)
 #else
 #define TSA_STAMP(i) do { } while (0)
+#define TSA_ACC(i) do { } while (0)
 #endif
 
 typedef short tsa_v4s __attribute__((ext_vector_type(4)));
@@ -65,106 +72,194 @@ __device__ __forceinline__ typename TT<T>::v8 tsa_frag_tr(const char* lds, int d
     return __builtin_bit_cast(typename TT<T>::v8, r);
 }
 
-// acc[j][i] = IMG[rows i*16.., K] * Bmat[N, K]^T for the wave's 48 columns of every 192-column pass; `epi(pass, acc)` runs when a
-// pass has seen all of K (the loop body is gemm_v4's: fragments of one 32-deep half step in registers, then its 27 MFMAs).  The first
-// stage of the next pass is already travelling when the epilogue runs.  Ends with every wave past a barrier and its stores complete.
-template <typename T, typename Epi>
-__device__ __forceinline__ void tsa_band_gemm(const char* IMG, char* BST, const void* Bmat, int b_bytes, int N, int Kd, int tid, Epi&& epi,
-                                              unsigned long long* wait_cycles = nullptr) {
+typedef unsigned int tsa_u4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+template <typename T>
+__device__ __forceinline__ tsa_u4 tsa_pack8(const float (&f)[8]) {
+    Vec8<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.v[e] = from_f<T>(f[e]);
+    return __builtin_bit_cast(tsa_u4, o);
+}
+
+constexpr int TSA_OOB = (int)0x80000000;       // a buffer offset no descriptor of this kernel covers: loads give 0, stores are dropped
+
+// out[rows of the band, N] = IMG[rows, K] * Bmat[N, K]^T.  A pass covers 256 columns = eight groups of 32; wave (h, cw) = (wave / 4,
+// wave % 4) owns row blocks h*5 .. h*5+4 (block 9 does not exist: skipped) x groups cw and cw + 4 (interleaved, so that a short last
+// pass still spreads over the waves).  A group is two MFMA column blocks whose weight rows are PERMUTED when they are DMA-ed into the
+// stage -- LDS row g*32 + b*16 + c holds weight row g*32 + (c/4)*8 + b*4 + c%4 -- so that the lane that owns tile columns 4 fg .. 4 fg+3
+// of both blocks owns the 8 CONSECUTIVE output columns g*32 + 8 fg .. +7: one 16-byte store instead of two 8-byte ones.  (A CU issues
+// one vector store per ~17 clocks whatever its width -- tools/probes/store_probe.hip: 26 B/clk with 8-byte lanes, 58 with 16.)
+// `conv(pass, acc, pend)` turns the finished accumulators of a pass into packed 16-bit outputs; their 10 stores per lane are NOT issued
+// there: two of them are issued at the head of each K-step of the NEXT pass and leave while its MFMAs run (buffer stores, the
+// row/column predicate folded into an out-of-range offset).  Ends with every wave past a barrier and all its stores complete.
+// Side job: the A image itself (n in phase 2, o in phase 4 -- both saved for the backward) is copied to `side` in 16-byte lanes, a few
+// instructions per K-step, instead of being stored by the phase that produced it.
+template <typename T, int KS, typename Pre, typename Conv, typename Grow>
+__device__ __forceinline__ void tsa_band_gemm(const char* IMG, char* BST, const void* Bmat, int b_bytes, int N, int tid,
+                                              void* out, int out_bytes, const int (&rowoff)[TSA_MBW], Pre&& pre, Conv&& conv,
+                                              void* side, int R, Grow&& grow, unsigned long long* wait_cycles = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef typename TT<T>::v8 v8;
+    constexpr int Kd = KS * 64;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
-    const int KS = Kd / 64, npass = (N + TSA_PW - 1) / TSA_PW;
+    const int h = wave >> 2, cw = wave & 3;
+    const int npass = (N + TSA_PW - 1) / TSA_PW, total = npass * KS;
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Bmat), 0, b_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(out, 0, out_bytes, 0x00020000);
     int vob[TSA_NPC];
-    auto set_pass = [&](int pass) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < TSA_NPC; ++i) {
-            const int id = (i * 4 + wave) * 64 + lane;           // 16-byte unit of the stage: row = id / 8, physical chunk = id % 8
-            const int r = id >> 3, pc = id & 7, lc = pc ^ (r & 7);
-            const int n = pass * TSA_PW + r;
-            vob[i] = n < N ? (n * Kd + lc * 8) * 2 : (int)0x80000000;   // beyond N: out of range of the buffer -> zeros
-        }
-    };
-    auto issue = [&](int stage, int ks) __attribute__((always_inline)) {
+    for (int i = 0; i < TSA_NPC; ++i) {
+        const int id = (i * TSA_WAVES + wave) * 64 + lane;       // 16-byte unit of the stage: LDS row = id / 8, physical chunk = id % 8
+        const int r = id >> 3, pc = id & 7, lc = pc ^ (r & 7);
+        const int n = (r & ~31) + ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3);    // the weight row this LDS row holds
+        vob[i] = (n * Kd + lc * 8) * 2;                          // rows beyond N lie beyond b_bytes: the descriptor returns zeros
+    }
+    int i_ks = 0, i_stage = 0, i_shift = 0;                      // the DMA's position: K-step, stage, byte shift of its pass
+    auto issue = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < TSA_NPC; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(BST + stage * TSA_BST + (i * 4 + wave) * 1024), 16,
-                                                     vob[i], ks * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(BST + i_stage * TSA_BST + (i * TSA_WAVES + wave) * 1024), 16,
+                                                     vob[i] + i_shift, i_ks * 128, 0, 0);
+        i_stage ^= 1;
+        if (++i_ks == KS) { i_ks = 0; i_shift += TSA_PW * Kd * 2; }
     };
-    set_pass(0);
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int pass = 0; pass < npass; ++pass) {
-        f32x4 acc[TSA_NB][TSA_MB];
+    tsa_u4 pend[TSA_NG][TSA_MBW];
+    auto drain = [&](int lo, int hi, int dpass) __attribute__((always_inline)) {     // stores [lo, hi) of pass dpass; literal bounds
 #pragma unroll
-        for (int j = 0; j < TSA_NB; ++j)
-#pragma unroll
-            for (int i = 0; i < TSA_MB; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bool live = pass * TSA_PW + wave * TSA_WN < N;     // a wave whose 48 columns lie beyond N idles through the pass
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) {
-                issue(cur ^ 1, ks + 1);
-            } else if (pass + 1 < npass) {
-                set_pass(pass + 1);
-                issue(cur ^ 1, 0);
+        for (int it = 0; it < TSA_ITEMS; ++it) {
+            if (it >= lo && it < hi) {
+                const int i = it / TSA_NG, g = it % TSA_NG, n = dpass * TSA_PW + (g * 4 + cw) * 32 + fg * 8;
+                __builtin_amdgcn_raw_buffer_store_b128(pend[g][i], rsO, n < N ? rowoff[i] + n * 2 : TSA_OOB, 0, 0);
             }
-            if (live) {
-                const char* As = IMG + ks * (TSA_RP * 128);
-                const char* Bs = BST + cur * TSA_BST;
+        }
+    };
+    __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(side ? side : out, 0, side ? out_bytes / N * Kd : 0, 0x00020000);
+    constexpr int SIDE_N = (TSA_RP * KS * 8 + TSA_WAVES * 64 - 1) / (TSA_WAVES * 64);     // 16-byte units of the image / 512 lanes
+    constexpr int SIDE_MAX = 2;                                  // units a wave copies per K-step at most
+    const int side_per = side ? min((SIDE_N + total - 1) / total, SIDE_MAX) : 0;
+    tsa_u4 sv[SIDE_MAX];                                         // read from the image during one step's MFMAs, stored at the head of the next
+    int svo[SIDE_MAX];
+    auto side_read = [&](int k, int s) __attribute__((always_inline)) {
+        const int id = (s * TSA_WAVES + wave) * 64 + lane;
+        const int row = id / (KS * 8), c = id - row * (KS * 8);
+        sv[k] = *reinterpret_cast<const tsa_u4*>(IMG + (c >> 3) * (TSA_RP * 128) + min(row, TSA_RP - 1) * 128 + (((c & 7) ^ (row & 7)) * 16));
+        svo[k] = (row < R && s < SIDE_N) ? grow(row) * (Kd * 2) + c * 16 : TSA_OOB;
+    };
+    issue();
+#pragma unroll
+    for (int k = 0; k < SIDE_MAX; ++k)
+        if (k < side_per) side_read(k, k);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int per = (TSA_ITEMS + KS - 1) / KS;               // stores drained per K-step
+    int q = 0, cur = 0;
+    for (int pass = 0; pass < npass; ++pass) {
+        f32x4 acc[TSA_NG][2][TSA_MBW];
+#pragma unroll
+        for (int g = 0; g < TSA_NG; ++g)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < TSA_MBW; ++i) acc[g][b][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bool live[TSA_NG];                                       // a group beyond N is skipped (wave-uniform)
+#pragma unroll
+        for (int g = 0; g < TSA_NG; ++g) live[g] = pass * TSA_PW + (g * 4 + cw) * 32 < N;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks, ++q) {
+            if (q + 1 < total) issue();
+            // a slice of the previous pass's stores, ahead of the MFMAs in program order: they leave the CU while the MFMAs run
+            if (pass > 0) drain(min(ks * per, TSA_ITEMS), min(ks * per + per, TSA_ITEMS), pass - 1);
+#pragma unroll
+            for (int k = 0; k < SIDE_MAX; ++k)
+                if (k < side_per) __builtin_amdgcn_raw_buffer_store_b128(sv[k], rsS, svo[k], 0, 0);
+            if (ks == KS - 1) pre(pass, pend);                   // every store of `pend` has been issued: the epilogue may preload into it
+            if (live[0]) {
+                const char* As = IMG + ks * (TSA_RP * 128) + h * (TSA_MBW * 16 * 128);
+                const char* Bs = BST + cur * TSA_BST + cw * (32 * 128);
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     const int chunk = ((kk * 4 + fg) ^ (fr & 7)) * 16;
-                    v8 af[TSA_MB], bf[TSA_NB];
+                    v8 af[TSA_MBW], bf[TSA_NG][2];
 #pragma unroll
-                    for (int i = 0; i < TSA_MB; ++i) af[i] = *reinterpret_cast<const v8*>(As + (i * 16 + fr) * 128 + chunk);
+                    for (int g = 0; g < TSA_NG; ++g)
 #pragma unroll
-                    for (int j = 0; j < TSA_NB; ++j) bf[j] = *reinterpret_cast<const v8*>(Bs + (wave * TSA_WN + j * 16 + fr) * 128 + chunk);
+                        for (int b = 0; b < 2; ++b) bf[g][b] = *reinterpret_cast<const v8*>(Bs + (g * 128 + b * 16 + fr) * 128 + chunk);
 #pragma unroll
-                    for (int i = 0; i < TSA_MB; ++i)
+                    for (int i = 0; i < TSA_MBW; ++i)
+                        if (i < TSA_MB - TSA_MBW || h == 0) af[i] = *reinterpret_cast<const v8*>(As + (i * 16 + fr) * 128 + chunk);
 #pragma unroll
-                        for (int j = 0; j < TSA_NB; ++j) acc[j][i] = TT<T>::mfma(bf[j], af[i], acc[j][i]);
+                    for (int i = 0; i < TSA_MBW; ++i)
+                        if (i < TSA_MB - TSA_MBW || h == 0) {
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) acc[0][b][i] = TT<T>::mfma(bf[0][b], af[i], acc[0][b][i]);
+                            if (live[1]) {
+#pragma unroll
+                                for (int b = 0; b < 2; ++b) acc[1][b][i] = TT<T>::mfma(bf[1][b], af[i], acc[1][b][i]);
+                            }
+                        }
                 }
             }
+#pragma unroll
+            for (int k = 0; k < SIDE_MAX; ++k)
+                if (k < side_per) side_read(k, (q + 1) * side_per + k);
 #ifdef TSA_STAMPS
             const unsigned long long w0 = __builtin_readcyclecounter();
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            __builtin_amdgcn_s_barrier();
 #ifdef TSA_STAMPS
             if (wait_cycles) *wait_cycles += __builtin_readcyclecounter() - w0;
 #endif
             cur ^= 1;
         }
-        if (live) epi(pass, acc);
+#ifdef TSA_STAMPS
+        const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
+        if (live[0]) conv(pass, acc, pend);
+#ifdef TSA_STAMPS
+        if (wait_cycles) wait_cycles[1] += __builtin_readcyclecounter() - c0;
+#endif
     }
+#ifdef TSA_STAMPS
+    const unsigned long long d0 = __builtin_readcyclecounter();
+#endif
+    drain(0, TSA_ITEMS, npass - 1);
+    if (side)
+        for (int sc = total * side_per; sc < SIDE_N; ++sc) {     // what the K-steps did not cover (short GEMMs only)
+            side_read(0, sc);
+            __builtin_amdgcn_raw_buffer_store_b128(sv[0], rsS, svo[0], 0, 0);
+        }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef TSA_STAMPS
+    if (wait_cycles) wait_cycles[2] += __builtin_readcyclecounter() - d0;
+#endif
 #endif
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void tsa_fwd_kernel(TsaParams p) {
+template <typename T, int KB>
+__global__ __launch_bounds__(512) void tsa_fwd_kernel(TsaParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
-    const int C = p.C, KB = C / 64, C8 = C / 8, Tn = p.T, HW = p.HW;
+    constexpr int C = KB * 64, C8 = C / 8;
+    const int Tn = p.T, HW = p.HW;
     char* IMG = smem;                                  // [KB][TSA_RP rows][128 B], 16-byte chunk index XOR (row & 7)
     char* BST = smem + KB * (TSA_RP * 128);            // two weight stages; per-wave V tiles in phase 3
     const int bands = HW / p.P;
     const int b = blockIdx.x / bands, p0 = (blockIdx.x - b * bands) * p.P;
     const int R = p.P * Tn;                            // real rows of the band; local row lr = pi * T + t
     const int row0 = b * Tn * HW + p0;                 // global row of (pixel p0, frame 0); frame t of pixel pi: row0 + t*HW + pi
-    auto grow = [&](int lr) __attribute__((always_inline)) { const int pi = lr / Tn; return row0 + (lr - pi * Tn) * HW + pi; };
-    const T* X = reinterpret_cast<const T*>(p.x);
+    const int rcpT = (65536 + Tn - 1) / Tn;            // lr / T == (lr * rcpT) >> 16 for lr < 4096, T <= 16
+    auto grow = [&](int lr) __attribute__((always_inline)) { const int pi = (lr * rcpT) >> 16; return row0 + (lr - pi * Tn) * HW + pi; };
     TSA_STAMP(0);
 #ifdef TSA_STAMPS
-    unsigned long long wait2 = 0, wait4 = 0;
-#define TSA_WAIT2 , &wait2
-#define TSA_WAIT4 , &wait4
+    unsigned long long wait2[3] = {0, 0, 0}, wait4[3] = {0, 0, 0};
+#define TSA_WAIT2 , wait2
+#define TSA_WAIT4 , wait4
 #else
 #define TSA_WAIT2
 #define TSA_WAIT4
@@ -174,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void tsa_fwd_kernel(TsaParams p) {
     {
         __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
         const int npieces = KB * (TSA_RP / 8);
-        for (int pq = wave; pq < npieces; pq += 4) {
+        for (int pq = wave; pq < npieces; pq += TSA_WAVES) {
             const int kblk = pq / (TSA_RP / 8), rg = pq - kblk * (TSA_RP / 8);
             const int row = rg * 8 + (lane >> 3), lc = (lane & 7) ^ (lane >> 3);
             const int voff = row < R ? (grow(row) * C + kblk * 64 + lc * 8) * 2 : (int)0x80000000;     // padding rows read zeros
@@ -184,112 +279,131 @@ __global__ __launch_bounds__(256, 2) void tsa_fwd_kernel(TsaParams p) {
         __syncthreads();
     }
     TSA_STAMP(1);
-    // ---- phase 1b: LayerNorm in place; 16 lanes per row, 4 rows per wave per step, 3 independent steps in flight -----------------------
+    // ---- phase 1b: LayerNorm in place; 16 lanes per row, 4 rows per wave per step, 3 independent steps in flight; row quad
+    //      (step * 8 + wave) of the band's 36.  The arithmetic is on float pairs (v_pk_add/mul/fma_f32): with two waves per SIMD this
+    //      phase is VALU-bound.  n goes to HBM from the image during phase 2, under the MFMAs ----------------------------------------------
     {
         const int l16 = lane & 15;
-        constexpr int NCH = (TSA_MAXC / 8 + 15) / 16;       // 16-byte chunks per lane (3 at C = 320)
+        constexpr int NCH = (C8 + 15) / 16;                 // 16-byte chunks per lane (3 at C = 320)
         constexpr int G = 3;                                // row groups in flight
-        float gm[NCH][8], bt[NCH][8];
+        f32x2v gm[NCH][4], bt[NCH][4];
         bool cv[NCH];
         int cl[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = l16 + 16 * j;
-            cv[j] = c < C8;
+            cv[j] = 16 * (j + 1) <= C8 || c < C8;           // a literal `true` for all but the last chunk
             cl[j] = min(c, C8 - 1);                         // invalid chunks read a valid address and are masked to zero
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                gm[j][e] = p.gamma[cl[j] * 8 + e];
-                bt[j][e] = p.beta[cl[j] * 8 + e];
+            for (int e = 0; e < 4; ++e) {
+                gm[j][e] = f32x2v{p.gamma[cl[j] * 8 + 2 * e], p.gamma[cl[j] * 8 + 2 * e + 1]};
+                bt[j][e] = f32x2v{p.beta[cl[j] * 8 + 2 * e], p.beta[cl[j] * 8 + 2 * e + 1]};
             }
         }
-        T* N1 = reinterpret_cast<T*>(p.n1);
         const float invC = 1.f / (float)C;
-        for (int it0 = 0; it0 < TSA_RP / 16; it0 += G) {
-            float v[G][NCH][8], mean[G], rstd[G];
+        constexpr int NQ = (TSA_RP / 4 + TSA_WAVES - 1) / TSA_WAVES;      // steps per wave (5; the last one only for waves 0-3)
+        for (int it0 = 0; it0 < NQ; it0 += G) {
+            f32x2v v[G][NCH][4];
+            float mean[G], rstd[G];
             int row[G];
+            bool inb[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                row[g] = wave * (TSA_RP / 4) + (it0 + g) * 4 + (lane >> 4);
+                const int quad = (it0 + g) * TSA_WAVES + wave;
+                inb[g] = quad < TSA_RP / 4;                  // wave-uniform
+                row[g] = min(quad, TSA_RP / 4 - 1) * 4 + (lane >> 4);
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
-                    load8<T>(reinterpret_cast<const T*>(IMG + (cl[j] >> 3) * (TSA_RP * 128) + row[g] * 128 + (((cl[j] & 7) ^ (row[g] & 7)) * 16)), v[g][j]);
+                    const Vec8<T> t = *reinterpret_cast<const Vec8<T>*>(IMG + (cl[j] >> 3) * (TSA_RP * 128) + row[g] * 128 + (((cl[j] & 7) ^ (row[g] & 7)) * 16));
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[g][j][e] = cv[j] ? v[g][j][e] : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        v[g][j][e] = f32x2v{to_f<T>(t.v[2 * e]), to_f<T>(t.v[2 * e + 1])};
+                        if (!cv[j]) v[g][j][e] = f32x2v{0.f, 0.f};
+                    }
                 }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                float s = 0.f;
+                f32x2v s2 = f32x2v{0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < NCH; ++j)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) s += v[g][j][e];
-                mean[g] = row16_sum(s) * invC;
+                    for (int e = 0; e < 4; ++e) s2 += v[g][j][e];
+                mean[g] = row16_sum(s2[0] + s2[1]) * invC;
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                float ss = 0.f;
+                f32x2v ss = f32x2v{0.f, 0.f};
+                const f32x2v m2 = f32x2v{mean[g], mean[g]};
 #pragma unroll
                 for (int j = 0; j < NCH; ++j)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = cv[j] ? v[g][j][e] - mean[g] : 0.f; ss += d * d; }
-                rstd[g] = rsqrtf(row16_sum(ss) * invC + p.eps);
+                    for (int e = 0; e < 4; ++e) {
+                        v[g][j][e] -= m2;                   // kept: the normalised value is d * (rstd * gamma) + beta
+                        if (!cv[j]) v[g][j][e] = f32x2v{0.f, 0.f};
+                        ss = __builtin_elementwise_fma(v[g][j][e], v[g][j][e], ss);
+                    }
+                rstd[g] = rsqrtf(row16_sum(ss[0] + ss[1]) * invC + p.eps);
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
+                if (!inb[g]) continue;
                 const bool real = row[g] < R;
-                const int gr = real ? grow(row[g]) : 0;
-                if (real && l16 == 0) *reinterpret_cast<float2*>(p.stats + (size_t)gr * 2) = float2{mean[g], rstd[g]};
+                if (real && l16 == 0) *reinterpret_cast<float2*>(p.stats + (size_t)grow(row[g]) * 2) = float2{mean[g], rstd[g]};
+                const f32x2v r2 = real ? f32x2v{rstd[g], rstd[g]} : f32x2v{0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
-                    float o[8];
+                    Vec8<T> o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = real ? (v[g][j][e] - mean[g]) * rstd[g] * gm[j][e] + bt[j][e] : 0.f;
-                    if (cv[j]) {
-                        store8<T>(reinterpret_cast<T*>(IMG + (cl[j] >> 3) * (TSA_RP * 128) + row[g] * 128 + (((cl[j] & 7) ^ (row[g] & 7)) * 16)), o);
-                        if (real && N1) store8<T>(N1 + (size_t)gr * C + cl[j] * 8, o);
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x2v y = __builtin_elementwise_fma(v[g][j][e], r2 * gm[j][e], real ? bt[j][e] : f32x2v{0.f, 0.f});
+                        o.v[2 * e] = from_f<T>(y[0]);
+                        o.v[2 * e + 1] = from_f<T>(y[1]);
                     }
+                    if (cv[j]) *reinterpret_cast<Vec8<T>*>(IMG + (cl[j] >> 3) * (TSA_RP * 128) + row[g] * 128 + (((cl[j] & 7) ^ (row[g] & 7)) * 16)) = o;
                 }
             }
         }
         __syncthreads();
     }
     TSA_STAMP(2);
-    // rows this lane owns in the accumulator layout: block i, row i*16 + fr
-    int growr[TSA_MB];
+    // rows this lane owns in the accumulator layout: block (wave / 4) * 5 + i, row block * 16 + fr
+    int growr[TSA_MBW];
 #pragma unroll
-    for (int i = 0; i < TSA_MB; ++i) growr[i] = (i * 16 + fr) < R ? grow(i * 16 + fr) : -1;
+    for (int i = 0; i < TSA_MBW; ++i) {
+        const int lr = ((wave >> 2) * TSA_MBW + i) * 16 + fr;
+        growr[i] = lr < R ? grow(lr) : -1;
+    }
 
     // ---- phase 2: qkv = n W_qkv^T ------------------------------------------------------------------------------------------------
     T* QKV = reinterpret_cast<T*>(p.qkv);
     const int N3 = 3 * C;
-    tsa_band_gemm<T>(IMG, BST, p.wqkv, p.wqkv_bytes, N3, C, tid, [&](int pass, f32x4 (&acc)[TSA_NB][TSA_MB]) __attribute__((always_inline)) {
-        const int nb = pass * TSA_PW + wave * TSA_WN + fg * 4;
+    {
+        int rowoff[TSA_MBW];
+#pragma unroll
+        for (int i = 0; i < TSA_MBW; ++i) rowoff[i] = growr[i] >= 0 ? growr[i] * N3 * 2 : TSA_OOB;
 #ifdef TSA_SKIP_QKV_STORE
-        if (p.T > 0) return;
+#pragma unroll
+        for (int i = 0; i < TSA_MBW; ++i) if (p.T > 0) rowoff[i] = TSA_OOB;
 #endif
+        tsa_band_gemm<T, KB>(IMG, BST, p.wqkv, p.wqkv_bytes, N3, tid, p.qkv, p.x_bytes * 3, rowoff,
+                             [&](int, tsa_u4 (&)[TSA_NG][TSA_MBW]) __attribute__((always_inline)) {},
+                             [&](int, f32x4 (&acc)[TSA_NG][2][TSA_MBW], tsa_u4 (&pend)[TSA_NG][TSA_MBW]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < TSA_MB; ++i) {
-            if (growr[i] < 0) continue;
-            T* dst = QKV + (size_t)growr[i] * N3 + nb;
+            for (int g = 0; g < TSA_NG; ++g)
 #pragma unroll
-            for (int j = 0; j < TSA_NB; ++j) {
-                if (nb + j * 16 < N3) {
-                    Vec4<T> o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(acc[j][i][e]);
-                    *reinterpret_cast<Vec4<T>*>(dst + j * 16) = o;
+                for (int i = 0; i < TSA_MBW; ++i) {
+                    const float f[8] = {acc[g][0][i][0], acc[g][0][i][1], acc[g][0][i][2], acc[g][0][i][3],
+                                        acc[g][1][i][0], acc[g][1][i][1], acc[g][1][i][2], acc[g][1][i][3]};
+                    pend[g][i] = tsa_pack8<T>(f);
                 }
-            }
-        }
-    } TSA_WAIT2);
+        }, p.n1, R, grow TSA_WAIT2);
+    }
     TSA_STAMP(3);
     // every wave's q/k/v stores are complete (vmcnt(0) before the last barrier) and visible to the other waves of this CU
 
     // ---- phase 3: attention over the frames of each (pixel, head); two problems per wave in flight, the next two being fetched ---------
     {
-        T* Og = reinterpret_cast<T*>(p.o);
         char* VsA = BST + wave * 4096;
         char* VsB = VsA + 2048;
         const int nprob = p.P * p.heads;
@@ -350,70 +464,103 @@ __global__ __launch_bounds__(256, 2) void tsa_fwd_kernel(TsaParams p) {
                     for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(o4[e]);
                     const int c = db * 2 + (fg >> 1);
                     *reinterpret_cast<Vec4<T>*>(IMG + hd * (TSA_RP * 128) + lr * 128 + ((c ^ (lr & 7)) * 16) + (fg & 1) * 8) = o;
-                    *reinterpret_cast<Vec4<T>*>(Og + (size_t)(row0 + pi + fr * HW) * C + hd * 64 + db * 16 + fg * 4) = o;
                 }
             }
         };
-        Loaded ca = load_prob(wave), cb = load_prob(wave + 4);
-        for (int pr = wave; pr < nprob; pr += 8) {
-            const Loaded na = load_prob(pr + 8), nb = load_prob(pr + 12);      // the next two problems travel while these are computed
-            const bool has_b = pr + 4 < nprob;
+#ifdef TSA_STAMPS
+        unsigned long long acc3[5] = {0, 0, 0, 0, 0}, last3 = 0;
+#endif
+        Loaded ca = load_prob(wave), cb = load_prob(wave + TSA_WAVES);
+        for (int pr = wave; pr < nprob; pr += 2 * TSA_WAVES) {
+            TSA_ACC(0);
+            const Loaded na = load_prob(pr + 2 * TSA_WAVES), nb = load_prob(pr + 3 * TSA_WAVES);      // the next two problems travel while these are computed
+            const bool has_b = pr + TSA_WAVES < nprob;
+            TSA_ACC(1);
             stage_v(ca, VsA);
             if (has_b) stage_v(cb, VsB);
+            TSA_ACC(2);
             const v8 pa = scores(ca);
             const v8 pb = scores(cb);
             __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's V tiles are in LDS
             __builtin_amdgcn_wave_barrier();
+            TSA_ACC(3);
             output(pr, pa, VsA);
-            if (has_b) output(pr + 4, pb, VsB);
+            if (has_b) output(pr + TSA_WAVES, pb, VsB);
             __builtin_amdgcn_wave_barrier();
+            TSA_ACC(4);
             ca = na;
             cb = nb;
         }
+#ifdef TSA_STAMPS
+        const unsigned long long t3 = __builtin_readcyclecounter();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef TSA_STAMPS
+        if (tid == 0) {
+            for (int i = 1; i < 5; ++i) p.stamps[blockIdx.x * 16 + 8 + i] = acc3[i];
+            p.stamps[blockIdx.x * 16 + 13] = __builtin_readcyclecounter() - t3;
+        }
+#endif
     }
     TSA_STAMP(4);
 
     // ---- phase 4: h1 = o W_o^T + b_o + cvec + h ----------------------------------------------------------------------------------
-    T* H1 = reinterpret_cast<T*>(p.h1);
-    tsa_band_gemm<T>(IMG, BST, p.wo, p.wo_bytes, C, C, tid, [&](int pass, f32x4 (&acc)[TSA_NB][TSA_MB]) __attribute__((always_inline)) {
-        const int nb = pass * TSA_PW + wave * TSA_WN + fg * 4;
-        // residual rows first: the compiler cannot know that h1 does not alias h, and a load issued between two stores costs a memory
-        // round trip (27 of them in a chain: 61 k cycles in the first version of this epilogue)
-        Vec4<T> r4[TSA_NB][TSA_MB];
+    {
+        int rowoff[TSA_MBW];
 #pragma unroll
-        for (int j = 0; j < TSA_NB; ++j)
+        for (int i = 0; i < TSA_MBW; ++i) rowoff[i] = growr[i] >= 0 ? growr[i] * C * 2 : TSA_OOB;
+        __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+        tsa_band_gemm<T, KB>(IMG, BST, p.wo, p.wo_bytes, C, tid, p.h1, p.x_bytes, rowoff,
+                             [&](int pass, tsa_u4 (&pend)[TSA_NG][TSA_MBW]) __attribute__((always_inline)) {
+            // the residual rows of this pass travel into `pend` while the pass's last K-step runs (buffer loads: rows of the
+            // padding and columns beyond C read zeros)
 #pragma unroll
-            for (int i = 0; i < TSA_MB; ++i) {
-                const bool ok = growr[i] >= 0 && nb + j * 16 < C;
-                r4[j][i] = *reinterpret_cast<const Vec4<T>*>(X + (size_t)(ok ? growr[i] : row0) * C + (ok ? nb + j * 16 : 0));
+            for (int g = 0; g < TSA_NG; ++g) {
+                const int n = pass * TSA_PW + (g * 4 + (wave & 3)) * 32 + fg * 8;
+#pragma unroll
+                for (int i = 0; i < TSA_MBW; ++i)
+                    pend[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, n < C ? rowoff[i] + n * 2 : TSA_OOB, 0, 0);
             }
-        float bb[TSA_NB][4];
+        },
+                             [&](int pass, f32x4 (&acc)[TSA_NG][2][TSA_MBW], tsa_u4 (&pend)[TSA_NG][TSA_MBW]) __attribute__((always_inline)) {
+            int nb[TSA_NG];
 #pragma unroll
-        for (int j = 0; j < TSA_NB; ++j)
+            for (int g = 0; g < TSA_NG; ++g) nb[g] = pass * TSA_PW + (g * 4 + (wave & 3)) * 32 + fg * 8;
+            float4 bb[TSA_NG][2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bb[j][e] = (nb + j * 16 < C) ? p.bo[nb + j * 16 + e] : 0.f;
+            for (int g = 0; g < TSA_NG; ++g)
 #pragma unroll
-        for (int i = 0; i < TSA_MB; ++i) {
-            const int gr = growr[i];
-            if (gr < 0) continue;
-            const float* rv = p.cvec ? p.cvec + (size_t)(p.rv_mod ? gr % p.rv_mod : gr / p.rv_rpg) * p.rv_ld : nullptr;
+                for (int e = 0; e < 2; ++e) bb[g][e] = *reinterpret_cast<const float4*>(p.bo + min(nb[g], C - 8) + 4 * e);
 #pragma unroll
-            for (int j = 0; j < TSA_NB; ++j) {
-                const int n = nb + j * 16;
-                if (n < C) {
-                    Vec4<T> o;
+            for (int i = 0; i < TSA_MBW; ++i) {
+                const int gr = max(growr[i], 0);
+                const float* rv = p.cvec ? p.cvec + (size_t)(p.rv_mod ? gr % p.rv_mod : gr / p.rv_rpg) * p.rv_ld : nullptr;
+                float4 rv4[TSA_NG][2];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(acc[j][i][e] + bb[j][e] + (rv ? rv[n + e] : 0.f) + to_f<T>(r4[j][i].v[e]));
-                    *reinterpret_cast<Vec4<T>*>(H1 + (size_t)gr * C + n) = o;
+                for (int g = 0; g < TSA_NG; ++g)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        rv4[g][e] = rv ? *reinterpret_cast<const float4*>(rv + min(nb[g], C - 8) + 4 * e) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < TSA_NG; ++g) {
+                    const Vec8<T> rr = __builtin_bit_cast(Vec8<T>, pend[g][i]);
+                    const float add[8] = {bb[g][0].x + rv4[g][0].x, bb[g][0].y + rv4[g][0].y, bb[g][0].z + rv4[g][0].z, bb[g][0].w + rv4[g][0].w,
+                                          bb[g][1].x + rv4[g][1].x, bb[g][1].y + rv4[g][1].y, bb[g][1].z + rv4[g][1].z, bb[g][1].w + rv4[g][1].w};
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = acc[g][e >> 2][i][e & 3] + add[e] + to_f<T>(rr.v[e]);
+                    pend[g][i] = tsa_pack8<T>(o);
                 }
             }
-        }
-    } TSA_WAIT4);
+        }, p.o, R, grow TSA_WAIT4);
+    }
     TSA_STAMP(5);
 #ifdef TSA_STAMPS
-    if (tid == 0) { p.stamps[blockIdx.x * 16 + 6] = wait2; p.stamps[blockIdx.x * 16 + 7] = wait4; }
+    if (tid == 0) {
+        p.stamps[blockIdx.x * 16 + 6] = wait2[0]; p.stamps[blockIdx.x * 16 + 7] = wait4[0];
+        p.stamps[blockIdx.x * 16 + 14] = (wait2[1] << 32) | wait2[2]; p.stamps[blockIdx.x * 16 + 15] = (wait4[1] << 32) | wait4[2];
+    }
 #endif
 #endif
 }
@@ -435,6 +582,8 @@ extern "C" int svdx_tsa_fwd(const void* x, const float* gamma, const float* beta
     SVDX_CHECK_ARG(B > 0 && T > 0 && T <= 16 && HW > 0 && C % 64 == 0 && C <= TSA_MAXC && heads * 64 == C,
                    "svdx_tsa_fwd: needs T <= 16, C = 64 * heads <= %d (got T=%d C=%d heads=%d)", TSA_MAXC, T, C, heads);
     SVDX_CHECK_ARG(!cvec || rv_mod > 0 || rv_rows_per_group > 0, "svdx_tsa_fwd: cvec needs a grouping");
+    SVDX_CHECK_ARG(!cvec || ((((uintptr_t)cvec) & 15) == 0 && rv_ld % 4 == 0), "svdx_tsa_fwd: cvec rows must be 16-byte aligned");
+    SVDX_CHECK_ARG((((uintptr_t)bo) & 15) == 0, "svdx_tsa_fwd: bo must be 16-byte aligned");
     SVDX_CHECK_ARG((((uintptr_t)x | (uintptr_t)wqkv | (uintptr_t)wo | (uintptr_t)qkv | (uintptr_t)o | (uintptr_t)h1 | (uintptr_t)n1) & 15) == 0,
                    "svdx_tsa_fwd: operands must be 16-byte aligned");
     const long M = (long)B * T * HW;
@@ -446,17 +595,22 @@ extern "C" int svdx_tsa_fwd(const void* x, const float* gamma, const float* beta
     p.B = B; p.T = T; p.HW = HW; p.C = C; p.heads = heads; p.P = svdx_tsa_pixels_per_band(T, HW); p.sl2 = scale * TSA_LOG2E;
     p.x_bytes = (int)(M * C * 2); p.wqkv_bytes = 3 * C * C * 2; p.wo_bytes = C * C * 2;
     SVDX_CHECK_ARG(p.P > 0, "svdx_tsa_fwd: no band size for T=%d HW=%d", T, HW);
-    const int lds = (C / 64) * (TSA_RP * 128) + 2 * TSA_BST;
+    const int lds = (C / 64) * (TSA_RP * 128) + TSA_NSTG * TSA_BST;
     const int blocks = B * (HW / p.P);
+#define TSA_LAUNCH(KBV)                                                                                                              \
+    case KBV: {                                                                                                                       \
+        static bool attr_set = false;                                                                                                 \
+        if (!attr_set) {                                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tsa_fwd_kernel<T, KBV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      KBV * (TSA_RP * 128) + TSA_NSTG * TSA_BST);                                                     \
+            attr_set = true;                                                                                                          \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((tsa_fwd_kernel<T, KBV>), dim3(blocks), dim3(64 * TSA_WAVES), lds, (hipStream_t)stream, p);                           \
+    } break;
     DISPATCH_DTYPE(dtype, {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tsa_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (TSA_MAXC / 64) * (TSA_RP * 128) + 2 * TSA_BST);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((tsa_fwd_kernel<T>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, p);
+        switch (C / 64) { TSA_LAUNCH(1) TSA_LAUNCH(2) TSA_LAUNCH(3) TSA_LAUNCH(4) TSA_LAUNCH(5) }
     });
+#undef TSA_LAUNCH
     SVDX_LAUNCH_CHECK("svdx_tsa_fwd");
     return 0;
 }

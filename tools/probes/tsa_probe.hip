@@ -31,25 +31,31 @@ int main() {
     const int blocks = B * (HW / p.P);
     hipMalloc(&stamps, blocks * 16 * 8);
     p.stamps = stamps;
-    const int lds = (C / 64) * (TSA_RP * 128) + 2 * TSA_BST;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&tsa_fwd_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int lds = (C / 64) * (TSA_RP * 128) + TSA_NSTG * TSA_BST;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&tsa_fwd_kernel<f16, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int nb : {blocks, 1}) {
-        for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((tsa_fwd_kernel<f16>), dim3(nb), dim3(256), lds, 0, p);
+        for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((tsa_fwd_kernel<f16, 5>), dim3(nb), dim3(512), lds, 0, p);
         hipEventRecord(e0);
-        for (int it = 0; it < 10; ++it) hipLaunchKernelGGL((tsa_fwd_kernel<f16>), dim3(nb), dim3(256), lds, 0, p);
+        for (int it = 0; it < 10; ++it) hipLaunchKernelGGL((tsa_fwd_kernel<f16, 5>), dim3(nb), dim3(512), lds, 0, p);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         std::vector<unsigned long long> h(nb * 16);
         hipMemcpy(h.data(), stamps, nb * 16 * 8, hipMemcpyDeviceToHost);
-        double ph[7] = {0}; 
+        double ph[7] = {0}, a3[6] = {0}, ex[4] = {0};
         for (int b = 0; b < nb; ++b) {
             for (int i = 0; i < 5; ++i) ph[i] += (double)(h[b * 16 + i + 1] - h[b * 16 + i]);
             ph[5] += (double)h[b * 16 + 6]; ph[6] += (double)h[b * 16 + 7];
+            for (int i = 1; i < 6; ++i) a3[i] += (double)h[b * 16 + 8 + i];
+            ex[0] += (double)(h[b * 16 + 14] >> 32); ex[1] += (double)(h[b * 16 + 14] & 0xffffffffull);
+            ex[2] += (double)(h[b * 16 + 15] >> 32); ex[3] += (double)(h[b * 16 + 15] & 0xffffffffull);
         }
         printf("blocks=%d  %.1f us/launch | mean cycles/block: dma %.0f  ln %.0f  qkv-gemm %.0f (waits %.0f)  attention %.0f  out-proj %.0f (waits %.0f)  total %.0f\n",
                nb, ms * 100.f, ph[0] / nb, ph[1] / nb, ph[2] / nb, ph[5] / nb, ph[3] / nb, ph[4] / nb, ph[6] / nb,
                (ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) / nb);
+        printf("   attention, wave 0: issue-next-loads %.0f  stage-V %.0f  scores+softmax %.0f  outputs %.0f  final drain+barrier %.0f\n",
+               a3[1] / nb, a3[2] / nb, a3[3] / nb, a3[4] / nb, a3[5] / nb);
+        printf("   qkv-gemm: epilogues %.0f  final drain %.0f | out-proj: epilogues %.0f  final drain %.0f\n", ex[0] / nb, ex[1] / nb, ex[2] / nb, ex[3] / nb);
     }
     return 0;
 }
