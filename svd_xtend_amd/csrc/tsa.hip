@@ -33,7 +33,6 @@ constexpr int TSA_PW = 4 * TSA_NG * 32;        // 256 columns per pass
 constexpr int TSA_BST = TSA_PW * 128;          // bytes of one B stage (K extent 64): 32 KiB
 constexpr int TSA_NPC = TSA_BST / 1024 / TSA_WAVES;   // DMA pieces per wave per stage (4)
 constexpr int TSA_NSTG = 2;
-constexpr int TSA_ITEMS = TSA_NG * TSA_MBW;    // 16-byte output stores per lane per pass (10)
 constexpr int TSA_MAXC = 320;
 
 struct TsaParams {
@@ -91,15 +90,22 @@ constexpr int TSA_OOB = (int)0x80000000;       // a buffer offset no descriptor 
 // stage -- LDS row g*32 + b*16 + c holds weight row g*32 + (c/4)*8 + b*4 + c%4 -- so that the lane that owns tile columns 4 fg .. 4 fg+3
 // of both blocks owns the 8 CONSECUTIVE output columns g*32 + 8 fg .. +7: one 16-byte store instead of two 8-byte ones.  (A CU issues
 // one vector store per ~17 clocks whatever its width -- tools/probes/store_probe.hip: 26 B/clk with 8-byte lanes, 58 with 16.)
-// `conv(pass, acc, pend)` turns the finished accumulators of a pass into packed 16-bit outputs; their 10 stores per lane are NOT issued
-// there: two of them are issued at the head of each K-step of the NEXT pass and leave while its MFMAs run (buffer stores, the
-// row/column predicate folded into an out-of-range offset).  Ends with every wave past a barrier and all its stores complete.
-// Side job: the A image itself (n in phase 2, o in phase 4 -- both saved for the backward) is copied to `side` in 16-byte lanes, a few
-// instructions per K-step, instead of being stored by the phase that produced it.
-template <typename T, int KS, typename Pre, typename Conv, typename Grow>
-__device__ __forceinline__ void tsa_band_gemm(const char* IMG, char* BST, const void* Bmat, int b_bytes, int N, int tid,
-                                              void* out, int out_bytes, const int (&rowoff)[TSA_MBW], Pre&& pre, Conv&& conv,
-                                              void* side, int R, Grow&& grow, unsigned long long* wait_cycles = nullptr) {
+//
+// A K-step is 64 deep: two 32-deep halves of 36 MFMAs per SIMD.  Everything that is not an MFMA is placed INSIDE the MFMA stream,
+// where its issue slot is cheap (an LDS-DMA piece costs ~60 clocks among MFMAs, 100-185 in a burst behind a barrier):
+//   - the four DMA pieces of the next weight stage go out one per row block of the first half;
+//   - the first half's A fragments were fetched during the previous step (the image never changes), so only the four B fragments are
+//     read behind the barrier; the second half's fragments travel under the first half's MFMAs;
+//   - the side job -- the A image itself (n in phase 2, o in phase 4: both saved for the backward) goes to `side`, one band row per
+//     unit (40 of the 64 lanes at C = 320; scalar row arithmetic, three vector instructions) -- sits between the halves.
+// Variants that were measured and dropped (tools/probes/tsa_probe): output stores parked in registers and drained under the next
+// pass (no gain once they were 16 bytes wide), 32-deep stages in a four-deep ring with counted vmcnt waits (twice the barriers, no
+// shorter waits: the step is issue-bound, not latency-bound).
+// `pre(pass)` runs at the head of a pass's last K-step (the out-projection starts its residual loads there), `epi(pass, acc)` after it.
+// Ends with every wave past a barrier and all its stores complete.
+template <typename T, int KS, typename Pre, typename Epi, typename Grow>
+__device__ __forceinline__ void tsa_band_gemm(const char* IMG, char* BST, const void* Bmat, int b_bytes, int N, int tid, Pre&& pre, Epi&& epi,
+                                              void* side, int side_bytes, int R, Grow&& grow, unsigned long long* wait_cycles = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef typename TT<T>::v8 v8;
     constexpr int Kd = KS * 64;
@@ -107,7 +113,6 @@ __device__ __forceinline__ void tsa_band_gemm(const char* IMG, char* BST, const 
     const int h = wave >> 2, cw = wave & 3;
     const int npass = (N + TSA_PW - 1) / TSA_PW, total = npass * KS;
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Bmat), 0, b_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(out, 0, out_bytes, 0x00020000);
     int vob[TSA_NPC];
 #pragma unroll
     for (int i = 0; i < TSA_NPC; ++i) {
@@ -117,43 +122,40 @@ __device__ __forceinline__ void tsa_band_gemm(const char* IMG, char* BST, const 
         vob[i] = (n * Kd + lc * 8) * 2;                          // rows beyond N lie beyond b_bytes: the descriptor returns zeros
     }
     int i_ks = 0, i_stage = 0, i_shift = 0;                      // the DMA's position: K-step, stage, byte shift of its pass
-    auto issue = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < TSA_NPC; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(BST + i_stage * TSA_BST + (i * TSA_WAVES + wave) * 1024), 16,
-                                                     vob[i] + i_shift, i_ks * 128, 0, 0);
+    auto issue_piece = [&](int i) __attribute__((always_inline)) {       // literal i
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(BST + i_stage * TSA_BST + (i * TSA_WAVES + wave) * 1024), 16,
+                                                 vob[i] + i_shift, i_ks * 128, 0, 0);
+    };
+    auto issue_done = [&]() __attribute__((always_inline)) {
         i_stage ^= 1;
         if (++i_ks == KS) { i_ks = 0; i_shift += TSA_PW * Kd * 2; }
     };
-    tsa_u4 pend[TSA_NG][TSA_MBW];
-    auto drain = [&](int lo, int hi, int dpass) __attribute__((always_inline)) {     // stores [lo, hi) of pass dpass; literal bounds
-#pragma unroll
-        for (int it = 0; it < TSA_ITEMS; ++it) {
-            if (it >= lo && it < hi) {
-                const int i = it / TSA_NG, g = it % TSA_NG, n = dpass * TSA_PW + (g * 4 + cw) * 32 + fg * 8;
-                __builtin_amdgcn_raw_buffer_store_b128(pend[g][i], rsO, n < N ? rowoff[i] + n * 2 : TSA_OOB, 0, 0);
-            }
-        }
+#ifdef TSA_NO_SIDE
+    side = nullptr;
+#endif
+    __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(side ? side : const_cast<void*>(Bmat), 0, side ? side_bytes : 0, 0x00020000);
+    // side job: unit u = band row u (wave-uniform), lane l < C/8 moves 16-byte chunk l
+    const int side_per = side ? (TSA_RP + TSA_WAVES * total - 1) / (TSA_WAVES * total) : 0;     // rows per wave per K-step
+    const int s_c = min(lane, KS * 8 - 1);
+    const int s_lds = (s_c >> 3) * (TSA_RP * 128), s_x = (s_c & 7) * 16;
+    const int s_off = lane < KS * 8 ? lane * 16 : TSA_OOB;
+    auto side_row = [&](int u) __attribute__((always_inline)) {  // u wave-uniform
+        const int row = min(u, TSA_RP - 1);
+        const tsa_u4 v = *reinterpret_cast<const tsa_u4*>(IMG + s_lds + row * 128 + (s_x ^ ((row & 7) * 16)));
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsS, u < R ? s_off : TSA_OOB, u < R ? grow(u) * (Kd * 2) : 0, 0);
     };
-    __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(side ? side : out, 0, side ? out_bytes / N * Kd : 0, 0x00020000);
-    constexpr int SIDE_N = (TSA_RP * KS * 8 + TSA_WAVES * 64 - 1) / (TSA_WAVES * 64);     // 16-byte units of the image / 512 lanes
-    constexpr int SIDE_MAX = 2;                                  // units a wave copies per K-step at most
-    const int side_per = side ? min((SIDE_N + total - 1) / total, SIDE_MAX) : 0;
-    tsa_u4 sv[SIDE_MAX];                                         // read from the image during one step's MFMAs, stored at the head of the next
-    int svo[SIDE_MAX];
-    auto side_read = [&](int k, int s) __attribute__((always_inline)) {
-        const int id = (s * TSA_WAVES + wave) * 64 + lane;
-        const int row = id / (KS * 8), c = id - row * (KS * 8);
-        sv[k] = *reinterpret_cast<const tsa_u4*>(IMG + (c >> 3) * (TSA_RP * 128) + min(row, TSA_RP - 1) * 128 + (((c & 7) ^ (row & 7)) * 16));
-        svo[k] = (row < R && s < SIDE_N) ? grow(row) * (Kd * 2) + c * 16 : TSA_OOB;
-    };
-    issue();
+    const char* Ah = IMG + h * (TSA_MBW * 16 * 128) + fr * 128;
+    const int ch0 = (fg ^ (fr & 7)) * 16, ch1 = ((4 + fg) ^ (fr & 7)) * 16;       // the lane's 16-byte chunk of the two 32-deep halves
+    const int offB = (cw * 32 + fr) * 128;
+    auto rows_ok = [&](int i) __attribute__((always_inline)) { return i < TSA_MB - TSA_MBW || h == 0; };
+    v8 a0[TSA_MBW], a1[TSA_MBW], b0[TSA_NG][2], b1[TSA_NG][2];
 #pragma unroll
-    for (int k = 0; k < SIDE_MAX; ++k)
-        if (k < side_per) side_read(k, k);
+    for (int i = 0; i < TSA_MBW; ++i) a0[i] = *reinterpret_cast<const v8*>(Ah + i * (16 * 128) + ch0);
+#pragma unroll
+    for (int i = 0; i < TSA_NPC; ++i) issue_piece(i);
+    issue_done();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    constexpr int per = (TSA_ITEMS + KS - 1) / KS;               // stores drained per K-step
     int q = 0, cur = 0;
     for (int pass = 0; pass < npass; ++pass) {
         f32x4 acc[TSA_NG][2][TSA_MBW];
@@ -168,42 +170,47 @@ __device__ __forceinline__ void tsa_band_gemm(const char* IMG, char* BST, const 
         for (int g = 0; g < TSA_NG; ++g) live[g] = pass * TSA_PW + (g * 4 + cw) * 32 < N;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks, ++q) {
-            if (q + 1 < total) issue();
-            // a slice of the previous pass's stores, ahead of the MFMAs in program order: they leave the CU while the MFMAs run
-            if (pass > 0) drain(min(ks * per, TSA_ITEMS), min(ks * per + per, TSA_ITEMS), pass - 1);
+            const bool more = q + 1 < total;
+            if (ks == KS - 1) pre(pass);
+            const char* As = Ah + ks * (TSA_RP * 128);
+            const char* An = Ah + (ks + 1 < KS ? ks + 1 : 0) * (TSA_RP * 128);
+            const char* Bs = BST + cur * TSA_BST + offB;
 #pragma unroll
-            for (int k = 0; k < SIDE_MAX; ++k)
-                if (k < side_per) __builtin_amdgcn_raw_buffer_store_b128(sv[k], rsS, svo[k], 0, 0);
-            if (ks == KS - 1) pre(pass, pend);                   // every store of `pend` has been issued: the epilogue may preload into it
-            if (live[0]) {
-                const char* As = IMG + ks * (TSA_RP * 128) + h * (TSA_MBW * 16 * 128);
-                const char* Bs = BST + cur * TSA_BST + cw * (32 * 128);
+            for (int g = 0; g < TSA_NG; ++g)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const int chunk = ((kk * 4 + fg) ^ (fr & 7)) * 16;
-                    v8 af[TSA_MBW], bf[TSA_NG][2];
+                for (int b = 0; b < 2; ++b) b0[g][b] = *reinterpret_cast<const v8*>(Bs + (g * 128 + b * 16) * 128 + ch0);
 #pragma unroll
-                    for (int g = 0; g < TSA_NG; ++g)
+            for (int g = 0; g < TSA_NG; ++g)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) bf[g][b] = *reinterpret_cast<const v8*>(Bs + (g * 128 + b * 16 + fr) * 128 + chunk);
+                for (int b = 0; b < 2; ++b) b1[g][b] = *reinterpret_cast<const v8*>(Bs + (g * 128 + b * 16) * 128 + ch1);
 #pragma unroll
-                    for (int i = 0; i < TSA_MBW; ++i)
-                        if (i < TSA_MB - TSA_MBW || h == 0) af[i] = *reinterpret_cast<const v8*>(As + (i * 16 + fr) * 128 + chunk);
+            for (int i = 0; i < TSA_MBW; ++i) a1[i] = *reinterpret_cast<const v8*>(As + i * (16 * 128) + ch1);
 #pragma unroll
-                    for (int i = 0; i < TSA_MBW; ++i)
-                        if (i < TSA_MB - TSA_MBW || h == 0) {
+            for (int i = 0; i < TSA_MBW; ++i) {
+                if (live[0] && rows_ok(i)) {
 #pragma unroll
-                            for (int b = 0; b < 2; ++b) acc[0][b][i] = TT<T>::mfma(bf[0][b], af[i], acc[0][b][i]);
-                            if (live[1]) {
+                    for (int b = 0; b < 2; ++b) acc[0][b][i] = TT<T>::mfma(b0[0][b], a0[i], acc[0][b][i]);
+                    if (live[1]) {
 #pragma unroll
-                                for (int b = 0; b < 2; ++b) acc[1][b][i] = TT<T>::mfma(bf[1][b], af[i], acc[1][b][i]);
-                            }
-                        }
+                        for (int b = 0; b < 2; ++b) acc[1][b][i] = TT<T>::mfma(b0[1][b], a0[i], acc[1][b][i]);
+                    }
                 }
+                if (i < TSA_NPC && more) issue_piece(i);         // the next stage: its slot was last read in step q - 1
             }
+            if (more) issue_done();
 #pragma unroll
-            for (int k = 0; k < SIDE_MAX; ++k)
-                if (k < side_per) side_read(k, (q + 1) * side_per + k);
+            for (int i = 0; i < TSA_MBW; ++i) a0[i] = *reinterpret_cast<const v8*>(An + i * (16 * 128) + ch0);
+            for (int k = 0; k < side_per; ++k) side_row((q * side_per + k) * TSA_WAVES + wave);
+#pragma unroll
+            for (int i = 0; i < TSA_MBW; ++i)
+                if (live[0] && rows_ok(i)) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[0][b][i] = TT<T>::mfma(b1[0][b], a1[i], acc[0][b][i]);
+                    if (live[1]) {
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) acc[1][b][i] = TT<T>::mfma(b1[1][b], a1[i], acc[1][b][i]);
+                    }
+                }
 #ifdef TSA_STAMPS
             const unsigned long long w0 = __builtin_readcyclecounter();
 #endif
@@ -217,7 +224,7 @@ __device__ __forceinline__ void tsa_band_gemm(const char* IMG, char* BST, const 
 #ifdef TSA_STAMPS
         const unsigned long long c0 = __builtin_readcyclecounter();
 #endif
-        if (live[0]) conv(pass, acc, pend);
+        if (live[0]) epi(pass, acc);
 #ifdef TSA_STAMPS
         if (wait_cycles) wait_cycles[1] += __builtin_readcyclecounter() - c0;
 #endif
@@ -225,12 +232,6 @@ __device__ __forceinline__ void tsa_band_gemm(const char* IMG, char* BST, const 
 #ifdef TSA_STAMPS
     const unsigned long long d0 = __builtin_readcyclecounter();
 #endif
-    drain(0, TSA_ITEMS, npass - 1);
-    if (side)
-        for (int sc = total * side_per; sc < SIDE_N; ++sc) {     // what the K-steps did not cover (short GEMMs only)
-            side_read(0, sc);
-            __builtin_amdgcn_raw_buffer_store_b128(sv[0], rsS, svo[0], 0, 0);
-        }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef TSA_STAMPS
@@ -386,18 +387,20 @@ __global__ __launch_bounds__(512) void tsa_fwd_kernel(TsaParams p) {
 #pragma unroll
         for (int i = 0; i < TSA_MBW; ++i) if (p.T > 0) rowoff[i] = TSA_OOB;
 #endif
-        tsa_band_gemm<T, KB>(IMG, BST, p.wqkv, p.wqkv_bytes, N3, tid, p.qkv, p.x_bytes * 3, rowoff,
-                             [&](int, tsa_u4 (&)[TSA_NG][TSA_MBW]) __attribute__((always_inline)) {},
-                             [&](int, f32x4 (&acc)[TSA_NG][2][TSA_MBW], tsa_u4 (&pend)[TSA_NG][TSA_MBW]) __attribute__((always_inline)) {
+        __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(p.qkv, 0, p.x_bytes * 3, 0x00020000);
+        tsa_band_gemm<T, KB>(IMG, BST, p.wqkv, p.wqkv_bytes, N3, tid, [&](int) __attribute__((always_inline)) {},
+                             [&](int pass, f32x4 (&acc)[TSA_NG][2][TSA_MBW]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int g = 0; g < TSA_NG; ++g)
+            for (int g = 0; g < TSA_NG; ++g) {
+                const int n = pass * TSA_PW + (g * 4 + (wave & 3)) * 32 + fg * 8;
 #pragma unroll
                 for (int i = 0; i < TSA_MBW; ++i) {
                     const float f[8] = {acc[g][0][i][0], acc[g][0][i][1], acc[g][0][i][2], acc[g][0][i][3],
                                         acc[g][1][i][0], acc[g][1][i][1], acc[g][1][i][2], acc[g][1][i][3]};
-                    pend[g][i] = tsa_pack8<T>(f);
+                    __builtin_amdgcn_raw_buffer_store_b128(tsa_pack8<T>(f), rsQ, n < N3 ? rowoff[i] + n * 2 : TSA_OOB, 0, 0);
                 }
-        }, p.n1, R, grow TSA_WAIT2);
+            }
+        }, p.n1, p.x_bytes, R, grow TSA_WAIT2);
     }
     TSA_STAMP(3);
     // every wave's q/k/v stores are complete (vmcnt(0) before the last barrier) and visible to the other waves of this CU
@@ -511,19 +514,21 @@ __global__ __launch_bounds__(512) void tsa_fwd_kernel(TsaParams p) {
 #pragma unroll
         for (int i = 0; i < TSA_MBW; ++i) rowoff[i] = growr[i] >= 0 ? growr[i] * C * 2 : TSA_OOB;
         __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
-        tsa_band_gemm<T, KB>(IMG, BST, p.wo, p.wo_bytes, C, tid, p.h1, p.x_bytes, rowoff,
-                             [&](int pass, tsa_u4 (&pend)[TSA_NG][TSA_MBW]) __attribute__((always_inline)) {
-            // the residual rows of this pass travel into `pend` while the pass's last K-step runs (buffer loads: rows of the
-            // padding and columns beyond C read zeros)
+        __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(p.h1, 0, p.x_bytes, 0x00020000);
+        tsa_u4 r8[TSA_NG][TSA_MBW];
+        tsa_band_gemm<T, KB>(IMG, BST, p.wo, p.wo_bytes, C, tid,
+                             [&](int pass) __attribute__((always_inline)) {
+            // the residual rows of this pass travel while its last K-step runs (buffer loads: rows of the padding and columns beyond
+            // C read zeros)
 #pragma unroll
             for (int g = 0; g < TSA_NG; ++g) {
                 const int n = pass * TSA_PW + (g * 4 + (wave & 3)) * 32 + fg * 8;
 #pragma unroll
                 for (int i = 0; i < TSA_MBW; ++i)
-                    pend[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, n < C ? rowoff[i] + n * 2 : TSA_OOB, 0, 0);
+                    r8[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, n < C ? rowoff[i] + n * 2 : TSA_OOB, 0, 0);
             }
         },
-                             [&](int pass, f32x4 (&acc)[TSA_NG][2][TSA_MBW], tsa_u4 (&pend)[TSA_NG][TSA_MBW]) __attribute__((always_inline)) {
+                             [&](int pass, f32x4 (&acc)[TSA_NG][2][TSA_MBW]) __attribute__((always_inline)) {
             int nb[TSA_NG];
 #pragma unroll
             for (int g = 0; g < TSA_NG; ++g) nb[g] = pass * TSA_PW + (g * 4 + (wave & 3)) * 32 + fg * 8;
@@ -544,16 +549,16 @@ __global__ __launch_bounds__(512) void tsa_fwd_kernel(TsaParams p) {
                         rv4[g][e] = rv ? *reinterpret_cast<const float4*>(rv + min(nb[g], C - 8) + 4 * e) : float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < TSA_NG; ++g) {
-                    const Vec8<T> rr = __builtin_bit_cast(Vec8<T>, pend[g][i]);
+                    const Vec8<T> rr = __builtin_bit_cast(Vec8<T>, r8[g][i]);
                     const float add[8] = {bb[g][0].x + rv4[g][0].x, bb[g][0].y + rv4[g][0].y, bb[g][0].z + rv4[g][0].z, bb[g][0].w + rv4[g][0].w,
                                           bb[g][1].x + rv4[g][1].x, bb[g][1].y + rv4[g][1].y, bb[g][1].z + rv4[g][1].z, bb[g][1].w + rv4[g][1].w};
                     float o[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = acc[g][e >> 2][i][e & 3] + add[e] + to_f<T>(rr.v[e]);
-                    pend[g][i] = tsa_pack8<T>(o);
+                    __builtin_amdgcn_raw_buffer_store_b128(tsa_pack8<T>(o), rsH, nb[g] < C ? rowoff[i] + nb[g] * 2 : TSA_OOB, 0, 0);
                 }
             }
-        }, p.o, R, grow TSA_WAIT4);
+        }, p.o, p.x_bytes, R, grow TSA_WAIT4);
     }
     TSA_STAMP(5);
 #ifdef TSA_STAMPS
