@@ -2,11 +2,17 @@
 (/root/reference/train_svd.py:283-291, called at :948 and :959-960) = the ENCODER half of diffusers'
 `AutoencoderKLTemporalDecoder` + `DiagonalGaussianDistribution.sample()` x `scaling_factor`.
 
-TEST INFRASTRUCTURE ONLY (see oracle/unet.py header).  GROUNDWORK for SURVEY.md section 8(f) rank 1: there is no product
-counterpart in svd_xtend_amd/ yet.  PARITY UNPINNED: diffusers is not installed here; the encoder is restated from the
-published module (diffusers.models.autoencoders.vae.Encoder with DownEncoderBlock2D x4, UNetMidBlock2D with one single-head
-attention, `quant_conv`), self-pinned only structurally (tests/test_oracle_vae.py): the diffusers state-dict key set and
-the parameter count of the SD / SVD VAE encoder (34,163,592 + 72 for quant_conv).
+TEST INFRASTRUCTURE ONLY (see oracle/unet.py header); the product counterpart is svd_xtend_amd/vae.py.  PARITY UNPINNED: diffusers
+is not installed here; the encoder is restated from the published module (diffusers.models.autoencoders.vae.Encoder with
+DownEncoderBlock2D x4, UNetMidBlock2D with one single-head attention, `quant_conv`), self-pinned only structurally
+(tests/test_oracle_vae.py): the diffusers state-dict key set and the parameter count of the SD / SVD VAE encoder (34,163,592 + 72
+for quant_conv).  tests/test_diffusers_pin.py compares it with the installed class the day diffusers is importable.
+
+The second half of the file is the TEMPORAL DECODER (`vae.decode(z, num_frames)`), the last stage of the validation sampler
+(/root/reference/train_svd.py:1106-1137 through StableVideoDiffusionPipeline.decode_latents): restated from
+diffusers 0.26 `autoencoder_kl_temporal_decoder.TemporalDecoder` (MidBlockTemporalDecoder / UpBlockTemporalDecoder built from
+`SpatioTemporalResBlock(temb_channels=None, eps=1e-6, temporal_eps=1e-5, merge_strategy="learned", merge_factor=0.0,
+switch_spatial_to_temporal_mix=True)`, a Conv3d (3,1,1) `time_conv_out` after `conv_out`).  Equally unpinned.
 
 Module / parameter names are diffusers' (`encoder.down_blocks.0.resnets.0.norm1.weight`, `encoder.mid_block.attentions.0.to_q.weight`,
 `quant_conv.weight`, ...), so `state_dict()` keys match the `encoder.*` / `quant_conv.*` subset of a real SVD `vae/` checkpoint.
@@ -151,3 +157,141 @@ def tensor_to_vae_latent(t: torch.Tensor, vae: VaeEncoderOracle, generator: Opti
     b, f = t.shape[:2]
     z = vae.sample(t.reshape(b * f, *t.shape[2:]), generator)
     return z.reshape(b, f, *z.shape[1:]) * vae.scaling_factor
+
+
+# --------------------------------------------------------------------------------------------------------------------------------
+# temporal decoder (diffusers.models.autoencoders.autoencoder_kl_temporal_decoder.TemporalDecoder)
+# --------------------------------------------------------------------------------------------------------------------------------
+class TemporalResnetBlock(nn.Module):
+    """diffusers.models.resnet.TemporalResnetBlock(temb_channels=None): GroupNorm over (C/32, T, H, W), Conv3d (3,1,1), SiLU,
+    identity shortcut (in == out everywhere in the decoder)."""
+
+    def __init__(self, c: int, eps: float):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(32, c, eps=eps)
+        self.conv1 = nn.Conv3d(c, c, (3, 1, 1), padding=(1, 0, 0))
+        self.norm2 = nn.GroupNorm(32, c, eps=eps)
+        self.conv2 = nn.Conv3d(c, c, (3, 1, 1), padding=(1, 0, 0))
+
+    def forward(self, x):                                  # [b, c, t, h, w]
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv2(F.silu(self.norm2(h)))
+        return x + h
+
+
+class LearnedBlender(nn.Module):
+    """AlphaBlender(alpha=0.0, merge_strategy="learned", switch_spatial_to_temporal_mix=True): alpha = 1 - sigmoid(mix_factor)."""
+
+    def __init__(self):
+        super().__init__()
+        self.mix_factor = nn.Parameter(torch.tensor([0.0]))
+
+    def forward(self, x_spatial, x_temporal):
+        alpha = 1.0 - torch.sigmoid(self.mix_factor)
+        return alpha * x_spatial + (1.0 - alpha) * x_temporal
+
+
+class SpatioTemporalResBlockDec(nn.Module):
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.spatial_res_block = ResnetBlock2D(cin, cout, eps=1e-6)
+        self.temporal_res_block = TemporalResnetBlock(cout, eps=1e-5)
+        self.time_mixer = LearnedBlender()
+
+    def forward(self, x, num_frames: int):                 # [b*t, c, h, w]
+        x = self.spatial_res_block(x)
+        bt, c, h, w = x.shape
+        x5 = x.reshape(bt // num_frames, num_frames, c, h, w).permute(0, 2, 1, 3, 4)
+        out = self.time_mixer(x5, self.temporal_res_block(x5))
+        return out.permute(0, 2, 1, 3, 4).reshape(bt, c, h, w)
+
+
+class MidBlockTemporalDecoder(nn.Module):
+    def __init__(self, c: int, layers: int):
+        super().__init__()
+        self.attentions = nn.ModuleList([Attention(c)])
+        self.resnets = nn.ModuleList([SpatioTemporalResBlockDec(c, c) for _ in range(layers)])
+
+    def forward(self, x, num_frames: int):
+        x = self.resnets[0](x, num_frames)
+        for resnet, attn in zip(self.resnets[1:], self.attentions):
+            x = resnet(attn(x), num_frames)
+        return x
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, c: int):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class UpBlockTemporalDecoder(nn.Module):
+    def __init__(self, cin: int, cout: int, layers: int, add_upsample: bool):
+        super().__init__()
+        self.resnets = nn.ModuleList([SpatioTemporalResBlockDec(cin if i == 0 else cout, cout) for i in range(layers)])
+        if add_upsample:
+            self.upsamplers = nn.ModuleList([Upsample2D(cout)])
+
+    def forward(self, x, num_frames: int):
+        for r in self.resnets:
+            x = r(x, num_frames)
+        if hasattr(self, "upsamplers"):
+            x = self.upsamplers[0](x)
+        return x
+
+
+class TemporalDecoder(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, block_out_channels: Sequence[int], layers_per_block: int):
+        super().__init__()
+        ch = list(block_out_channels)
+        self.conv_in = nn.Conv2d(in_channels, ch[-1], 3, padding=1)
+        self.mid_block = MidBlockTemporalDecoder(ch[-1], layers_per_block)
+        self.up_blocks = nn.ModuleList()
+        rev = ch[::-1]
+        cout = rev[0]
+        for i, c in enumerate(rev):
+            cin, cout = cout, c
+            self.up_blocks.append(UpBlockTemporalDecoder(cin, cout, layers_per_block + 1, add_upsample=i != len(ch) - 1))
+        self.conv_norm_out = nn.GroupNorm(32, ch[0], eps=1e-6)
+        self.conv_out = nn.Conv2d(ch[0], out_channels, 3, padding=1)
+        self.time_conv_out = nn.Conv3d(out_channels, out_channels, (3, 1, 1), padding=(1, 0, 0))
+
+    def forward(self, z, num_frames: int):                 # [b*t, latent, h, w] -> [b*t, out, 8h, 8w]
+        x = self.conv_in(z)
+        x = self.mid_block(x, num_frames)
+        for blk in self.up_blocks:
+            x = blk(x, num_frames)
+        x = self.conv_out(F.silu(self.conv_norm_out(x)))
+        bt, c, h, w = x.shape
+        x5 = x.reshape(bt // num_frames, num_frames, c, h, w).permute(0, 2, 1, 3, 4)
+        x5 = self.time_conv_out(x5)
+        return x5.permute(0, 2, 1, 3, 4).reshape(bt, c, h, w)
+
+
+class VaeOracle(VaeEncoderOracle):
+    """The whole `AutoencoderKLTemporalDecoder` under diffusers' key names (`encoder.*`, `decoder.*`, `quant_conv.*`): `decode(z,
+    num_frames)` as the class does it (image_only_indicator is all-zero and unused by the "learned" blender)."""
+
+    def __init__(self, in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                 scaling_factor=0.18215):
+        super().__init__(in_channels, latent_channels, block_out_channels, layers_per_block, scaling_factor)
+        self.decoder = TemporalDecoder(latent_channels, out_channels, block_out_channels, layers_per_block)
+
+    def decode(self, z, num_frames: int):
+        return self.decoder(z, num_frames)
+
+
+def decode_latents(latents: torch.Tensor, vae: VaeOracle, num_frames: int, decode_chunk_size: int = 14) -> torch.Tensor:
+    """StableVideoDiffusionPipeline.decode_latents: [b, f, 4, h, w] latents -> [b, 3, f, 8h, 8w] float frames; the decoder sees
+    chunks of `decode_chunk_size` frames, each chunk as ONE clip of that many frames (that is what the pipeline does)."""
+    b = latents.shape[0]
+    latents = latents.flatten(0, 1) / vae.scaling_factor
+    frames = []
+    for i in range(0, latents.shape[0], decode_chunk_size):
+        chunk = latents[i:i + decode_chunk_size]
+        frames.append(vae.decode(chunk, chunk.shape[0]))
+    frames = torch.cat(frames, dim=0)
+    return frames.reshape(b, num_frames, *frames.shape[1:]).permute(0, 2, 1, 3, 4).float()

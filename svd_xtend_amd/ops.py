@@ -734,8 +734,10 @@ class ConvOp:
         return h, w
 
     def fwd(self, rt: Runtime, x: torch.Tensor, n_img: int, h: int, w: int, T: int = 0,
-            res: Optional[torch.Tensor] = None, rowvec=None, rv_ld=0, rv_rpg=0, ldc: Optional[int] = None):
-        """x: [n_img*h*w, cin_p] (t3: n_img = B, rows = B*T*h*w).  Returns ([M, cout], ho, wo)."""
+            res: Optional[torch.Tensor] = None, rowvec=None, rv_ld=0, rv_rpg=0, ldc: Optional[int] = None,
+            out: Optional[torch.Tensor] = None):
+        """x: [n_img*h*w, cin_p] (t3: n_img = B, rows = B*T*h*w).  Returns ([M, cout], ho, wo); `out` [M, ldc]: write the cout
+        columns into the caller's (wider) rows instead of a fresh tensor."""
         ho, wo = self.out_hw(h, w)
         if self.kind == "t3":
             M = n_img * T * h * w
@@ -744,7 +746,7 @@ class ConvOp:
             M = n_img * ho * wo
             g = self._gather(n_img, ho if self.ups else h, wo if self.ups else w, ho, wo, self.cin_p, self.cin_p)
         ldc = ldc or self.cout
-        y = rt.empty(M, ldc)
+        y = out if out is not None else rt.empty(M, ldc)
         Kd = self.taps * self.cin_p
         gemm_act(rt, x, self.w, y, M, self.cout, Kd, self.cin_p, Kd, ldc, bias=self.b, rowvec=rowvec, rv_ld=rv_ld,
                  rv_rpg=rv_rpg, res=res, ldres=self.cout if res is not None else 0, gather=g)

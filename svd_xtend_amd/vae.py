@@ -5,7 +5,7 @@ conditioning frame (:957-960); the VAE is frozen (:659) and loaded from `<model>
 Same surface as the diffusers class for what the train script touches: `from_pretrained(path, subfolder="vae", variant=...)`,
 `.config.scaling_factor`, `.requires_grad_(False)`, `.to(device, dtype=...)`, `vae.encode(x).latent_dist.sample()` /
 `.mode()` / `.mean` / `.logvar`; diffusers state-dict keys (`encoder.*`, `quant_conv.*`; the `decoder.*` half of a checkpoint is
-skipped -- the training step never decodes).  The arithmetic is libsvdx kernel launches on channels-last rows [n*h*w, C]:
+loaded too: the validation sampler decodes).  The arithmetic is libsvdx kernel launches on channels-last rows [n*h*w, C]:
 
   conv_in (3 -> C0)          svdx_patch_rows (im2col of the 3-channel image, K = 27 padded to 64) + plain GEMM
   ResnetBlock2D              svdx_gn_stats/apply (+SiLU), implicit-GEMM 3x3 convs, the 1x1 shortcut / identity as the GEMM residual
@@ -15,7 +15,15 @@ skipped -- the training step never decodes).  The arithmetic is libsvdx kernel l
   conv_out + quant_conv      ONE 3x3 conv: the 1x1 `quant_conv` is folded into conv_out's weights at prepare() (exact: both linear)
 
 Forward only (no gradients exist on this path).  Frames are processed in chunks that keep every operand below the 2 GiB range of
-the GEMM's buffer addressing (51 frames at 512x320, 14 at 1024x576)."""
+the GEMM's buffer addressing (51 frames at 512x320, 14 at 1024x576).
+
+The TEMPORAL DECODER half (`vae.decode(z, num_frames)`) is the last stage of the validation sampler (train_svd.py:1106-1137 through
+StableVideoDiffusionPipeline.decode_latents; svd_xtend_amd/pipeline.py): diffusers' `TemporalDecoder` --
+conv_in, a mid block (SpatioTemporalResBlock, single-head attention, SpatioTemporalResBlock), four up blocks of three
+SpatioTemporalResBlocks (+ nearest-x2 upsample folded into the following conv's gather), GroupNorm + SiLU + conv_out, and the
+Conv3d (3,1,1) `time_conv_out`.  A SpatioTemporalResBlock here has no time embedding and a "learned" AlphaBlender with
+`switch_spatial_to_temporal_mix`: out = s + sigmoid(mix_factor) * H(s) with s the spatial resnet's output and H the temporal
+resnet's residual branch -- the factor is folded into the temporal conv2 weights at prepare() (as in the UNet's resnets)."""
 from __future__ import annotations
 
 import json
@@ -142,6 +150,100 @@ class _Encoder(nn.Module):
         self.conv_out = nn.Conv2d(ch[-1], 2 * latent_channels, 3, padding=1)
 
 
+class _TemporalResnet(nn.Module):
+    """diffusers TemporalResnetBlock(temb_channels=None): 3-D GroupNorm (a clip is one sample of T*h*w rows), Conv3d (3,1,1)."""
+
+    def __init__(self, c: int, eps: float):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(32, c, eps=eps)
+        self.conv1 = nn.Conv3d(c, c, (3, 1, 1), padding=(1, 0, 0))
+        self.norm2 = nn.GroupNorm(32, c, eps=eps)
+        self.conv2 = nn.Conv3d(c, c, (3, 1, 1), padding=(1, 0, 0))
+
+    def build(self, rt: Runtime, out_scale: float) -> None:
+        self.gn1, self.gn2 = GroupNormOp(self.norm1, True), GroupNormOp(self.norm2, True)
+        self.c1 = ConvOp(self.conv1.weight, self.conv1.bias, "t3")
+        self.c2 = ConvOp(self.conv2.weight, self.conv2.bias, "t3")
+        self.c1.pack(rt, need_dx=False)
+        self.c2.pack(rt, need_dx=False, out_scale=out_scale)
+
+    def fwd(self, rt: Runtime, x, B: int, T: int, h: int, w: int):
+        a, _ = self.gn1.fwd(rt, x, B, T * h * w)
+        y, _, _ = self.c1.fwd(rt, a, B, h, w, T=T)
+        a, _ = self.gn2.fwd(rt, y, B, T * h * w)
+        return self.c2.fwd(rt, a, B, h, w, T=T, res=x)[0]
+
+
+class _Mixer(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.mix_factor = nn.Parameter(torch.tensor([0.0]))
+
+
+class _STResBlock(nn.Module):
+    """SpatioTemporalResBlock(temb_channels=None, eps=1e-6, temporal_eps=1e-5, merge_strategy="learned", merge_factor=0.0,
+    switch_spatial_to_temporal_mix=True)."""
+
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.spatial_res_block = _Resnet(cin, cout)
+        self.temporal_res_block = _TemporalResnet(cout, 1e-5)
+        self.time_mixer = _Mixer()
+
+    def build(self, rt: Runtime) -> None:
+        self.spatial_res_block.build(rt)
+        # alpha = 1 - sigmoid(mix): out = alpha s + (1 - alpha)(s + H(s)) = s + sigmoid(mix) H(s)
+        self.temporal_res_block.build(rt, float(torch.sigmoid(self.time_mixer.mix_factor.data.float()).item()))
+
+    def fwd(self, rt: Runtime, x, B: int, T: int, h: int, w: int):
+        s = self.spatial_res_block.fwd(rt, x, B * T, h, w)
+        return self.temporal_res_block.fwd(rt, s, B, T, h, w)
+
+
+class _Upsample(nn.Module):
+    def __init__(self, c: int):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+    def build(self, rt: Runtime) -> None:
+        self.op = ConvOp(self.conv.weight, self.conv.bias, "3x3", ups=True)
+        self.op.pack(rt, need_dx=False)
+
+
+class _MidBlockDec(nn.Module):
+    def __init__(self, c: int, layers: int):
+        super().__init__()
+        self.attentions = nn.ModuleList([_Attention(c)])
+        self.resnets = nn.ModuleList([_STResBlock(c, c) for _ in range(layers)])
+
+
+class _UpBlockDec(nn.Module):
+    def __init__(self, cin: int, cout: int, layers: int, add_upsample: bool):
+        super().__init__()
+        self.resnets = nn.ModuleList([_STResBlock(cin if i == 0 else cout, cout) for i in range(layers)])
+        if add_upsample:
+            self.upsamplers = nn.ModuleList([_Upsample(cout)])
+
+
+class _Decoder(nn.Module):
+    """diffusers.models.autoencoders.autoencoder_kl_temporal_decoder.TemporalDecoder."""
+
+    def __init__(self, in_channels: int, out_channels: int, block_out_channels: Sequence[int], layers_per_block: int):
+        super().__init__()
+        ch = list(block_out_channels)
+        self.conv_in = nn.Conv2d(in_channels, ch[-1], 3, padding=1)
+        self.mid_block = _MidBlockDec(ch[-1], layers_per_block)
+        self.up_blocks = nn.ModuleList()
+        rev = ch[::-1]
+        cout = rev[0]
+        for i, c in enumerate(rev):
+            cin, cout = cout, c
+            self.up_blocks.append(_UpBlockDec(cin, cout, layers_per_block + 1, add_upsample=i != len(ch) - 1))
+        self.conv_norm_out = nn.GroupNorm(32, ch[0], eps=1e-6)
+        self.conv_out = nn.Conv2d(ch[0], out_channels, 3, padding=1)
+        self.time_conv_out = nn.Conv3d(out_channels, out_channels, (3, 1, 1), padding=(1, 0, 0))
+
+
 class DiagonalGaussianDistribution:
     """diffusers.models.autoencoders.vae.DiagonalGaussianDistribution over moments given as (mean, logvar) [n, c, h, w] floats."""
 
@@ -174,6 +276,7 @@ class AutoencoderKLTemporalDecoder(nn.Module):
                                    block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
                                    scaling_factor=scaling_factor, **other)
         self.encoder = _Encoder(in_channels, latent_channels, block_out_channels, layers_per_block)
+        self.decoder = _Decoder(latent_channels, out_channels, block_out_channels, layers_per_block)
         self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
         self.rt: Optional[Runtime] = None
         self._requested_dtype = None
@@ -181,8 +284,8 @@ class AutoencoderKLTemporalDecoder(nn.Module):
     # ---- loading ------------------------------------------------------------------------------------------------------
     @classmethod
     def from_pretrained(cls, path, subfolder: Optional[str] = None, variant: Optional[str] = None, torch_dtype=None, **unused):
-        """`<path>/<subfolder>/config.json` + `diffusion_pytorch_model[.<variant>].safetensors` (train_svd.py:649-650); decoder keys
-        are ignored, encoder / quant_conv keys are loaded strictly."""
+        """`<path>/<subfolder>/config.json` + `diffusion_pytorch_model[.<variant>].safetensors` (train_svd.py:649-650), loaded
+        strictly (encoder, decoder, quant_conv)."""
         from safetensors.torch import load_file
         folder = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(folder, CONFIG_NAME)) as f:
@@ -191,7 +294,7 @@ class AutoencoderKLTemporalDecoder(nn.Module):
         wpath = os.path.join(folder, WEIGHTS_NAME.format(variant=f".{variant}" if variant else ""))
         if not os.path.exists(wpath) and variant:
             wpath = os.path.join(folder, WEIGHTS_NAME.format(variant=""))
-        sd = {k: v.float() for k, v in load_file(wpath).items() if k.startswith(("encoder.", "quant_conv."))}
+        sd = {k: v.float() for k, v in load_file(wpath).items()}
         model.load_state_dict(sd, strict=True)
         if torch_dtype is not None and torch_dtype != torch.float32:
             model._requested_dtype = torch_dtype
@@ -234,7 +337,38 @@ class AutoencoderKLTemporalDecoder(nn.Module):
         self._folded = (nn.Parameter(Wf.contiguous(), requires_grad=False), nn.Parameter(bf.contiguous(), requires_grad=False))
         self.c_out = ConvOp(self._folded[0], self._folded[1], "3x3")
         self.c_out.pack(rt, need_dx=False)
+        self._prepare_decoder(rt)
         return self
+
+    def _prepare_decoder(self, rt: Runtime) -> None:
+        dec, dev = self.decoder, rt.dev
+        self.zpad = 64                                             # latent channels zero-padded to the K granule of the gather
+        self.d_in = ConvOp(dec.conv_in.weight, dec.conv_in.bias, "3x3", cin_pad=self.zpad)
+        self.d_in.pack(rt, need_dx=False)
+        for r in dec.mid_block.resnets:
+            r.build(rt)
+        dec.mid_block.attentions[0].build(rt)
+        for blk in dec.up_blocks:
+            for r in blk.resnets:
+                r.build(rt)
+            if hasattr(blk, "upsamplers"):
+                blk.upsamplers[0].build(rt)
+        self.d_gn_out = GroupNormOp(dec.conv_norm_out, True)
+        # conv_out (C0 -> 3) and time_conv_out (3 -> 3 over frames): output channels padded to 8 with zero filters; conv_out writes
+        # its 8 columns into zeroed 64-wide rows, the input pitch of the temporal conv's gather
+        co, c0 = self.config.out_channels, self.config.block_out_channels[0]
+        self.opad = 8
+        w = torch.zeros(self.opad, c0, 3, 3, dtype=torch.float32, device=dev)
+        b = torch.zeros(self.opad, dtype=torch.float32, device=dev)
+        w[:co], b[:co] = dec.conv_out.weight.data.float(), dec.conv_out.bias.data.float()
+        wt = torch.zeros(self.opad, co, 3, 1, 1, dtype=torch.float32, device=dev)
+        bt = torch.zeros(self.opad, dtype=torch.float32, device=dev)
+        wt[:co], bt[:co] = dec.time_conv_out.weight.data.float(), dec.time_conv_out.bias.data.float()
+        self._dec_padded = [nn.Parameter(t, requires_grad=False) for t in (w, b, wt, bt)]
+        self.d_out = ConvOp(self._dec_padded[0], self._dec_padded[1], "3x3")
+        self.d_out.pack(rt, need_dx=False)
+        self.d_tout = ConvOp(self._dec_padded[2], self._dec_padded[3], "t3", cin_pad=self.zpad)
+        self.d_tout.pack(rt, need_dx=False)
 
     # ---- forward ------------------------------------------------------------------------------------------------------
     def _moments_rows(self, x: torch.Tensor):
@@ -294,8 +428,57 @@ class AutoencoderKLTemporalDecoder(nn.Module):
             return (dist,)
         return SimpleNamespace(latent_dist=dist)
 
-    def decode(self, *a, **k):
-        raise NotImplementedError("the temporal decoder is not on the training path (train_svd.py only encodes inside the step)")
+    def max_decode_frames(self, h: int, w: int) -> int:
+        """Frames per `decode` call that keep the largest decoder activation (the upsampled input of the last up block, or the
+        64-wide rows in front of `time_conv_out`) inside the 2 GiB reach of the GEMM's 32-bit buffer offsets."""
+        ch = self.config.block_out_channels
+        s = 2 ** (len(ch) - 1)
+        per = max(ch[1] * (h * s) * (w * s), ch[-1] * (h * s // 2) * (w * s // 2), 64 * (h * s) * (w * s)) * 2
+        return max(1, (2 ** 31 - 1) // per)
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, num_frames: int = 1, image_only_indicator=None, return_dict: bool = True):
+        """z [b*num_frames, latent_channels, h, w] (already divided by `scaling_factor`, as the pipeline does) -> `.sample`
+        [b*num_frames, out_channels, 8h, 8w] floats.  `image_only_indicator` is accepted and unused: the decoder's blenders are
+        "learned", not "learned_with_images"."""
+        if self.rt is None:
+            self.prepare()
+        rt, dec = self.rt, self.decoder
+        k = rt.k
+        if z.ndim != 4 or z.shape[1] != self.config.latent_channels or z.shape[0] % num_frames:
+            raise ValueError(f"expected [b*{num_frames}, {self.config.latent_channels}, h, w], got {tuple(z.shape)}")
+        n, zc, h, w = z.shape
+        if n > self.max_decode_frames(h, w):
+            raise ValueError(f"decode at most {self.max_decode_frames(h, w)} frames of {h}x{w} latents per call (decode_chunk_size)")
+        B, T = n // num_frames, num_frames
+        rt.begin_pass(0)
+        x0 = rt.empty(n * h * w, self.zpad)
+        k.nchw_to_rows(z.to(device=rt.dev, dtype=torch.float32).contiguous(), x0, n, zc, h, w, self.zpad, 1.0)
+        y, _, _ = self.d_in.fwd(rt, x0, n, h, w)
+        del x0
+        mid = dec.mid_block
+        y = mid.resnets[0].fwd(rt, y, B, T, h, w)
+        for resnet, attn in zip(mid.resnets[1:], mid.attentions):
+            y = attn.fwd(rt, y, n, h, w)
+            y = resnet.fwd(rt, y, B, T, h, w)
+        for blk in dec.up_blocks:
+            for r in blk.resnets:
+                y = r.fwd(rt, y, B, T, h, w)
+            if hasattr(blk, "upsamplers"):
+                y, h, w = blk.upsamplers[0].op.fwd(rt, y, n, h, w)
+        a, _ = self.d_gn_out.fwd(rt, y, n, h * w)
+        del y
+        rows = rt.empty(n * h * w, self.zpad)
+        k.zero(rows)
+        self.d_out.fwd(rt, a, n, h, w, ldc=self.zpad, out=rows)
+        del a
+        out_rows, _, _ = self.d_tout.fwd(rt, rows, B, h, w, T=T)    # [n*h*w, 8]
+        co = self.config.out_channels
+        out = torch.empty(n, co, h, w, dtype=torch.float32, device=rt.dev)
+        k.rows_to_nchw(out_rows, out, n, co, h, w, self.opad)
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)
 
 
 def tensor_to_vae_latent(t: torch.Tensor, vae: AutoencoderKLTemporalDecoder, generator: Optional[torch.Generator] = None) -> torch.Tensor:

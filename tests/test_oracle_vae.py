@@ -4,7 +4,7 @@ keys, and each non-standard piece against an independent formulation."""
 import torch
 import torch.nn.functional as F
 
-from oracle.vae import SVD_VAE_CONFIG, TINY_VAE_CONFIG, Attention, Downsample2D, VaeEncoderOracle, tensor_to_vae_latent
+from oracle.vae import SVD_VAE_CONFIG, TINY_VAE_CONFIG, Attention, Downsample2D, VaeEncoderOracle, VaeOracle, tensor_to_vae_latent
 
 
 def test_svd_vae_encoder_parameter_count_and_keys():

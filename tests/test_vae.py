@@ -1,10 +1,11 @@
 """the VAE-encode step before the UNet (`tensor_to_vae_latent`, /root/reference/train_svd.py:283-291, :948,
-:957-960) on the HIP path (svd_xtend_amd/vae.py) against the oracle's restatement of diffusers' encoder (oracle/vae.py).
+:957-960) on the HIP path (svd_xtend_amd/vae.py) against the oracle's restatement of diffusers' encoder (oracle/vae.py); and the
+temporal decoder behind the validation sampler (8(f) rank 4, train_svd.py:1106-1137) against the oracle's TemporalDecoder.
 CPU tests run the host orchestration on the fp32 emulation of the C-ABI; `-m gpu` tests run the real kernels."""
 import pytest
 import torch
 
-from oracle.vae import SVD_VAE_CONFIG, VaeEncoderOracle
+from oracle.vae import SVD_VAE_CONFIG, VaeOracle, decode_latents
 from svd_xtend_amd.vae import AutoencoderKLTemporalDecoder, tensor_to_vae_latent
 
 gpu = pytest.mark.gpu
@@ -12,11 +13,13 @@ SMALL = dict(in_channels=3, latent_channels=4, block_out_channels=(64, 128, 128,
 
 
 def make_pair(cfg, seed, dev="cpu"):
-    orc = VaeEncoderOracle(**cfg)
+    orc = VaeOracle(**cfg)
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for n, p in orc.named_parameters():
-            if p.ndim == 1:
+            if n.endswith("mix_factor"):
+                p.copy_(torch.randn(p.shape, generator=g))            # sigmoid(mix) away from the 0.5 of a fresh blender
+            elif p.ndim == 1:
                 p.copy_((1.0 if "norm" in n and n.endswith("weight") else 0.0) + 0.1 * torch.randn(p.shape, generator=g))
             else:
                 p.copy_(torch.randn(p.shape, generator=g) * (1.0 / p[0].numel()) ** 0.5)
@@ -30,11 +33,14 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
-def test_state_dict_keys_are_diffusers_encoder_keys():
-    orc = VaeEncoderOracle(**SMALL)
+def test_state_dict_keys_are_diffusers_keys():
+    orc = VaeOracle(**SMALL)
     vae = AutoencoderKLTemporalDecoder(**SMALL)
-    assert list(vae.state_dict().keys()) == list(orc.state_dict().keys())
-    assert sum(p.numel() for p in AutoencoderKLTemporalDecoder(**SVD_VAE_CONFIG).parameters()) == 34_163_592 + 72
+    assert sorted(vae.state_dict().keys()) == sorted(orc.state_dict().keys())
+    assert {k: tuple(v.shape) for k, v in vae.state_dict().items()} == {k: tuple(v.shape) for k, v in orc.state_dict().items()}
+    full = AutoencoderKLTemporalDecoder(**SVD_VAE_CONFIG)
+    assert sum(p.numel() for n, p in full.named_parameters() if not n.startswith("decoder.")) == 34_163_592 + 72
+    assert sum(p.numel() for p in full.parameters()) == 97_742_847            # the SVD `vae/` checkpoint
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 48), (1, 40, 24)])       # 40x24 -> 5x3 = 15 tokens: padded attention reduction
@@ -75,13 +81,44 @@ def test_from_pretrained_reads_a_diffusers_vae_folder(tmp_path, emu_backend):
     folder = tmp_path / "vae"
     folder.mkdir()
     sd = {k: v.half().contiguous() for k, v in orc.state_dict().items()}
-    sd["decoder.conv_in.weight"] = torch.zeros(4, 4, 3, 3, dtype=torch.float16)            # the decoder half is skipped
     save_file(sd, str(folder / "diffusion_pytorch_model.fp16.safetensors"))
     (folder / "config.json").write_text(json.dumps({"_class_name": "AutoencoderKLTemporalDecoder", "force_upcast": True, **SMALL}))
     v2 = AutoencoderKLTemporalDecoder.from_pretrained(str(tmp_path), subfolder="vae", variant="fp16")
     assert v2.config.scaling_factor == 0.18215 and v2.config.force_upcast is True
     for k, v in v2.state_dict().items():
         assert torch.equal(v, sd[k].float()), k
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 4, 6), (2, 2, 5, 3)])     # (clips, frames, latent h, w)
+def test_decoder_matches_oracle_on_the_emulated_kernels(emu_backend, shape):
+    B, T, h, w = shape
+    orc, vae = make_pair(SMALL, 11)
+    vae.prepare(torch.float32)
+    z = torch.randn(B * T, 4, h, w, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        want = orc.decode(z, T)
+    got = vae.decode(z, num_frames=T).sample
+    assert got.shape == (B * T, 3, 8 * h, 8 * w)
+    assert rel(got, want) <= 3e-5, rel(got, want)
+    # frames of different clips do not mix; frames of one clip do (the temporal convolutions)
+    if B == 2:
+        z2 = z.clone()
+        z2[T:] = torch.randn(T, 4, h, w, generator=torch.Generator().manual_seed(13))
+        assert torch.allclose(vae.decode(z2, num_frames=T).sample[:T], got[:T], atol=1e-6)
+
+
+def test_decode_latents_chunks_like_the_pipeline(emu_backend):
+    """StableVideoDiffusionPipeline.decode_latents: 1 / scaling_factor, chunks of decode_chunk_size frames each decoded as one clip."""
+    from svd_xtend_amd.pipeline import decode_latents as product_decode_latents
+    orc, vae = make_pair(SMALL, 14)
+    vae.prepare(torch.float32)
+    lat = torch.randn(1, 5, 4, 3, 4, generator=torch.Generator().manual_seed(15)) * 0.18215
+    with torch.no_grad():
+        want = decode_latents(lat, orc, 5, decode_chunk_size=2)
+    got = product_decode_latents(lat, vae, 5, decode_chunk_size=2)
+    assert got.shape == (1, 3, 5, 24, 32) and rel(got, want) <= 3e-5
+    with pytest.raises(ValueError):
+        vae.decode(torch.zeros(3, 4, 3, 4), num_frames=2)
 
 
 @gpu
@@ -113,3 +150,33 @@ def test_encoder_matches_oracle_at_the_svd_widths():
     r = (rel(d.mean.cpu(), mean), rel(d.logvar.cpu(), logvar))
     print("vae 512x320 fp16 rel-L2 (mean, logvar):", r)
     assert r[0] <= 1e-2 and r[1] <= 1e-2, r
+
+
+@gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_decoder_matches_oracle_small(dt):
+    dev = torch.device("cuda")
+    orc, vae = make_pair(SMALL, 11, dev)
+    vae.prepare(dt)
+    for (B, T, h, w) in [(1, 3, 4, 6), (2, 2, 5, 3), (1, 8, 8, 8)]:
+        z = torch.randn(B * T, 4, h, w, generator=torch.Generator().manual_seed(12))
+        with torch.no_grad():
+            want = orc.decode(z, T)
+        got = vae.decode(z.to(dev), num_frames=T).sample.cpu()
+        tol = 1e-2 if dt == torch.float16 else 6e-2
+        assert rel(got, want) <= tol, (B, T, h, w, rel(got, want))
+
+
+@gpu
+def test_decoder_matches_oracle_at_the_svd_widths():
+    """The real decoder (512 / 512 / 256 / 128 channels, 63.6 M parameters) on a 3-frame clip of 16x24 latents (128x192 pixels):
+    every GEMM has the real N / K, the temporal layers their three taps; fp16 against the fp32 oracle."""
+    dev = torch.device("cuda")
+    orc, vae = make_pair(SVD_VAE_CONFIG, 16, dev)
+    vae.prepare(torch.float16)
+    z = torch.randn(3, 4, 16, 24, generator=torch.Generator().manual_seed(17))
+    with torch.no_grad():
+        want = orc.decode(z, 3)
+    got = vae.decode(z.to(dev), num_frames=3).sample.cpu()
+    print("vae decoder 128x192 x3 fp16 rel-L2:", rel(got, want))
+    assert rel(got, want) <= 1e-2
