@@ -2,7 +2,7 @@
 `_resize_with_antialiasing` (:140-166, with its helpers :169-248) -> un-normalise -> CLIP normalisation -> CLIP vision tower
 -> `image_embeds`.
 
-TEST INFRASTRUCTURE ONLY (see oracle/unet.py header).  GROUNDWORK for SURVEY.md section 8(f) rank 2: no product counterpart yet.
+TEST INFRASTRUCTURE ONLY (see oracle/unet.py header); the product counterpart is svd_xtend_amd/clip.py.
 PINNED: the resize is checked against outputs of the reference's own functions (tests/golden/resize_antialias.safetensors, made by
 tests/golden/make_golden_resize.py, which executes the reference's function definitions from /root/reference/train_svd.py in this
 container); the vision tower is `transformers.CLIPVisionModelWithProjection` itself (installed here; the reference calls the same

@@ -84,6 +84,18 @@ __device__ __forceinline__ tsa_u4 tsa_pack8(const float (&f)[8]) {
 
 constexpr int TSA_OOB = (int)0x80000000;       // a buffer offset no descriptor of this kernel covers: loads give 0, stores are dropped
 
+// 16-byte buffer store followed by two wait states.  A gfx950 vector store of more than 8 bytes reads its data VGPRs a few clocks
+// AFTER it issues: a VALU / MFMA / LDS-return write to one of them in the next two issue slots lands in the stored data
+// (tools/probes/storewar_probe.hip: 23 % of the stores with no wait state, 0.4 % with one, none with two).  LLVM's hazard recognizer
+// inserts ONE wait state, and none at all when the store takes its scalar offset from an SGPR (GCNHazardRecognizer treats that
+// form as hazard-free) -- which is the form the image side copy uses: its first version put a v_xor of the data register right
+// behind the store and the saved `o` came out with a lane offset in place of a value in ~1 element per million.  So every wide store of
+// this kernel is issued through this wrapper (the nop sits among MFMAs: it costs nothing), and tests/test_store_hazard.py scans the
+// ISA of every kernel in the library for the pattern.
+__device__ __forceinline__ void tsa_store16(tsa_u4 v, __amdgpu_buffer_rsrc_t rs, int voffset, int soffset) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(voffset), "s"(rs), "s"(soffset) : "memory");
+}
+
 // out[rows of the band, N] = IMG[rows, K] * Bmat[N, K]^T.  A pass covers 256 columns = eight groups of 32; wave (h, cw) = (wave / 4,
 // wave % 4) owns row blocks h*5 .. h*5+4 (block 9 does not exist: skipped) x groups cw and cw + 4 (interleaved, so that a short last
 // pass still spreads over the waves).  A group is two MFMA column blocks whose weight rows are PERMUTED when they are DMA-ed into the
@@ -142,7 +154,7 @@ __device__ __forceinline__ void tsa_band_gemm(const char* IMG, char* BST, const 
     auto side_row = [&](int u) __attribute__((always_inline)) {  // u wave-uniform
         const int row = min(u, TSA_RP - 1);
         const tsa_u4 v = *reinterpret_cast<const tsa_u4*>(IMG + s_lds + row * 128 + (s_x ^ ((row & 7) * 16)));
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsS, u < R ? s_off : TSA_OOB, u < R ? grow(u) * (Kd * 2) : 0, 0);
+        tsa_store16(v, rsS, u < R ? s_off : TSA_OOB, u < R ? grow(u) * (Kd * 2) : 0);
     };
     const char* Ah = IMG + h * (TSA_MBW * 16 * 128) + fr * 128;
     const int ch0 = (fg ^ (fr & 7)) * 16, ch1 = ((4 + fg) ^ (fr & 7)) * 16;       // the lane's 16-byte chunk of the two 32-deep halves
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(512) void tsa_fwd_kernel(TsaParams p) {
                 for (int i = 0; i < TSA_MBW; ++i) {
                     const float f[8] = {acc[g][0][i][0], acc[g][0][i][1], acc[g][0][i][2], acc[g][0][i][3],
                                         acc[g][1][i][0], acc[g][1][i][1], acc[g][1][i][2], acc[g][1][i][3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(tsa_pack8<T>(f), rsQ, n < N3 ? rowoff[i] + n * 2 : TSA_OOB, 0, 0);
+                    tsa_store16(tsa_pack8<T>(f), rsQ, n < N3 ? rowoff[i] + n * 2 : TSA_OOB, 0);
                 }
             }
         }, p.n1, p.x_bytes, R, grow TSA_WAIT2);
@@ -555,7 +567,7 @@ __global__ __launch_bounds__(512) void tsa_fwd_kernel(TsaParams p) {
                     float o[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = acc[g][e >> 2][i][e & 3] + add[e] + to_f<T>(rr.v[e]);
-                    __builtin_amdgcn_raw_buffer_store_b128(tsa_pack8<T>(o), rsH, nb[g] < C ? rowoff[i] + nb[g] * 2 : TSA_OOB, 0, 0);
+                    tsa_store16(tsa_pack8<T>(o), rsH, nb[g] < C ? rowoff[i] + nb[g] * 2 : TSA_OOB, 0);
                 }
             }
         }, p.o, p.x_bytes, R, grow TSA_WAIT4);
