@@ -8,17 +8,20 @@
 // (the rows of one pixel sit HW rows apart -- they are gathered by address, nothing is transposed).  With P*T = 140 rows at the
 // 64x40 level of the benched shape, 35840 rows are exactly 256 bands = one per CU.
 //   phase 1  the band's rows are DMA-ed (buffer_load ... lds) into an XOR-swizzled LDS image [C/64][144 rows][128 B] and
-//            layer-normalised IN PLACE (16 lanes per row, fp32 statistics); n and (mean, rstd) also go to HBM -- the weight-gradient
-//            GEMM dW_qkv = dqkv^T n and the LayerNorm backward need them
+//            layer-normalised IN PLACE (16 lanes per row, fp32 statistics on float pairs); (mean, rstd) go to HBM here, n during
+//            phase 2 -- the weight-gradient GEMM dW_qkv = dqkv^T n and the LayerNorm backward need them
 //   phase 2  qkv = n W_qkv^T on v_mfma_f32_16x16x32: the image is the resident A operand, W_qkv streams through a double-buffered
-//            LDS stage (lean buffer_load ... lds pieces, as gemm_v4); 8 waves = 2 row halves x 4 column groups of 48, so every SIMD
-//            holds two waves and one's LDS latency hides under the other's MFMAs; q, k, v go to HBM (saved for the backward) with
-//            their stores drained under the next pass's MFMAs, and are read back by phase 3 from L2
+//            LDS stage (lean buffer_load ... lds pieces, as gemm_v4); 8 waves = 2 row halves x 4 column groups, so every SIMD holds
+//            two waves and one's LDS latency hides under the other's MFMAs; passes of 256 columns with the weight rows permuted so
+//            that q, k, v leave as 16-byte stores (saved for the backward; read back by phase 3 from L2); the image is copied to n
+//            one band row per K-step between the MFMA halves
 //   phase 3  per (pixel, head): S^T = K Q^T (2 MFMAs, T padded to 16 and masked), softmax over the 4 lanes that share a query,
 //            O^T = V^T P^T (4 MFMAs, V^T fragments by ds_read_b64_tr_b16 from a per-wave 2 KiB tile); O overwrites the image (the
-//            out-projection's A operand) and goes to HBM (dW_o = dh1^T o needs it)
-//   phase 4  h1 = o W_o^T + b_o + cvec + h with the same streaming GEMM loop; the residual is re-read from L2
-// HBM traffic per row: read h once; write n, q, k, v, o, h1 once (all but h1 are needed by the backward).
+//            out-projection's A operand)
+//   phase 4  h1 = o W_o^T + b_o + cvec + h with the same streaming GEMM loop; the residual rows are fetched during the last K-step
+//            of a pass; the image is copied to o (dW_o = dh1^T o needs it) as in phase 2
+// HBM traffic per row: read h once (+ once more from L2 for the residual); write n, q, k, v, o, h1 once (all but h1 are needed by
+// the backward).  Measured budget, the variants that were dropped and the wide-store data hazard: DESIGN.md section 6.
 #include "common.h"
 
 namespace {
