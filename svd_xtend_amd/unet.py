@@ -111,6 +111,21 @@ class _FeedForward(nn.Module):
         y = self.p2.fwd(rt, g, M, res=res)
         return y, pre, g
 
+    def fwd_ln(self, rt, ln, x, M, res, need_n: bool):
+        """LayerNorm `ln` + this feed-forward.  At the widths the band kernel admits (C a multiple of 64 up to 320: the 64x40 level of
+        the benched shape) the norm and the GEGLU projection are ONE launch (svdx_ln_geglu_fwd): no HBM round trip of the normalised
+        rows, the activation band staged once for all 2F output columns.  Returns (y, pre, g, n or None, stats)."""
+        F = self.inner
+        if (rt.fuse_ffn and hasattr(rt.k, "ln_geglu_fwd") and rt.fuse_geglu and self.dim % 64 == 0 and self.dim <= K.TSA_MAX_C
+                and F % 128 == 0 and M * 2 * F * 2 < 2 ** 31):
+            g, pre, st = rt.empty(M, F), rt.empty(M, 2 * F), rt.f32(M, 2)
+            n = rt.empty(M, self.dim) if need_n else None
+            rt.k.ln_geglu_fwd(x, ln.mod.weight.data, ln.mod.bias.data, ln.eps, self.p1.w, self.p1.b, n, st, pre, g, M, self.dim, F)
+            return self.p2.fwd(rt, g, M, res=res), pre, g, n, st
+        n, st = ln.fwd(rt, x, M)
+        y, pre, g = self.fwd(rt, n, M, res)
+        return y, pre, g, n, st
+
     def bwd(self, rt, dy, x_saved, pre, g, M):
         """returns d(input of p1); accumulates weight grads when trainable."""
         k = rt.k
@@ -272,8 +287,7 @@ class BasicTransformerBlock(nn.Module):
         k.attn_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], o, lse, g.N, self.heads, S, 3 * C, C, HEAD_DIM ** -0.5)
         cvec, cv = self.attn2.cross_vec(rt, ctx, g.B)
         h2, xs_o = _proj_fwd(rt, self.attn1.o, self.attn1.o_lora, o, M, res=h, rowvec=cvec, rv_ld=C, rv_rpg=g.T * g.HW)
-        n3, st3 = self.ln3.fwd(rt, h2, M)
-        h3, pre, _ = self.ff.fwd(rt, n3, M, res=h2)
+        h3, pre, _, _, st3 = self.ff.fwd_ln(rt, self.ln3, h2, M, res=h2, need_n=False)
         self.sv = (h, st1, qkv, o, lse, h2, st3, pre, n1, xs_qkv, xs_o, cv, ctx)
         return h3
 
@@ -357,8 +371,8 @@ class TemporalBasicTransformerBlock(nn.Module):
 
     def fwd(self, rt: Runtime, x, g: Geom, tctx):
         k, C, M = rt.k, self.dim, g.M
-        n0, st0 = self.ln0.fwd(rt, x, M)
-        h, pre0, g0 = self.ff_in.fwd(rt, n0, M, res=x)
+        keep_n = self.trainable and self.ff.p1.trainable            # the weight gradients of the feed-forwards read the normalised rows
+        h, pre0, g0, n0, st0 = self.ff_in.fwd_ln(rt, self.ln0, x, M, res=x, need_n=keep_n)
         cvec, cv = self.attn2.cross_vec(rt, tctx, g.B)
         if self._tsa_fused(rt, g):
             n1 = rt.empty(M, C) if self.trainable else None
@@ -373,8 +387,7 @@ class TemporalBasicTransformerBlock(nn.Module):
             o = rt.empty(M, C)
             k.tattn_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], o, g.B, g.T, g.HW, self.heads, 3 * C, C, HEAD_DIM ** -0.5)
             h1, xs_o = _proj_fwd(rt, self.attn1.o, self.attn1.o_lora, o, M, res=h, rowvec=cvec, rv_ld=C, **self._rv(g))
-        n3, st3 = self.ln3.fwd(rt, h1, M)
-        out, pre, gg = self.ff.fwd(rt, n3, M, res=h1)
+        out, pre, gg, n3, st3 = self.ff.fwd_ln(rt, self.ln3, h1, M, res=h1, need_n=keep_n)
         if not self.trainable:
             n0 = g0 = n1 = n3 = gg = None
         elif not self.ff.p1.trainable:               # adapters only (config 5): the feed-forwards are frozen

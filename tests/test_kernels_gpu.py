@@ -6,7 +6,7 @@ import torch
 
 gpu = pytest.mark.gpu
 GROUPS = ["gemm_tn", "gemm_geglu", "gemm_plain_v4", "gemm_gather_v4", "gemm_plain_v6", "gemm_gather_v6", "gemm_plain_v0", "gemm_plain_v1", "gemm_gather_v0", "gemm_gather_v1", "small", "groupnorm", "layernorm",
-          "attention", "temporal_attention", "tsa", "encoders", "elementwise", "optim"]
+          "attention", "temporal_attention", "tsa", "ffn", "encoders", "elementwise", "optim"]
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +30,7 @@ def test_kernel_group(pair, group, dt):
            "small": lambda: kc.check_small(pair, dt), "groupnorm": lambda: kc.check_groupnorm(pair, dt),
            "layernorm": lambda: kc.check_layernorm(pair, dt), "attention": lambda: kc.check_attention(pair, dt),
            "temporal_attention": lambda: kc.check_temporal_attention(pair, dt),
-           "tsa": lambda: kc.check_tsa(pair, dt), "encoders": lambda: kc.check_encoders(pair, dt),
+           "tsa": lambda: kc.check_tsa(pair, dt), "ffn": lambda: kc.check_ffn(pair, dt), "encoders": lambda: kc.check_encoders(pair, dt),
            "elementwise": lambda: kc.check_elementwise(pair, dt), "optim": lambda: kc.check_optim(pair, dt)}
     bad = [(l, e, t) for l, e, t in fns[group]() if not (e <= t and math.isfinite(e))]
     assert not bad, f"{len(bad)} mismatches, first: {bad[:5]}"
