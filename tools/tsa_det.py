@@ -1,3 +1,7 @@
+"""Run-to-run reproducibility of the fused temporal self-attention (svdx_tsa_fwd): the same inputs into output buffers pre-filled with
+different values must give identical bits, at the small widths of the test topology and at the benched level shapes.  The tool that
+found the wide-store data hazard; the assertion form is tests/test_kernels_gpu.py.
+    python tools/tsa_det.py"""
 import sys, torch
 sys.path.insert(0, '/root/repo')
 from svd_xtend_amd import kernels as K
