@@ -30,6 +30,37 @@ __global__ __launch_bounds__(512) void k(void* out, int bytes, int iters) {
     }
 }
 
+// the same experiment with an 8-byte store (LLVM assumes no hazard at all for <= 64 bits of data): MODE = wait states
+template <int MODE>
+__global__ __launch_bounds__(512) void k2(void* out, int bytes, int iters) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, bytes, 0x00020000);
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
+    for (int it = 0; it < iters; ++it) {
+        const int off = (it * n + tid) * 16;
+        if (MODE == 0)
+            asm volatile("v_mov_b32 v20, %0\n v_mov_b32 v21, %1\n s_nop 4\n buffer_store_dwordx2 v[20:21], %2, %3, 0 offen\n v_mov_b32 v20, 0xdeadbeef\n"
+                         ::"v"(it), "v"(tid), "v"(off), "s"(rs) : "v20", "v21", "memory");
+        else
+            asm volatile("v_mov_b32 v20, %0\n v_mov_b32 v21, %1\n s_nop 4\n buffer_store_dwordx2 v[20:21], %2, %3, 0 offen\n s_nop 0\n v_mov_b32 v20, 0xdeadbeef\n"
+                         ::"v"(it), "v"(tid), "v"(off), "s"(rs) : "v20", "v21", "memory");
+    }
+}
+
+template <int MODE>
+long run2(unsigned* out, long bytes, int blocks, int iters, std::vector<unsigned>& h) {
+    long bad_total = 0;
+    const long n = (long)blocks * 512;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemset(out, 0, bytes);
+        hipLaunchKernelGGL(k2<MODE>, dim3(blocks), dim3(512), 0, 0, out, (int)bytes, iters);
+        hipDeviceSynchronize();
+        hipMemcpy(h.data(), out, bytes, hipMemcpyDeviceToHost);
+        for (long i = 0; i < n * iters; ++i)
+            if (h[i * 4] != (unsigned)(i / n)) ++bad_total;
+    }
+    return bad_total;
+}
+
 template <int MODE>
 long run(unsigned* out, long bytes, int blocks, int iters, std::vector<unsigned>& h) {
     long bad_total = 0;
@@ -62,5 +93,8 @@ int main() {
     printf("  s_nop 7 (8)  : %ld\n", run<8>(out, bytes, blocks, iters, h));
     printf("  2 x s_nop 7  : %ld\n", run<16>(out, bytes, blocks, iters, h));
     printf("  s_waitcnt expcnt(0): %ld\n", run<100>(out, bytes, blocks, iters, h));
+    printf("buffer_store_dwordx2 (8 bytes), same experiment:\n");
+    printf("  0 wait states: %ld\n", run2<0>(out, bytes, blocks, iters, h));
+    printf("  1 wait state : %ld\n", run2<1>(out, bytes, blocks, iters, h));
     return 0;
 }
