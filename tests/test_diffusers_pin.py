@@ -52,3 +52,50 @@ def test_oracle_vae_encoder_matches_diffusers():
         mean, logvar = orc.moments(x)
     assert torch.allclose(mean, d.mean, atol=1e-5, rtol=1e-5), float((mean - d.mean).abs().max())
     assert torch.allclose(logvar, d.logvar, atol=1e-5, rtol=1e-5), float((logvar - d.logvar).abs().max())
+
+
+def test_oracle_temporal_decoder_matches_diffusers():
+    """oracle/vae.py's TemporalDecoder (the last stage of the validation sampler) against diffusers' AutoencoderKLTemporalDecoder.decode."""
+    diffusers = pytest.importorskip("diffusers")
+    from oracle.vae import VaeOracle
+    cfg = dict(block_out_channels=(32, 64, 64, 64), layers_per_block=2, latent_channels=4)
+    orc = VaeOracle(**cfg)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for n, p in orc.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.05 if p.ndim > 1 else 0.02) + (1.0 if p.ndim == 1 and p.numel() > 8 else 0.0))
+    ref = diffusers.AutoencoderKLTemporalDecoder(**cfg)
+    assert sorted(ref.state_dict().keys()) == sorted(orc.state_dict().keys())
+    ref.load_state_dict(orc.state_dict(), strict=True)
+    z = torch.randn(6, 4, 5, 7, generator=g)                    # two clips of three frames
+    with torch.no_grad():
+        want = ref.decode(z, num_frames=3).sample
+        got = orc.decode(z, 3)
+    assert torch.allclose(got, want, atol=1e-5, rtol=1e-5), float((got - want).abs().max())
+
+
+def test_sampler_pieces_match_diffusers_scheduler():
+    """oracle/sampler.py's Karras sigmas, continuous timesteps, init_noise_sigma, input scaling and v-prediction Euler step, and the
+    product's EulerDiscreteScheduler, against diffusers' EulerDiscreteScheduler in SVD's configuration."""
+    diffusers = pytest.importorskip("diffusers")
+    from oracle import sampler as O
+    from svd_xtend_amd.pipeline import EulerDiscreteScheduler
+    ref = diffusers.EulerDiscreteScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000,
+                                           prediction_type="v_prediction", sigma_min=0.002, sigma_max=700.0, timestep_spacing="leading",
+                                           timestep_type="continuous", use_karras_sigmas=True, steps_offset=1, interpolation_type="linear")
+    ref.set_timesteps(25)
+    mine = EulerDiscreteScheduler()
+    mine.set_timesteps(25)
+    sig = O.karras_sigmas(25)
+    assert torch.allclose(ref.sigmas.float(), sig, rtol=1e-5, atol=1e-7) and torch.allclose(mine.sigmas, sig)
+    assert torch.allclose(ref.timesteps.float(), mine.timesteps, rtol=1e-5, atol=1e-6)
+    assert abs(float(ref.init_noise_sigma) - mine.init_noise_sigma) < 1e-3
+    g = torch.Generator().manual_seed(6)
+    x, v = torch.randn(1, 3, 4, 5, 5, generator=g), torch.randn(1, 3, 4, 5, 5, generator=g)
+    for i in range(3):
+        t = ref.timesteps[i]
+        assert torch.allclose(ref.scale_model_input(x, t), mine.scale_model_input(x, t), rtol=1e-5, atol=1e-6)
+        a, b = ref.step(v, t, x).prev_sample, mine.step(v, t, x).prev_sample
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5), (i, float((a - b).abs().max()))
+        assert torch.allclose(b, O.euler_step_v(x, v, float(sig[i]), float(sig[i + 1])), rtol=1e-5, atol=1e-5)
+        x = b
