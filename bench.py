@@ -182,6 +182,9 @@ def main():
     ap.add_argument("--with-vae", action="store_true",
                     help="also time the step with the VAE encode of the next micro-batch (train_svd.py:948, 957-960) on a second "
                          "stream; reported as a second field, the headline metric stays UNet-only")
+    ap.add_argument("--launch-log", default=None,
+                    help="developer aid: write the ordered list of libsvdx calls of ONE eager step (entry name + scalar arguments) to this "
+                         "JSON file; tools/step_trace.py joins it with a rocprofv3 kernel trace of the graph-replayed steps")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -261,6 +264,14 @@ def main():
     for _ in range(max(1, args.warmup)):
         step_eager()
     torch.cuda.synchronize()
+    if args.launch_log and rank == 0:
+        trainer.rt.k.launch_log = []
+        step_eager()
+        torch.cuda.synchronize()
+        os.makedirs(os.path.dirname(os.path.abspath(args.launch_log)), exist_ok=True)
+        with open(args.launch_log, "w") as f:
+            json.dump(trainer.rt.k.launch_log, f)
+        trainer.rt.k.launch_log = None
     exec_mode = "eager"
     step = step_eager
     if not args.no_graph:

@@ -184,6 +184,8 @@ class HipBackend:
         if not self.lib.svdx_device_ok():
             raise SvdxError("libsvdx.so reports no usable gfx950 device: " + self.last_error())
         self._zero_page = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+        self._log_extra = None
+        self.launch_log = None      # developer aid (bench.py --launch-log): a list that receives (entry, args) of every call, in order
 
     def last_error(self) -> str:
         buf = ctypes.create_string_buffer(512)
@@ -191,6 +193,9 @@ class HipBackend:
         return buf.value.decode(errors="replace")
 
     def _call(self, name, *args):
+        if self.launch_log is not None:
+            self.launch_log.append((name, [a if isinstance(a, (int, float)) or a is None else "obj" for a in args], self._log_extra))
+            self._log_extra = None
         rc = getattr(self.lib, name)(*args)
         if rc != 0:
             raise SvdxError(f"{name} failed ({rc}): {self.last_error()}")
@@ -205,6 +210,8 @@ class HipBackend:
              variant=0, epilogue=EPI_NONE, aux_in=None, aux_out=None, aux_dim=0, dual=None):
         """dual = (A2, B2, K2, lda2, ldb2[, a2_seg_n]): second operand pair reduced into the same accumulators (svdx_gemm_dual)."""
         g = gather.to_c() if gather is not None else None
+        if self.launch_log is not None and gather is not None:
+            self._log_extra = [gather.mode, gather.cin, gather.stride, gather.ups]
         if dual is not None:
             A2, B2, K2, lda2, ldb2 = dual[:5]
             seg = dual[5] if len(dual) > 5 else 0
