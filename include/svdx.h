@@ -96,9 +96,11 @@ int svdx_gemm_dual(const void* A, const void* B, void* C, int M, int N, int K, i
  * a_colsum (may be NULL): the column sums of A -- the Linear bias gradient, computed on the MFMA pipe from the dY tiles the GEMM stages
  * anyway.  Unsplit (split_k == 1): a_colsum[n] += sum_r A[r*lda + n] (one owner per column, no atomics).  SVDX_OUT_F32_SLAB:
  * a_colsum is float[split_k][N] and slice z STORES its partial into row z; svdx_gemm_finalize(colsum_slabs = a_colsum, ...) adds
- * the rows in order -- a fixed summation order, so the bias gradient is run-to-run identical. */
+ * the rows in order -- a fixed summation order, so the bias gradient is run-to-run identical.  With split_k > 1 a_colsum needs the
+ * slab mode.  stages: LDS stages of the K-loop ring, 2 (two workgroups per CU, drained every K-step), 3 or 4 (one workgroup per CU
+ * with 2 / 3 row tiles in flight across the barrier: grids that cannot put two workgroups on a CU anyway); 0 = 2. */
 int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
-                 float* a_colsum, const void* zero_page, int out_mode, int split_k, int dtype, void* stream);
+                 float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, int dtype, void* stream);
 
 /* Epilogue of a split-K GEMM run with SVDX_OUT_F32_SLAB: v = sum_z acc[z*slab_stride + m*N + n] + bias + rowvec + res (same operand
  * meaning as svdx_gemm); c_is_f32_accumulate: 0 -> C[m*ldc+n] = (dtype)v, 1 -> ((float*)C)[m*ldc+n] += v, 2 -> ((float*)C)[m*ldc+n] = v

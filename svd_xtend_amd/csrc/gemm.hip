@@ -364,7 +364,7 @@ __device__ __forceinline__ typename TT<T>::v8 tn_frag(const char* tile, int colb
     return __builtin_bit_cast(typename TT<T>::v8, r);
 }
 
-template <typename T>
+template <typename T, int NSTG>
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
@@ -447,18 +447,48 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
             }
         }
     };
-    issue(kt_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
-        issue(kt + 1, cur ^ 1);
-        compute(cur);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
+    // the same stage ring as gemm_v4_kernel (see its K-loop banner): NSTG - 1 tiles staged ahead, counted vmcnt + raw s_barrier when
+    // NSTG > 2.  Every wave issues 8 pieces (4 of A, 4 of B) per tile.
+    static_assert(NSTG >= 2 && NSTG <= 4, "2 to 4 LDS stages");
+    constexpr int LA = NSTG - 1;
+    auto wait_tiles = [&](int t) __attribute__((always_inline)) {
+        if (NSTG == 2 || t <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (t == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    };
+    auto stage_barrier = [&]() __attribute__((always_inline)) {
+        if (NSTG == 2) { __syncthreads(); return; }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int n_tiles = kt_end - kt_begin;
+#pragma unroll
+    for (int t = 0; t < LA; ++t)
+        if (t < n_tiles) issue(kt_begin + t, t);
+    wait_tiles(min(LA, n_tiles) - 1);
+    stage_barrier();
+    {
+        int cur = 0, nxt = LA, kt = 0;
+        for (; kt + LA < n_tiles; ++kt) {
+            issue(kt_begin + kt + LA, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur);
+            wait_tiles(LA - 1);
+            stage_barrier();
+            cur = cur + 1 == NSTG ? 0 : cur + 1;
+            nxt = nxt + 1 == NSTG ? 0 : nxt + 1;
+        }
+        for (; kt < n_tiles; ++kt) {
+            compute(cur);
+            if (kt + 1 < n_tiles) {
+                wait_tiles(n_tiles - 2 - kt);
+                stage_barrier();
+            }
+            cur = cur + 1 == NSTG ? 0 : cur + 1;
+        }
     }
-    compute(cur);
     __syncthreads();
     if (do_cs && (lane & 15) == 0) {        // every column of the 16x16 result holds the sums: lanes 0/16/32/48 own rows 4*(lane>>4)..+3
 #pragma unroll
@@ -493,20 +523,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
 //  * Tried and dropped: a 5-stage / 4-stage LDS ring with counted vmcnt + raw s_barrier (no gain in
 //    situ, slower in isolation: the loop is not latency bound), direct 8-byte epilogue stores (worse DRAM efficiency).
 // ================================================================================================================
-template <typename T, int NB, int MB, bool DUAL>
-__global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
+template <typename T, int NB, int MB, bool DUAL, int WGM, int NSTG>
+__global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and LDS-DMA builtin only exist in the device pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
-    constexpr int BM4 = 32 * MB;                      // tile rows: 128 (MB = 4) or 160 (MB = 5, one wave of blocks at M = 35840, N = 320)
+    constexpr int NT = 128 * WGM;                     // threads: WGM x 2 waves (WGM = 2: four waves, WGM = 4: eight = two per SIMD)
+    constexpr int BM4 = 16 * MB * WGM;                // tile rows: 128 / 160 (four waves) or 256 / 320 (eight waves)
     constexpr int WM4 = 16 * MB;                      // rows per wave
     constexpr int BN3 = 32 * NB;                      // 2 waves along N, NB/2... each wave owns NB*16 columns
     constexpr int WN3 = 16 * NB;                      // columns per wave
     constexpr int KT = BK;                             // K extent of one stage
-    constexpr int NSTG = 2;
     constexpr int STAGE3 = (BM4 + BN3) * KT * 2;
     constexpr int CPRW = KT / 8;                       // 16-byte chunks per staged row (8 | 4)
-    constexpr int RPP = NTHREADS / CPRW;               // rows covered by one load pass (32 | 64)
+    constexpr int RPP = NT / CPRW;                     // rows covered by one load pass (32 | 64)
     constexpr int NLA = BM4 / RPP;                      // A loads per thread per stage (4 | 2)
     constexpr int NLB = (BN3 + RPP - 1) / RPP;         // B loads per thread per stage (NB | 3 or 2)
     constexpr int ROWB = KT * 2;                       // bytes per staged row (128 | 64)
@@ -586,18 +616,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
     // (MI355X_MICROARCH.md), so the pieces of the NEXT stage are spread between the MFMA rows of the current one instead of being
     // issued as a burst in front of them (which left the wave's MFMA pipe idle for ~1000 cycles per K-step).
     constexpr int NPIECE = NLA + NLB;
+    // Eight waves cover 64 tile rows per pass, so a 160-row B tile ends in the middle of its third pass: the waves whose 8 rows lie
+    // beyond the tile have nothing to fetch there and skip that piece (their vmcnt arithmetic below counts one piece less per tile).
+    constexpr bool B_PARTIAL = NLB * RPP > BN3;
+    const bool skip_last = B_PARTIAL && (NLB - 1) * RPP + wave_u * (64 / CPRW) >= BN3;
     auto issue_piece = [&](int stage, int pi) __attribute__((always_inline)) {
         char* As = smem + stage * STAGE3;
         char* Bs = As + BM4 * KT * 2;
         if (pi < NLA) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(As + (pi * 256 + wave_u * 64) * 16), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(As + (pi * NT + wave_u * 64) * 16), 16,
                                                      voa[pi], ci0 * 2, 0, 0);
         } else {
             const int i = pi - NLA;
-            // the dummy pass (tile rows >= BN3: waves 2,3 of the last pass) lands zeros in a scratch area behind the stages
-            char* dst = ((i * RPP + RPP <= BN3) || wave_u * 64 / CPRW + i * RPP < BN3) ? Bs + (i * 256 + wave_u * 64) * 16
-                                                                                        : smem + NSTG * STAGE3 + wave_u * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)dst, 16, vob[i], (tap * cin + ci0) * 2, 0, 0);
+            if (B_PARTIAL && i == NLB - 1 && skip_last) return;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(Bs + (i * NT + wave_u * 64) * 16), 16, vob[i],
+                                                     (tap * cin + ci0) * 2, 0, 0);
         }
     };
     const int n_main = kt_end - kt_begin;                          // K-tiles of the main pair handled by this block
@@ -631,8 +664,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
-    // compute stage `stage`; when ISSUE, stage the next K-tile into `stage ^ 1` piece by piece between the MFMA rows
-#define SVDX_V4_COMPUTE(stage, ISSUE)                                                                                        \
+    // compute stage `stage`; when ISSUE, stage a later K-tile into `nstage` piece by piece between the MFMA rows
+#define SVDX_V4_COMPUTE(stage, nstage, ISSUE)                                                                                \
     {                                                                                                                        \
         const char* As_ = smem + (stage) * STAGE3;                                                                           \
         const char* Bs_ = As_ + BM4 * KT * 2;                                                                                \
@@ -647,28 +680,66 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
                 _Pragma("unroll") for (int j = 0; j < MB; ++j) acc[i][j] = TT<T>::mfma(bf[i], af[j], acc[i][j]);             \
                 if (ISSUE && kk * NB + i < NPIECE) {                                                                         \
                     __builtin_amdgcn_sched_barrier(0);                                                                       \
-                    issue_piece((stage) ^ 1, kk * NB + i);                                                                   \
+                    issue_piece((nstage), kk * NB + i);                                                                      \
                     __builtin_amdgcn_sched_barrier(0);                                                                       \
                 }                                                                                                            \
             }                                                                                                                \
         }                                                                                                                    \
     }
     static_assert(NPIECE <= (KT / 32) * NB, "not enough MFMA rows to hide the staging pieces");
-    {
-#pragma unroll
-        for (int pi = 0; pi < NPIECE; ++pi) issue_piece(0, pi);
-        advance_k();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int cur = 0;
-        for (int kt = 0; kt < n_tiles - 1; ++kt) {
-            SVDX_V4_COMPUTE(cur, true);
-            advance_k();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            cur ^= 1;
+    static_assert(NSTG >= 2 && NSTG <= 4, "2 to 4 LDS stages");
+    // The stages form a ring: while tile kt is computed, tiles kt+1 .. kt+NSTG-2 are in flight and the pieces of tile kt+NSTG-1 are
+    // issued into the stage tile kt-1 just left.  One barrier per K-step.  With more than two stages the wait in front of it is a
+    // COUNTED vmcnt -- it retires this wave's pieces of tile kt+1 and leaves the younger tiles in flight across the barrier, which
+    // must then be the raw s_barrier (__syncthreads() fences with vmcnt(0) while an LDS-DMA is pending); every wave issues the same
+    // number of pieces per tile, so the count is exact.  The two-stage form (wait for everything, __syncthreads) is the round-1 loop:
+    // right when two workgroups share a CU and hide each other's drain; the ring is for grids of <= 1 workgroup per CU (the 10x16 /
+    // 5x8 levels, where a drained K-step is one exposed L2 / HBM round trip) and for the eight-wave tiles.
+    auto wait_tiles = [&](int t) __attribute__((always_inline)) {          // leave at most the t youngest tiles in flight (wave-uniform)
+        if (NSTG == 2 || t <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+        if (B_PARTIAL && skip_last) {
+            if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE - 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NPIECE - 1)) : "memory");
+        } else {
+            if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPIECE) : "memory");
         }
-        SVDX_V4_COMPUTE(cur, false);
+    };
+    auto stage_barrier = [&]() __attribute__((always_inline)) {
+        if (NSTG == 2) { __syncthreads(); return; }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+        constexpr int LA = NSTG - 1;                                       // tiles staged ahead of the one being computed
+#pragma unroll
+        for (int t = 0; t < LA; ++t)
+            if (t < n_tiles) {
+#pragma unroll
+                for (int pi = 0; pi < NPIECE; ++pi) issue_piece(t, pi);
+                advance_k();
+            }
+        wait_tiles(min(LA, n_tiles) - 1);
+        stage_barrier();
+        int cur = 0, nxt = LA, kt = 0;
+        for (; kt + LA < n_tiles; ++kt) {
+            SVDX_V4_COMPUTE(cur, nxt, true);
+            advance_k();
+            wait_tiles(LA - 1);
+            stage_barrier();
+            cur = cur + 1 == NSTG ? 0 : cur + 1;
+            nxt = nxt + 1 == NSTG ? 0 : nxt + 1;
+        }
+        for (; kt < n_tiles; ++kt) {
+            SVDX_V4_COMPUTE(cur, nxt, false);
+            if (kt + 1 < n_tiles) {
+                wait_tiles(n_tiles - 2 - kt);
+                stage_barrier();
+            }
+            cur = cur + 1 == NSTG ? 0 : cur + 1;
+        }
     }
 #undef SVDX_V4_COMPUTE
 
@@ -713,7 +784,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
             T* pre = reinterpret_cast<T*>(p.C);
             T* hh = reinterpret_cast<T*>(p.aux_out);
             constexpr int NPAIR = BN3 / 32;
-            for (int id = tid; id < BM4 * NPAIR * 2; id += NTHREADS) {
+            for (int id = tid; id < BM4 * NPAIR * 2; id += NT) {
                 const int row = id / (NPAIR * 2), r2 = id - row * (NPAIR * 2);
                 const int pr = r2 >> 1, c2 = r2 & 1;
                 const int m = m0 + row;
@@ -739,7 +810,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
             // the tile holds d(h) for columns n0..; read (value, gate) from pre and emit d(pre) = [dh*gelu(g) | dh*a*gelu'(g)]
             const T* pre = reinterpret_cast<const T*>(p.aux_in);
             T* dpre = reinterpret_cast<T*>(p.C);
-            for (int id = tid; id < BM4 * CPR; id += NTHREADS) {
+            for (int id = tid; id < BM4 * CPR; id += NT) {
                 const int row = id / CPR, c = id - row * CPR;
                 const int m = m0 + row;
                 if (m >= p.M) continue;
@@ -763,7 +834,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v4_kernel(GemmParams p) {
         T* Ct2 = reinterpret_cast<T*>(p.C);
         const T* R2 = (z == 0) ? reinterpret_cast<const T*>(p.res) : nullptr;
 #pragma unroll 2
-        for (int id = tid; id < BM4 * CPR; id += NTHREADS) {
+        for (int id = tid; id < BM4 * CPR; id += NT) {
             const int row = id / CPR, c = id - row * CPR;
             const int m = m0 + row;
             if (m >= p.M) continue;
@@ -1035,17 +1106,23 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
     return 0;
 }
 
-template <typename T, int NB, int MB>
+template <typename T, int NB, int MB, int WGM = 2, int NSTG = 2>
 int launch_gemm_v4(GemmParams p, hipStream_t st) {
-    constexpr int LDS = 2 * (32 * MB + 32 * NB) * BK * 2;
+    constexpr int BMT = 16 * MB * WGM, BNT = 32 * NB;
+    constexpr int LDS_STG = NSTG * (BMT + BNT) * BK * 2, LDS_EPI = BMT * (BNT + 8) * 2;      // K-loop stages | the rounded output tile parked for the coalesced stores
+    constexpr int LDS = LDS_STG > LDS_EPI ? LDS_STG : LDS_EPI;
+    static_assert(LDS <= 160 * 1024, "stages (and the epilogue tile parked in them) must fit the 160 KiB LDS");
+    constexpr bool HAS_DUAL = WGM == 2 && NSTG == 2;            // the LoRA second-operand loop is only instantiated for the round-1 tiles
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, MB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, MB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, MB, false, WGM, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (HAS_DUAL)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, MB, HAS_DUAL, WGM, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    p.tiles_m = cdiv(p.M, 32 * MB);
-    p.tiles_n = p.epi == SVDX_EPI_GEGLU_FWD ? cdiv(p.aux_dim, 16 * NB) : cdiv(p.N, 32 * NB);
+    if (p.K2 > 0 && !HAS_DUAL) { svdx_set_error("svdx_gemm_dual: this tile variant has no second-operand loop"); return -2; }
+    p.tiles_m = cdiv(p.M, BMT);
+    p.tiles_n = p.epi == SVDX_EPI_GEGLU_FWD ? cdiv(p.aux_dim, 16 * NB) : cdiv(p.N, BNT);
     p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 15) == 0));
     // XCD arrangement (see the kernel): least operand re-fetch among the arrangements that keep >= 90 % of the best tile balance
     static const int force_xn = getenv("SVDX_XCD_N") ? atoi(getenv("SVDX_XCD_N")) : -1;     // developer knob: 0 = old split, 1/2/4/8
@@ -1070,22 +1147,22 @@ int launch_gemm_v4(GemmParams p, hipStream_t st) {
         gx = 8 * p.sub_m * p.sub_n;
     }
     dim3 grid(gx, p.split_k);
-    if (p.K2 > 0) hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB, true>), grid, dim3(NTHREADS), LDS, st, p);
-    else hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB, false>), grid, dim3(NTHREADS), LDS, st, p);
+    if (p.K2 > 0) hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB, HAS_DUAL, WGM, NSTG>), grid, dim3(128 * WGM), LDS, st, p);
+    else hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB, false, WGM, NSTG>), grid, dim3(128 * WGM), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm");
     return 0;
 }
 
-template <typename T>
+template <typename T, int NSTG>
 int launch_gemm_tn(const GemmParams& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * STAGE_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  NSTG * STAGE_BYTES);
         attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
-    hipLaunchKernelGGL((gemm_tn_kernel<T>), grid, dim3(NTHREADS), 2 * STAGE_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_tn_kernel<T, NSTG>), grid, dim3(NTHREADS), NSTG * STAGE_BYTES, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm_tn");
     return 0;
 }
@@ -1093,8 +1170,11 @@ int launch_gemm_tn(const GemmParams& p, hipStream_t st) {
 }  // namespace
 
 extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
-                            float* a_colsum, const void* zero_page, int out_mode, int split_k, int dtype, void* stream) {
+                            float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, int dtype, void* stream) {
     SVDX_CHECK_ARG(A && B && C && zero_page && R > 0 && N > 0 && K > 0, "svdx_gemm_tn: bad args");
+    SVDX_CHECK_ARG(stages == 0 || (stages >= 2 && stages <= 4), "svdx_gemm_tn: stages=%d (0 = default, 2..4)", stages);
+    // the unsplit / ADD modes read-modify-write a_colsum from every z slice: one slice only (SVDX_OUT_F32_SLAB keeps a row per slice)
+    SVDX_CHECK_ARG(!a_colsum || split_k == 1 || out_mode == SVDX_OUT_F32_SLAB, "svdx_gemm_tn: a_colsum with split_k > 1 needs slab output");
     SVDX_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
                        ((uintptr_t)zero_page & 15) == 0, "svdx_gemm_tn: operands must be 16-byte aligned, N/K multiples of 8");
     SVDX_CHECK_ARG(out_mode == SVDX_OUT_F32 || out_mode == SVDX_OUT_F32_ADD || out_mode == SVDX_OUT_F32_SLAB ||
@@ -1109,7 +1189,11 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
     p.tiles_m = cdiv(N, BM); p.tiles_n = cdiv(K, BN);
     p.vec_ok = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) && (K % 8 == 0);
     p.slab_stride = (long)N * ldc;
-    DISPATCH_DTYPE(dtype, return launch_gemm_tn<T>(p, (hipStream_t)stream));
+    DISPATCH_DTYPE(dtype, {
+        if (stages == 3) return launch_gemm_tn<T, 3>(p, (hipStream_t)stream);
+        if (stages == 4) return launch_gemm_tn<T, 4>(p, (hipStream_t)stream);
+        return launch_gemm_tn<T, 2>(p, (hipStream_t)stream);
+    });
 }
 
 static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -1199,12 +1283,26 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
         if (variant >= 2 && a_bytes > 0 && b_bytes > 0) {
             p.a_bytes = (int)a_bytes; p.b_bytes = (int)b_bytes;
             // tile choice: variant 4 = heuristic; 6 / 7 / 8 force 160x160 / 128x160 / 128x128 (the host autotuner times them)
-            const bool nb5 = epilogue == SVDX_EPI_GEGLU_FWD || variant == 8 ? false : (N % 160 == 0);
+            const bool nb5 = epilogue == SVDX_EPI_GEGLU_FWD || variant == 8 || variant == 17 || variant == 18 || variant == 21 ? false : (N % 160 == 0);
             // 160-row tiles when they turn a 1.1-wave grid (512 resident blocks) into a single wave, e.g. M = 35840, N = 320:
             // 280 x 2 = 560 tiles of 128 rows vs 224 x 2 = 448 tiles of 160 rows
             const long t128 = (long)cdiv(M, 128) * cdiv(N, 160), t160 = (long)cdiv(M, 160) * cdiv(N, 160);
             const bool mb5 = nb5 && ((variant == 6) ||
                                      (variant == 4 && split_k == 1 && (cdiv(t128, 512) * 4 > cdiv(t160, 512) * 5) && t160 >= 384));
+            if (variant >= 16) {
+                // ring-staged tiles (see the K-loop banner), one workgroup per CU:
+                //   16: 256x160, 3 stages, eight waves   17: 256x128, 3 stages, eight waves   18: 256x256, 2 stages, eight waves
+                //   20: 128x160, 4 stages, four waves    21: 128x128, 4 stages, four waves
+                // A 160-wide request on an N that 160 does not divide (or with the GEGLU-forward epilogue) takes the 128-wide sibling;
+                // 256-wide tiles need N % 256 == 0 (their GEGLU epilogues have no partial column tile).
+                const int n_cols = epilogue == SVDX_EPI_GEGLU_FWD ? 2 * aux_dim : N;
+                switch (variant) {
+                    case 18: if (n_cols % 256 == 0) return launch_gemm_v4<T, 8, 4, 4, 2>(p, st);   // else: fall through to 256 x 128
+                    case 16: case 17: return nb5 ? launch_gemm_v4<T, 5, 4, 4, 3>(p, st) : launch_gemm_v4<T, 4, 4, 4, 3>(p, st);
+                    case 20: case 21: return nb5 ? launch_gemm_v4<T, 5, 4, 2, 4>(p, st) : launch_gemm_v4<T, 4, 4, 2, 4>(p, st);
+                    default: svdx_set_error("svdx_gemm: unknown variant %d", variant); return -2;
+                }
+            }
             if (mb5) return launch_gemm_v4<T, 5, 5>(p, st);
             return nb5 ? launch_gemm_v4<T, 5, 4>(p, st) : launch_gemm_v4<T, 4, 4>(p, st);
         }

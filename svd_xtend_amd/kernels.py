@@ -64,7 +64,7 @@ class Gather:
 _SIGS = {
     "svdx_gemm": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifii" "ippi" "ip",
     "svdx_gemm_dual": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifi" "pp" "iiii" "ip",
-    "svdx_gemm_tn": "ppp" "iiiiii" "pp" "ii" "ip",
+    "svdx_gemm_tn": "ppp" "iiiiii" "pp" "iii" "ip",
     "svdx_gemm_finalize": "pil" "pi" "iii" "pp" "iii" "pi" "ppi" "ip",
     "svdx_small_linear": "pppp" "iiii" "iii" "ip",
     "svdx_outer_acc": "ppp" "iii" "f" "p",
@@ -227,8 +227,8 @@ class HipBackend:
                    _p(self._zero_page), out_mode, float(alpha), split_k, variant, epilogue, _p(aux_in), _p(aux_out), aux_dim,
                    _dt(A), self._stream())
 
-    def gemm_tn(self, A, B, C, R, N, K, lda, ldb, ldc, out_mode=OUT_F32_ADD, split_k=1, a_colsum=None):
-        self._call("svdx_gemm_tn", _p(A), _p(B), _f32(C), R, N, K, lda, ldb, ldc, _f32(a_colsum), _p(self._zero_page), out_mode, split_k,
+    def gemm_tn(self, A, B, C, R, N, K, lda, ldb, ldc, out_mode=OUT_F32_ADD, split_k=1, a_colsum=None, stages=0):
+        self._call("svdx_gemm_tn", _p(A), _p(B), _f32(C), R, N, K, lda, ldb, ldc, _f32(a_colsum), _p(self._zero_page), out_mode, split_k, stages,
                    _dt(A), self._stream())
 
     def gemm_finalize(self, acc, nsplit, slab_stride, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,

@@ -138,7 +138,7 @@ class Runtime:
 
 
 def choose_split(rt: "Runtime", M: int, N: int, Kd: int, ldc: int, bn: int = 0) -> int:
-    """Split-K factor for bn-wide output tiles (0: the kernel's default width for this N) when the grid cannot fill the chip."""
+    """Split-K factor for bn-wide two-stage output tiles (0: the kernel's default width for this N) when the grid cannot fill the chip."""
     bn = bn or (160 if N % 160 == 0 else 128)
     tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
     kt = Kd // 64
@@ -153,22 +153,89 @@ def choose_split(rt: "Runtime", M: int, N: int, Kd: int, ldc: int, bn: int = 0) 
     return split
 
 
-def choose_cfg(rt: "Runtime", M: int, N: int, Kd: int, ldc: int):
-    """(split, variant) without a measurement.  One measured rule on top of `choose_split` (in-situ sweeps, bench.py --tune):
-    when 160 x 160 tiles times a split factor land the grid just under the 512 resident workgroups while every split still
-    owns >= 40 K-steps, that shape wins by 5-23 % (8960 x 640 with K >= 5120: 224 tiles x 2; 2240 x 1280 with K >= 10240:
-    112 tiles x 4) over the default 128 x 160 tiles, whose grids leave a third of the slots empty."""
-    if rt.gemm_variant == 4 and rt.split_k and N % 160 == 0 and N % 4 == 0 and ldc % 4 == 0:
-        t160 = -(-M // 160) * (N // 160)
-        kt = Kd // 64
-        s = 512 // t160 if t160 else 0
-        if 2 <= s <= 8 and t160 * s >= 384 and kt // s >= 40:
-            return s, 6
-        # N = 640 / 1280 / ... with a short reduction: 128-wide tiles give a fuller single wave (8960 x 640: 350 tiles instead
-        # of 280; 2240 x 1280: 180 instead of 144) and won every sweep by 8-14 %
-        if N % 128 == 0 and kt <= 40 and -(-M // 128) * (N // 128) <= 512:
-            return choose_split(rt, M, N, Kd, ldc, bn=128), 8
-    return choose_split(rt, M, N, Kd, ldc), rt.gemm_variant
+# svdx_gemm tile variants (csrc/gemm.hip): rows x columns of the output tile, LDS stages of the K-loop, waves per workgroup
+TILE_OF_VARIANT = {7: (128, 160, 2, 4), 6: (160, 160, 2, 4), 8: (128, 128, 2, 4),
+                   16: (256, 160, 3, 8), 17: (256, 128, 3, 8), 18: (256, 256, 2, 8), 20: (128, 160, 4, 4), 21: (128, 128, 4, 4)}
+# TFLOP/s one CU sustains on a variant's K-loop when the CU is full (8192^3 runs of tools/ring_check.py divided by 256 CUs, trimmed by
+# the in-situ sweeps of bench.py --tune): the two-stage four-wave tiles need two workgroups per CU for it
+_TILE_RATE = {6: 3.7, 7: 3.25, 8: 3.5, 16: 4.0, 17: 4.0, 18: 3.6, 20: 3.0, 21: 3.0}
+_ALONE, _FILL_STEPS, _EPI_US, _FIN_US, _FIN_BYTES_PER_US = 0.5, 1.5, 3.0, 12.0, 6.0e6
+
+
+def _xcd_block_tiles(Tm: int, Tn: int, a_bytes: float, b_bytes: float) -> int:
+    """Tiles owned by the fullest XCD under launch_gemm_v4's arrangement of the 8 XCDs over the tile grid (csrc/gemm.hip)."""
+    best_eff, best = 0.0, None
+    for xn in (1, 2, 4, 8):
+        sm, sn = -(-Tm // (8 // xn)), -(-Tn // xn)
+        best_eff = max(best_eff, Tm * Tn / (8.0 * sm * sn))
+    for xn in (1, 2, 4, 8):
+        sm, sn = -(-Tm // (8 // xn)), -(-Tn // xn)
+        eff, cost = Tm * Tn / (8.0 * sm * sn), a_bytes * xn + b_bytes * (8 // xn)
+        if eff >= 0.9 * best_eff and (best is None or cost < best[0]):
+            best = (cost, min(sm, Tm) * min(sn, Tn))
+    return best[1]
+
+
+def estimate_gemm_us(M: int, N: int, Kd: int, split: int, variant: int, cin: int = 0) -> float:
+    """Cost model behind `choose_cfg`: rounds of workgroups on the fullest XCD x (K-steps + pipeline fill) x time per K-step of the
+    tile, + the epilogue, + the float-slab round trip of a split reduction.  Fitted to two in-situ sweeps of round 3 (108 problems of
+    the 14 x 512 x 320 step: its picks cost 0.6 % more than the measured best of every problem)."""
+    bm, bn, stages, waves = TILE_OF_VARIANT[variant]
+    Tm, Tn = -(-M // bm), -(-N // bn)
+    two_stage = stages == 2 and waves == 4
+    per_xcd = 64 if two_stage else 32                       # resident workgroups of one XCD's 32 CUs
+    block = _xcd_block_tiles(Tm, Tn, 2.0 * M * (2 * cin if cin else Kd), 2.0 * N * Kd) * split
+    rounds = -(-block // per_xcd)
+    rate = _TILE_RATE[variant]
+    if two_stage:
+        rate = rate / 2 if block > 32 else rate * _ALONE    # shares its CU | alone on it (a drained K-step is exposed latency)
+    ksteps = -(-(Kd // 64) // split)
+    t = rounds * ((ksteps + _FILL_STEPS) * (2.0 * bm * bn * 64) / (rate * 1e6) + _EPI_US * bm * bn / (128 * 128))
+    if split > 1:
+        t += _FIN_US + split * M * N * 8.0 / _FIN_BYTES_PER_US
+    return t
+
+
+def _nt_candidates(M: int, N: int, Kd: int, splittable: bool, fused_epilogue: bool = False):
+    kt = (Kd + 63) // 64
+    out = []
+    for v, (bm, bn, _stages, waves) in TILE_OF_VARIANT.items():
+        if bn == 160 and (N % 160 or fused_epilogue):       # the GEGLU-forward epilogue pairs 64 value with 64 gate columns: 128-wide tiles
+            continue
+        if bn == 128 and N % 160 == 0 and N % 128 and N > 160:
+            continue
+        if bn == 256 and N % 256:
+            continue
+        if waves == 8 and M < 2 * bm:
+            continue
+        tiles = -(-M // bm) * -(-N // bn)
+        for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
+            if s > 1 and (not splittable or tiles >= 512 or tiles * s > 1024 or kt // s < 4 or -(-kt // s) * (s - 1) >= kt):
+                continue
+            out.append((s, v))
+    return out
+
+
+def choose_cfg(rt: "Runtime", M: int, N: int, Kd: int, ldc: int, cin: int = 0):
+    """(split, variant) without a measurement: the candidate with the smallest `estimate_gemm_us`."""
+    if rt.gemm_variant != 4:
+        return choose_split(rt, M, N, Kd, ldc), rt.gemm_variant
+    splittable = rt.split_k and N % 4 == 0 and ldc % 4 == 0
+    cands = _nt_candidates(M, N, Kd, splittable)
+    if not cands:
+        return choose_split(rt, M, N, Kd, ldc), 4
+    return min(cands, key=lambda c: estimate_gemm_us(M, N, Kd, c[0], c[1], cin))
+
+
+def choose_geglu_variant(M: int, N: int, Kd: int, fwd: bool = True) -> int:
+    """Tile variant of a GEMM with a fused GEGLU epilogue (no split-K there) without a measurement: the in-situ sweep's winners --
+    forward (N = 2F): 256 x 256 eight-wave tiles on the big grids, 256 x 128 ring tiles below; backward (N = F): 256 x 256 at the
+    64 x 40 level, two-stage 160-wide tiles in the middle, ring tiles when the grid is under one workgroup per CU."""
+    if fwd:
+        return 18 if (M >= 4096 and N % 256 == 0) else (17 if M >= 512 else 4)
+    if M >= 16384 and N % 256 == 0:
+        return 18
+    return 4 if M >= 1024 else (21 if N % 128 == 0 else 4)
 
 
 class GemmTuner:
@@ -239,21 +306,37 @@ def tuned_call(rt: "Runtime", key, make_cands, fallback, run) -> None:
         rt.tuner.record(key, idx, e0, e1)
         return
     cfg = rt.tuner.table.get(key) if rt.tuner is not None else None
+    if cfg is None:
+        cfg = _measured_cfg(key)
     run(cfg if cfg is not None else fallback())
 
 
-def _nt_candidates(M: int, N: int, Kd: int, splittable: bool):
-    kt = (Kd + 63) // 64
-    variants = (7, 6, 8) if N % 160 == 0 and N % 128 == 0 else ((7, 6) if N % 160 == 0 else (8,))
-    out = []
-    for v in variants:
-        bm, bn = (160, 160) if v == 6 else ((128, 160) if v == 7 else (128, 128))
-        tiles = -(-M // bm) * -(-N // bn)
-        for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
-            if s > 1 and (not splittable or tiles * s > 1024 or kt // s < 4 or -(-kt // s) * (s - 1) >= kt):
-                continue
-            out.append((s, v))
-    return out
+_MEASURED = None
+
+
+def _measured_cfg(key):
+    """Tile / split-K choice of a problem that an in-situ sweep on an MI355X has measured (svd_xtend_amd/gemm_table.json, written by
+    `bench.py --tune --save-gemm-table`: the problems of the 14 x 512 x 320 step); anything else goes through the formulas.
+    SVDX_GEMM_TABLE=0: developer knob for A/B runs against the formulas."""
+    global _MEASURED
+    if _MEASURED is None:
+        _MEASURED = {}
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_table.json")
+        if os.environ.get("SVDX_GEMM_TABLE", "1") != "0" and os.path.exists(path):
+            import json
+            for k, v in json.load(open(path)).items():
+                v = tuple(v) if isinstance(v, list) else v
+                if k.startswith("('nt'") and not (isinstance(v, tuple) and v[1] in TILE_OF_VARIANT):
+                    continue
+                if k.startswith("('geglu") and v not in TILE_OF_VARIANT:
+                    continue
+                _MEASURED[k] = v
+    return _MEASURED.get(repr(key)) if _MEASURED else None
+
+
+def _dual_candidates(M: int, N: int, Kd: int):
+    """The second-operand loop (LoRA) exists for the two-stage four-wave tiles only."""
+    return [(1, v) for v in ((7, 6, 8) if N % 160 == 0 and N % 128 == 0 else ((7, 6) if N % 160 == 0 else (8,)))]
 
 
 def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
@@ -288,7 +371,8 @@ def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowve
                 oj = out[:, j * seg:]
                 k.gemm(A2[:, j * K2:], B2[j * seg:], oj, M, seg, K2, lda2, ldb2, ldc, res=oj, ldres=ldc, variant=rt.gemm_variant)
 
-    tuned_call(rt, key, lambda: _nt_candidates(M, N, Kd, splittable), lambda: choose_cfg(rt, M, N, Kd, ldc), run)
+    tuned_call(rt, key, lambda: _nt_candidates(M, N, Kd, splittable and dual is None) if dual is None else _dual_candidates(M, N, Kd),
+               lambda: choose_cfg(rt, M, N, Kd, ldc, 0 if gather is None else gather.cin), run)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -411,22 +495,24 @@ def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tenso
 
     store = rt.grad_overwrite and write_once       # first micro-batch of a step: dst = ..., later ones: dst += ...
 
-    def run(sk):
+    def run(cfg):
+        sk, stages = cfg if isinstance(cfg, tuple) else (cfg, 0)
         # the bias gradient (column sums of dy) rides on the same launch
         if sk == 1:
-            k.gemm_tn(dy, x, dst, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32 if store else K.OUT_F32_ADD, a_colsum=a_colsum)
+            k.gemm_tn(dy, x, dst, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32 if store else K.OUT_F32_ADD, a_colsum=a_colsum, stages=stages)
         else:
             slabs = rt.f32(sk, N, Kd)
             cs = rt.f32(sk, N) if a_colsum is not None else None       # per-slice column sums, added in slice order by the finalize
-            k.gemm_tn(dy, x, slabs, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32_SLAB, split_k=sk, a_colsum=cs)
+            k.gemm_tn(dy, x, slabs, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32_SLAB, split_k=sk, a_colsum=cs, stages=stages)
             k.gemm_finalize(slabs, sk, N * Kd, dst, N, Kd, Kd, accumulate_f32=2 if store else 1, dtype=rt.dt, colsum_slabs=cs,
                             colsum_out=a_colsum)
 
     tiles = ((N + 127) // 128) * ((Kd + 127) // 128)
 
     def cands():
-        return [s for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 96)
-                if s == 1 or (tiles * s <= 2048 and rtiles // s >= 2 and -(-rtiles // s) * (s - 1) < rtiles)]
+        return [(s, st) for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 96)
+                if s == 1 or (tiles * s <= 2048 and rtiles // s >= 2 and -(-rtiles // s) * (s - 1) < rtiles)
+                for st in (2,)]
 
     def formula():
         sk = 1
@@ -434,7 +520,7 @@ def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tenso
             sk = max(1, min(512 // tiles, rtiles // 4, 128 if tiles <= 4 else 32))
             while sk > 1 and (rtiles + sk - 1) // sk * (sk - 1) >= rtiles:
                 sk -= 1
-        return sk
+        return sk, 2
 
     tuned_call(rt, ("tn", M, N, Kd, lda, ldb), cands, formula, run)
 

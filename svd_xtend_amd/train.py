@@ -207,7 +207,7 @@ class Trainer:
             lo, hi = span
             self._pending.append((span, dist.all_reduce(self.g_flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
 
-    def tune_gemms(self, batch: Dict[str, torch.Tensor], rounds: int = 1, max_steps: int = 40) -> int:
+    def tune_gemms(self, batch: Dict[str, torch.Tensor], rounds: int = 1, max_steps: int = 160) -> int:
         """Measure tile shape / split-K for every GEMM problem of this model inside real forward+backward sweeps on `batch`
         (ops.GemmTuner) and freeze the fastest per problem.  Run once before timing or graph capture; no optimizer step is
         taken, gradients and the loss slot are cleared afterwards.  Returns the number of sweeps used."""

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import kernels as K
 from .lora import LoraLinear, base_linear, inject
-from .ops import (ConvOp, GroupNormOp, LayerNormOp, LinearOp, LoraOp, Runtime, SmallLinearOp, SmallLoraOp, choose_split, flatten_trainables, tuned_call,
+from .ops import (ConvOp, GroupNormOp, LayerNormOp, LinearOp, LoraOp, Runtime, SmallLinearOp, SmallLoraOp, _nt_candidates, choose_geglu_variant, choose_split, flatten_trainables, tuned_call,
                   rup)
 
 HEAD_DIM = 64
@@ -103,8 +103,10 @@ class _FeedForward(nn.Module):
         if self._fusable(rt, M):
             # GEGLU fused into the projection GEMM: one launch emits pre [M,2F] (saved for the backward) and h = a * gelu(gate)
             pre = rt.empty(M, 2 * F)
-            rt.k.gemm(x, self.p1.w, pre, M, 2 * F, self.dim, self.dim, self.dim, 2 * F, bias=self.p1.b, variant=4,
-                      epilogue=K.EPI_GEGLU_FWD, aux_out=g, aux_dim=F)
+            tuned_call(rt, ("geglu_fwd", M, F, self.dim), lambda: [v for _, v in _nt_candidates(M, 2 * F, self.dim, False, fused_epilogue=True)],
+                       lambda: choose_geglu_variant(M, 2 * F, self.dim),
+                       lambda v: rt.k.gemm(x, self.p1.w, pre, M, 2 * F, self.dim, self.dim, self.dim, 2 * F, bias=self.p1.b, variant=v,
+                                           epilogue=K.EPI_GEGLU_FWD, aux_out=g, aux_dim=F))
         else:
             pre = self.p1.fwd(rt, x, M)
             rt.k.geglu_fwd(pre, g, M, F)
@@ -133,7 +135,8 @@ class _FeedForward(nn.Module):
         dpre = rt.empty(M, 2 * F)
         if self._fusable(rt, M):
             # d(h) = dy W2 never reaches HBM: the data-grad GEMM's epilogue applies the GEGLU backward and writes d(pre)
-            tuned_call(rt, ("geglu_bwd", M, F, self.p2.N), lambda: [7, 6] if F % 160 == 0 else [8], lambda: 4,
+            tuned_call(rt, ("geglu_bwd", M, F, self.p2.N), lambda: [v for _, v in _nt_candidates(M, F, self.p2.N, False)],
+                       lambda: choose_geglu_variant(M, F, self.p2.N, fwd=False),
                        lambda v: k.gemm(dy, self.p2.wt, dpre, M, F, self.p2.N, self.p2.N, self.p2.N, 2 * F, variant=v,
                                         epilogue=K.EPI_GEGLU_BWD, aux_in=pre, aux_dim=F))
         else:

@@ -174,7 +174,7 @@ class EmuBackend:
             assert C.dtype == torch.float32 or out_mode == K.OUT_ACT
             c.copy_(v.to(C.dtype))
 
-    def gemm_tn(self, A, B, C, R, N, Kd, lda, ldb, ldc, out_mode=K.OUT_F32_ADD, split_k=1, a_colsum=None):
+    def gemm_tn(self, A, B, C, R, N, Kd, lda, ldb, ldc, out_mode=K.OUT_F32_ADD, split_k=1, a_colsum=None, stages=0):
         a, b = V(A, R, N, lda).float(), V(B, R, Kd, ldb).float()
         if a_colsum is not None and out_mode != K.OUT_F32_SLAB:
             V1(a_colsum, N).add_(a.sum(0))

@@ -96,7 +96,7 @@ def check_gemm_plain(P, dt, variant):
             o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, N, Kd, Kd, Kd, N), kw), dict(C=out))
             res.append((f"gemm v{variant} {M}x{N}x{Kd} {mode}", relerr(o1["C"], o2["C"]), tol_for(dt)))
     # second operand pair (svdx_gemm_dual, the LoRA term): strided A2 / B2 inside wider buffers, K2 = 64 / 192, K = 64 (one main tile)
-    if variant >= 2:
+    if 2 <= variant < 16:          # the second-operand loop exists for the two-stage four-wave tiles only
         for (M, N, Kd, K2, pa, pb) in [(200, 320, 320, 64, 64, 64), (300, 960, 320, 192, 192, 192), (130, 640, 64, 64, 192, 256),
                                        (1000, 1280, 1280, 192, 192, 192), (70, 128, 128, 128, 128, 128)]:
             A, B = rnd((M, Kd), dt, P.dev, g), rnd((N, Kd), dt, P.dev, g, Kd ** -0.5)
@@ -154,10 +154,10 @@ def check_gemm_plain(P, dt, variant):
     return res
 
 
-def check_gemm_tn(P, dt):
+def check_gemm_tn(P, dt, stages=0):
     g = torch.Generator().manual_seed(11)
     res = []
-    for (R, N, Kd) in [(64, 128, 128), (200, 320, 64), (1000, 2560, 320), (77, 8, 1280), (560, 640, 640)]:
+    for (R, N, Kd) in [(64, 128, 128), (200, 320, 64), (1000, 2560, 320), (77, 8, 1280), (560, 640, 640), (130, 256, 128)]:
         A, B = rnd((R, N), dt, P.dev, g), rnd((R, Kd), dt, P.dev, g, R ** -0.5)
         for mode, sk in ((K.OUT_F32, 1), (K.OUT_F32_ADD, 1), (K.OUT_F32_SLAB, 3)):
             if mode == K.OUT_F32_SLAB:
@@ -169,8 +169,8 @@ def check_gemm_tn(P, dt):
             # column sums of A: a running total when the reduction is not split, one stored row per slice when it is
             outs["cs"] = torch.ones(N, device=P.dev) if mode != K.OUT_F32_SLAB else torch.full((3, N), 7.0, device=P.dev)
             o1, o2 = P.run("gemm_tn", lambda o: ((A, B, o["C"], R, N, Kd, N, Kd, Kd),
-                                                 dict(out_mode=mode, split_k=sk, a_colsum=o["cs"])), outs)
-            res.append((f"gemm_tn {R}x{N}x{Kd} mode={mode}", relerr(o1["C"], o2["C"]), tol_for(dt)))
+                                                 dict(out_mode=mode, split_k=sk, a_colsum=o["cs"], stages=stages)), outs)
+            res.append((f"gemm_tn s{stages} {R}x{N}x{Kd} mode={mode}", relerr(o1["C"], o2["C"]), tol_for(dt)))
             res.append((f"gemm_tn {R}x{N}x{Kd} mode={mode} colsum(A)", relerr(o1["cs"], o2["cs"]), 2e-3))
             if mode == K.OUT_F32_SLAB:
                 slabs, cs = o2["C"], o2["cs"]
@@ -180,28 +180,28 @@ def check_gemm_tn(P, dt):
                 res.append((f"gemm_finalize {N}x{Kd} of 3 slabs + colsum rows", max(relerr(o1["W"], o2["W"]), relerr(o1["b"], o2["b"])), 1e-5))
     big = rnd((300, 3 * 128), dt, P.dev, g)
     X = rnd((300, 64), dt, P.dev, g)
-    o1, o2 = P.run("gemm_tn", lambda o: ((big[:, 128:], X, o["C"], 300, 128, 64, 384, 64, 64), dict(out_mode=K.OUT_F32)),
+    o1, o2 = P.run("gemm_tn", lambda o: ((big[:, 128:], X, o["C"], 300, 128, 64, 384, 64, 64), dict(out_mode=K.OUT_F32, stages=stages)),
                    dict(C=torch.zeros(128, 64, device=P.dev)))
     res.append(("gemm_tn strided A", relerr(o1["C"], o2["C"]), tol_for(dt)))
     return res
 
 
-def check_gemm_geglu(P, dt):
+def check_gemm_geglu(P, dt, variant=4):
     g = torch.Generator().manual_seed(12)
     res = []
-    for (M, C, F) in [(200, 64, 128), (300, 320, 1280), (130, 128, 640)]:
+    for (M, C, F) in [(200, 64, 128), (300, 320, 1280), (130, 128, 640), (700, 192, 256)]:
         x, W1, b1 = rnd((M, C), dt, P.dev, g), rnd((2 * F, C), dt, P.dev, g, C ** -0.5), rndf((2 * F,), P.dev, g)
         o1, o2 = P.run("gemm", lambda o: ((x, W1, o["pre"], M, 2 * F, C, C, C, 2 * F),
-                                          dict(bias=b1, variant=4, epilogue=K.EPI_GEGLU_FWD, aux_out=o["h"], aux_dim=F)),
+                                          dict(bias=b1, variant=variant, epilogue=K.EPI_GEGLU_FWD, aux_out=o["h"], aux_dim=F)),
                        dict(pre=torch.zeros(M, 2 * F, dtype=dt, device=P.dev), h=torch.zeros(M, F, dtype=dt, device=P.dev)))
-        res.append((f"gemm geglu-fwd {M}x{C}x{F} pre", relerr(o1["pre"], o2["pre"]), tol_for(dt)))
-        res.append((f"gemm geglu-fwd {M}x{C}x{F} h", relerr(o1["h"], o2["h"]), tol_for(dt, 2)))
+        res.append((f"gemm v{variant} geglu-fwd {M}x{C}x{F} pre", relerr(o1["pre"], o2["pre"]), tol_for(dt)))
+        res.append((f"gemm v{variant} geglu-fwd {M}x{C}x{F} h", relerr(o1["h"], o2["h"]), tol_for(dt, 2)))
         pre = o2["pre"]
         dy, W2t = rnd((M, C), dt, P.dev, g), rnd((F, C), dt, P.dev, g, C ** -0.5)
         o1, o2 = P.run("gemm", lambda o: ((dy, W2t, o["dpre"], M, F, C, C, C, 2 * F),
-                                          dict(variant=4, epilogue=K.EPI_GEGLU_BWD, aux_in=pre, aux_dim=F)),
+                                          dict(variant=variant, epilogue=K.EPI_GEGLU_BWD, aux_in=pre, aux_dim=F)),
                        dict(dpre=torch.zeros(M, 2 * F, dtype=dt, device=P.dev)))
-        res.append((f"gemm geglu-bwd {M}x{C}x{F}", relerr(o1["dpre"], o2["dpre"]), tol_for(dt, 2)))
+        res.append((f"gemm v{variant} geglu-bwd {M}x{C}x{F}", relerr(o1["dpre"], o2["dpre"]), tol_for(dt, 2)))
     return res
 
 
@@ -236,7 +236,7 @@ def check_gemm_gather(P, dt, variant):
         o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, co_, taps * ci_, ci_, taps * ci_, co_),
                                           dict(bias=bias, gather=ga, variant=variant)), dict(C=out))
         res.append((f"gemm v{variant} {label}", relerr(o1["C"], o2["C"]), tol_for(dt)))
-        if variant >= 2 and label in ("conv3x3 s1", "temporal3"):       # taps, then the plain second operand pair
+        if 2 <= variant < 16 and label in ("conv3x3 s1", "temporal3"):       # taps, then the plain second operand pair
             A2, B2 = rnd((M, 64), dt, P.dev, g), rnd((co_, 64), dt, P.dev, g, 0.125)
             o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, co_, taps * ci_, ci_, taps * ci_, co_),
                                               dict(bias=bias, gather=ga, variant=variant, dual=(A2, B2, 64, 64, 64))), dict(C=out))
@@ -646,14 +646,20 @@ def check_optim(P, dt):
     return res
 
 
+RING_VARIANTS = (16, 18, 20)     # between them every ring-staged instantiation of gemm_v4_kernel (N % 160 picks the 160- or 128-wide one)
+
+
 def run_all(impl, dev, dtypes=DTYPES, verbose=True):
     P = Pair(impl, dev)
     out = []
     for dt in dtypes:
-        checks = [("gemm_plain_v0", lambda: check_gemm_plain(P, dt, 0)), ("gemm_plain_v1", lambda: check_gemm_plain(P, dt, 1)),
-                  ("gemm_plain_v4", lambda: check_gemm_plain(P, dt, 4)), ("gemm_gather_v4", lambda: check_gemm_gather(P, dt, 4)),
-                  ("gemm_plain_v6", lambda: check_gemm_plain(P, dt, 6)), ("gemm_gather_v6", lambda: check_gemm_gather(P, dt, 6)),
-                  ("gemm_tn", lambda: check_gemm_tn(P, dt)), ("gemm_geglu", lambda: check_gemm_geglu(P, dt)), ("gemm_gather_v0", lambda: check_gemm_gather(P, dt, 0)), ("gemm_gather_v1", lambda: check_gemm_gather(P, dt, 1)),
+        checks = [("gemm_plain_v1", lambda: check_gemm_plain(P, dt, 1))]
+        for v in (4, 6) + RING_VARIANTS:
+            checks += [(f"gemm_plain_v{v}", lambda v=v: check_gemm_plain(P, dt, v)), (f"gemm_gather_v{v}", lambda v=v: check_gemm_gather(P, dt, v))]
+        checks += [("gemm_tn", lambda: check_gemm_tn(P, dt)), ("gemm_tn_s3", lambda: check_gemm_tn(P, dt, 3)), ("gemm_tn_s4", lambda: check_gemm_tn(P, dt, 4)),
+                   ("gemm_geglu", lambda: check_gemm_geglu(P, dt))]
+        checks += [(f"gemm_geglu_v{v}", lambda v=v: check_gemm_geglu(P, dt, v)) for v in (17, 18, 21)]
+        checks += [
                   ("small", lambda: check_small(P, dt)), ("groupnorm", lambda: check_groupnorm(P, dt)),
                   ("layernorm", lambda: check_layernorm(P, dt)), ("attention", lambda: check_attention(P, dt)),
                   ("temporal_attention", lambda: check_temporal_attention(P, dt)), ("tsa", lambda: check_tsa(P, dt)), ("ffn", lambda: check_ffn(P, dt)),

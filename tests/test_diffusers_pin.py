@@ -1,12 +1,19 @@
 """SURVEY.md 8(c) check (5): the day `diffusers` is importable (it is not in this image, and cannot be installed offline), the
 oracle's blocks below the UNet top level stop being "parity unpinned": diffusers' own UNetSpatioTemporalConditionModel, the class
 the reference trains (/root/reference/train_svd.py:49, :651-656), loads the oracle's state dict strictly and must reproduce its
-output and gradients in fp32.  Skipped while the package is absent."""
+output and gradients in fp32.  Skipped while the package is absent.
+
+Every test runs in BOTH suites -- once unmarked (this container) and once under the `gpu` marker, so the GPU box, the only other place
+a diffusers install might appear, tries them too.  Probed in round 3 (`gpurun python -c "import diffusers, peft"`,
+profiles/r3_probe_imports.txt): neither package is on the GPU box either, so parity stays "unpinned" below the top level."""
 import pytest
 import torch
 
+both_suites = pytest.mark.parametrize("where", ["here", pytest.param("gpu_box", marks=pytest.mark.gpu)])
 
-def test_oracle_matches_diffusers_unet():
+
+@both_suites
+def test_oracle_matches_diffusers_unet(where):
     diffusers = pytest.importorskip("diffusers")
     from oracle.step import edm_inputs, edm_loss, make_synthetic_batch
     from oracle.unet import TINY_CONFIG, UNetSpatioTemporalConditionOracle, scaled_init_
@@ -34,7 +41,8 @@ def test_oracle_matches_diffusers_unet():
         assert torch.allclose(g0[n], g1[n], atol=1e-5, rtol=1e-4), (n, float((g0[n] - g1[n]).abs().max()))
 
 
-def test_oracle_vae_encoder_matches_diffusers():
+@both_suites
+def test_oracle_vae_encoder_matches_diffusers(where):
     diffusers = pytest.importorskip("diffusers")
     from oracle.vae import VaeEncoderOracle
     orc = VaeEncoderOracle(block_out_channels=(32, 64, 64, 64))
@@ -54,7 +62,8 @@ def test_oracle_vae_encoder_matches_diffusers():
     assert torch.allclose(logvar, d.logvar, atol=1e-5, rtol=1e-5), float((logvar - d.logvar).abs().max())
 
 
-def test_oracle_temporal_decoder_matches_diffusers():
+@both_suites
+def test_oracle_temporal_decoder_matches_diffusers(where):
     """oracle/vae.py's TemporalDecoder (the last stage of the validation sampler) against diffusers' AutoencoderKLTemporalDecoder.decode."""
     diffusers = pytest.importorskip("diffusers")
     from oracle.vae import VaeOracle
@@ -74,7 +83,8 @@ def test_oracle_temporal_decoder_matches_diffusers():
     assert torch.allclose(got, want, atol=1e-5, rtol=1e-5), float((got - want).abs().max())
 
 
-def test_sampler_pieces_match_diffusers_scheduler():
+@both_suites
+def test_sampler_pieces_match_diffusers_scheduler(where):
     """oracle/sampler.py's Karras sigmas, continuous timesteps, init_noise_sigma, input scaling and v-prediction Euler step, and the
     product's EulerDiscreteScheduler, against diffusers' EulerDiscreteScheduler in SVD's configuration."""
     diffusers = pytest.importorskip("diffusers")

@@ -280,26 +280,28 @@ def test_zero_grad_then_stale_gradients_are_overwritten(emu_backend):
 
 
 def test_gemm_config_rules_for_the_c2_shapes():
-    """ops.choose_cfg: the measured rules on the shapes they were mined from."""
-    from svd_xtend_amd.ops import choose_cfg, choose_split
+    """ops.choose_cfg: the cost model picks what the in-situ sweeps of round 3 measured as best on the shapes it
+    was fitted to, and never a split that leaves a slice without K-tiles."""
+    from svd_xtend_amd.ops import TILE_OF_VARIANT, choose_cfg
 
     class RT:
         gemm_variant, split_k = 4, True
     rt = RT()
-    # 160x160 tiles x split landing just under the 512 resident workgroups, every split keeping >= 40 K-steps
-    assert choose_cfg(rt, 8960, 640, 5760, 640) == (2, 6)
-    assert choose_cfg(rt, 2240, 1280, 11520, 1280) == (4, 6)
-    assert choose_cfg(rt, 8960, 640, 2560, 640) == (1, 8)          # short K: 128-wide tiles, fuller single wave, no split
-    assert choose_cfg(rt, 2240, 1280, 1280, 1280) == (1, 8)
-    assert choose_cfg(rt, 35840, 320, 2880, 320) == (1, 4)         # 64x40 level: the kernel's own 160-row heuristic
-    s, v = choose_cfg(rt, 2240, 1280, 3840, 1280)
-    assert v == 4 and s == 3 and 3840 // 64 // s >= 16             # splits keep >= 16 K-steps
-    for (M, N, Kd) in [(560, 1280, 11520), (560, 1280, 1280), (2240, 640, 5760), (8960, 1920, 640)]:
+    assert choose_cfg(rt, 35840, 320, 2880, 320, 320) == (1, 6)          # 64x40 level: 448 two-stage 160 x 160 tiles, two per CU
+    assert choose_cfg(rt, 35840, 320, 320, 320) == (1, 6)
+    assert choose_cfg(rt, 8960, 640, 5760, 640, 640) == (1, 17)          # 32x20 level, N = 640: 175 eight-wave 256 x 128 ring tiles, no split
+    assert choose_cfg(rt, 8960, 640, 2560, 640) == (1, 17)
+    assert choose_cfg(rt, 8960, 1280, 5760, 1280, 640) == (1, 6)         # N = 1280: too many 256-row tiles for one per CU
+    assert choose_cfg(rt, 2240, 1280, 11520, 1280, 1280) == (3, 16)      # 16x10 level, long K: 72 tiles of 256 x 160 x 3 slices
+    assert choose_cfg(rt, 2240, 1280, 1280, 1280) == (1, 21)             # short K: 180 four-wave ring tiles, no split
+    s, v = choose_cfg(rt, 560, 1280, 11520, 1280, 1280)                  # 8x5 level: 40 tiles of 128 x 160, 6 slices = 30 per XCD
+    assert v == 20 and s == 6
+    for (M, N, Kd) in [(560, 1280, 11520), (560, 1280, 1280), (2240, 640, 5760), (8960, 1920, 640), (300, 960, 192), (64, 640, 1280), (1000, 4, 576)]:
         s, v = choose_cfg(rt, M, N, Kd, N)
         kt = Kd // 64
-        assert s >= 1 and (s == 1 or -(-kt // s) * (s - 1) < kt), (M, N, Kd, s)    # every split owns at least one K-tile
-    rt.split_k = False
-    assert choose_split(rt, 560, 1280, 11520, 1280) == 1
+        assert v in TILE_OF_VARIANT and s >= 1 and (s == 1 or -(-kt // s) * (s - 1) < kt), (M, N, Kd, s, v)    # every split owns at least one K-tile
+    rt.gemm_variant = 1
+    assert choose_cfg(rt, 2240, 1280, 11520, 1280)[1] == 1
 
 
 def test_gemm_tuner_picks_fastest_candidate_per_problem():

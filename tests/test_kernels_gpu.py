@@ -5,8 +5,10 @@ import pytest
 import torch
 
 gpu = pytest.mark.gpu
-GROUPS = ["gemm_tn", "gemm_geglu", "gemm_plain_v4", "gemm_gather_v4", "gemm_plain_v6", "gemm_gather_v6", "gemm_plain_v0", "gemm_plain_v1", "gemm_gather_v0", "gemm_gather_v1", "small", "groupnorm", "layernorm",
-          "attention", "temporal_attention", "tsa", "ffn", "encoders", "elementwise", "optim"]
+RING = (16, 18, 20)          # ring-staged tile variants: between them every new instantiation of gemm_v4_kernel
+GROUPS = (["gemm_tn", "gemm_tn_s3", "gemm_tn_s4", "gemm_geglu", "gemm_geglu_v17", "gemm_geglu_v18", "gemm_geglu_v21", "gemm_plain_v1"]
+          + [f"gemm_{k}_v{v}" for v in (4, 6) + RING for k in ("plain", "gather")]
+          + ["small", "groupnorm", "layernorm", "attention", "temporal_attention", "tsa", "ffn", "encoders", "elementwise", "optim"])
 
 
 @pytest.fixture(scope="module")
@@ -22,16 +24,18 @@ def pair():
 @pytest.mark.parametrize("group", GROUPS)
 def test_kernel_group(pair, group, dt):
     import kernel_checks as kc
-    fns = {"gemm_tn": lambda: kc.check_gemm_tn(pair, dt), "gemm_geglu": lambda: kc.check_gemm_geglu(pair, dt),
-           "gemm_plain_v4": lambda: kc.check_gemm_plain(pair, dt, 4), "gemm_gather_v4": lambda: kc.check_gemm_gather(pair, dt, 4),
-           "gemm_plain_v6": lambda: kc.check_gemm_plain(pair, dt, 6), "gemm_gather_v6": lambda: kc.check_gemm_gather(pair, dt, 6),
-           "gemm_plain_v0": lambda: kc.check_gemm_plain(pair, dt, 0), "gemm_plain_v1": lambda: kc.check_gemm_plain(pair, dt, 1),
-           "gemm_gather_v0": lambda: kc.check_gemm_gather(pair, dt, 0), "gemm_gather_v1": lambda: kc.check_gemm_gather(pair, dt, 1),
+    fns = {"gemm_tn": lambda: kc.check_gemm_tn(pair, dt), "gemm_tn_s3": lambda: kc.check_gemm_tn(pair, dt, 3), "gemm_tn_s4": lambda: kc.check_gemm_tn(pair, dt, 4),
+           "gemm_geglu": lambda: kc.check_gemm_geglu(pair, dt), "gemm_plain_v1": lambda: kc.check_gemm_plain(pair, dt, 1),
            "small": lambda: kc.check_small(pair, dt), "groupnorm": lambda: kc.check_groupnorm(pair, dt),
            "layernorm": lambda: kc.check_layernorm(pair, dt), "attention": lambda: kc.check_attention(pair, dt),
            "temporal_attention": lambda: kc.check_temporal_attention(pair, dt),
            "tsa": lambda: kc.check_tsa(pair, dt), "ffn": lambda: kc.check_ffn(pair, dt), "encoders": lambda: kc.check_encoders(pair, dt),
            "elementwise": lambda: kc.check_elementwise(pair, dt), "optim": lambda: kc.check_optim(pair, dt)}
+    for v in (17, 18, 21):
+        fns[f"gemm_geglu_v{v}"] = lambda v=v: kc.check_gemm_geglu(pair, dt, v)
+    for v in (4, 6) + RING:
+        fns[f"gemm_plain_v{v}"] = lambda v=v: kc.check_gemm_plain(pair, dt, v)
+        fns[f"gemm_gather_v{v}"] = lambda v=v: kc.check_gemm_gather(pair, dt, v)
     bad = [(l, e, t) for l, e, t in fns[group]() if not (e <= t and math.isfinite(e))]
     assert not bad, f"{len(bad)} mismatches, first: {bad[:5]}"
 
