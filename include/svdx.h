@@ -97,8 +97,9 @@ int svdx_gemm_dual(const void* A, const void* B, void* C, int M, int N, int K, i
  * anyway.  Unsplit (split_k == 1): a_colsum[n] += sum_r A[r*lda + n] (one owner per column, no atomics).  SVDX_OUT_F32_SLAB:
  * a_colsum is float[split_k][N] and slice z STORES its partial into row z; svdx_gemm_finalize(colsum_slabs = a_colsum, ...) adds
  * the rows in order -- a fixed summation order, so the bias gradient is run-to-run identical.  With split_k > 1 a_colsum needs the
- * slab mode.  stages: LDS stages of the K-loop ring, 2 (two workgroups per CU, drained every K-step), 3 or 4 (one workgroup per CU
- * with 2 / 3 row tiles in flight across the barrier: grids that cannot put two workgroups on a CU anyway); 0 = 2. */
+ * slab mode.  stages selects the kernel: 0 / 2 = four waves, 128 x 128 output tiles, two LDS stages (two workgroups per CU, drained
+ * every K-step); 3 / 4 = the same tile with 2 / 3 row tiles in flight across the barrier (one workgroup per CU); 18 = eight waves,
+ * 256 x 256 output tiles, one workgroup per CU (outputs of >= 1024 x 512 that 180-256 such tiles x row slices cover). */
 int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
                  float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, int dtype, void* stream);
 

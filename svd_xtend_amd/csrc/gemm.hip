@@ -507,6 +507,196 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
 }
 
 
+// ----------------------------------------------------------------------------------------------------------------
+// Eight-wave TN tiles: 128*PA output rows x 128*PB output columns (instantiated: 256 x 256), one workgroup per CU.
+// The weight gradients of the step are [2560..10240] x [320..1280] outputs over 560..35840 rows: with 128 x 128 tiles the grids are
+// 60-800 tiles that need up to 32 row slices to fill the chip; the larger tiles stage 2/3 (256 x 128) or 1/2 (256 x 256) of the
+// operand bytes per flop and need a quarter of the slices.  Same operand layout as gemm_tn_kernel: an operand tile is PA (PB)
+// panels of [64 r][128 cols] with that kernel's 8-byte-unit swizzle, fragments by ds_read_b64_tr_b16; accumulators are kept
+// transposed (acc = mfma(B_frag, A_frag)) so that a lane owns 4 consecutive output columns: results leave as 16-byte stores
+// straight from the registers.  Stage ring as in gemm_v4_kernel.
+// ----------------------------------------------------------------------------------------------------------------
+template <typename T, int PA, int PB, int NSTG>
+__global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename TT<T>::v8 v8;
+    constexpr int NT = 512;
+    constexpr int TM = 128 * PA, TK = 128 * PB;                    // output tile
+    constexpr int WMN = 2 * PA, WNN = 8 / WMN;                     // waves along the output rows / columns (64 rows each)
+    constexpr int NJ = TK / WNN / 16;                              // 16-column blocks per wave (4 | 8)
+    constexpr int PANEL = 64 * 256;                                // bytes of one [64 r][128 cols] panel
+    constexpr int STAGE = (PA + PB) * PANEL;
+    constexpr int NPIECE = 2 * (PA + PB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WNN, wn = wave % WNN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int pid_m = swz / p.tiles_n, pid_n = swz - pid_m * p.tiles_n;
+    const int m0 = pid_m * TM, n0 = pid_n * TK;
+    const int R = p.K;
+    const int kt_total = (R + BK - 1) / BK;
+    const int z = blockIdx.y;
+    const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
+    const int kt_begin = z * kt_per;
+    const int kt_end = min(kt_total, kt_begin + kt_per);
+    if (kt_begin >= kt_end) {
+        if (p.a_colsum && p.out_mode == SVDX_OUT_F32_SLAB && pid_n == 0 && tid < TM && m0 + tid < p.M) p.a_colsum[(size_t)z * p.M + m0 + tid] = 0.f;
+        return;
+    }
+    const int pc = tid & 15, ld_row = tid >> 4;                   // ld_row 0..31; rows ld_row + 32 * i of a panel
+    const T* zero = reinterpret_cast<const T*>(p.zero_page);
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+        char* As = smem + stage * STAGE;
+        char* Bs = As + PA * PANEL;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = i * 32 + ld_row;
+            const int lc = pc ^ (tn_rid(row) << 1);
+            const int r = kt * BK + row;
+            const int base = (i * NT + wave_u * 64) * 16;            // chunk id inside the panel = i * 512 + tid = row * 16 + pc
+#pragma unroll
+            for (int pa = 0; pa < PA; ++pa) {
+                const int ca = m0 + pa * 128 + lc * 8;
+                const T* src = (r < R && ca < p.M) ? A + (size_t)r * p.lda + ca : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(As + pa * PANEL + base), 16, 0, 0);
+            }
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                const int cb = n0 + pb * 128 + lc * 8;
+                const T* src = (r < R && cb < p.N) ? B + (size_t)r * p.ldb + cb : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(Bs + pb * PANEL + base), 16, 0, 0);
+            }
+        }
+    };
+    f32x4 acc[4][NJ];                                             // [16-row block i][16-column block j], transposed inside a block
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = p.a_colsum != nullptr && pid_n == 0 && wn == 0;      // bias gradient = A^T * ones (see gemm_tn_kernel)
+    f32x4 accb[4];
+    v8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        const char* As = smem + stage * STAGE;
+        const char* Bs = As + PA * PANEL;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v8 af[4], bf[NJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int blk = wm * 4 + i;
+                af[i] = tn_frag<T>(As + (blk >> 3) * PANEL, blk & 7, ks, fr, fg);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int blk = wn * NJ + j;
+                bf[j] = tn_frag<T>(Bs + (blk >> 3) * PANEL, blk & 7, ks, fr, fg);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = TT<T>::mfma(bf[j], af[i], acc[i][j]);
+            if (do_cs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accb[i] = TT<T>::mfma(af[i], ones, accb[i]);
+            }
+        }
+    };
+    static_assert(NSTG >= 2 && NSTG <= 3, "2 or 3 LDS stages");
+    constexpr int LA = NSTG - 1;
+    auto wait_tiles = [&](int t) __attribute__((always_inline)) {
+        if (NSTG == 2 || t <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+    };
+    auto stage_barrier = [&]() __attribute__((always_inline)) {
+        if (NSTG == 2) { __syncthreads(); return; }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int n_tiles = kt_end - kt_begin;
+#pragma unroll
+    for (int t = 0; t < LA; ++t)
+        if (t < n_tiles) issue(kt_begin + t, t);
+    wait_tiles(min(LA, n_tiles) - 1);
+    stage_barrier();
+    {
+        int cur = 0, nxt = LA, kt = 0;
+        for (; kt + LA < n_tiles; ++kt) {
+            issue(kt_begin + kt + LA, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur);
+            wait_tiles(LA - 1);
+            stage_barrier();
+            cur = cur + 1 == NSTG ? 0 : cur + 1;
+            nxt = nxt + 1 == NSTG ? 0 : nxt + 1;
+        }
+        for (; kt < n_tiles; ++kt) {
+            compute(cur);
+            if (kt + 1 < n_tiles) {
+                wait_tiles(n_tiles - 2 - kt);
+                stage_barrier();
+            }
+            cur = cur + 1 == NSTG ? 0 : cur + 1;
+        }
+    }
+    if (do_cs && fr == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = m0 + wm * 64 + i * 16 + fg * 4 + e;
+                if (n >= p.M) continue;
+                if (p.out_mode == SVDX_OUT_F32_SLAB) p.a_colsum[(size_t)z * p.M + n] = accb[i][e];
+                else p.a_colsum[n] += accb[i][e];
+            }
+    }
+    float* Cf = reinterpret_cast<float*>(p.C) + (p.out_mode == SVDX_OUT_F32_SLAB ? (size_t)z * p.slab_stride : 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = m0 + wm * 64 + i * 16 + fr;
+        if (n >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int k = n0 + wn * (16 * NJ) + j * 16 + fg * 4;
+            if (k >= p.N) continue;
+            float* o = Cf + (size_t)n * p.ldc + k;
+            const f32x4 v = acc[i][j] * p.alpha;
+            if (p.vec_ok && k + 4 <= p.N) {
+                if (p.out_mode == SVDX_OUT_F32) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o));      // a weight gradient: read next by the optimizer
+                else if (p.out_mode == SVDX_OUT_F32_SLAB) *reinterpret_cast<f32x4*>(o) = v;
+                else if (p.out_mode == SVDX_OUT_F32_ADD) *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(o) + v;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(o + e, v[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (k + e >= p.N) continue;
+                    if (p.out_mode == SVDX_OUT_F32 || p.out_mode == SVDX_OUT_F32_SLAB) o[e] = v[e];
+                    else if (p.out_mode == SVDX_OUT_F32_ADD) o[e] += v[e];
+                    else atomicAdd(o + e, v[e]);
+                }
+            }
+        }
+    }
+}
+
+
 // ================================================================================================================
 // variant 4 (production): 128 x (32*NB) x 64 tile, NB = 4 or 5, lean K-loop.
 //  * All channel counts of the SVD UNet are multiples of 320, so BN = 160 tiles N exactly (BN = 128 wastes 17 % of the MFMA
@@ -1167,12 +1357,29 @@ int launch_gemm_tn(const GemmParams& p, hipStream_t st) {
     return 0;
 }
 
+template <typename T, int PA, int PB, int NSTG>
+int launch_gemm_tn8(GemmParams p, hipStream_t st) {
+    constexpr int LDS = NSTG * (PA + PB) * 64 * 256;
+    static_assert(LDS <= 160 * 1024, "stages must fit the 160 KiB LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn8_kernel<T, PA, PB, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    p.tiles_m = cdiv(p.M, 128 * PA);
+    p.tiles_n = cdiv(p.N, 128 * PB);
+    dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
+    hipLaunchKernelGGL((gemm_tn8_kernel<T, PA, PB, NSTG>), grid, dim3(512), LDS, st, p);
+    SVDX_LAUNCH_CHECK("svdx_gemm_tn");
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
                             float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, int dtype, void* stream) {
     SVDX_CHECK_ARG(A && B && C && zero_page && R > 0 && N > 0 && K > 0, "svdx_gemm_tn: bad args");
-    SVDX_CHECK_ARG(stages == 0 || (stages >= 2 && stages <= 4), "svdx_gemm_tn: stages=%d (0 = default, 2..4)", stages);
+    SVDX_CHECK_ARG(stages == 0 || (stages >= 2 && stages <= 4) || stages == 18, "svdx_gemm_tn: stages=%d (0 = default, 2..4, 18)", stages);
     // the unsplit / ADD modes read-modify-write a_colsum from every z slice: one slice only (SVDX_OUT_F32_SLAB keeps a row per slice)
     SVDX_CHECK_ARG(!a_colsum || split_k == 1 || out_mode == SVDX_OUT_F32_SLAB, "svdx_gemm_tn: a_colsum with split_k > 1 needs slab output");
     SVDX_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
@@ -1190,6 +1397,7 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
     p.vec_ok = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) && (K % 8 == 0);
     p.slab_stride = (long)N * ldc;
     DISPATCH_DTYPE(dtype, {
+        if (stages == 18) return launch_gemm_tn8<T, 2, 2, 2>(p, (hipStream_t)stream);
         if (stages == 3) return launch_gemm_tn<T, 3>(p, (hipStream_t)stream);
         if (stages == 4) return launch_gemm_tn<T, 4>(p, (hipStream_t)stream);
         return launch_gemm_tn<T, 2>(p, (hipStream_t)stream);

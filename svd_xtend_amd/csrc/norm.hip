@@ -330,122 +330,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
 }
 
-// R rows per wave in flight (latency hiding: a C=320 row is a single 640-byte load per operand).  Affine gradients are
-// block-reduced in LDS and then either written to `partial[block][2C]` (reduced by ln_param_reduce_kernel: no global atomics --
-// device-scope float atomics run at ~15/ns chip-wide, which made this kernel atomic-bound) or, without scratch, added atomically.
-template <typename T, int LN_MAXCH, int R>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                     const T* __restrict__ add, const T* __restrict__ add2, float add2_scale,
-                                                     T* __restrict__ dx, float* dgamma, float* dbeta, float* partial, int rows,
-                                                     int C) {
-    extern __shared__ float red[];   // [2][C] when affine grads are requested
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cc = C / 8;
-    const bool affine = dgamma != nullptr;
-    if (affine) {
-        for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
-        __syncthreads();
-    }
-    float gmv[LN_MAXCH][8], pg[LN_MAXCH][8], pb[LN_MAXCH][8];
-#pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int j = lane + i * 64;
-            gmv[i][e] = j < cc ? gamma[j * 8 + e] : 0.f;
-            pg[i][e] = pb[i][e] = 0.f;
-        }
-    const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    for (int row0 = wid * R; row0 < rows; row0 += nw * R) {
-        float xh[R][LN_MAXCH][8], dg[R][LN_MAXCH][8], s1[R], s2[R], rstd[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int row = min(row0 + k, rows - 1);
-            const bool live = row0 + k < rows;
-            const float mean = stats[(size_t)row * 2];
-            rstd[k] = stats[(size_t)row * 2 + 1];
-            s1[k] = s2[k] = 0.f;
-#pragma unroll
-            for (int i = 0; i < LN_MAXCH; ++i) {
-                const int j = lane + i * 64;
-                if (j < cc) {
-                    float xv[8], dv[8];
-                    load8<T>(x + (size_t)row * C + j * 8, xv);
-                    load8<T>(dy + (size_t)row * C + j * 8, dv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float d = live ? dv[e] : 0.f;
-                        xh[k][i][e] = (xv[e] - mean) * rstd[k];
-                        dg[k][i][e] = d * gmv[i][e];
-                        s1[k] += dg[k][i][e];
-                        s2[k] += dg[k][i][e] * xh[k][i][e];
-                        pg[i][e] += d * xh[k][i][e];
-                        pb[i][e] += d;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int row = row0 + k;
-            const float m1 = wave_sum(s1[k]) / C, m2 = wave_sum(s2[k]) / C;
-            if (row < rows) {
-#pragma unroll
-                for (int i = 0; i < LN_MAXCH; ++i) {
-                    const int j = lane + i * 64;
-                    if (j < cc) {
-                        float o[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = rstd[k] * (dg[k][i][e] - m1 - xh[k][i][e] * m2);
-                        if (add) {
-                            float av[8];
-                            load8<T>(add + (size_t)row * C + j * 8, av);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] += av[e];
-                        }
-                        if (add2) {
-                            float av[8];
-                            load8<T>(add2 + (size_t)row * C + j * 8, av);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] += add2_scale * av[e];
-                        }
-                        store8<T>(dx + (size_t)row * C + j * 8, o);
-                    }
-                }
-            }
-        }
-    }
-    if (affine) {
-        // the four waves add their column partials one after the other: a fixed summation order (float atomics would leave the
-        // gradient of the affine parameters run-to-run different in its last bits)
-        for (int w = 0; w < 4; ++w) {
-            if (wave == w) {
-#pragma unroll
-                for (int i = 0; i < LN_MAXCH; ++i) {
-                    const int j = lane + i * 64;
-                    if (j < cc) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            red[j * 8 + e] += pg[i][e];
-                            red[C + j * 8 + e] += pb[i][e];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        if (partial) {
-            for (int i = threadIdx.x; i < 2 * C; i += 256) partial[(size_t)blockIdx.x * 2 * C + i] = red[i];
-        } else {
-            for (int i = threadIdx.x; i < C; i += 256) {
-                atomicAdd(dgamma + i, red[i]);
-                atomicAdd(dbeta + i, red[C + i]);
-            }
-        }
-    }
-}
-
 // ---- LayerNorm, 16 lanes per row (C <= 640): a wave normalises FOUR rows per step, the row sums are DPP reductions inside the
 // 16-lane group (no LDS crossbar), every lane keeps the affine parameters of its NCH chunks.  One wave per row spent a full wave of
 // instruction issue on 640 bytes: the kernels were issue / latency bound at 2.9-3.1 TB/s.
@@ -505,71 +389,103 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(const T* __restrict__ x, 
     }
 }
 
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void ln_bwd16_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ stats,
-                                                       const float* __restrict__ gamma, const T* __restrict__ add, const T* __restrict__ add2,
-                                                       float add2_scale, T* __restrict__ dx, float* dgamma, float* dbeta, float* partial, int rows,
-                                                       int C) {
-    extern __shared__ float red[];   // [16 row groups][C] when affine grads are requested
-    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+// ---- LayerNorm backward: LANES lanes per row, every lane owns the 16-byte chunks ll, ll + LANES, ... (NCH of them) of its row.
+// Round 3 rewrite.  The round-2 kernels kept the per-column affine-gradient accumulators of up to five chunks per lane in registers
+// (2 x 5 x 8 floats) beside four operand rows: 213 VGPRs at C = 320 and 355 at C = 640 -- one or two waves per SIMD on a kernel that
+// only has memory latency to hide (25-28 us per launch where the operands stream in 8 us).  Here the lane count follows the row
+// width so that NCH <= 3 at every width of the UNet (16 / 32 / 64 lanes for C = 320 / 640 / 1280: 2.5 chunks per lane), the frozen
+// LayerNorms compile without the accumulators (AFFINE = false), and nothing but the operand chunks themselves stays live across the
+// row reduction.  Affine gradients: block partials through a [row groups][C] LDS slab added in a fixed order, then either one
+// `partial[block][2C]` row (reduced by ln_param_reduce_kernel -- deterministic) or, without scratch, float atomics.
+template <int LANES>
+__device__ __forceinline__ float ln_group_sum(float v) {
+    v = row16_sum(v);
+    if (LANES >= 32) v += __shfl_xor(v, 16, 64);
+    if (LANES >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <typename T, int LANES, int NCH, bool AFFINE>
+__global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ stats,
+                                                        const float* __restrict__ gamma, const T* __restrict__ add, const T* __restrict__ add2,
+                                                        float add2_scale, T* __restrict__ dx, float* dgamma, float* dbeta, float* partial, int rows,
+                                                        int C) {
+    extern __shared__ float red[];   // AFFINE: [256 / LANES row groups][C]
+    constexpr int GROUPS = 256 / LANES;
+    const int ll = threadIdx.x % LANES, grp = threadIdx.x / LANES;
     const int cc = C / 8;
-    const bool affine = dgamma != nullptr;
-    float gm[NCH][8], pg[NCH][8], pb[NCH][8];
+    float gm[NCH][8], pg[AFFINE ? NCH : 1][8], pb[AFFINE ? NCH : 1][8];
     bool cv[NCH];
     int cl[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-        const int c = l16 + 16 * j;
+        const int c = ll + LANES * j;
         cv[j] = c < cc;
         cl[j] = min(c, cc - 1);
         gn_load8f(gamma + cl[j] * 8, gm[j]);
+        if (AFFINE) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pg[j][e] = pb[j][e] = 0.f;
+            for (int e = 0; e < 8; ++e) pg[j][e] = pb[j][e] = 0.f;
+        }
     }
     const float invC = 1.f / (float)C;
-    for (int row = blockIdx.x * 16 + grp; row < rows; row += gridDim.x * 16) {
-        Vec8<T> xr[NCH], dr[NCH], ar[NCH], a2r[NCH];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const size_t off = (size_t)row * C + cl[j] * 8;
-            xr[j] = *reinterpret_cast<const Vec8<T>*>(x + off);
-            dr[j] = *reinterpret_cast<const Vec8<T>*>(dy + off);
-            if (add) ar[j] = *reinterpret_cast<const Vec8<T>*>(add + off);
-            if (add2) a2r[j] = *reinterpret_cast<const Vec8<T>*>(add2 + off);
-        }
-        const float2 mr = *reinterpret_cast<const float2*>(stats + (size_t)row * 2);
-        float xh[NCH][8], dg[NCH][8];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = cv[j] ? to_f<T>(dr[j].v[e]) : 0.f;
-                xh[j][e] = cv[j] ? (to_f<T>(xr[j].v[e]) - mr.x) * mr.y : 0.f;
-                dg[j][e] = d * gm[j][e];
-                s1 += dg[j][e];
-                s2 += dg[j][e] * xh[j][e];
-                pg[j][e] += d * xh[j][e];
-                pb[j][e] += d;
-            }
-        const float m1 = row16_sum(s1) * invC, m2 = row16_sum(s2) * invC;
+    for (int row = blockIdx.x * GROUPS + grp; row < rows; row += gridDim.x * GROUPS) {
+        Vec8<T> xr[NCH], dr[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             if (cv[j]) {
+                const size_t off = (size_t)row * C + cl[j] * 8;
+                xr[j] = *reinterpret_cast<const Vec8<T>*>(x + off);
+                dr[j] = *reinterpret_cast<const Vec8<T>*>(dy + off);
+            }
+        }
+        const float2 mr = *reinterpret_cast<const float2*>(stats + (size_t)row * 2);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (cv[j]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = to_f<T>(dr[j].v[e]);
+                    const float xh = (to_f<T>(xr[j].v[e]) - mr.x) * mr.y;
+                    const float dg = d * gm[j][e];
+                    s1 += dg;
+                    s2 += dg * xh;
+                    if (AFFINE) {
+                        pg[j][e] += d * xh;
+                        pb[j][e] += d;
+                    }
+                }
+            }
+        }
+        const float m1 = ln_group_sum<LANES>(s1) * invC, m2 = ln_group_sum<LANES>(s2) * invC;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (cv[j]) {
+                const size_t off = (size_t)row * C + cl[j] * 8;
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    o[e] = mr.y * (dg[j][e] - m1 - xh[j][e] * m2);
-                    if (add) o[e] += to_f<T>(ar[j].v[e]);
-                    if (add2) o[e] += add2_scale * to_f<T>(a2r[j].v[e]);
+                    const float xh = (to_f<T>(xr[j].v[e]) - mr.x) * mr.y;
+                    o[e] = mr.y * (to_f<T>(dr[j].v[e]) * gm[j][e] - m1 - xh * m2);
                 }
-                store8<T>(dx + (size_t)row * C + cl[j] * 8, o);
+                if (add) {
+                    const Vec8<T> ar = *reinterpret_cast<const Vec8<T>*>(add + off);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += to_f<T>(ar.v[e]);
+                }
+                if (add2) {
+                    const Vec8<T> ar = *reinterpret_cast<const Vec8<T>*>(add2 + off);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += add2_scale * to_f<T>(ar.v[e]);
+                }
+                store8<T>(dx + off, o);
             }
         }
     }
-    if (affine) {
-        // column partials: every 16-lane group parks its own in LDS, then each thread adds the 16 groups of its columns in order;
-        // gamma and beta gradients take turns in the same [16][C] slab (40 KiB at C = 640: three workgroups per CU)
+    if (AFFINE) {
+        // column partials: every row group parks its own in LDS, then each thread adds the groups of its columns in order; gamma and
+        // beta gradients take turns in the same [GROUPS][C] slab (20 KiB at the three widths of the UNet)
         float* mine = red + (size_t)grp * C;
 #pragma unroll 1
         for (int which = 0; which < 2; ++which) {
@@ -584,7 +500,7 @@ __global__ __launch_bounds__(256) void ln_bwd16_kernel(const T* __restrict__ dy,
             for (int i = threadIdx.x; i < C; i += 256) {
                 float t = 0.f;
 #pragma unroll
-                for (int g = 0; g < 16; ++g) t += red[(size_t)g * C + i];
+                for (int g = 0; g < GROUPS; ++g) t += red[(size_t)g * C + i];
                 if (partial) partial[(size_t)blockIdx.x * 2 * C + which * C + i] = t;
                 else atomicAdd((which == 0 ? dgamma : dbeta) + i, t);
             }
@@ -697,43 +613,33 @@ extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, co
                            void* stream) {
     SVDX_CHECK_ARG(rows > 0 && C % 8 == 0 && C / 8 <= 64 * LN_MAXCH_LIMIT, "svdx_ln_bwd: C=%d unsupported", C);
     SVDX_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "svdx_ln_bwd: dgamma/dbeta must come together");
-    const int nch = (C / 8 + 63) / 64;
-    const int R = nch == 1 ? 4 : (nch == 2 ? 2 : 1);
-    // affine grads: with scratch, up to SVDX_LN_PARTIAL_ROWS blocks each leave one [2C] partial row (>= 4 iterations per wave);
-    // without, every block ends with 2*C float atomics, so keep one block per CU there
-    int blocks = min(cdiv(rows, 4 * R), 2048);
-    if (dgamma) blocks = scratch ? max(1, min(cdiv(rows, 4 * R), SVDX_LN_PARTIAL_ROWS)) : min(blocks, 256);
-    const size_t sh = dgamma ? sizeof(float) * 2 * C : 0;
     hipStream_t st = (hipStream_t)stream;
-    const int nch16 = (C / 8 + 15) / 16;
-    if (nch16 <= 5) {                       // C <= 640: 16 lanes per row, 16 rows per block per step
-        blocks = min(cdiv(rows, 16), 2048);
-        if (dgamma) blocks = scratch ? max(1, min(cdiv(rows, 32), SVDX_LN_PARTIAL_ROWS)) : min(blocks, 256);
-        const size_t sh16 = dgamma ? sizeof(float) * 16 * C : 0;
-        DISPATCH_DTYPE(dtype, {
-            static bool attr_set = false;                // once per dtype: the [16][2C] float slab is 80 KiB at C = 640
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd16_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd16_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd16_kernel<T, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd16_kernel<T, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                attr_set = true;
-            }
-        });
-#define LN_BWD16(NCH) hipLaunchKernelGGL((ln_bwd16_kernel<T, NCH>), dim3(blocks), dim3(256), sh16, st, (const T*)dy, (const T*)x, stats, gamma, \
-                                         (const T*)add, (const T*)add2, add2_scale, (T*)dx, dgamma, dbeta, scratch, rows, C)
-        DISPATCH_DTYPE(dtype, { if (nch16 == 1) LN_BWD16(1); else if (nch16 == 2) LN_BWD16(2); else if (nch16 == 3) LN_BWD16(3); else LN_BWD16(5); });
-#undef LN_BWD16
-        SVDX_LAUNCH_CHECK("svdx_ln_bwd");
-        if (dgamma && scratch) {
-            hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, st, scratch, blocks, C, dgamma, dbeta);
-            SVDX_LAUNCH_CHECK("svdx_ln_bwd(param reduce)");
-        }
-        return 0;
+    const int cc = C / 8;
+    // lanes per row: the fewest of 16 / 32 / 64 that cover the row with at most three chunks per lane (C <= 384 / 768 / 1536); wider
+    // rows take four chunks on 64 lanes
+    const int lanes = cc <= 48 ? 16 : (cc <= 96 ? 32 : 64);
+    const int nch = (cc + lanes - 1) / lanes;
+    const int groups = 256 / lanes;
+    // affine grads: with scratch, up to SVDX_LN_PARTIAL_ROWS blocks each leave one [2C] partial row; without, every block ends with
+    // 2*C float atomics, so keep one block per CU there
+    int blocks = min(cdiv(rows, groups), 2048);
+    if (dgamma) blocks = scratch ? max(1, min(cdiv(rows, 2 * groups), SVDX_LN_PARTIAL_ROWS)) : min(blocks, 256);
+    const size_t sh = dgamma ? sizeof(float) * groups * C : 0;
+    SVDX_CHECK_ARG(sh <= 64 * 1024, "svdx_ln_bwd: C=%d too wide for the affine-gradient slab", C);
+#define LN_BWD(L, N)                                                                                                                  \
+    {                                                                                                                                 \
+        if (dgamma)                                                                                                                   \
+            hipLaunchKernelGGL((ln_bwd_kernel<T, L, N, true>), dim3(blocks), dim3(256), sh, st, (const T*)dy, (const T*)x, stats, gamma, \
+                               (const T*)add, (const T*)add2, add2_scale, (T*)dx, dgamma, dbeta, scratch, rows, C);                    \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((ln_bwd_kernel<T, L, N, false>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, stats, gamma, \
+                               (const T*)add, (const T*)add2, add2_scale, (T*)dx, dgamma, dbeta, scratch, rows, C);                    \
     }
-#define LN_BWD(NCH, RR) hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, RR>), dim3(blocks), dim3(256), sh, st, (const T*)dy, \
-                                           (const T*)x, stats, gamma, (const T*)add, (const T*)add2, add2_scale, (T*)dx, dgamma, dbeta, scratch, rows, C)
-    DISPATCH_DTYPE(dtype, { if (nch == 1) LN_BWD(1, 4); else if (nch == 2) LN_BWD(2, 2); else if (nch == 3) LN_BWD(3, 1); else LN_BWD(4, 1); });
+    DISPATCH_DTYPE(dtype, {
+        if (lanes == 16) { if (nch == 1) LN_BWD(16, 1) else if (nch == 2) LN_BWD(16, 2) else LN_BWD(16, 3) }
+        else if (lanes == 32) LN_BWD(32, 3)
+        else { if (nch <= 3) LN_BWD(64, 3) else LN_BWD(64, 4) }
+    });
 #undef LN_BWD
     SVDX_LAUNCH_CHECK("svdx_ln_bwd");
     if (dgamma && scratch) {

@@ -216,12 +216,18 @@ def _nt_candidates(M: int, N: int, Kd: int, splittable: bool, fused_epilogue: bo
     return out
 
 
-def choose_cfg(rt: "Runtime", M: int, N: int, Kd: int, ldc: int, cin: int = 0):
-    """(split, variant) without a measurement: the candidate with the smallest `estimate_gemm_us`."""
+def _dual_candidates(M: int, N: int, Kd: int):
+    """The second-operand loop (LoRA) exists for the two-stage four-wave tiles only."""
+    return [(1, v) for v in ((7, 6, 8) if N % 160 == 0 and N % 128 == 0 else ((7, 6) if N % 160 == 0 else (8,)))]
+
+
+def choose_cfg(rt: "Runtime", M: int, N: int, Kd: int, ldc: int, cin: int = 0, dual: bool = False):
+    """(split, variant) without a measurement: the candidate with the smallest `estimate_gemm_us`.  dual: the launch carries a
+    second operand pair (LoRA), which only the unsplit two-stage four-wave tiles implement."""
     if rt.gemm_variant != 4:
-        return choose_split(rt, M, N, Kd, ldc), rt.gemm_variant
+        return (1 if dual else choose_split(rt, M, N, Kd, ldc)), rt.gemm_variant
     splittable = rt.split_k and N % 4 == 0 and ldc % 4 == 0
-    cands = _nt_candidates(M, N, Kd, splittable)
+    cands = _dual_candidates(M, N, Kd) if dual else _nt_candidates(M, N, Kd, splittable)
     if not cands:
         return choose_split(rt, M, N, Kd, ldc), 4
     return min(cands, key=lambda c: estimate_gemm_us(M, N, Kd, c[0], c[1], cin))
@@ -334,11 +340,6 @@ def _measured_cfg(key):
     return _MEASURED.get(repr(key)) if _MEASURED else None
 
 
-def _dual_candidates(M: int, N: int, Kd: int):
-    """The second-operand loop (LoRA) exists for the two-stage four-wave tiles only."""
-    return [(1, v) for v in ((7, 6, 8) if N % 160 == 0 and N % 128 == 0 else ((7, 6) if N % 160 == 0 else (8,)))]
-
-
 def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
              res=None, ldres=0, gather=None, dual=None, alpha: float = 1.0) -> None:
     """Activation-dtype GEMM.  Tile shape and split-K factor come from the GemmTuner table when the model was tuned
@@ -372,7 +373,7 @@ def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowve
                 k.gemm(A2[:, j * K2:], B2[j * seg:], oj, M, seg, K2, lda2, ldb2, ldc, res=oj, ldres=ldc, variant=rt.gemm_variant)
 
     tuned_call(rt, key, lambda: _nt_candidates(M, N, Kd, splittable and dual is None) if dual is None else _dual_candidates(M, N, Kd),
-               lambda: choose_cfg(rt, M, N, Kd, ldc, 0 if gather is None else gather.cin), run)
+               lambda: choose_cfg(rt, M, N, Kd, ldc, 0 if gather is None else gather.cin, dual is not None and rt.fuse_dual), run)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -507,14 +508,26 @@ def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tenso
             k.gemm_finalize(slabs, sk, N * Kd, dst, N, Kd, Kd, accumulate_f32=2 if store else 1, dtype=rt.dt, colsum_slabs=cs,
                             colsum_out=a_colsum)
 
-    tiles = ((N + 127) // 128) * ((Kd + 127) // 128)
+    TN_TILES = {2: (128, 128), 18: (256, 256)}     # svdx_gemm_tn `stages`: output tile (rows of dst, columns)
+
+    def tiles_of(v):
+        tm, tk = TN_TILES[v]
+        return -(-N // tm) * -(-Kd // tk)
 
     def cands():
-        return [(s, st) for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 96)
-                if s == 1 or (tiles * s <= 2048 and rtiles // s >= 2 and -(-rtiles // s) * (s - 1) < rtiles)
-                for st in (2,)]
+        return [(s, v) for v in TN_TILES if v == 2 or (N >= 2 * TN_TILES[v][0] - 128 and Kd >= 2 * TN_TILES[v][1] - 128)
+                for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 96)
+                if s == 1 or (tiles_of(v) * s <= (2048 if v == 2 else 768) and rtiles // s >= 2 and -(-rtiles // s) * (s - 1) < rtiles)]
 
     def formula():
+        # 256 x 256 eight-wave tiles when (with a few row slices) they cover the output in one round of <= 256 workgroups: the
+        # 16x10 / 32x20-level feed-forward gradients (10240 x 1280 over 2240 rows: 98 against 107 us in the step; 5120 x 640 over 8960)
+        if N >= 1024 and Kd >= 512 and rtiles >= 16:
+            t18 = tiles_of(18)
+            sk = max(1, min(256 // t18, rtiles // 32))
+            if 180 <= t18 * sk <= 256:
+                return sk, 18
+        tiles = tiles_of(2)
         sk = 1
         if tiles < 256 and rtiles >= 16:
             sk = max(1, min(512 // tiles, rtiles // 4, 128 if tiles <= 4 else 32))

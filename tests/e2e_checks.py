@@ -285,11 +285,11 @@ def run_lora(verbose=False, dev=None, ranks=(64, 8)):
 # attention, spatial sequences of 2560 / 640 / 160 / 40, the 2C -> C resnets behind a skip concat with their 1x1 shortcut.
 # layers_per_block = 1 keeps the CPU oracle at seconds per case.
 # ----------------------------------------------------------------------------------------------------------------------
-def level_config(C, heads, cross_dim=1024, layers=1):
+def level_config(C, heads, cross_dim=1024, layers=1, num_frames=14):
     return dict(in_channels=8, out_channels=4, down_block_types=("CrossAttnDownBlockSpatioTemporal",),
                 up_block_types=("CrossAttnUpBlockSpatioTemporal",), block_out_channels=(C,), addition_time_embed_dim=256,
                 projection_class_embeddings_input_dim=768, layers_per_block=layers, cross_attention_dim=cross_dim,
-                transformer_layers_per_block=1, num_attention_heads=(heads,), num_frames=14)
+                transformer_layers_per_block=1, num_attention_heads=(heads,), num_frames=num_frames)
 
 
 C2_LEVELS = {           # name: (C, heads, h, w) at T = 14
@@ -300,13 +300,19 @@ C2_LEVELS = {           # name: (C, heads, h, w) at T = 14
 }
 
 
-def run_levels(levels=None, dtypes=(torch.float16,), T=14, lora_r=0, verbose=False, dev=None, seed=11):
+C4_LEVELS = {           # reference config 4 (25 frames of 1024 x 576, latent 72 x 128): its two deepest levels at T = 25
+    "L2 1280ch 18x32": (1280, 20, 18, 32),
+    "L3 1280ch 9x16": (1280, 20, 9, 16),
+}
+
+
+def run_levels(levels=None, dtypes=(torch.float16,), T=14, lora_r=0, verbose=False, dev=None, seed=11, table=None):
     dev = dev or torch.device("cuda")
     res = {}
-    for name, (C, heads, h, w) in C2_LEVELS.items():
+    for name, (C, heads, h, w) in (table or C2_LEVELS).items():
         if levels is not None and name.split()[0] not in levels:
             continue
-        cfg = level_config(C, heads)
+        cfg = level_config(C, heads, num_frames=T)
         t0 = time.time()
         ref = oracle_step(cfg, 1, T, h, w, seed=seed, lr=1e-4, cross_dim=cfg["cross_attention_dim"], lora_r=lora_r)
         t_or = time.time() - t0

@@ -122,6 +122,24 @@ def test_c5_lora_level_blocks_match_oracle(level):
 
 
 @gpu
+@pytest.mark.parametrize("level,lora_r", [("L2", 0), ("L3", 0), ("L3", 64)])
+def test_c4_level_blocks_match_oracle(level, lora_r):
+    """Reference config 4 (/root/reference/train_svd.py:318 --num_frames 25, 1024 x 576): the T = 25 path -- temporal attention with the
+    frame axis padded 25 -> 32 and masked, no fused temporal self-attention (T > 16), Conv3d over 25 frames, 3-D GroupNorm over 25 x HW
+    rows -- at the two deepest levels of that shape (576 and 144 pixels per frame, 1280 channels), one optimizer step against the CPU
+    oracle in fp16; the 144-pixel level also with LoRA r = 64 adapters (bf16, config 5's recipe on config 4's frame count)."""
+    import torch
+
+    import e2e_checks
+    dt = torch.bfloat16 if lora_r else torch.float16
+    res = e2e_checks.run_levels(levels=[level], dtypes=(dt,), T=25, lora_r=lora_r, verbose=True, table=e2e_checks.C4_LEVELS)
+    assert len(res) == 1
+    for key, r in res.items():
+        e2e_checks.assert_parity(key, r)
+        assert r["n_grads"] >= 30 or lora_r, r
+
+
+@gpu
 def test_full_topology_c1_matches_oracle():
     """c1' = 8 frames 256x192 through the full 1,524,623,082-parameter UNet, fp16 and bf16: loss <= 1e-3 / 8e-3, gradient cosine
     of every trainable tensor (416 of them, minus the ones whose gradient is exactly zero), prediction, updated weights."""

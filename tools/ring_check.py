@@ -88,7 +88,7 @@ def do_check():
         for v in kc.RING_VARIANTS:
             groups += [(f"plain v{v}", lambda v=v: kc.check_gemm_plain(P, dt, v)), (f"gather v{v}", lambda v=v: kc.check_gemm_gather(P, dt, v))]
         groups += [(f"geglu v{v}", lambda v=v: kc.check_gemm_geglu(P, dt, v)) for v in (17, 18, 21)]
-        groups += [(f"tn s{s}", lambda s=s: kc.check_gemm_tn(P, dt, s)) for s in (0, 3, 4)]
+        groups += [(f"tn s{s}", lambda s=s: kc.check_gemm_tn(P, dt, s)) for s in (0, 3, 4, 18)]
         for name, fn in groups:
             try:
                 rows = fn()
@@ -177,6 +177,43 @@ def do_time():
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "ring_time.json"), "w"))
 
 
+TN_SHAPES = [(35840, 2560, 320), (35840, 320, 1280), (35840, 960, 320), (35840, 320, 320), (8960, 5120, 640), (8960, 640, 2560), (8960, 1920, 640),
+             (8960, 640, 640), (2240, 10240, 1280), (2240, 1280, 5120), (2240, 3840, 1280), (2240, 1280, 1280), (560, 10240, 1280), (560, 1280, 5120)]
+
+
+def do_tn_time():
+    """weight-gradient shapes of the step (R rows, output N x K) over (kernel variant, row slices)"""
+    dt = torch.float16
+    tiles_of = {2: (128, 128), 18: (256, 256)}
+    for (R, N, Kd) in TN_SHAPES:
+        A = torch.randn(R, N, device=dev).to(dt)
+        B = torch.randn(R, Kd, device=dev).to(dt)
+        dst = torch.zeros(N, Kd, device=dev)
+        cs_out = torch.zeros(N, device=dev)
+        rt = (R + 63) // 64
+        res = {}
+        for v, (tm, tk) in tiles_of.items():
+            tiles = -(-N // tm) * -(-Kd // tk)
+            for sk in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32):
+                if sk > 1 and (tiles * sk > (1200 if v == 2 else 600) or rt // sk < 4):
+                    continue
+                if sk == 1:
+                    fn = lambda: be.gemm_tn(A, B, dst, R, N, Kd, N, Kd, Kd, out_mode=K.OUT_F32, a_colsum=cs_out, stages=v)
+                else:
+                    slabs = torch.empty(sk, N, Kd, device=dev)
+                    cs = torch.empty(sk, N, device=dev)
+
+                    def fn(slabs=slabs, cs=cs, sk=sk):
+                        be.gemm_tn(A, B, slabs, R, N, Kd, N, Kd, Kd, out_mode=K.OUT_F32_SLAB, split_k=sk, a_colsum=cs, stages=v)
+                        be.gemm_finalize(slabs, sk, N * Kd, dst, N, Kd, Kd, accumulate_f32=2, dtype=dt, colsum_slabs=cs, colsum_out=cs_out)
+                res[f"v{v}s{sk}"] = timeit(fn)
+        fl = 2.0 * R * N * Kd
+        old = min(((k, u) for k, u in res.items() if k.startswith("v2s")), key=lambda kv: kv[1])
+        best = sorted(res.items(), key=lambda kv: kv[1])[:5]
+        print(f"tn R={R:6d} {N:5d}x{Kd:5d}  old best {old[0]:7s} {old[1]:7.1f} us {fl / old[1] / 1e6:5.0f} TF | " +
+              "  ".join(f"{k} {u:.1f} ({fl / u / 1e6:.0f})" for k, u in best), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "race", "time"]
     if "check" in what:
@@ -185,3 +222,5 @@ if __name__ == "__main__":
         do_race()
     if "time" in what:
         do_time()
+    if "tn" in what:
+        do_tn_time()
