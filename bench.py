@@ -154,8 +154,8 @@ def cpu_baseline(dev=None, dtype=torch.float16, c2=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)      # ~11 s of GPU work: long enough for an outside power / utilisation sampler to see it
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=14)
     ap.add_argument("--height", type=int, default=320)     # pixels; README.md:40-53 trains 512x320
     ap.add_argument("--width", type=int, default=512)
@@ -178,9 +178,13 @@ def main():
     ap.add_argument("--grad-accum", type=int, default=1,
                     help="micro-batches per optimizer step (reference config 4 runs gradient_accumulation_steps = 2); gradients are "
                          "reduced over ranks on the last one only")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="N > 1: ONE all-reduce of the flat gradient buffer after the backward sweep instead of one per transformer "
-                         "block started during it (A/B switch for the scaling runs)")
+    ap.add_argument("--overlap", default="buckets", choices=["buckets", "single", "vae"],
+                    help="N > 1, how the gradient sum over ranks is scheduled: `buckets` = one all-reduce per transformer block started "
+                         "during the backward sweep (default); `single` = ONE all-reduce of the flat buffer after the sweep; `vae` = that "
+                         "one all-reduce with the VAE encode of the NEXT micro-batch (train_svd.py:948) replayed beside it and AdamW after "
+                         "the wait -- north_star's schedule; reported as a second field next to the UNet-only headline, with the part of "
+                         "the collective that stayed exposed")
+    ap.add_argument("--no-overlap", action="store_true", help="alias of --overlap single")
     ap.add_argument("--no-cpu-c2", action="store_true", help="skip the single CPU-oracle step at the benched shape")
     ap.add_argument("--with-vae", action="store_true",
                     help="also time the step with the VAE encode of the next micro-batch (train_svd.py:948, 957-960) on a second "
@@ -189,6 +193,10 @@ def main():
                     help="developer aid: write the ordered list of libsvdx calls of ONE eager step (entry name + scalar arguments) to this "
                          "JSON file; tools/step_trace.py joins it with a rocprofv3 kernel trace of the graph-replayed steps")
     args = ap.parse_args()
+    if args.no_overlap:
+        args.overlap = "single"
+    if args.overlap == "vae":
+        args.with_vae = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher the driver contract describes -- one rank per GPU under
@@ -238,7 +246,7 @@ def main():
             model.add_adapter(LoraConfig(r=args.lora_rank, lora_alpha=args.lora_rank, init_lora_weights="gaussian"))
     trainer = Trainer(model, dtype=dt, lr=1e-5, grad_accum=args.grad_accum)
     trainer.rt.gemm_variant = args.gemm_variant
-    trainer.overlap = not args.no_overlap
+    trainer.overlap = args.overlap == "buckets"
     n_params = sum(p.numel() for p in model.parameters())
     n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
     B, T, h, w = 1, args.frames, args.height // 8, args.width // 8
@@ -255,9 +263,9 @@ def main():
     def opt_step():
         trainer.optimizer_step()
 
-    def step_eager():
+    def step_eager(side_work=None):
         fwd_bwd()
-        trainer.allreduce_grads()
+        trainer.finish_grads(side_work)
         opt_step()
 
     # ---- one-off GEMM tuning (untimed set-up, like graph capture), warmup (eager), then capture -------------
@@ -348,11 +356,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        trainer.exposed_events = [] if world > 1 else None
         for _ in range(args.steps):
-            with torch.cuda.stream(side):
-                gv.replay()                              # frozen, no dependency on the update: free to run under the all-reduce / AdamW
-            step()
+            if args.overlap == "vae":
+                step(side_work=gv.replay)                # ONE collective in flight, the next clip's encode queued beside it, AdamW after
+            else:
+                with torch.cuda.stream(side):
+                    gv.replay()                          # frozen, no dependency on the update: free to run under the all-reduce / AdamW
+                step()
         torch.cuda.synchronize()
+        exposed = trainer.exposed_events
+        trainer.exposed_events = None
         if world > 1:
             dist.barrier()
         el2 = time.perf_counter() - t1
@@ -364,7 +378,10 @@ def main():
                     "vae_ms_alone": vae_alone, "frames_encoded_per_step": frames,
                     "what": "UNet step + AutoencoderKLTemporalDecoder.encode of the next clip (T + 1 frames, pixels resident in HBM) on a second "
                             "HIP stream, both replayed from hipGraphs; the headline `value` above is the UNet step alone",
-                    "latent_mean_abs": float(z.abs().mean())}
+                    "latent_mean_abs": float(z.abs().mean()),
+                    "schedule": ("one all-reduce after the backward sweep, the encode replayed beside it on the compute stream, AdamW after the wait"
+                                 if args.overlap == "vae" else "encode on a second stream beside the whole step"),
+                    "allreduce_ms_exposed": (sum(a.elapsed_time(b) for a, b in exposed) / len(exposed)) if exposed else None}
         del vae, gv, pix
 
     # ---- what RCCL saw: ranks (an all-reduce of ones) and the cost of the gradient exchange on its own -------------------------
@@ -500,18 +517,20 @@ def main():
     if rank == 0:
         full = (not args.tiny) and (T, h, w) == (14, 40, 64) and not args.lora_rank
         line = {
-            "metric": "train-step samples/sec (14-frame 512x320 fp16 SVD UNet)" if not args.lora_rank else
+            "metric": "train-step samples/sec (tiny debug topology)" if args.tiny else
+                      "train-step samples/sec (14-frame 512x320 fp16 SVD UNet)" if not args.lora_rank else
                       f"train-step samples/sec (14-frame 512x320 {args.dtype} SVD UNet, LoRA r={args.lora_rank})",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic latents/CLIP embed, random-init weights (no checkpoints offline)",
-            "config": {"workload": f"SVD UNet train step, {T} frames {args.width}x{args.height}, batch 1/GPU"
+            "config": {"workload": f"{'TINY debug topology (not the SVD UNet)' if args.tiny else 'SVD UNet'} train step, {T} frames {args.width}x{args.height}, batch 1/GPU"
                                    f"{' x %d micro-batches' % args.grad_accum if args.grad_accum > 1 else ''}, "
                                    f"{n_params} params ({n_train} trainable: "
                                    f"{'LoRA r=%d adapters on to_q/to_k/to_v/to_out.0' % args.lora_rank if args.lora_rank else 'temporal_transformer_block*'}), "
                                    "fwd + EDM loss + bwd + grad all-reduce + AdamW",
                        "global_batch": world * B * args.grad_accum, "grad_accum": args.grad_accum, "parallelism": f"dp{world}",
-                       "grad_allreduce": ("none" if world == 1 else "one collective after backward" if args.no_overlap else
+                       "grad_allreduce": ("none" if world == 1 else "one collective after backward" if args.overlap == "single" else
+                                          "one collective after backward, under the next clip's VAE encode" if args.overlap == "vae" else
                                           "per-transformer-block buckets overlapped with the backward sweep"),
                        "ranks_seen": ranks_seen, "allreduce_ms": allreduce_ms, "allreduce_bytes": trainer.n_total * 4,
                        "exec": exec_mode, "gemm_tuning_sweeps": tune_sweeps,

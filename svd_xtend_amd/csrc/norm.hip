@@ -19,12 +19,15 @@ struct GnGeom {
 // temporal norm has only 64 distinct addresses and >1000 blocks: same-address atomics serialise), readers add them up.
 // The sums are 64-bit FIXED-POINT integers: integer addition is associative, so the result does not depend on the order in which
 // the blocks' atomics land -- the statistics (and with them the whole step) are run-to-run identical, which float atomics are not.
-// Scale 2^k per (kind, count): k = 62 - (bits of the largest term) - ceil(log2(count)), so that no sum can leave 63 bits while
-// |x| <= 2^16 (the fp16 range), |dz gamma| <= 2^18, |xhat| <= 2^8; a block's float partial converts exactly (24 significant bits).
+// Scale 2^k per (kind, count): k = 62 - (bits of the largest term) - ceil(log2(count)).  The plain sum is safe over the whole fp16
+// range (|x| <= 2^16); the sum of squares is scaled for a group whose ROOT-MEAN-SQUARE stays below 2^12 -- 2^24 per term instead of
+// the worst case 2^32: eight more fraction bits, which clip-wide norms over 8 x 576 x 1024 rows need for groups of small activations
+// (with the worst-case scale a block partial was rounded to 1/32 there; a group with an rms of 4096 has left fp16 training long
+// before).  Backward: |dz gamma| <= 2^18, |xhat| <= 2^8.  A block's float partial converts exactly (24 significant bits).
 __host__ __device__ __forceinline__ void gn_fixed_scales(long cnt, int mode, int& k0, int& k1) {
     int lg = 0;
     while ((1L << lg) < cnt) ++lg;
-    const int b0 = mode == 0 ? 16 : 18, b1 = mode == 0 ? 32 : 26;
+    const int b0 = mode == 0 ? 16 : 18, b1 = mode == 0 ? 24 : 26;
     k0 = 62 - b0 - lg; k1 = 62 - b1 - lg;
     k0 = k0 < 0 ? 0 : (k0 > 40 ? 40 : k0);
     k1 = k1 < 0 ? 0 : (k1 > 40 ? 40 : k1);

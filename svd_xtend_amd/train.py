@@ -101,12 +101,18 @@ class Trainer:
         self.micro = 0
         self.schedule = dict(name="constant", num_warmup_steps=0, num_training_steps=0, num_cycles=0.0, power=1.0, lr_end=1e-7,
                              steps_per_step=1)
+        src = (dist.get_global_rank(process_group, 0) if process_group is not None else 0) if self.world > 1 else 0
+        if self.world > 1:
+            # DistributedDataParallel's constructor broadcast (train_svd.py:815 through accelerate.prepare -> _sync_module_states): the
+            # replicas start from rank 0's module state whatever each rank holds locally.  Frozen parameters and buffers first, before
+            # they are packed for the kernels; the trainables travel as the flat buffer below.
+            for t in list(model.parameters()) + list(model.buffers()):
+                if not t.requires_grad:
+                    dist.broadcast(t.data, src=src, group=process_group)
         self._build_runtime()
         if self.world > 1:
-            # DistributedDataParallel's constructor broadcast (train_svd.py:815 through accelerate.prepare): the replicas start from
-            # rank 0's trainables whatever each rank drew locally (peft's gaussian LoRA init uses the process-global generator)
-            dist.broadcast(self.p_flat, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
-                           group=process_group)
+            # ... and the trainables (peft's gaussian LoRA init uses the process-global generator: ranks do differ there)
+            dist.broadcast(self.p_flat, src=src, group=process_group)
             self.weights_changed()
 
     def _build_runtime(self) -> None:
@@ -146,6 +152,7 @@ class Trainer:
         # gradient buckets for overlapping the all-reduce with the backward sweep: one contiguous slice of g_flat per transformer
         # block (its trainables are adjacent in named_parameters order), reduced as soon as backward_rows leaves the block
         self.overlap = True
+        self.exposed_events = None      # a list: finish_grads() records the exposed part of the collective (bench.py)
         self._pending = []              # (span, work) of the all-reduces started during THIS step's backward sweep (zero_grad clears)
         self._buckets = {}
         off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
@@ -260,6 +267,39 @@ class Trainer:
         self._pending = []
         return None
 
+    def finish_grads(self, side_work=None) -> None:
+        """Complete the gradient sum over ranks, with `side_work()` issued on the compute stream while the collective is in flight.
+        north_star's schedule: ONE all-reduce of the flat gradient buffer started when the backward sweep ends, the frozen
+        conditioners of the NEXT micro-batch (VAE encode + CLIP embed, which the reference runs at the top of its next iteration,
+        train_svd.py:948, :975) beside it, AdamW after the wait -- `trainer.overlap = False` + a `side_work`.  With the per-block
+        buckets (`overlap = True`) most of the sum already ran under the backward sweep; the side work then covers the tail.
+        When `self.exposed_events` is a list, the (side work queued, collective waited for) event pair of the step is appended: the
+        time between them is the part of the collective nothing hid."""
+        if self.world == 1:
+            if side_work is not None:
+                side_work()
+            return
+        if self._pending:                                 # bucket mode: start what the sweep did not cover, then the side work
+            done = {span for span, _ in self._pending}
+            for span in list(self._buckets.values()) + self._rest:
+                if span not in done and span[1] > span[0]:
+                    self._pending.append((span, dist.all_reduce(self.g_flat[span[0]:span[1]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
+            works = [w for _, w in self._pending]
+        else:
+            works = [dist.all_reduce(self.g_flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)]
+        if side_work is not None:
+            side_work()
+        ev = None
+        if self.exposed_events is not None and self.g_flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        for w in works:
+            w.wait()
+        if ev is not None:
+            ev[1].record()
+            self.exposed_events.append(ev)
+        self._pending = []
+
     # ---- optimizer step (unscale + inf check + AdamW + re-pack), no host sync -----------------------------
     def optimizer_step(self):
         k = self.rt.k
@@ -277,16 +317,17 @@ class Trainer:
         self.model.refresh_trainable(masters_changed_on_host=False)
         self.micro = 0
 
-    def step(self, batch) -> None:
+    def step(self, batch, side_work=None) -> None:
         """Whole optimizer step: zero, fwd/bwd of the `grad_accum` micro-batches (one dict, or a sequence of them -- config 4 of
-        the reference runs gradient_accumulation_steps = 2), all-reduce (overlapped with the last backward sweep), AdamW."""
+        the reference runs gradient_accumulation_steps = 2), gradient sum over ranks (per-block buckets under the last backward
+        sweep, or one collective under `side_work` -- see `finish_grads`), AdamW."""
         batches = [batch] if isinstance(batch, dict) else list(batch)
         if len(batches) != self.grad_accum:
             raise ValueError(f"expected {self.grad_accum} micro-batch(es), got {len(batches)}")
         self.zero_grad()
         for b in batches:
             self.forward_backward(**b)
-        self.allreduce_grads()
+        self.finish_grads(side_work)
         self.optimizer_step()
 
     # ---- learning-rate schedule, evaluated on the device from the optimizer's step counter --------------------
@@ -391,7 +432,9 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
 
-    def __call__(self) -> None:
+    def __call__(self, side_work=None) -> None:
+        """side_work: callable queued between the backward sweep and the optimizer, beside the gradient collective
+        (`Trainer.finish_grads`) -- e.g. the replay of the next micro-batch's VAE-encode graph."""
         tr = self.tr
         multi = tr.world > 1
         for i, g in enumerate(self.graphs):
@@ -399,7 +442,7 @@ class GraphedStep:
             if multi and tr.overlap and i < len(self.spans) and self.spans[i] is not None:
                 lo, hi = self.spans[i]
                 tr._pending.append(((lo, hi), dist.all_reduce(tr.g_flat[lo:hi], op=dist.ReduceOp.SUM, group=tr.pg, async_op=True)))
-        tr.allreduce_grads()
+        tr.finish_grads(side_work)
         self.g_opt.replay()
 
 

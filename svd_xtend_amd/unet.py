@@ -370,6 +370,8 @@ class TemporalBasicTransformerBlock(nn.Module):
             return False
         if self.dim > K.TSA_MAX_C or self.dim % 64 or g.T > K.TSA_MAX_T:
             return False
+        if g.M * 3 * self.dim * 2 >= 2 ** 31:                     # the kernel addresses q/k/v with 32-bit buffer offsets: larger batches take the unfused path
+            return False
         return K.tsa_pixels_per_band(g.T, g.HW) * g.T >= 96
 
     def fwd(self, rt: Runtime, x, g: Geom, tctx):

@@ -88,7 +88,7 @@ def gn_fixed_scales(cnt: int, mode: int):
     lg = 0
     while (1 << lg) < cnt:
         lg += 1
-    b0, b1 = (16, 32) if mode == 0 else (18, 26)
+    b0, b1 = (16, 24) if mode == 0 else (18, 26)
     return min(max(62 - b0 - lg, 0), 40), min(max(62 - b1 - lg, 0), 40)
 
 

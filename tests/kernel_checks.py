@@ -288,8 +288,10 @@ def check_small(P, dt):
 def check_groupnorm(P, dt):
     g = torch.Generator().manual_seed(4)
     res = []
-    for (n_s, rows, C) in [(3, 70, 64), (2, 200, 320), (1, 333, 960), (2, 64, 2560), (5, 16, 192), (1, 4000, 320)]:
-        x = (rnd((n_s * rows, C), dt, P.dev, g) * 1.5 + 0.3).to(dt)
+    # last case: a clip-wide norm over 2^18 rows of small activations (|x| ~ 1e-2): the fixed-point sum of squares must keep them
+    for (n_s, rows, C, mag) in [(3, 70, 64, 1.5), (2, 200, 320, 1.5), (1, 333, 960, 1.5), (2, 64, 2560, 1.5), (5, 16, 192, 1.5), (1, 4000, 320, 1.5),
+                                (1, 262144, 64, 0.01)]:
+        x = (rnd((n_s * rows, C), dt, P.dev, g) * mag + 0.2 * mag).to(dt)
         dy = rnd((n_s * rows, C), dt, P.dev, g)
         add = rnd((n_s * rows, C), dt, P.dev, g)
         gamma, beta = 1 + 0.1 * rndf((C,), P.dev, g), 0.1 * rndf((C,), P.dev, g)

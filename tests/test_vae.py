@@ -180,3 +180,26 @@ def test_decoder_matches_oracle_at_the_svd_widths():
     got = vae.decode(z.to(dev), num_frames=3).sample.cpu()
     print("vae decoder 128x192 x3 fp16 rel-L2:", rel(got, want))
     assert rel(got, want) <= 1e-2
+
+
+@gpu
+def test_decode_chunk_of_8_at_the_reference_validation_resolution():
+    """/root/reference/train_svd.py:1130-1138 validates at 1024 x 576 with decode_chunk_size = 8: eight frames of 72x128 latents put
+    2.4 GB activations in front of the last up block, beyond the 2 GiB reach of the buffer-addressed GEMM kernel (max_decode_frames =
+    7).  The chunk must decode through the 64-bit-pointer kernel -- and that kernel must agree with the fast one on this decoder's op
+    mix, checked at a size both can run (the fp16 results of the two kernels differ only by accumulation order)."""
+    dev = torch.device("cuda")
+    _, vae = make_pair(SVD_VAE_CONFIG, 23, dev)
+    vae.prepare(torch.float16)
+    assert vae.max_decode_frames(72, 128) < 8
+    z = torch.randn(8, 4, 72, 128, generator=torch.Generator().manual_seed(5)).to(dev)
+    out = vae.decode(z, num_frames=8).sample
+    assert out.shape == (8, 3, 576, 1024) and bool(torch.isfinite(out).all())
+    zs = z[:3, :, :16, :24].contiguous()
+    fast = vae.decode(zs, num_frames=3).sample
+    vae.rt.gemm_variant = 1
+    try:
+        slow = vae.decode(zs, num_frames=3).sample
+    finally:
+        vae.rt.gemm_variant = 4
+    assert rel(slow.cpu(), fast.cpu()) <= 2e-3, rel(slow.cpu(), fast.cpu())
