@@ -477,244 +477,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
     }
 }
 
-// ================================================================================================================
-// temporal attention: one wave per (clip, pixel, head); TP_ = padded frame count (16 or 32)
-// ================================================================================================================
-template <typename T, int TPAD>
-struct TemporalCfg {
-    static constexpr int LPQ = 64 / TPAD;       // lanes per query
-    static constexpr int DCH = 64 / LPQ;        // head-dim slice per lane
-};
-
-template <typename T>
-__device__ __forceinline__ void tload_rows(char* dst, const T* base, size_t tstride, int Tn, int lane) {
-    for (int id = lane; id < Tn * 8; id += 64) {
-        const int t = id >> 3, c = id & 7;
-        *reinterpret_cast<uint4*>(dst + t * 128 + c * 16) = *reinterpret_cast<const uint4*>(base + (size_t)t * tstride + c * 8);
-    }
-}
-
-template <typename T, int TPAD>
-__global__ __launch_bounds__(256) void tattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                                                        T* __restrict__ o, int B, int Tn, int HW, int heads, int ld, int ld_o,
-                                                        float sl2, long nprob) {
-    typedef TemporalCfg<T, TPAD> Cfg;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    char* Kl = smem + wave * (2 * TPAD * 128);
-    char* Vl = Kl + TPAD * 128;
-    const long prob = (long)blockIdx.x * 4 + wave;
-    if (prob >= nprob) return;
-    const int h = (int)(prob % heads);
-    const long bp = prob / heads;
-    const int p = (int)(bp % HW), b = (int)(bp / HW);
-    const size_t row0 = (size_t)b * Tn * HW + p;
-    const size_t ts = (size_t)HW * ld;
-    tload_rows<T>(Kl, k + row0 * ld + h * 64, ts, Tn, lane);
-    tload_rows<T>(Vl, v + row0 * ld + h * 64, ts, Tn, lane);
-    const int tq = lane / Cfg::LPQ, part = lane % Cfg::LPQ;
-    const int tqc = min(tq, Tn - 1);
-    float qv[Cfg::DCH];
-    {
-        const T* qp = q + (row0 + (size_t)tqc * HW) * ld + h * 64 + part * Cfg::DCH;
-#pragma unroll
-        for (int c = 0; c < Cfg::DCH / 8; ++c) {
-            float t8[8];
-            load8<T>(qp + c * 8, t8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qv[c * 8 + e] = t8[e];
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0);   // LDS writes of this wave are visible to its own later reads after the wait
-    __builtin_amdgcn_wave_barrier();
-    float sc[TPAD];
-    float mx = -1e30f;
-#pragma unroll
-    for (int tk = 0; tk < TPAD; ++tk) {
-        float a = 0.f;
-        if (tk < Tn) {
-#pragma unroll
-            for (int c = 0; c < Cfg::DCH / 8; ++c) {
-                float k8[8];
-                load8<T>(reinterpret_cast<const T*>(Kl + tk * 128) + part * Cfg::DCH + c * 8, k8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a += qv[c * 8 + e] * k8[e];
-            }
-        }
-#pragma unroll
-        for (int off = 1; off < Cfg::LPQ; off <<= 1) a += __shfl_xor(a, off, 64);
-        a = tk < Tn ? a * sl2 : -1e30f;
-        sc[tk] = a;
-        mx = fmaxf(mx, a);
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int tk = 0; tk < TPAD; ++tk) { sc[tk] = fexp2(sc[tk] - mx); sum += sc[tk]; }
-    const float inv = 1.f / sum;
-    float ov[Cfg::DCH];
-#pragma unroll
-    for (int e = 0; e < Cfg::DCH; ++e) ov[e] = 0.f;
-#pragma unroll
-    for (int tk = 0; tk < TPAD; ++tk) {
-        if (tk < Tn) {
-            const float pw = sc[tk] * inv;
-#pragma unroll
-            for (int c = 0; c < Cfg::DCH / 8; ++c) {
-                float v8_[8];
-                load8<T>(reinterpret_cast<const T*>(Vl + tk * 128) + part * Cfg::DCH + c * 8, v8_);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ov[c * 8 + e] += pw * v8_[e];
-            }
-        }
-    }
-    if (tq < Tn) {
-        T* op = o + (row0 + (size_t)tq * HW) * ld_o + h * 64 + part * Cfg::DCH;
-#pragma unroll
-        for (int c = 0; c < Cfg::DCH / 8; ++c) {
-            float t8[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t8[e] = ov[c * 8 + e];
-            store8<T>(op + c * 8, t8);
-        }
-    }
-}
-
-template <typename T, int TPAD>
-__global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                                                        const T* __restrict__ d_o, T* __restrict__ dq, T* __restrict__ dk,
-                                                        T* __restrict__ dv, int B, int Tn, int HW, int heads, int ld, int ld_o,
-                                                        int ld_d, float scale, long nprob) {
-    typedef TemporalCfg<T, TPAD> Cfg;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int WAVE_BYTES = 4 * TPAD * 128 + 2 * TPAD * (TPAD + 1) * 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    char* Ql = smem + wave * WAVE_BYTES;
-    char* Kl = Ql + TPAD * 128;
-    char* Vl = Kl + TPAD * 128;
-    char* Dl = Vl + TPAD * 128;
-    float* Pm = reinterpret_cast<float*>(Dl + TPAD * 128);   // [TPAD][TPAD+1] probabilities
-    float* Sm = Pm + TPAD * (TPAD + 1);                      // [TPAD][TPAD+1] dS
-    const long prob = (long)blockIdx.x * 4 + wave;
-    if (prob >= nprob) return;
-    const int h = (int)(prob % heads);
-    const long bp = prob / heads;
-    const int p = (int)(bp % HW), b = (int)(bp / HW);
-    const size_t row0 = (size_t)b * Tn * HW + p;
-    const float sl2 = scale * LOG2E;
-    tload_rows<T>(Ql, q + row0 * ld + h * 64, (size_t)HW * ld, Tn, lane);
-    tload_rows<T>(Kl, k + row0 * ld + h * 64, (size_t)HW * ld, Tn, lane);
-    tload_rows<T>(Vl, v + row0 * ld + h * 64, (size_t)HW * ld, Tn, lane);
-    tload_rows<T>(Dl, d_o + row0 * ld_o + h * 64, (size_t)HW * ld_o, Tn, lane);
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    const int tq = lane / Cfg::LPQ, part = lane % Cfg::LPQ;
-    const int tqc = min(tq, Tn - 1);
-    float qv[Cfg::DCH], dov[Cfg::DCH];
-#pragma unroll
-    for (int c = 0; c < Cfg::DCH / 8; ++c) {
-        float a8[8], b8[8];
-        load8<T>(reinterpret_cast<const T*>(Ql + tqc * 128) + part * Cfg::DCH + c * 8, a8);
-        load8<T>(reinterpret_cast<const T*>(Dl + tqc * 128) + part * Cfg::DCH + c * 8, b8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { qv[c * 8 + e] = a8[e]; dov[c * 8 + e] = b8[e]; }
-    }
-    float sc[TPAD], dp[TPAD];
-    float mx = -1e30f;
-#pragma unroll
-    for (int tk = 0; tk < TPAD; ++tk) {
-        float a = 0.f, d = 0.f;
-        if (tk < Tn) {
-#pragma unroll
-            for (int c = 0; c < Cfg::DCH / 8; ++c) {
-                float k8[8], v8_[8];
-                load8<T>(reinterpret_cast<const T*>(Kl + tk * 128) + part * Cfg::DCH + c * 8, k8);
-                load8<T>(reinterpret_cast<const T*>(Vl + tk * 128) + part * Cfg::DCH + c * 8, v8_);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { a += qv[c * 8 + e] * k8[e]; d += dov[c * 8 + e] * v8_[e]; }
-            }
-        }
-#pragma unroll
-        for (int off = 1; off < Cfg::LPQ; off <<= 1) { a += __shfl_xor(a, off, 64); d += __shfl_xor(d, off, 64); }
-        a = tk < Tn ? a * sl2 : -1e30f;
-        sc[tk] = a;
-        dp[tk] = d;
-        mx = fmaxf(mx, a);
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int tk = 0; tk < TPAD; ++tk) { sc[tk] = fexp2(sc[tk] - mx); sum += sc[tk]; }
-    const float inv = 1.f / sum;
-    float dsum = 0.f;
-#pragma unroll
-    for (int tk = 0; tk < TPAD; ++tk) { sc[tk] *= inv; dsum += sc[tk] * dp[tk]; }
-    // dS = P * (dP - sum_k P dP); dQ[tq] = scale * sum_k dS[tq,k] K[k]
-    float dqv[Cfg::DCH];
-#pragma unroll
-    for (int e = 0; e < Cfg::DCH; ++e) dqv[e] = 0.f;
-    const bool qvalid = tq < Tn;
-#pragma unroll
-    for (int tk = 0; tk < TPAD; ++tk) {
-        const float ds = qvalid && tk < Tn ? sc[tk] * (dp[tk] - dsum) : 0.f;
-        if (part == 0 && tq < TPAD) {
-            Pm[tq * (TPAD + 1) + tk] = qvalid ? sc[tk] : 0.f;
-            Sm[tq * (TPAD + 1) + tk] = ds;
-        }
-        if (tk < Tn) {
-#pragma unroll
-            for (int c = 0; c < Cfg::DCH / 8; ++c) {
-                float k8[8];
-                load8<T>(reinterpret_cast<const T*>(Kl + tk * 128) + part * Cfg::DCH + c * 8, k8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dqv[c * 8 + e] += ds * k8[e];
-            }
-        }
-    }
-    if (qvalid) {
-        T* op = dq + (row0 + (size_t)tq * HW) * ld_d + h * 64 + part * Cfg::DCH;
-#pragma unroll
-        for (int c = 0; c < Cfg::DCH / 8; ++c) {
-            float t8[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t8[e] = dqv[c * 8 + e] * scale;
-            store8<T>(op + c * 8, t8);
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    // now the lane owns key tk = tq: dV[tk] = sum_q P[q,tk] dO[q] ; dK[tk] = scale * sum_q dS[q,tk] Q[q]
-    float dkv_[Cfg::DCH], dvv[Cfg::DCH];
-#pragma unroll
-    for (int e = 0; e < Cfg::DCH; ++e) { dkv_[e] = 0.f; dvv[e] = 0.f; }
-    const int tkc = min(tq, TPAD - 1);
-#pragma unroll
-    for (int t2 = 0; t2 < TPAD; ++t2) {
-        if (t2 < Tn) {
-            const float pw = Pm[t2 * (TPAD + 1) + tkc];
-            const float dsw = Sm[t2 * (TPAD + 1) + tkc];
-#pragma unroll
-            for (int c = 0; c < Cfg::DCH / 8; ++c) {
-                float q8[8], d8[8];
-                load8<T>(reinterpret_cast<const T*>(Ql + t2 * 128) + part * Cfg::DCH + c * 8, q8);
-                load8<T>(reinterpret_cast<const T*>(Dl + t2 * 128) + part * Cfg::DCH + c * 8, d8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { dvv[c * 8 + e] += pw * d8[e]; dkv_[c * 8 + e] += dsw * q8[e]; }
-            }
-        }
-    }
-    if (qvalid) {
-        T* kp = dk + (row0 + (size_t)tq * HW) * ld_d + h * 64 + part * Cfg::DCH;
-        T* vp = dv + (row0 + (size_t)tq * HW) * ld_d + h * 64 + part * Cfg::DCH;
-#pragma unroll
-        for (int c = 0; c < Cfg::DCH / 8; ++c) {
-            float a8[8], b8[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { a8[e] = dkv_[c * 8 + e] * scale; b8[e] = dvv[c * 8 + e]; }
-            store8<T>(kp + c * 8, a8);
-            store8<T>(vp + c * 8, b8);
-        }
-    }
-}
-
 }  // namespace
 
 #define ATTN_ARGS_OK(ld_, ptr_) ((ld_) % 8 == 0 && (((uintptr_t)(ptr_)) & 15) == 0)
@@ -765,54 +527,5 @@ extern "C" int svdx_attn_bwd_dq(const void* q, const void* k, const void* v, con
                                              (const T*)k, (const T*)v, (const T*)d_o, lse, D, (T*)dq, heads, S, ld, ld_o, ld_d,
                                              scale));
     SVDX_LAUNCH_CHECK("svdx_attn_bwd_dq");
-    return 0;
-}
-
-extern "C" int svdx_tattn_fwd(const void* q, const void* k, const void* v, void* o, int B, int Tn, int HW, int heads, int ld,
-                              int ld_o, float scale, int dtype, void* stream) {
-    SVDX_CHECK_ARG(q && k && v && o && B > 0 && Tn > 0 && Tn <= 32 && HW > 0 && heads > 0, "svdx_tattn_fwd: bad args (T<=32)");
-    SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ATTN_ARGS_OK(ld_o, o), "svdx_tattn_fwd: alignment");
-    const long nprob = (long)B * HW * heads;
-    const int blocks = cdiv(nprob, 4);
-    hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DTYPE(dtype, {
-        if (Tn <= 16)
-            hipLaunchKernelGGL((tattn_fwd_kernel<T, 16>), dim3(blocks), dim3(256), 4 * 2 * 16 * 128, st, (const T*)q, (const T*)k,
-                               (const T*)v, (T*)o, B, Tn, HW, heads, ld, ld_o, scale * LOG2E, nprob);
-        else
-            hipLaunchKernelGGL((tattn_fwd_kernel<T, 32>), dim3(blocks), dim3(256), 4 * 2 * 32 * 128, st, (const T*)q, (const T*)k,
-                               (const T*)v, (T*)o, B, Tn, HW, heads, ld, ld_o, scale * LOG2E, nprob);
-    });
-    SVDX_LAUNCH_CHECK("svdx_tattn_fwd");
-    return 0;
-}
-
-template <typename T, int TPAD>
-static int launch_tattn_bwd(const void* q, const void* k, const void* v, const void* d_o, void* dq, void* dk, void* dv, int B, int Tn,
-                            int HW, int heads, int ld, int ld_o, int ld_d, float scale, long nprob, hipStream_t st) {
-    constexpr int WAVE_BYTES = 4 * TPAD * 128 + 2 * TPAD * (TPAD + 1) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_bwd_kernel<T, TPAD>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  4 * WAVE_BYTES);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((tattn_bwd_kernel<T, TPAD>), dim3(cdiv(nprob, 4)), dim3(256), 4 * WAVE_BYTES, st, (const T*)q, (const T*)k,
-                       (const T*)v, (const T*)d_o, (T*)dq, (T*)dk, (T*)dv, B, Tn, HW, heads, ld, ld_o, ld_d, scale, nprob);
-    return 0;
-}
-
-extern "C" int svdx_tattn_bwd(const void* q, const void* k, const void* v, const void* d_o, void* dq, void* dk, void* dv, int B,
-                              int Tn, int HW, int heads, int ld, int ld_o, int ld_d, float scale, int dtype, void* stream) {
-    SVDX_CHECK_ARG(q && k && v && d_o && dq && dk && dv && B > 0 && Tn > 0 && Tn <= 32, "svdx_tattn_bwd: bad args (T<=32)");
-    SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ATTN_ARGS_OK(ld_o, d_o) &&
-                       ATTN_ARGS_OK(ld_d, dq) && ATTN_ARGS_OK(ld_d, dk) && ATTN_ARGS_OK(ld_d, dv), "svdx_tattn_bwd: alignment");
-    const long nprob = (long)B * HW * heads;
-    hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DTYPE(dtype, {
-        if (Tn <= 16) launch_tattn_bwd<T, 16>(q, k, v, d_o, dq, dk, dv, B, Tn, HW, heads, ld, ld_o, ld_d, scale, nprob, st);
-        else launch_tattn_bwd<T, 32>(q, k, v, d_o, dq, dk, dv, B, Tn, HW, heads, ld, ld_o, ld_d, scale, nprob, st);
-    });
-    SVDX_LAUNCH_CHECK("svdx_tattn_bwd");
     return 0;
 }
