@@ -146,7 +146,7 @@ int svdx_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, f
                 int rows, int C, float eps, int dtype, void* stream);
 /* dx = LN'(dy) (+ add) (+ add2_scale * add2);  dgamma/dbeta (float, accumulated into, may both be NULL).  scratch: NULL (block sums go in by
  * float atomics) or SVDX_LN_PARTIAL_ROWS*2*C floats of workspace (per-block partial rows + a reducing pass: ~4x faster). */
-#define SVDX_LN_PARTIAL_ROWS 512
+#define SVDX_LN_PARTIAL_ROWS 2048
 int svdx_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* add, const void* add2,
                 float add2_scale, void* dx, float* dgamma, float* dbeta, float* scratch, int rows, int C, int dtype, void* stream);
 

@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("SVDX_LIB") or os.path.join(_HERE, "csrc", "libsvdx.so
 F16, BF16 = 0, 1
 OUT_ACT, OUT_F32, OUT_F32_ATOMIC, OUT_F32_SLAB, OUT_F32_ADD = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GEGLU_FWD, EPI_GEGLU_BWD = 0, 1, 2
-LN_PARTIAL_ROWS = 512
+LN_PARTIAL_ROWS = 2048
 GN_REPLICAS = 8
 GN_STAT_FLOATS = 4             # floats of storage per (replica, sample, group) of a GroupNorm statistics buffer: two int64
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3, GATHER_CONV3X3_PAD0 = 0, 1, 2, 3, 4
@@ -185,6 +185,7 @@ class HipBackend:
             raise SvdxError("libsvdx.so reports no usable gfx950 device: " + self.last_error())
         self._zero_page = torch.zeros(1024, dtype=torch.uint8, device="cuda")
         self._log_extra = None
+        self.n_calls = 0
         self.launch_log = None      # developer aid (bench.py --launch-log): a list that receives (entry, args) of every call, in order
 
     def last_error(self) -> str:
@@ -193,6 +194,7 @@ class HipBackend:
         return buf.value.decode(errors="replace")
 
     def _call(self, name, *args):
+        self.n_calls += 1                          # GraphedStep cuts a graph segment only where launches were captured since the last cut
         if self.launch_log is not None:
             self.launch_log.append((name, [a if isinstance(a, (int, float)) or a is None else "obj" for a in args], self._log_extra))
             self._log_extra = None

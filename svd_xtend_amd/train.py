@@ -9,6 +9,7 @@ Everything on the timed path is libsvdx kernels; torch supplies memory, streams 
 from __future__ import annotations
 
 import os
+import warnings
 from typing import Dict, List, Optional
 
 import torch
@@ -388,7 +389,7 @@ class GraphedStep:
             raise ValueError(f"expected {trainer.grad_accum} micro-batch(es), got {len(batches)}")
         self.tr = trainer
         self.graphs: List[torch.cuda.CUDAGraph] = []
-        self.spans: List[Optional[tuple]] = []
+        self.spans: List[list] = []                      # per graph segment: the flat-buffer slices whose gradients it completed
         tr = trainer
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -412,17 +413,34 @@ class GraphedStep:
             g.capture_begin(pool=pool, capture_error_mode="thread_local")
             self.graphs.append(g)
             try:
+                calls = lambda: getattr(tr.rt.k, "n_calls", None)       # launches issued so far (None: a backend that does not count)
+                mark = [calls()]
+
                 def cut(module):
                     if not cut_blocks:
                         return                           # nothing to interleave: the whole sweep stays one graph
+                    span = tr._buckets.get(id(module))
+                    if mark[0] is not None and calls() == mark[0] and self.spans:
+                        # no launch since the previous cut (the sweep left two blocks back to back): an empty segment would be a
+                        # wasted replay -- this block's slice joins the previous segment's collective instead
+                        if span is not None:
+                            self.spans[-1].append(span)
+                        return
                     self.graphs[-1].capture_end()
-                    self.spans.append(tr._buckets.get(id(module)))
+                    self.spans.append([span] if span is not None else [])
                     g2 = torch.cuda.CUDAGraph()
                     g2.capture_begin(pool=pool, capture_error_mode="thread_local")
                     self.graphs.append(g2)
+                    mark[0] = calls()
                 sweep(cut)
             finally:
-                self.graphs[-1].capture_end()
+                empty = mark[0] is not None and calls() == mark[0] and len(self.graphs) > 1
+                with warnings.catch_warnings():
+                    if empty:                            # torch warns about ending an empty capture; this one is dropped, not replayed
+                        warnings.simplefilter("ignore")
+                    self.graphs[-1].capture_end()
+                if empty:
+                    self.graphs.pop()                    # nothing was launched after the last cut
             self.g_opt = torch.cuda.CUDAGraph()
             self.g_opt.capture_begin(pool=pool, capture_error_mode="thread_local")
             try:
@@ -439,9 +457,9 @@ class GraphedStep:
         multi = tr.world > 1
         for i, g in enumerate(self.graphs):
             g.replay()
-            if multi and tr.overlap and i < len(self.spans) and self.spans[i] is not None:
-                lo, hi = self.spans[i]
-                tr._pending.append(((lo, hi), dist.all_reduce(tr.g_flat[lo:hi], op=dist.ReduceOp.SUM, group=tr.pg, async_op=True)))
+            if multi and tr.overlap and i < len(self.spans):
+                for lo, hi in self.spans[i]:             # the gradient slices the segment just completed
+                    tr._pending.append(((lo, hi), dist.all_reduce(tr.g_flat[lo:hi], op=dist.ReduceOp.SUM, group=tr.pg, async_op=True)))
         tr.finish_grads(side_work)
         self.g_opt.replay()
 

@@ -331,7 +331,7 @@ def check_layernorm(P, dt):
         st = o2["st"]
         for affine in (False, True, "scratch"):
             outs = dict(dx=torch.zeros_like(x), dg=torch.ones(C, device=P.dev), db=torch.ones(C, device=P.dev))
-            scr = torch.full((512 * 2 * C,), float("nan"), device=P.dev) if affine == "scratch" else None
+            scr = torch.full((K.LN_PARTIAL_ROWS * 2 * C,), float("nan"), device=P.dev) if affine == "scratch" else None
             o1, o2 = P.run("ln_bwd", lambda o: ((dy, x, st, gamma, add if affine else None, o["dx"],
                                                  o["dg"] if affine else None, o["db"] if affine else None, rows, C),
                                                 dict(scratch=scr, add2=dy if affine == "scratch" else None, add2_scale=0.37)), outs)
