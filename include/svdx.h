@@ -216,17 +216,6 @@ int svdx_tsa_fwd(const void* x, const float* gamma, const float* beta, float eps
                  const float* cvec, int rv_ld, int rv_rows_per_group, int rv_mod, void* n1, float* stats, void* qkv, void* o, void* h1,
                  int B, int T, int HW, int C, int heads, float scale, int dtype, void* stream);
 
-/* LayerNorm + GEGLU projection of a transformer feed-forward as one launch (csrc/ffn.hip):
- *   n = LayerNorm(x) (gamma, beta, eps);  [a | g] = n w1^T + b1 with w1 [2F, C] (value rows first, gate rows next: diffusers GEGLU.proj);
- *   pre [M, 2F] = [a | g] rounded to the activation dtype;  hh [M, F] = a * gelu(g) from the rounded values (== svdx_geglu_fwd(pre)).
- * Replaces svdx_ln_fwd + svdx_gemm(SVDX_EPI_GEGLU_FWD) for norm3 -> ff / norm_in -> ff_in of diffusers' BasicTransformerBlock and
- * TemporalBasicTransformerBlock (/root/reference/src/unet_spatio_temporal_condition.py:170-192).  stats [M, 2] = (mean, rstd) for
- * svdx_ln_bwd; n [M, C] or NULL (only the weight gradient of a trainable w1 needs it).  C a multiple of 64 up to 320, F a multiple of
- * 128, M * 2F * 2 bytes below 2 GiB.  A workgroup owns svdx_ln_geglu_rows_per_band() consecutive rows. */
-int svdx_ln_geglu_rows_per_band(void);
-int svdx_ln_geglu_fwd(const void* x, const float* gamma, const float* beta, float eps, const void* w1, const float* b1, void* n,
-                      float* stats, void* pre, void* hh, int M, int C, int F, int dtype, void* stream);
-
 /* ---- frozen conditioners either side of the step (csrc/encoders.hip) --------------------------------------
  * svdx_patch_rows: im2col of a few-channel NCHW float image into GEMM rows,
  *   out[(n*ho + y)*wo + x][(c*kh + dy)*kw + dx] = mul * in[n][c][y*stride + dy - pad][x*stride + dx - pad]   (0 outside, 0 for k >= C*kh*kw up to ldk)

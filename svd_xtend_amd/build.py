@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["common.cpp", "gemm.hip", "norm.hip", "elementwise.hip", "attention.hip", "tattn.hip", "optim.hip", "encoders.hip", "tsa.hip", "ffn.hip"]
+SOURCES = ["common.cpp", "gemm.hip", "norm.hip", "elementwise.hip", "attention.hip", "tattn.hip", "optim.hip", "encoders.hip", "tsa.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 LIB = os.path.join(CSRC, "libsvdx.so")
 

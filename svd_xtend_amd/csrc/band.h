@@ -1,5 +1,5 @@
 // band.h -- the pieces shared by the kernels that keep a BAND of activation rows resident in LDS and stream weights past it
-// (tsa.hip: the fused temporal self-attention; ffn.hip: LayerNorm + GEGLU projection): the swizzled LDS image [C/64][144 rows][128 B],
+// (tsa.hip: the fused temporal self-attention; round 2's LayerNorm + GEGLU projection kernel was removed in round 3): the swizzled LDS image [C/64][144 rows][128 B],
 // its load and in-place LayerNorm, and the streaming GEMM whose A operand the image is.
 #pragma once
 #include "common.h"

@@ -433,15 +433,18 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const T* __restrict__ dy
     }
     const float invC = 1.f / (float)C;
     for (int row = blockIdx.x * GROUPS + grp; row < rows; row += gridDim.x * GROUPS) {
-        Vec8<T> xr[NCH], dr[NCH], ar[NCH], a2r[NCH];          // every operand of the row is requested before the first use
+        // every operand of the row is requested before the first use (four chunks per lane with the affine accumulators would spill:
+        // that instantiation -- rows wider than 1536, none in the UNet -- fetches the two addends late instead)
+        constexpr bool PRE = !(AFFINE && NCH > 3);
+        Vec8<T> xr[NCH], dr[NCH], ar[PRE ? NCH : 1], a2r[PRE ? NCH : 1];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             if (cv[j]) {
                 const size_t off = (size_t)row * C + cl[j] * 8;
                 xr[j] = *reinterpret_cast<const Vec8<T>*>(x + off);
                 dr[j] = *reinterpret_cast<const Vec8<T>*>(dy + off);
-                if (add) ar[j] = *reinterpret_cast<const Vec8<T>*>(add + off);
-                if (add2) a2r[j] = *reinterpret_cast<const Vec8<T>*>(add2 + off);
+                if (PRE && add) ar[j] = *reinterpret_cast<const Vec8<T>*>(add + off);
+                if (PRE && add2) a2r[j] = *reinterpret_cast<const Vec8<T>*>(add2 + off);
             }
         }
         const float2 mr = *reinterpret_cast<const float2*>(stats + (size_t)row * 2);
@@ -475,12 +478,14 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const T* __restrict__ dy
                     o[e] = mr.y * (to_f<T>(dr[j].v[e]) * gm[j][e] - m1 - xh * m2);
                 }
                 if (add) {
+                    const Vec8<T> a8 = PRE ? ar[PRE ? j : 0] : *reinterpret_cast<const Vec8<T>*>(add + off);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] += to_f<T>(ar[j].v[e]);
+                    for (int e = 0; e < 8; ++e) o[e] += to_f<T>(a8.v[e]);
                 }
                 if (add2) {
+                    const Vec8<T> a8 = PRE ? a2r[PRE ? j : 0] : *reinterpret_cast<const Vec8<T>*>(add2 + off);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] += add2_scale * to_f<T>(a2r[j].v[e]);
+                    for (int e = 0; e < 8; ++e) o[e] += add2_scale * to_f<T>(a8.v[e]);
                 }
                 store8<T>(dx + off, o);
             }

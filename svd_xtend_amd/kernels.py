@@ -82,7 +82,6 @@ _SIGS = {
     "svdx_tattn_fwd": "pppp" "iiii" "ii" "f" "ip",
     "svdx_tattn_bwd": "ppppppp" "iiii" "iii" "f" "ip",
     "svdx_tsa_fwd": "ppp" "f" "ppp" "piii" "ppppp" "iiiii" "f" "ip",
-    "svdx_ln_geglu_fwd": "ppp" "f" "pp" "pppp" "iii" "ip",
     "svdx_geglu_fwd": "pp" "ii" "ip",
     "svdx_geglu_bwd": "ppp" "ii" "ip",
     "svdx_add": "ppp" "l" "ip",
@@ -115,8 +114,7 @@ _SIGS = {
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "l": ctypes.c_int64, "z": ctypes.c_size_t}
 
-EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band",
-                                    "svdx_ln_geglu_rows_per_band")
+EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band")
 TSA_MAX_C, TSA_MAX_T, TSA_BAND_ROWS = 320, 16, 144
 
 
@@ -299,10 +297,6 @@ class HipBackend:
     def tattn_bwd(self, q, k, v, d_o, dq, dk, dv, B, T, HW, heads, ld, ld_o, ld_d, scale):
         self._call("svdx_tattn_bwd", _p(q), _p(k), _p(v), _p(d_o), _p(dq), _p(dk), _p(dv), B, T, HW, heads,
                    ld, ld_o, ld_d, float(scale), _dt(q), self._stream())
-
-    def ln_geglu_fwd(self, x, gamma, beta, eps, w1, b1, n, stats, pre, hh, M, C, F):
-        self._call("svdx_ln_geglu_fwd", _p(x), _f32(gamma), _f32(beta), float(eps), _p(w1), _f32(b1), _p(n), _f32(stats), _p(pre), _p(hh),
-                   M, C, F, _dt(x), self._stream())
 
     def tsa_fwd(self, x, gamma, beta, eps, wqkv, wo, bo, cvec, rv_ld, rv_rpg, rv_mod, n1, stats, qkv, o, h1, B, T, HW, C, heads, scale):
         self._call("svdx_tsa_fwd", _p(x), _f32(gamma), _f32(beta), float(eps), _p(wqkv), _p(wo), _f32(bo), _f32(cvec), rv_ld, rv_rpg,

@@ -74,10 +74,6 @@ class Runtime:
         # temporal self-attention op (norm1 -> q/k/v -> attention over frames -> out-projection + residual) as one launch when
         # the level qualifies (csrc/tsa.hip); SVDX_FUSE_TSA=0: developer knob for A/B runs
         self.fuse_tsa = os.environ.get("SVDX_FUSE_TSA", "1") != "0"
-        # LayerNorm + GEGLU projection of a feed-forward as one launch at the widths the band kernel admits (csrc/ffn.hip).  Built,
-        # parity-tested and measured: 123 us against 150 us for the two launches at the 64x40 level, but no change of the step time
-        # (52.8 / 53.0 ms without, 52.8 / 53.1 with, same box) -- so it is opt-in: SVDX_FUSE_FFN=1
-        self.fuse_ffn = os.environ.get("SVDX_FUSE_FFN", "0") == "1"
         self.fuse_dual = os.environ.get("SVDX_LORA_FUSED", "1") != "0"   # developer knob for A/B runs: adapter term as its own launch
         self.tuner = None           # GemmTuner (Trainer.tune_gemms): measured tile / split-K per GEMM problem
         # transposed 16-bit twins ([K,N], operand of the data-grad GEMM) of the trainable nn.Linear weights live in one arena so

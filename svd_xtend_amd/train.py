@@ -124,7 +124,7 @@ class Trainer:
         model.prepare(dtype)
         self.rt = model.rt
         if old is not None:              # a rebuild after load_state: keep what the caller tuned / set on the previous runtime
-            for knob in ("tuner", "gemm_variant", "split_k", "fuse_geglu", "fuse_dual", "fuse_tsa", "fuse_ffn"):
+            for knob in ("tuner", "gemm_variant", "split_k", "fuse_geglu", "fuse_dual", "fuse_tsa"):
                 setattr(self.rt, knob, getattr(old, knob))
         # AdamW walks a tile table so that it can also emit the transposed 16-bit twins the data-grad GEMMs read
         tiled = bool(self.params) and os.environ.get("SVDX_ADAM_TILED", "1") != "0"      # developer knob for A/B runs

@@ -483,22 +483,6 @@ class EmuBackend:
             v = v + V(cvec, int(gi.max()) + 1, C, rv_ld)[gi]
         V(h1, M, C, C).copy_((v + xf).to(dt))
 
-    def ln_geglu_fwd(self, x, gamma, beta, eps, w1, b1, n, stats, pre, hh, M, C, F):
-        """The two launches the fused op replaces (svdx_ln_fwd, svdx_gemm with the GEGLU epilogue), with their roundings."""
-        dt = x.dtype
-        xf = V(x, M, C, C).float()
-        mean = xf.mean(1, keepdim=True)
-        rstd = torch.rsqrt(((xf - mean) ** 2).mean(1, keepdim=True) + eps)
-        V(stats, M, 2, 2).copy_(torch.cat([mean, rstd], 1))
-        nn_ = ((xf - mean) * rstd * V1(gamma, C) + V1(beta, C)).to(dt)
-        if n is not None:
-            V(n, M, C, C).copy_(nn_)
-        p = (nn_.float() @ V(w1, 2 * F, C, C).float().t() + V1(b1, 2 * F)[None]).to(dt)
-        V(pre, M, 2 * F, 2 * F).copy_(p)
-        pf = p.float()
-        V(hh, M, F, F).copy_((pf[:, :F] * gelu(pf[:, F:])).to(dt))
-
-    # ---- frozen conditioners ----
     def patch_rows(self, inp, out, n_img, C, H, W, kh, kw, stride, pad, ho, wo, ldk, mul=1.0):
         import torch.nn.functional as F
         x = V1(inp, n_img * C * H * W).view(n_img, C, H, W) * mul

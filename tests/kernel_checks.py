@@ -430,31 +430,6 @@ def check_tsa(P, dt):
     return res
 
 
-def check_ffn(P, dt):
-    """svdx_ln_geglu_fwd (LayerNorm -> GEGLU projection in one launch, csrc/ffn.hip) against the emulation of the two launches it
-    replaces: the benched 64x40 level (M = 35840, C = 320, F = 1280: 248 full bands + one of 128 rows), a single partial band, every C
-    the kernel admits, F of one and of several passes, with and without the saved n."""
-    g = torch.Generator().manual_seed(19)
-    res = []
-    for (M, C, F, keep_n) in [(35840, 320, 1280, True), (100, 64, 128, False), (144, 128, 512, True), (433, 192, 256, True), (290, 256, 384, False)]:
-        x = rnd((M, C), dt, P.dev, g)
-        x[:, :8] += 3.0
-        gamma, beta = 1.0 + 0.1 * rndf((C,), P.dev, g), 0.1 * rndf((C,), P.dev, g)
-        w1, b1 = rnd((2 * F, C), dt, P.dev, g, C ** -0.5), 0.3 * rndf((2 * F,), P.dev, g)
-        outs = dict(st=torch.zeros(M, 2, device=P.dev), pre=torch.zeros(M, 2 * F, dtype=dt, device=P.dev), hh=torch.zeros(M, F, dtype=dt, device=P.dev))
-        if keep_n:
-            outs["n"] = torch.zeros(M, C, dtype=dt, device=P.dev)
-        o1, o2 = P.run("ln_geglu_fwd", lambda o: ((x, gamma, beta, 1e-5, w1, b1, o.get("n"), o["st"], o["pre"], o["hh"], M, C, F), {}), outs)
-        tag = f"ln_geglu_fwd M={M} C={C} F={F}"
-        if keep_n:
-            res.append((f"{tag} n", relerr(o1["n"], o2["n"]), tol_for(dt)))
-        res.append((f"{tag} stats", relerr(o1["st"], o2["st"]), 1e-4))
-        res.append((f"{tag} pre", relerr(o1["pre"], o2["pre"]), tol_for(dt, 2)))
-        res.append((f"{tag} h", relerr(o1["hh"], o2["hh"]), tol_for(dt, 2)))
-        res.append((f"{tag} h 1-cos(rows)", 1.0 - cos_rows_min(o1["hh"], o2["hh"]), 1e-4 if dt == torch.float16 else 2e-3))
-    return res
-
-
 def check_encoders(P, dt):
     """svdx_patch_rows / svdx_softmax_rows / svdx_act_rows (csrc/encoders.hip) and the pad-0 stride-2 gather of the VAE downsample."""
     g = torch.Generator().manual_seed(18)
@@ -665,7 +640,7 @@ def run_all(impl, dev, dtypes=DTYPES, verbose=True):
         checks += [
                   ("small", lambda: check_small(P, dt)), ("groupnorm", lambda: check_groupnorm(P, dt)),
                   ("layernorm", lambda: check_layernorm(P, dt)), ("attention", lambda: check_attention(P, dt)),
-                  ("temporal_attention", lambda: check_temporal_attention(P, dt)), ("tsa", lambda: check_tsa(P, dt)), ("ffn", lambda: check_ffn(P, dt)),
+                  ("temporal_attention", lambda: check_temporal_attention(P, dt)), ("tsa", lambda: check_tsa(P, dt)),
                   ("encoders", lambda: check_encoders(P, dt)), ("elementwise", lambda: check_elementwise(P, dt)),
                   ("optim", lambda: check_optim(P, dt))]
         for name, fn in checks:

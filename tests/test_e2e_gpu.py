@@ -21,21 +21,6 @@ def test_train_step_matches_oracle_tiny():
 
 
 @gpu
-def test_train_step_matches_oracle_with_the_fused_ln_geglu(monkeypatch):
-    """The opt-in LayerNorm + GEGLU band kernel (SVDX_FUSE_FFN=1, csrc/ffn.hip) in place of svdx_ln_fwd + the GEGLU-epilogue GEMM:
-    same parity bar as the default path, on the tiny topology (C = 64 / 128 levels) and on the 320-channel level block at the
-    benched shape."""
-    import e2e_checks
-    monkeypatch.setenv("SVDX_FUSE_FFN", "1")
-    res = e2e_checks.run_all(verbose=True)
-    for key, r in res.items():
-        e2e_checks.assert_parity(key, r)
-    import torch
-    for key, r in e2e_checks.run_levels(levels=["L0"], dtypes=(torch.float16,), verbose=True).items():
-        e2e_checks.assert_parity(key, r)
-
-
-@gpu
 def test_graphed_step_follows_eager_trajectory():
     """hipGraph segments cut at the transformer blocks (where the overlapped all-reduce starts) replay the same step."""
     import e2e_checks

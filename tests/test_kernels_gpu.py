@@ -8,7 +8,7 @@ gpu = pytest.mark.gpu
 RING = (16, 18, 20)          # ring-staged tile variants: between them every new instantiation of gemm_v4_kernel
 GROUPS = (["gemm_tn", "gemm_tn_s3", "gemm_tn_s4", "gemm_tn_v18", "gemm_geglu", "gemm_geglu_v17", "gemm_geglu_v18", "gemm_geglu_v21", "gemm_plain_v1"]
           + [f"gemm_{k}_v{v}" for v in (4, 6) + RING for k in ("plain", "gather")]
-          + ["small", "groupnorm", "layernorm", "attention", "temporal_attention", "tsa", "ffn", "encoders", "elementwise", "optim"])
+          + ["small", "groupnorm", "layernorm", "attention", "temporal_attention", "tsa", "encoders", "elementwise", "optim"])
 
 
 @pytest.fixture(scope="module")
@@ -29,7 +29,7 @@ def test_kernel_group(pair, group, dt):
            "small": lambda: kc.check_small(pair, dt), "groupnorm": lambda: kc.check_groupnorm(pair, dt),
            "layernorm": lambda: kc.check_layernorm(pair, dt), "attention": lambda: kc.check_attention(pair, dt),
            "temporal_attention": lambda: kc.check_temporal_attention(pair, dt),
-           "tsa": lambda: kc.check_tsa(pair, dt), "ffn": lambda: kc.check_ffn(pair, dt), "encoders": lambda: kc.check_encoders(pair, dt),
+           "tsa": lambda: kc.check_tsa(pair, dt), "encoders": lambda: kc.check_encoders(pair, dt),
            "elementwise": lambda: kc.check_elementwise(pair, dt), "optim": lambda: kc.check_optim(pair, dt)}
     for v in (18,):
         fns[f"gemm_tn_v{v}"] = lambda v=v: kc.check_gemm_tn(pair, dt, v)

@@ -19,7 +19,7 @@ FAMILIES = [   # (kernel-name regex, entries whose calls launch exactly one such
     (r"attn_fwd_kernel", ["svdx_attn_fwd"]), (r"attn_bwd_dkv_kernel", ["svdx_attn_bwd_dkv"]), (r"attn_bwd_dq_kernel", ["svdx_attn_bwd_dq"]),
     (r"attn_bwd_prep_kernel", ["svdx_attn_bwd_prep"]),
     (r"tattn_fwd_kernel", ["svdx_tattn_fwd"]), (r"tattn_bwd_kernel", ["svdx_tattn_bwd"]), (r"tsa_fwd_kernel", ["svdx_tsa_fwd"]),
-    (r"tsa_bwd_kernel", ["svdx_tsa_bwd"]), (r"ln_geglu_kernel", ["svdx_ln_geglu_fwd"]),
+    (r"tsa_bwd_kernel", ["svdx_tsa_bwd"]),
     (r"gn_reduce_kernel", ["svdx_gn_stats", "svdx_gn_bwd_stats"]), (r"gn_apply_kernel", ["svdx_gn_apply", "svdx_gn_bwd_apply"]),
     (r"ln_fwd(16)?_kernel", ["svdx_ln_fwd"]), (r"ln_bwd(16)?_kernel", ["svdx_ln_bwd"]),
     (r"binary_kernel", ["svdx_add", "svdx_blend", "svdx_blend_bwd"]), (r"add_rowvec_kernel", ["svdx_add_rowvec"]),
