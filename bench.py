@@ -171,8 +171,6 @@ def main():
                     help="in-situ GEMM tile/split-K tuning sweeps before timing (faster while the GPU is cool, ~1%% slower "
                          "than the built-in formula once the step is power-limited: off by default)")
     ap.add_argument("--tune-rounds", type=int, default=1, help="--tune: sweeps over the candidate list of the largest problem")
-    ap.add_argument("--save-gemm-table", default=None,
-                    help="--tune: merge the frozen choices into this JSON file (svd_xtend_amd/gemm_table.json is what ops.tuned_call reads)")
     ap.add_argument("--gemm-table", action="store_true", help="dump per-shape GEMM timings of one step")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny topology instead of the SVD config")
     ap.add_argument("--grad-accum", type=int, default=1,
@@ -272,11 +270,6 @@ def main():
     tune_sweeps = 0
     if args.tune and args.gemm_variant == 4:
         tune_sweeps = trainer.tune_gemms(batch, rounds=args.tune_rounds, max_steps=400)
-        if args.save_gemm_table and rank == 0:
-            tab = json.load(open(args.save_gemm_table)) if os.path.exists(args.save_gemm_table) else {}
-            tab.update({repr(k): (list(v) if isinstance(v, tuple) else v) for k, v in trainer.rt.tuner.table.items()})
-            with open(args.save_gemm_table, "w") as f:
-                json.dump(tab, f, indent=0, sort_keys=True)
     for _ in range(max(1, args.warmup)):
         step_eager()
     torch.cuda.synchronize()

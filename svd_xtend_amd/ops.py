@@ -308,32 +308,7 @@ def tuned_call(rt: "Runtime", key, make_cands, fallback, run) -> None:
         rt.tuner.record(key, idx, e0, e1)
         return
     cfg = rt.tuner.table.get(key) if rt.tuner is not None else None
-    if cfg is None:
-        cfg = _measured_cfg(key)
     run(cfg if cfg is not None else fallback())
-
-
-_MEASURED = None
-
-
-def _measured_cfg(key):
-    """Tile / split-K choice of a problem that an in-situ sweep on an MI355X has measured (svd_xtend_amd/gemm_table.json, written by
-    `bench.py --tune --save-gemm-table`: the problems of the 14 x 512 x 320 step); anything else goes through the formulas.
-    SVDX_GEMM_TABLE=0: developer knob for A/B runs against the formulas."""
-    global _MEASURED
-    if _MEASURED is None:
-        _MEASURED = {}
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_table.json")
-        if os.environ.get("SVDX_GEMM_TABLE", "1") != "0" and os.path.exists(path):
-            import json
-            for k, v in json.load(open(path)).items():
-                v = tuple(v) if isinstance(v, list) else v
-                if k.startswith("('nt'") and not (isinstance(v, tuple) and v[1] in TILE_OF_VARIANT):
-                    continue
-                if k.startswith("('geglu") and v not in TILE_OF_VARIANT:
-                    continue
-                _MEASURED[k] = v
-    return _MEASURED.get(repr(key)) if _MEASURED else None
 
 
 def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
