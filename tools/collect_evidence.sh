@@ -11,7 +11,7 @@ commit=$(git rev-parse --short HEAD 2>/dev/null || echo worktree)
 # 1. kernel stats + step trace of the graph-replayed default step
 rocprofv3 --kernel-trace -d $O/ev_tr -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --launch-log $O/launch_log.json > $O/${tag}_bench_under_profiler.json 2> $O/ev_tr.err
 DB=$(ls $O/ev_tr/*/*_results.db | head -1)
-{ echo "# rocprofv3 --kernel-trace -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline   (last 50 % of the dispatches = graph-replayed steps; tools/prof_summary.py)"; python tools/prof_summary.py $DB --skip-first-fraction 0.5; } > $O/${tag}_rocprofv3_kernel_stats.txt 2>> $O/ev_tr.err
+{ echo "# rocprofv3 --kernel-trace -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline   (last 40 % of the dispatches = graph-replayed steps only; tools/prof_summary.py)"; python tools/prof_summary.py $DB --skip-first-fraction 0.6; } > $O/${tag}_rocprofv3_kernel_stats.txt 2>> $O/ev_tr.err
 python tools/step_trace.py $DB $O/launch_log.json $O/step_trace.json > $O/${tag}_step_trace.txt 2> $O/step_trace.err
 python tools/step_categories.py $O/step_trace.json > $O/${tag}_step_categories.txt
 rm -rf $O/ev_tr
