@@ -440,6 +440,11 @@ def main():
             if orig_tsa is not None:
                 k.tsa_fwd = timed_tsa
         try:
+            # The events must time kernels, not the host: an eager step is ~1900 launches + 1400 event records, and wherever the
+            # host falls behind (the 8x5 / 16x10 levels: 20 us kernels) the idle gap would land inside an event pair.  A spin kernel
+            # holds the stream for ~40 ms first, so the whole step is enqueued before its first kernel starts.
+            torch.cuda.synchronize()
+            torch.cuda._sleep(int(0.040 * 2.1e9))
             fwd_bwd()
             torch.cuda.synchronize()
         finally:

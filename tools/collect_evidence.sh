@@ -2,19 +2,20 @@
 # Measurement artefacts of one round, from one GPU box (run through gpurun; copies land in gpurun_out/<tag>_*):
 #   kernel stats of the default bench (rocprofv3 --kernel-trace), the per-call step trace, HBM traffic per kernel family (separate
 #   FETCH_SIZE / WRITE_SIZE counter passes, MI355X_MICROARCH.md HBM section) and the in-step MFMA utilisation per kernel symbol.
-# usage: tools/collect_evidence.sh <tag>      (counter passes never combine --pmc with sys / hip / hsa traces)
+# usage: tools/collect_evidence.sh <tag> [stats-only]      (counter passes never combine --pmc with sys / hip / hsa traces)
 tag=${1:-rX}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 O=gpurun_out
 commit=$(git rev-parse --short HEAD 2>/dev/null || echo worktree)
 # 1. kernel stats + step trace of the graph-replayed default step
-rocprofv3 --kernel-trace -d $O/ev_tr -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --launch-log $O/launch_log.json > $O/${tag}_bench_under_profiler.json 2> $O/ev_tr.err
+rocprofv3 --kernel-trace -d $O/ev_tr -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-roofline --launch-log $O/launch_log.json > $O/${tag}_bench_under_profiler.json 2> $O/ev_tr.err
 DB=$(ls $O/ev_tr/*/*_results.db | head -1)
-{ echo "# rocprofv3 --kernel-trace -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline   (last 40 % of the dispatches = graph-replayed steps only; tools/prof_summary.py)"; python tools/prof_summary.py $DB --skip-first-fraction 0.6; } > $O/${tag}_rocprofv3_kernel_stats.txt 2>> $O/ev_tr.err
+{ echo "# rocprofv3 --kernel-trace -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-roofline   (last 40 % of the dispatches = graph-replayed steps only; tools/prof_summary.py)"; python tools/prof_summary.py $DB --last-fraction=0.40; } > $O/${tag}_rocprofv3_kernel_stats.txt 2>> $O/ev_tr.err
 python tools/step_trace.py $DB $O/launch_log.json $O/step_trace.json > $O/${tag}_step_trace.txt 2> $O/step_trace.err
 python tools/step_categories.py $O/step_trace.json > $O/${tag}_step_categories.txt
 rm -rf $O/ev_tr
+if [ "$2" = "stats-only" ]; then head -8 $O/${tag}_rocprofv3_kernel_stats.txt; exit 0; fi
 # 2. HBM traffic: two counter passes over two eager steps
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/ev_$c -- python bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > /dev/null 2> $O/ev_$c.err
