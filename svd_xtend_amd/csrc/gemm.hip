@@ -867,7 +867,9 @@ __global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
             _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                   \
                 bf[i] = *reinterpret_cast<const v8*>(Bs_ + (wn * WN3 + i * 16 + fr) * ROWB + chunk);                         \
             _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                                 \
+                __builtin_amdgcn_s_setprio(1);  /* the MFMA row outranks the other waves' loads and LDS reads */            \
                 _Pragma("unroll") for (int j = 0; j < MB; ++j) acc[i][j] = TT<T>::mfma(bf[i], af[j], acc[i][j]);             \
+                __builtin_amdgcn_s_setprio(0);                                                                               \
                 if (ISSUE && kk * NB + i < NPIECE) {                                                                         \
                     __builtin_amdgcn_sched_barrier(0);                                                                       \
                     issue_piece((nstage), kk * NB + i);                                                                      \
