@@ -15,6 +15,7 @@
 //   wave of plain VALU work on data addressed in place with stride HW*ld -- the (B*T,HW,C)<->(B*HW,T,C)
 //   transposes of the reference never happen.  The op is HBM-bound (AI = T/2 flop/B).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -132,7 +133,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
     const int ntiles = (S + 63) / 64;
     Tile2 rk = load_rows<T>(kb_, ld, 0, S, tid);
     Tile2 rv = load_rows<T>(vb_, ld, 0, S, tid);
-    for (int t = 0; t < ntiles; ++t) {
+    // one KV/Q tile; the out-of-range mask exists only in the instance that runs the last, partial tile
+    auto tile = [&](const int t, auto tail_c) __attribute__((always_inline)) {
+        constexpr bool tail = decltype(tail_c)::value;
         __syncthreads();
         store_rows(Ks, rk, tid);
         store_rows(Vs, rv, tid);
@@ -155,17 +158,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) s[kb][qb] = TT<T>::mfma(kf, qf[qb][ks], s[kb][qb]);
             }
-        const bool tail = (t == ntiles - 1) && (S & 63);          // only the last KV tile can hold out-of-range keys
+        if constexpr (tail) {                                               // compiled into the partial-tile instance only
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t * 64 + kb * 16 + fg * 4 + r >= S) s[kb][qb][r] = -1e30f;
+        }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             float mx = -1e30f;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (tail && t * 64 + kb * 16 + fg * 4 + r >= S) s[kb][qb][r] = -1e30f;
-                    mx = fmaxf(mx, s[kb][qb][r]);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             mx = fmaxf(mx * sl2, -1e30f);                           // scaled (log2) domain; keeps -1e30 finite
@@ -178,17 +186,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
                 for (int db = 0; db < 4; ++db) oacc[db][qb] *= alpha;
             }
-            const float mref = mrow[qb];
-            float ps = 0.f;
+            const float nmref = -mrow[qb];
+            f32x4 ps = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = fexp2(fmaf(s[kb][qb][r], sl2, -mref));
-                    s[kb][qb][r] = p;
-                    ps += p;
-                }
-            lrow[qb] += ps;
+            for (int kb = 0; kb < 4; ++kb) {                        // whole-vector arithmetic: packed fp32 FMA / add
+                const f32x4 e = s[kb][qb] * sl2 + nmref;
+                const f32x4 pr = {fexp2(e[0]), fexp2(e[1]), fexp2(e[2]), fexp2(e[3])};
+                s[kb][qb] = pr;
+                ps += pr;
+            }
+            lrow[qb] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
         }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
@@ -202,7 +209,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
                 for (int qb = 0; qb < 2; ++qb) oacc[db][qb] = TT<T>::mfma(vf, pf[qb], oacc[db][qb]);
             }
         }
-    }
+    };
+    for (int t = 0; t < (S >> 6); ++t) tile(t, std::false_type{});
+    if (S & 63) tile(ntiles - 1, std::true_type{});
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         float lt = lrow[qb];
@@ -275,8 +284,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
             qf[qb][ks] = *reinterpret_cast<const v8*>(qb_ + (size_t)qi * ld + ks * 32 + fg * 8);
             dof[qb][ks] = *reinterpret_cast<const v8*>(dob + (size_t)qi * ld_o + ks * 32 + fg * 8);
         }
-        lse2[qb] = lse[(size_t)(n * heads + h) * S + qi] * LOG2E;
-        dd[qb] = Dv[(size_t)(n * heads + h) * S + qi];
+        lse2[qb] = -lse[(size_t)(n * heads + h) * S + qi] * LOG2E;       // both kept NEGATED: the loop adds them (packed fp32 add / FMA)
+        dd[qb] = -Dv[(size_t)(n * heads + h) * S + qi];
     }
     f32x4 acc[4][2];
 #pragma unroll
@@ -287,7 +296,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
     const int ntiles = (S + 63) / 64;
     Tile2 rk = load_rows<T>(kb_, ld, 0, S, tid);
     Tile2 rv = load_rows<T>(vb_, ld, 0, S, tid);
-    for (int t = 0; t < ntiles; ++t) {
+    // one KV/Q tile; the out-of-range mask exists only in the instance that runs the last, partial tile
+    auto tile = [&](const int t, auto tail_c) __attribute__((always_inline)) {
+        constexpr bool tail = decltype(tail_c)::value;
         __syncthreads();
         store_rows(Ks, rk, tid);
         store_rows(Vs, rv, tid);
@@ -314,17 +325,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
                     dp[kb][qb] = TT<T>::mfma(vf, dof[qb][ks], dp[kb][qb]);
                 }
             }
-        const bool tail = (t == ntiles - 1) && (S & 63);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+            for (int kb = 0; kb < 4; ++kb) {
+                // whole-vector arithmetic: packed fp32 FMA / add / mul (two elements per VALU issue)
+                const f32x4 e = s[kb][qb] * sl2 + lse2[qb];
+                const f32x4 g = dp[kb][qb] + dd[qb];
+                const f32x4 pr = {fexp2(e[0]), fexp2(e[1]), fexp2(e[2]), fexp2(e[3])};
+                s[kb][qb] = pr * g;                                   // dS^T
+                if (kb & 1) __builtin_amdgcn_sched_barrier(0);        // bounds how many blocks the scheduler keeps in flight (144 vs 196 VGPRs)
+            }
+        if constexpr (tail) {                                               // compiled into the partial-tile instance only
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float p = fexp2(fmaf(s[kb][qb][r], sl2, -lse2[qb]));
-                    if (tail && t * 64 + kb * 16 + fg * 4 + r >= S) p = 0.f;
-                    s[kb][qb][r] = p * (dp[kb][qb][r] - dd[qb]);      // dS^T
-                }
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t * 64 + kb * 16 + fg * 4 + r >= S) s[kb][qb][r] = 0.f;
+        }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             v8 df[2];
@@ -337,7 +357,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
                 for (int qb = 0; qb < 2; ++qb) acc[db][qb] = TT<T>::mfma(ktf, df[qb], acc[db][qb]);
             }
         }
-    }
+    };
+    for (int t = 0; t < (S >> 6); ++t) tile(t, std::false_type{});
+    if (S & 63) tile(ntiles - 1, std::true_type{});
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int qi = q0 + qb * 16 + fr;
@@ -361,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128 + 512];
     char* Qs = smem;
     char* dOs = smem + 64 * 128;
-    float* Ls = reinterpret_cast<float*>(smem + 2 * 64 * 128);   // [64] lse*log2e, then [64] D
+    float* Ls = reinterpret_cast<float*>(smem + 2 * 64 * 128);   // [64] -lse*log2e, then [64] -D
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int h = blockIdx.y, n = blockIdx.z;
     const int k0 = blockIdx.x * 128 + wave * 32;
@@ -398,10 +420,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
         rq = load_rows<T>(qb_, ld, tt_ * 64, S, tid);                       \
         rdo = load_rows<T>(dob, ld_o, tt_ * 64, S, tid);                    \
         const int qi_ = min(tt_ * 64 + (tid & 63), S - 1);                  \
-        rls = tid < 64 ? lsb[qi_] * LOG2E : dvb[qi_];                       \
+        rls = tid < 64 ? -lsb[qi_] * LOG2E : -dvb[qi_];                     \
     }
     SVDX_DKV_PREFETCH(0);
-    for (int t = 0; t < ntiles; ++t) {
+    // one KV/Q tile; the out-of-range mask exists only in the instance that runs the last, partial tile
+    auto tile = [&](const int t, auto tail_c) __attribute__((always_inline)) {
+        constexpr bool tail = decltype(tail_c)::value;
         __syncthreads();
         store_rows(Qs, rq, tid);
         store_rows(dOs, rdo, tid);
@@ -426,20 +450,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
                     dp[qb][kb] = TT<T>::mfma(df, vf[kb][ks], dp[qb][kb]);
                 }
             }
-        const bool tail = (t == ntiles - 1) && (S & 63);
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qb * 16 + fg * 4);
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ls + 64 + qb * 16 + fg * 4);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb) {
+                // whole-vector arithmetic: packed fp32 FMA / add / mul (two elements per VALU issue)
+                const f32x4 e = s[qb][kb] * sl2 + l4;
+                const f32x4 pr = {fexp2(e[0]), fexp2(e[1]), fexp2(e[2]), fexp2(e[3])};
+                s[qb][kb] = pr;
+                dp[qb][kb] = pr * (dp[qb][kb] + d4);               // dS
+            }
+        }
+        if constexpr (tail) {                                               // compiled into the partial-tile instance only
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float p = fexp2(fmaf(s[qb][kb][r], sl2, -l4[r]));
-                    if (tail && t * 64 + qb * 16 + fg * 4 + r >= S) p = 0.f;
-                    s[qb][kb][r] = p;
-                    dp[qb][kb][r] = p * (dp[qb][kb][r] - d4[r]);   // dS
-                }
+            for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t * 64 + qb * 16 + fg * 4 + r >= S) { s[qb][kb][r] = 0.f; dp[qb][kb][r] = 0.f; }
         }
         // dV^T[d,key] += dO^T[d,q] P[q,key] ;  dK^T[d,key] += Q^T[d,q] dS[q,key]
 #pragma unroll
@@ -461,7 +492,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restric
                 }
             }
         }
-    }
+    };
+    for (int t = 0; t < (S >> 6); ++t) tile(t, std::false_type{});
+    if (S & 63) tile(ntiles - 1, std::true_type{});
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         const int ki = k0 + kb * 16 + fr;
