@@ -425,7 +425,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
     for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // a 320-wide output ends in the middle of its third 128-wide tile: the waves whose 64 x 64 quadrant lies entirely outside the
+    // output (wave-uniform) skip their fragment reads and MFMAs and only take part in the staging and the barriers
+    const bool quad_live = m0 + wm * 64 < p.M && n0 + wn * 64 < p.N;
     auto compute = [&](int stage) __attribute__((always_inline)) {
+        if (!quad_live) return;
         const char* As = smem + stage * STAGE_BYTES;
         const char* Bs = As + BM * BK * 2;
         const int fr = lane & 15, fg = lane >> 4;
