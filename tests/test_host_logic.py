@@ -287,13 +287,16 @@ def test_gemm_config_rules_for_the_c2_shapes():
     rt = RT()
     assert choose_cfg(rt, 35840, 320, 2880, 320, 320) == (1, 6)          # 64x40 level: 448 two-stage 160 x 160 tiles, two per CU
     assert choose_cfg(rt, 35840, 320, 320, 320) == (1, 6)
-    assert choose_cfg(rt, 8960, 640, 5760, 640, 640) == (1, 17)          # 32x20 level, N = 640: 175 eight-wave 256 x 128 ring tiles, no split
-    assert choose_cfg(rt, 8960, 640, 2560, 640) == (1, 17)
-    assert choose_cfg(rt, 8960, 1280, 5760, 1280, 640) == (1, 6)         # N = 1280: too many 256-row tiles for one per CU
-    assert choose_cfg(rt, 2240, 1280, 11520, 1280, 1280) == (3, 16)      # 16x10 level, long K: 72 tiles of 256 x 160 x 3 slices
+    assert choose_cfg(rt, 8960, 640, 5760, 640, 640) == (1, 22)          # 32x20 level, N = 640: 47 x 5 = 235 eight-wave 192 x 128 ring tiles on 256 CUs
+    assert choose_cfg(rt, 8960, 640, 2560, 640) == (1, 22)               #   (256-row tiles: 175)
+    assert choose_cfg(rt, 8960, 1280, 5760, 1280, 640) == (1, 6)         # N = 1280: 448 two-stage 160 x 160 tiles, two per CU
+    assert choose_cfg(rt, 8960, 1920, 640, 1920) == (1, 7)               # q/k/v projection: 840 two-stage 128 x 160 tiles
+    assert choose_cfg(rt, 2240, 1280, 11520, 1280, 1280) == (2, 22)      # 16x10 level, long K: 120 tiles of 192 x 128 x 2 slices
+    assert choose_cfg(rt, 2240, 1280, 3840, 1280, 1280) == (2, 22)
     assert choose_cfg(rt, 2240, 1280, 1280, 1280) == (1, 21)             # short K: 180 four-wave ring tiles, no split
-    s, v = choose_cfg(rt, 560, 1280, 11520, 1280, 1280)                  # 8x5 level: 40 tiles of 128 x 160, 6 slices = 30 per XCD
-    assert v == 20 and s == 6
+    assert choose_cfg(rt, 560, 1280, 3840, 1280, 1280) == (6, 22)        # 8x5 level: 3 x 10 tiles of 192 x 128, 6 slices
+    s, v = choose_cfg(rt, 560, 1280, 11520, 1280, 1280)
+    assert v in (22, 23) and 6 <= s <= 10
     for (M, N, Kd) in [(560, 1280, 11520), (560, 1280, 1280), (2240, 640, 5760), (8960, 1920, 640), (300, 960, 192), (64, 640, 1280), (1000, 4, 576)]:
         s, v = choose_cfg(rt, M, N, Kd, N)
         kt = Kd // 64
