@@ -152,10 +152,10 @@ def choose_split(rt: "Runtime", M: int, N: int, Kd: int, ldc: int, bn: int = 0) 
 # svdx_gemm tile variants (csrc/gemm.hip): rows x columns of the output tile, LDS stages of the K-loop, waves per workgroup
 TILE_OF_VARIANT = {7: (128, 160, 2, 4), 6: (160, 160, 2, 4), 8: (128, 128, 2, 4),
                    16: (256, 160, 3, 8), 17: (256, 128, 3, 8), 18: (256, 256, 2, 8), 20: (128, 160, 4, 4), 21: (128, 128, 4, 4),
-                   23: (192, 160, 3, 8), 22: (192, 128, 3, 8)}
+                   23: (192, 160, 3, 8), 22: (192, 128, 3, 8), 25: (96, 160, 4, 4), 24: (96, 128, 4, 4)}
 # TFLOP/s one CU sustains on a variant's K-loop when the CU is full (8192^3 runs of tools/ring_check.py divided by 256 CUs, trimmed by
 # the in-situ sweeps of bench.py --tune): the two-stage four-wave tiles need two workgroups per CU for it
-_TILE_RATE = {6: 4.05, 7: 3.5, 8: 3.5, 16: 4.4, 17: 4.0, 18: 3.6, 20: 2.75, 21: 2.5, 22: 3.8, 23: 3.8}
+_TILE_RATE = {6: 4.05, 7: 3.5, 8: 3.5, 16: 4.4, 17: 4.0, 18: 3.6, 20: 2.75, 21: 2.5, 22: 3.8, 23: 3.8, 24: 2.4, 25: 2.05}
 _ALONE, _FILL_STEPS, _EPI_US, _FIN_US, _FIN_BYTES_PER_US = 0.5, 1.5, 3.0, 12.0, 6.0e6
 
 

@@ -623,7 +623,7 @@ def check_optim(P, dt):
     return res
 
 
-RING_VARIANTS = (16, 18, 20, 23) # between them every ring-staged instantiation of gemm_v4_kernel (N % 160 picks the 160- or 128-wide one)
+RING_VARIANTS = (16, 18, 20, 23, 25) # between them every ring-staged instantiation of gemm_v4_kernel (N % 160 picks the 160- or 128-wide one)
 
 
 def run_all(impl, dev, dtypes=DTYPES, verbose=True):

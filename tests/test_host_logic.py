@@ -292,9 +292,9 @@ def test_gemm_config_rules_for_the_c2_shapes():
     assert choose_cfg(rt, 8960, 1280, 5760, 1280, 640) == (1, 6)         # N = 1280: 448 two-stage 160 x 160 tiles, two per CU
     assert choose_cfg(rt, 8960, 1920, 640, 1920) == (1, 7)               # q/k/v projection: 840 two-stage 128 x 160 tiles
     assert choose_cfg(rt, 2240, 1280, 11520, 1280, 1280) == (2, 22)      # 16x10 level, long K: 120 tiles of 192 x 128 x 2 slices
-    assert choose_cfg(rt, 2240, 1280, 3840, 1280, 1280) == (2, 22)
-    assert choose_cfg(rt, 2240, 1280, 1280, 1280) == (1, 21)             # short K: 180 four-wave ring tiles, no split
-    assert choose_cfg(rt, 560, 1280, 3840, 1280, 1280) == (6, 22)        # 8x5 level: 3 x 10 tiles of 192 x 128, 6 slices
+    assert choose_cfg(rt, 2240, 1280, 3840, 1280, 1280) == (1, 24)       # medium / short K: 24 x 10 = 240 four-wave ring tiles of 96 x 128, no split
+    assert choose_cfg(rt, 2240, 1280, 1280, 1280) == (1, 24)             #   (128-row tiles: 180)
+    assert choose_cfg(rt, 560, 1280, 3840, 1280, 1280) == (3, 24)        # 8x5 level: 6 x 10 tiles of 96 x 128, 3 slices
     s, v = choose_cfg(rt, 560, 1280, 11520, 1280, 1280)
     assert v in (22, 23) and 6 <= s <= 10
     for (M, N, Kd) in [(560, 1280, 11520), (560, 1280, 1280), (2240, 640, 5760), (8960, 1920, 640), (300, 960, 192), (64, 640, 1280), (1000, 4, 576)]:
