@@ -69,7 +69,13 @@ int         svdx_device_ok(void);
  * acc[m,n] = sum_k Aeff[m,k] * B[n,k];  v = alpha*acc + bias[n] + rowvec[g(m)*rv_ld + n] + res[m*ldres+n]
  * g(m) = rv_mod ? m % rv_mod : m / rv_rows_per_group.   B is [N,K] row-major (ldb).
  * out_mode ACT: C[m*ldc+n] = (dtype)v ; F32: float store ; F32_ATOMIC: atomicAdd (split_k >= 1).
- * epilogue (variant 4 only): SVDX_EPI_GEGLU_FWD / _BWD fuse diffusers' GEGLU (attention.py) into the projection GEMMs, aux_dim = F. */
+ * epilogue (variant >= 2): SVDX_EPI_GEGLU_FWD / _BWD fuse diffusers' GEGLU (attention.py) into the projection GEMMs, aux_dim = F.
+ * variant = output tile of the launch (rows x columns, LDS stages of the K-loop, waves):  0 / 1 the plain 128x128 kernels (1: operands
+ * beyond the 2 GiB buffer reach);  4 heuristic among 6 / 7 / 8 = 160x160 / 128x160 / 128x128, two stages, four waves, two workgroups per CU;
+ * ring-staged, one workgroup per CU:  16 / 17 / 18 = 256x160 / 256x128 / 256x256 (eight waves; 3, 3, 2 stages),  20 / 21 = 128x160 / 128x128
+ * (four waves, 4 stages),  23 / 22 = 192x160 / 192x128 (eight waves, 3 stages),  25 / 24 = 96x160 / 96x128 (four waves, 4 stages).
+ * A 160-wide variant takes its 128-wide sibling when N % 160 != 0 or under the GEGLU-forward epilogue; 18 needs N % 256 == 0 (else 17).
+ * The host side picks per problem (svd_xtend_amd/ops.py: choose_cfg). */
 int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
               const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
               const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
