@@ -5,7 +5,7 @@ import pytest
 import torch
 
 gpu = pytest.mark.gpu
-RING = (16, 18, 20)          # ring-staged tile variants: between them every new instantiation of gemm_v4_kernel
+RING = (16, 18, 20, 23, 25)  # ring-staged tile variants: between them every instantiation of gemm_v4_kernel (kernel_checks.RING_VARIANTS: N % 160 picks the 160- or 128-wide sibling)
 GROUPS = (["gemm_tn", "gemm_tn_s3", "gemm_tn_s4", "gemm_tn_v18", "gemm_geglu", "gemm_geglu_v17", "gemm_geglu_v18", "gemm_geglu_v21", "gemm_plain_v1"]
           + [f"gemm_{k}_v{v}" for v in (4, 6) + RING for k in ("plain", "gather")]
           + ["small", "groupnorm", "layernorm", "attention", "temporal_attention", "tsa", "encoders", "elementwise", "optim"])
