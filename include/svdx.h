@@ -73,7 +73,8 @@ int         svdx_device_ok(void);
  * variant = output tile of the launch (rows x columns, LDS stages of the K-loop, waves):  0 / 1 the plain 128x128 kernels (1: operands
  * beyond the 2 GiB buffer reach);  4 heuristic among 6 / 7 / 8 = 160x160 / 128x160 / 128x128, two stages, four waves, two workgroups per CU;
  * ring-staged, one workgroup per CU:  16 / 17 / 18 = 256x160 / 256x128 / 256x256 (eight waves; 3, 3, 2 stages),  20 / 21 = 128x160 / 128x128
- * (four waves, 4 stages),  23 / 22 = 192x160 / 192x128 (eight waves, 3 stages),  25 / 24 = 96x160 / 96x128 (four waves, 4 stages).
+ * (four waves, 4 stages),  23 / 22 = 192x160 / 192x128 (eight waves, 3 stages),  25 / 24 = 96x160 / 96x128 (four waves, 4 stages);
+ * 26 = 192x128, eight waves, TWO stages (80 KB of LDS: two workgroups per CU -- the tile under the GEGLU epilogues).
  * A 160-wide variant takes its 128-wide sibling when N % 160 != 0 or under the GEGLU-forward epilogue; 18 needs N % 256 == 0 (else 17).
  * The host side picks per problem (svd_xtend_amd/ops.py: choose_cfg). */
 int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,

@@ -230,15 +230,26 @@ def choose_cfg(rt: "Runtime", M: int, N: int, Kd: int, ldc: int, cin: int = 0, d
     return min(cands, key=lambda c: estimate_gemm_us(M, N, Kd, c[0], c[1], cin))
 
 
+GEGLU_TWO_PER_CU = 26      # 192 x 128, eight waves, two stages: 80 KB of LDS, two workgroups per CU (csrc/gemm.hip); used under GEGLU epilogues only
+
+
+def geglu_candidates(M: int, N: int, Kd: int, fwd: bool = True):
+    """Tile variants the in-situ tuner tries for a GEMM with a fused GEGLU epilogue (no split-K there)."""
+    vs = [v for _, v in _nt_candidates(M, N, Kd, False, fused_epilogue=fwd)]
+    return vs + [GEGLU_TWO_PER_CU]
+
+
 def choose_geglu_variant(M: int, N: int, Kd: int, fwd: bool = True) -> int:
-    """Tile variant of a GEMM with a fused GEGLU epilogue (no split-K there) without a measurement: the in-situ sweep's winners --
-    forward (N = 2F): 256 x 256 eight-wave tiles on the big grids, 256 x 128 ring tiles below; backward (N = F): 256 x 256 at the
-    64 x 40 level, two-stage 160-wide tiles in the middle, ring tiles when the grid is under one workgroup per CU."""
-    if fwd:
-        return 18 if (M >= 4096 and N % 256 == 0) else (17 if M >= 512 else 4)
-    if M >= 16384 and N % 256 == 0:
+    """Tile variant of a GEMM with a fused GEGLU epilogue (no split-K there) without a measurement.  Under these epilogues a
+    workgroup runs its main loop, the GELU polynomial and its 200-400 KB of stores one after the other, so two workgroups per CU
+    matter more than the main loop: the two-stage eight-wave 192 x 128 tile is the default (isolated, us: forward M = 35840
+    111.4 -> 100.2, M = 2240 73.8 -> 70.1; backward 126.4 -> 105.3 / 68.6 -> 57.8 / 53.8 -> 44.3 at M = 35840 / 8960 / 2240);
+    the 256 x 256 tile keeps the forward at the 32x20 level (80.3 against 80.9), ring tiles the 8x5 level (M = 560)."""
+    if M < 1024:
+        return (17 if M >= 512 else 4) if fwd else (21 if N % 128 == 0 else 4)
+    if fwd and 4096 <= M < 16384 and N % 256 == 0:
         return 18
-    return 4 if M >= 1024 else (21 if N % 128 == 0 else 4)
+    return GEGLU_TWO_PER_CU
 
 
 class GemmTuner:

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import kernels as K
 from .lora import LoraLinear, base_linear, inject
-from .ops import (ConvOp, GroupNormOp, LayerNormOp, LinearOp, LoraOp, Runtime, SmallLinearOp, SmallLoraOp, _nt_candidates, choose_geglu_variant, choose_split, flatten_trainables, tuned_call,
+from .ops import (ConvOp, GroupNormOp, LayerNormOp, LinearOp, LoraOp, Runtime, SmallLinearOp, SmallLoraOp, choose_geglu_variant, geglu_candidates, choose_split, flatten_trainables, tuned_call,
                   rup)
 
 HEAD_DIM = 64
@@ -103,7 +103,7 @@ class _FeedForward(nn.Module):
         if self._fusable(rt, M):
             # GEGLU fused into the projection GEMM: one launch emits pre [M,2F] (saved for the backward) and h = a * gelu(gate)
             pre = rt.empty(M, 2 * F)
-            tuned_call(rt, ("geglu_fwd", M, F, self.dim), lambda: [v for _, v in _nt_candidates(M, 2 * F, self.dim, False, fused_epilogue=True)],
+            tuned_call(rt, ("geglu_fwd", M, F, self.dim), lambda: geglu_candidates(M, 2 * F, self.dim),
                        lambda: choose_geglu_variant(M, 2 * F, self.dim),
                        lambda v: rt.k.gemm(x, self.p1.w, pre, M, 2 * F, self.dim, self.dim, self.dim, 2 * F, bias=self.p1.b, variant=v,
                                            epilogue=K.EPI_GEGLU_FWD, aux_out=g, aux_dim=F))
@@ -115,7 +115,7 @@ class _FeedForward(nn.Module):
 
     def fwd_ln(self, rt, ln, x, M, res, need_n: bool):
         """LayerNorm `ln` + this feed-forward.  Returns (y, pre, g, n, stats).  (Round 2's one-launch LayerNorm + GEGLU band kernel was
-        removed in round 3: with the 256 x 256 eight-wave tiles under the GEGLU epilogue the two launches are 0.15 ms/step faster.)"""
+        removed in round 3: with eight-wave tiles under the GEGLU epilogue the two launches are 0.15 ms/step faster.)"""
         n, st = ln.fwd(rt, x, M)
         y, pre, g = self.fwd(rt, n, M, res)
         return y, pre, g, n, st
@@ -127,7 +127,7 @@ class _FeedForward(nn.Module):
         dpre = rt.empty(M, 2 * F)
         if self._fusable(rt, M):
             # d(h) = dy W2 never reaches HBM: the data-grad GEMM's epilogue applies the GEGLU backward and writes d(pre)
-            tuned_call(rt, ("geglu_bwd", M, F, self.p2.N), lambda: [v for _, v in _nt_candidates(M, F, self.p2.N, False)],
+            tuned_call(rt, ("geglu_bwd", M, F, self.p2.N), lambda: geglu_candidates(M, F, self.p2.N, fwd=False),
                        lambda: choose_geglu_variant(M, F, self.p2.N, fwd=False),
                        lambda v: k.gemm(dy, self.p2.wt, dpre, M, F, self.p2.N, self.p2.N, self.p2.N, 2 * F, variant=v,
                                         epilogue=K.EPI_GEGLU_BWD, aux_in=pre, aux_dim=F))

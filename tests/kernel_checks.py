@@ -636,7 +636,7 @@ def run_all(impl, dev, dtypes=DTYPES, verbose=True):
         checks += [("gemm_tn", lambda: check_gemm_tn(P, dt)), ("gemm_tn_s3", lambda: check_gemm_tn(P, dt, 3)), ("gemm_tn_s4", lambda: check_gemm_tn(P, dt, 4)),
                    ("gemm_tn_v18", lambda: check_gemm_tn(P, dt, 18)),
                    ("gemm_geglu", lambda: check_gemm_geglu(P, dt))]
-        checks += [(f"gemm_geglu_v{v}", lambda v=v: check_gemm_geglu(P, dt, v)) for v in (17, 18, 21)]
+        checks += [(f"gemm_geglu_v{v}", lambda v=v: check_gemm_geglu(P, dt, v)) for v in (17, 18, 21, 26)]
         checks += [
                   ("small", lambda: check_small(P, dt)), ("groupnorm", lambda: check_groupnorm(P, dt)),
                   ("layernorm", lambda: check_layernorm(P, dt)), ("attention", lambda: check_attention(P, dt)),

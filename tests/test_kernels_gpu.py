@@ -6,7 +6,7 @@ import torch
 
 gpu = pytest.mark.gpu
 RING = (16, 18, 20, 23, 25)  # ring-staged tile variants: between them every instantiation of gemm_v4_kernel (kernel_checks.RING_VARIANTS: N % 160 picks the 160- or 128-wide sibling)
-GROUPS = (["gemm_tn", "gemm_tn_s3", "gemm_tn_s4", "gemm_tn_v18", "gemm_geglu", "gemm_geglu_v17", "gemm_geglu_v18", "gemm_geglu_v21", "gemm_plain_v1"]
+GROUPS = (["gemm_tn", "gemm_tn_s3", "gemm_tn_s4", "gemm_tn_v18", "gemm_geglu", "gemm_geglu_v17", "gemm_geglu_v18", "gemm_geglu_v21", "gemm_geglu_v26", "gemm_plain_v1"]
           + [f"gemm_{k}_v{v}" for v in (4, 6) + RING for k in ("plain", "gather")]
           + ["small", "groupnorm", "layernorm", "attention", "temporal_attention", "tsa", "encoders", "elementwise", "optim"])
 
@@ -33,7 +33,7 @@ def test_kernel_group(pair, group, dt):
            "elementwise": lambda: kc.check_elementwise(pair, dt), "optim": lambda: kc.check_optim(pair, dt)}
     for v in (18,):
         fns[f"gemm_tn_v{v}"] = lambda v=v: kc.check_gemm_tn(pair, dt, v)
-    for v in (17, 18, 21):
+    for v in (17, 18, 21, 26):
         fns[f"gemm_geglu_v{v}"] = lambda v=v: kc.check_gemm_geglu(pair, dt, v)
     for v in (4, 6) + RING:
         fns[f"gemm_plain_v{v}"] = lambda v=v: kc.check_gemm_plain(pair, dt, v)
