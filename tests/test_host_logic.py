@@ -346,3 +346,17 @@ def test_lora_adapter_state_dict_round_trip():
     assert all(torch.equal(sd[k], sd2[k]) for k in sd)
     with pytest.raises(KeyError):
         load_lora_state_dict(m2, {"unet.nope.lora_A.weight": torch.zeros(1)})
+
+
+def test_geglu_tile_rule():
+    """ops.choose_geglu_variant: the two-per-CU eight-wave tile under every GEGLU epilogue with M >= 1024 except the 32x20-level forward
+    (256 x 256), ring tiles below; the rule's answer is always among the candidates the in-situ tuner sweeps."""
+    from svd_xtend_amd.ops import GEGLU_TWO_PER_CU, choose_geglu_variant, geglu_candidates
+    for (M, C) in [(35840, 320), (8960, 640), (2240, 1280), (560, 1280), (230400, 320), (57600, 640), (14400, 1280), (3600, 1280)]:
+        F = 4 * C
+        f, b = choose_geglu_variant(M, 2 * F, C), choose_geglu_variant(M, F, C, fwd=False)
+        assert f in geglu_candidates(M, 2 * F, C) and b in geglu_candidates(M, F, C, fwd=False), (M, C, f, b)
+        if M < 1024:
+            assert GEGLU_TWO_PER_CU not in (f, b)
+        else:
+            assert b == GEGLU_TWO_PER_CU and f == (18 if 4096 <= M < 16384 else GEGLU_TWO_PER_CU)
