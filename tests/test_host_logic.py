@@ -360,3 +360,28 @@ def test_geglu_tile_rule():
             assert GEGLU_TWO_PER_CU not in (f, b)
         else:
             assert b == GEGLU_TWO_PER_CU and f == (18 if 4096 <= M < 16384 else GEGLU_TWO_PER_CU)
+
+
+def test_tile_table_matches_the_kernel_dispatch():
+    """ops.TILE_OF_VARIANT (what the cost model believes a variant's tile is) against the template arguments csrc/gemm.hip dispatches that
+    variant to: rows = 16 * MB * WGM, columns = 32 * NB, stages = NSTG, waves = 2 * WGM."""
+    import os
+    import re
+    from svd_xtend_amd.ops import GEGLU_TWO_PER_CU, TILE_OF_VARIANT
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "svd_xtend_amd", "csrc", "gemm.hip")).read()
+    seen = {}
+    for line in src.splitlines():
+        m = re.match(r"\s*((?:case \d+: )+)(.*)", line)
+        if not m or "launch_gemm_v4<" not in m.group(2):
+            continue
+        variants = [int(v) for v in re.findall(r"case (\d+):", m.group(1))]
+        tiles = [tuple(int(x) for x in t) for t in re.findall(r"launch_gemm_v4<T, (\d+), (\d+), (\d+), (\d+)>", m.group(2))]
+        assert tiles, line
+        for v in variants:
+            seen[v] = tiles
+    for v, (bm, bn, stages, waves) in TILE_OF_VARIANT.items():
+        if v < 16:
+            continue                                   # 6 / 7 / 8: the two-stage four-wave defaults of launch_gemm_v4<T, NB, MB>
+        geo = {(16 * mb * wgm, 32 * nb, nstg, 2 * wgm) for nb, mb, wgm, nstg in seen[v]}
+        assert (bm, bn, stages, waves) in geo, (v, (bm, bn, stages, waves), geo)
+    assert {(16 * mb * wgm, 32 * nb, nstg, 2 * wgm) for nb, mb, wgm, nstg in seen[GEGLU_TWO_PER_CU]} == {(192, 128, 2, 8)}
