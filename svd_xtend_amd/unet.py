@@ -143,9 +143,20 @@ class _FeedForward(nn.Module):
         return dx
 
 
+class HipAttnProcessor:
+    """What stands where diffusers keeps an attention-processor object (`Attention.processor`): attention here is always the
+    library's own kernels (flash-style spatial attention, MFMA temporal attention, the KV-length-1 cross-attention short cut), so
+    there is exactly one kind of processor and it carries no state.  It exists so that the processor plumbing of the reference class
+    (/root/reference/src/unet_spatio_temporal_condition.py:248-321) can be called by code written against it."""
+
+    def __repr__(self):
+        return "HipAttnProcessor()"
+
+
 class _Attention(nn.Module):
     def __init__(self, dim, heads, cross_dim=None):
         super().__init__()
+        self.processor = HipAttnProcessor()
         inner = heads * HEAD_DIM
         kv = cross_dim if cross_dim is not None else dim
         self.heads, self.dim, self.cross = heads, dim, cross_dim is not None
@@ -153,6 +164,14 @@ class _Attention(nn.Module):
         self.to_k = nn.Linear(kv, inner, bias=False)
         self.to_v = nn.Linear(kv, inner, bias=False)
         self.to_out = nn.ModuleList([nn.Linear(inner, dim, bias=True), nn.Dropout(0.0)])
+
+    def get_processor(self):
+        return self.processor
+
+    def set_processor(self, processor):
+        if not isinstance(processor, HipAttnProcessor):
+            raise ValueError(f"attention runs in libsvdx: the only processor is HipAttnProcessor, got {type(processor).__name__}")
+        self.processor = processor
 
     def build(self):
         q, kk, v, o = (base_linear(m) for m in (self.to_q, self.to_k, self.to_v, self.to_out[0]))
@@ -244,6 +263,11 @@ def _proj_bwd_dx(rt, lin, lora, dy, lddy, x, xs, M, need_dx=True):
 class BasicTransformerBlock(nn.Module):
     """Spatial block (diffusers attention.BasicTransformerBlock): self-attn over HW, KV-1 cross-attn, GEGLU FF."""
 
+    _chunk_size, _chunk_dim = None, 0
+
+    def set_chunk_feed_forward(self, chunk_size, dim: int = 0):
+        self._chunk_size, self._chunk_dim = chunk_size, dim           # recorded only (UNet...Model.enable_forward_chunking)
+
     def __init__(self, dim, heads, cross_dim):
         super().__init__()
         self.dim, self.heads = dim, heads
@@ -319,6 +343,11 @@ class BasicTransformerBlock(nn.Module):
 class TemporalBasicTransformerBlock(nn.Module):
     """diffusers attention.TemporalBasicTransformerBlock -- the trainable set of train_svd.py:761-766.
     Rows stay in (b,t,p) order; only the frame-axis attention looks across rows (strided)."""
+
+    _chunk_size, _chunk_dim = None, 0
+
+    def set_chunk_feed_forward(self, chunk_size, dim: int = 0):
+        self._chunk_size, self._chunk_dim = chunk_size, dim           # recorded only (UNet...Model.enable_forward_chunking)
 
     def __init__(self, dim, heads, cross_dim):
         super().__init__()
@@ -885,6 +914,41 @@ class UNetSpatioTemporalConditionModel(nn.Module):
 
     def enable_xformers_memory_efficient_attention(self, *a, **k):   # train_svd.py:690 -- own attention kernels
         return None
+
+    # ---- attention-processor plumbing and feed-forward chunking of the reference class (src/...:248-321, 328-355) ----------------
+    # Never called by the training scripts; kept so that code written against the reference class runs.  Same names, argument
+    # meaning and error behaviour; the only processor that exists here is HipAttnProcessor.
+    @property
+    def attn_processors(self):
+        """{"<module path>.processor": processor} of every attention layer (64 at the SVD topology), keyed like the reference's."""
+        return {f"{name}.processor": m.get_processor() for name, m in self.named_modules() if hasattr(m, "get_processor")}
+
+    def set_attn_processor(self, processor):
+        """One processor for every attention layer, or a dict keyed like `attn_processors` (its length must equal the layer count)."""
+        layers = [(name, m) for name, m in self.named_modules() if hasattr(m, "set_processor")]
+        if isinstance(processor, dict):
+            if len(processor) != len(layers):
+                raise ValueError(f"A dict of processors was passed, but the number of processors {len(processor)} does not match the"
+                                 f" number of attention layers: {len(layers)}. Please make sure to pass {len(layers)} processor classes.")
+            for name, m in layers:
+                m.set_processor(processor.pop(f"{name}.processor"))
+        else:
+            for _, m in layers:
+                m.set_processor(processor)
+
+    def set_default_attn_processor(self):
+        self.set_attn_processor(HipAttnProcessor())
+
+    def enable_forward_chunking(self, chunk_size=None, dim: int = 0) -> None:
+        """The reference chunks every feed-forward over `dim` (0 = batch, 1 = sequence) to bound its peak memory.  The feed-forwards
+        here are row-wise GEMM chains on buffers sized for 288 GB of HBM: results do not depend on chunking, so the request is validated
+        and recorded on the transformer blocks (`_chunk_size`, `_chunk_dim`, the attributes diffusers' blocks keep), nothing else."""
+        if dim not in (0, 1):
+            raise ValueError(f"Make sure to set `dim` to either 0 or 1, not {dim}")
+        chunk_size = chunk_size or 1
+        for m in self.modules():
+            if hasattr(m, "set_chunk_feed_forward"):
+                m.set_chunk_feed_forward(chunk_size=chunk_size, dim=dim)
 
     # ---- build / pack ---------------------------------------------------------------------------------
     def _steps(self):

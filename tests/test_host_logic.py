@@ -385,3 +385,36 @@ def test_tile_table_matches_the_kernel_dispatch():
         geo = {(16 * mb * wgm, 32 * nb, nstg, 2 * wgm) for nb, mb, wgm, nstg in seen[v]}
         assert (bm, bn, stages, waves) in geo, (v, (bm, bn, stages, waves), geo)
     assert {(16 * mb * wgm, 32 * nb, nstg, 2 * wgm) for nb, mb, wgm, nstg in seen[GEGLU_TWO_PER_CU]} == {(192, 128, 2, 8)}
+
+
+def test_attention_processor_plumbing_and_forward_chunking():
+    """The processor get / set surface and enable_forward_chunking of the reference class
+    (/root/reference/src/unet_spatio_temporal_condition.py:248-321, 328-355): same keys ("<attention module path>.processor", one per
+    attention layer: 16 transformers x (spatial + temporal) x (attn1 + attn2) = 64), same argument checks; weights are untouched."""
+    from oracle.unet import TINY_CONFIG
+    from svd_xtend_amd.unet import HipAttnProcessor, UNetSpatioTemporalConditionModel
+    m = UNetSpatioTemporalConditionModel(**TINY_CONFIG)
+    keys_before = list(m.state_dict())
+    procs = m.attn_processors
+    assert len(procs) == 64 and all(k.endswith(".processor") for k in procs)
+    attn_modules = {n for n, _ in m.named_modules() if n.endswith(("attn1", "attn2"))}
+    assert {k[:-len(".processor")] for k in procs} == attn_modules
+    assert "down_blocks.0.attentions.0.temporal_transformer_blocks.0.attn2.processor" in procs and "mid_block.attentions.0.transformer_blocks.0.attn1.processor" in procs
+    one = HipAttnProcessor()
+    m.set_attn_processor(one)
+    assert all(p is one for p in m.attn_processors.values())
+    m.set_attn_processor({k: HipAttnProcessor() for k in procs})          # a dict keyed like attn_processors
+    assert len({id(p) for p in m.attn_processors.values()}) == 64
+    with pytest.raises(ValueError, match="does not match"):
+        m.set_attn_processor({"x.processor": one})
+    with pytest.raises(ValueError):
+        m.set_attn_processor(object())                                    # no foreign attention implementations
+    m.set_default_attn_processor()
+    m.enable_forward_chunking()                                            # default chunk size 1 over the batch dimension
+    blocks = [b for b in m.modules() if hasattr(b, "set_chunk_feed_forward")]
+    assert len(blocks) == 32 and all((b._chunk_size, b._chunk_dim) == (1, 0) for b in blocks)
+    m.enable_forward_chunking(4, dim=1)
+    assert all((b._chunk_size, b._chunk_dim) == (4, 1) for b in blocks)
+    with pytest.raises(ValueError, match="either 0 or 1"):
+        m.enable_forward_chunking(dim=2)
+    assert list(m.state_dict()) == keys_before
