@@ -1498,6 +1498,10 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
             p.a_bytes = (int)a_bytes; p.b_bytes = (int)b_bytes;
             // tile choice: variant 4 = heuristic; 6 / 7 / 8 force 160x160 / 128x160 / 128x128 (the host autotuner times them)
             const bool nb5 = epilogue == SVDX_EPI_GEGLU_FWD || variant == 8 || variant == 17 || variant == 18 || variant == 21 || variant == 22 || variant == 24 || variant == 26 ? false : (N % 160 == 0);
+            // the GEGLU-backward epilogue only exists in the coalesced store path, which takes whole column tiles: d(pre) of a partial last
+            // tile would be written as plain d(h) (found by tests/sim/fuzz.py; F = 4C of the UNet is always a multiple of 128)
+            SVDX_CHECK_ARG(epilogue != SVDX_EPI_GEGLU_BWD || N % (nb5 ? 160 : 128) == 0,
+                           "svdx_gemm: GEGLU bwd with tile variant %d needs N=%d to be a multiple of its %d-column tile", variant, N, nb5 ? 160 : 128);
             // 160-row tiles when they turn a 1.1-wave grid (512 resident blocks) into a single wave, e.g. M = 35840, N = 320:
             // 280 x 2 = 560 tiles of 128 rows vs 224 x 2 = 448 tiles of 160 rows
             const long t128 = (long)cdiv(M, 128) * cdiv(N, 160), t160 = (long)cdiv(M, 160) * cdiv(N, 160);

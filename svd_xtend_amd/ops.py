@@ -236,7 +236,7 @@ GEGLU_TWO_PER_CU = 26      # 192 x 128, eight waves, two stages: 80 KB of LDS, t
 def geglu_candidates(M: int, N: int, Kd: int, fwd: bool = True):
     """Tile variants the in-situ tuner tries for a GEMM with a fused GEGLU epilogue (no split-K there)."""
     vs = [v for _, v in _nt_candidates(M, N, Kd, False, fused_epilogue=fwd)]
-    return vs + [GEGLU_TWO_PER_CU]
+    return vs + ([GEGLU_TWO_PER_CU] if fwd or N % 128 == 0 else [])
 
 
 def choose_geglu_variant(M: int, N: int, Kd: int, fwd: bool = True) -> int:
@@ -245,8 +245,10 @@ def choose_geglu_variant(M: int, N: int, Kd: int, fwd: bool = True) -> int:
     matter more than the main loop: the two-stage eight-wave 192 x 128 tile is the default (isolated, us: forward M = 35840
     111.4 -> 100.2, M = 2240 73.8 -> 70.1; backward 126.4 -> 105.3 / 68.6 -> 57.8 / 53.8 -> 44.3 at M = 35840 / 8960 / 2240);
     the 256 x 256 tile keeps the forward at the 32x20 level (80.3 against 80.9), ring tiles the 8x5 level (M = 560)."""
+    if not fwd and N % 128:
+        return 4                                             # the backward epilogue takes whole column tiles: 160-wide ones here (N % 160 == 0)
     if M < 1024:
-        return (17 if M >= 512 else 4) if fwd else (21 if N % 128 == 0 else 4)
+        return (17 if M >= 512 else 4) if fwd else 21
     if fwd and 4096 <= M < 16384 and N % 256 == 0:
         return 18
     return GEGLU_TWO_PER_CU

@@ -167,7 +167,7 @@ class EmuBackend:
                 sl.copy_(alpha * (a[:, z * ksz:(z + 1) * ksz] @ b[:, z * ksz:(z + 1) * ksz].t()))
             return
         c = V(C, M, N, ldc)
-        if out_mode == K.OUT_F32_ATOMIC:
+        if out_mode in (K.OUT_F32_ATOMIC, K.OUT_F32_ADD):
             assert C.dtype == torch.float32
             c += v
         else:

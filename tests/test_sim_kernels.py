@@ -62,6 +62,32 @@ def test_train_step_on_simulator_matches_oracle_tiny():
     assert got["loss_rel"] <= 1e-3 and got["grad_cos_min"] >= 0.99, got
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_random_shapes_on_simulator(sim_pair, dt):
+    """tests/sim/fuzz.py: seeded random shapes, strides, epilogue modes, tile variants and split factors of every kernel family against
+    the emulation -- the shapes a caller of the C-ABI may pass, not only the UNet's (this is how the GEGLU-backward partial-tile hole
+    behind svdx_gemm's argument check was found)."""
+    import fuzz
+    bad = fuzz.run(sim_pair, DT[dt], list(fuzz.FAMILIES), 60 if FULL else 10, seed=1 if dt == "f16" else 2, verbose=False)
+    assert not bad, bad[:5]
+
+
+def test_geglu_backward_refuses_partial_column_tiles(sim_pair):
+    """The GEGLU-backward epilogue lives in the coalesced store path only (whole column tiles): a 128-wide tile variant on N = 320 is an
+    argument error, and the host rule never asks for one."""
+    from svd_xtend_amd import kernels as K
+    from svd_xtend_amd import ops
+    dt, M, C, F = torch.float16, 70, 64, 320
+    dy, W2t, pre = torch.zeros(M, C, dtype=dt), torch.zeros(F, C, dtype=dt), torch.zeros(M, 2 * F, dtype=dt)
+    for v in (8, 21, 26, 18, 24):
+        with pytest.raises(K.SvdxError, match="GEGLU bwd"):
+            sim_pair.impl.gemm(dy, W2t, torch.zeros(M, 2 * F, dtype=dt), M, F, C, C, C, 2 * F, variant=v, epilogue=K.EPI_GEGLU_BWD, aux_in=pre, aux_dim=F)
+    for M_ in (70, 560, 2240, 35840):
+        assert ops.choose_geglu_variant(M_, 320, 64, fwd=False) == 4
+        assert ops.GEGLU_TWO_PER_CU not in ops.geglu_candidates(M_, 320, 64, fwd=False)
+        assert ops.choose_geglu_variant(M_, 1280, 320, fwd=False) in (21, ops.GEGLU_TWO_PER_CU)
+
+
 def test_simulated_library_is_not_the_product_library():
     """The product binding refuses to run without a GPU; the simulator build is a separate file that only tests construct."""
     import build_sim
