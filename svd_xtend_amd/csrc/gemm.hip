@@ -1497,7 +1497,7 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
         if (variant >= 2 && a_bytes > 0 && b_bytes > 0) {
             p.a_bytes = (int)a_bytes; p.b_bytes = (int)b_bytes;
             // tile choice: variant 4 = heuristic; 6 / 7 / 8 force 160x160 / 128x160 / 128x128 (the host autotuner times them)
-            const bool nb5 = epilogue == SVDX_EPI_GEGLU_FWD || variant == 8 || variant == 17 || variant == 18 || variant == 21 || variant == 22 || variant == 24 || variant == 26 ? false : (N % 160 == 0);
+            const bool nb5 = epilogue == SVDX_EPI_GEGLU_FWD || variant == 8 || variant == 17 || variant == 18 || variant == 21 || variant == 22 || variant == 24 || variant == 26 || variant == 27 ? false : (N % 160 == 0);
             // the GEGLU-backward epilogue only exists in the coalesced store path, which takes whole column tiles: d(pre) of a partial last
             // tile would be written as plain d(h) (found by tests/sim/fuzz.py; F = 4C of the UNet is always a multiple of 128)
             SVDX_CHECK_ARG(epilogue != SVDX_EPI_GEGLU_BWD || N % (nb5 ? 160 : 128) == 0,
@@ -1516,6 +1516,8 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
                 //   25:  96x160, 4 stages, four waves    24:  96x128, 4 stages, four waves   (M = 2240, N = 1280, short K: 240 tiles, not 180)
                 //   26: 192x128, TWO stages, eight waves: 80 KB of LDS and 114 VGPRs, so TWO workgroups share a CU -- the tile under the GEGLU
                 //       epilogues, where main loop, GELU polynomial and 275-366 MB of stores run one after the other inside a workgroup
+                //   28: 128x160, 27: 128x128, TWO stages, eight waves (72 / 64 KB of LDS: two workgroups per CU): candidates of the in-situ
+                //       tuner for the short-K linears, not yet in the cost model (no measured rate)
                 // A 160-wide request on an N that 160 does not divide (or with the GEGLU-forward epilogue) takes the 128-wide sibling;
                 // 256-wide tiles need N % 256 == 0 (their GEGLU epilogues have no partial column tile).
                 const int n_cols = epilogue == SVDX_EPI_GEGLU_FWD ? 2 * aux_dim : N;
@@ -1525,6 +1527,7 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
                     case 20: case 21: return nb5 ? launch_gemm_v4<T, 5, 4, 2, 4>(p, st) : launch_gemm_v4<T, 4, 4, 2, 4>(p, st);
                     case 22: case 23: return nb5 ? launch_gemm_v4<T, 5, 3, 4, 3>(p, st) : launch_gemm_v4<T, 4, 3, 4, 3>(p, st);
                     case 26: return launch_gemm_v4<T, 4, 3, 4, 2>(p, st);
+                    case 27: case 28: return nb5 ? launch_gemm_v4<T, 5, 2, 4, 2>(p, st) : launch_gemm_v4<T, 4, 2, 4, 2>(p, st);
                     case 24: case 25: return nb5 ? launch_gemm_v4<T, 5, 3, 2, 4>(p, st) : launch_gemm_v4<T, 4, 3, 2, 4>(p, st);
                     default: svdx_set_error("svdx_gemm: unknown variant %d", variant); return -2;
                 }

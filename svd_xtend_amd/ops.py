@@ -153,6 +153,8 @@ def choose_split(rt: "Runtime", M: int, N: int, Kd: int, ldc: int, bn: int = 0) 
 TILE_OF_VARIANT = {7: (128, 160, 2, 4), 6: (160, 160, 2, 4), 8: (128, 128, 2, 4),
                    16: (256, 160, 3, 8), 17: (256, 128, 3, 8), 18: (256, 256, 2, 8), 20: (128, 160, 4, 4), 21: (128, 128, 4, 4),
                    23: (192, 160, 3, 8), 22: (192, 128, 3, 8), 25: (96, 160, 4, 4), 24: (96, 128, 4, 4)}
+# instantiated in csrc/gemm.hip and offered to the in-situ tuner (bench.py --tune), but without a measured rate: the cost model never picks them
+STAGED_TILES = {27: (128, 128, 2, 8), 28: (128, 160, 2, 8)}
 # TFLOP/s one CU sustains on a variant's K-loop when the CU is full (8192^3 runs of tools/ring_check.py divided by 256 CUs, trimmed by
 # the in-situ sweeps of bench.py --tune): the two-stage four-wave tiles need two workgroups per CU for it
 _TILE_RATE = {6: 4.05, 7: 3.5, 8: 3.5, 16: 4.4, 17: 4.0, 18: 3.6, 20: 2.75, 21: 2.5, 22: 3.8, 23: 3.8, 24: 2.4, 25: 2.05}
@@ -193,10 +195,10 @@ def estimate_gemm_us(M: int, N: int, Kd: int, split: int, variant: int, cin: int
     return t
 
 
-def _nt_candidates(M: int, N: int, Kd: int, splittable: bool, fused_epilogue: bool = False):
+def _nt_candidates(M: int, N: int, Kd: int, splittable: bool, fused_epilogue: bool = False, staged: bool = False):
     kt = (Kd + 63) // 64
     out = []
-    for v, (bm, bn, _stages, waves) in TILE_OF_VARIANT.items():
+    for v, (bm, bn, _stages, waves) in list(TILE_OF_VARIANT.items()) + (list(STAGED_TILES.items()) if staged else []):
         if bn == 160 and (N % 160 or fused_epilogue):       # the GEGLU-forward epilogue pairs 64 value with 64 gate columns: 128-wide tiles
             continue
         if bn == 128 and N % 160 == 0 and N % 128 and N > 160:
@@ -235,7 +237,7 @@ GEGLU_TWO_PER_CU = 26      # 192 x 128, eight waves, two stages: 80 KB of LDS, t
 
 def geglu_candidates(M: int, N: int, Kd: int, fwd: bool = True):
     """Tile variants the in-situ tuner tries for a GEMM with a fused GEGLU epilogue (no split-K there)."""
-    vs = [v for _, v in _nt_candidates(M, N, Kd, False, fused_epilogue=fwd)]
+    vs = [v for _, v in _nt_candidates(M, N, Kd, False, fused_epilogue=fwd, staged=True)]
     return vs + ([GEGLU_TWO_PER_CU] if fwd or N % 128 == 0 else [])
 
 
@@ -357,7 +359,7 @@ def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowve
                 oj = out[:, j * seg:]
                 k.gemm(A2[:, j * K2:], B2[j * seg:], oj, M, seg, K2, lda2, ldb2, ldc, res=oj, ldres=ldc, variant=rt.gemm_variant)
 
-    tuned_call(rt, key, lambda: _nt_candidates(M, N, Kd, splittable and dual is None) if dual is None else _dual_candidates(M, N, Kd),
+    tuned_call(rt, key, lambda: _nt_candidates(M, N, Kd, splittable and dual is None, staged=True) if dual is None else _dual_candidates(M, N, Kd),
                lambda: choose_cfg(rt, M, N, Kd, ldc, 0 if gather is None else gather.cin, dual is not None and rt.fuse_dual), run)
 
 

@@ -18,7 +18,7 @@ import emul  # noqa: E402
 import kernel_checks as kc  # noqa: E402
 from svd_xtend_amd import kernels as K  # noqa: E402
 
-NT_VARIANTS = (1, 4, 6, 7, 8, 16, 17, 18, 20, 21, 22, 23, 24, 25, 26)
+NT_VARIANTS = (1, 4, 6, 7, 8, 16, 17, 18, 20, 21, 22, 23, 24, 25, 26, 27, 28)
 HEAD = 64
 
 
@@ -131,7 +131,7 @@ def fuzz_tn(P, dt, rng, g):
 
 
 def fuzz_geglu(P, dt, rng, g):
-    v = rng.choice((4, 6, 8, 16, 17, 18, 20, 21, 22, 24, 26))
+    v = rng.choice((4, 6, 8, 16, 17, 18, 20, 21, 22, 24, 26, 27))
     M, C, F = pick_dim(rng, 1, 600), 64 * rng.randint(1, 6), 64 * rng.randint(1, 10)
     x, W1, b1 = kc.rnd((M, C), dt, P.dev, g), kc.rnd((2 * F, C), dt, P.dev, g, C ** -0.5), kc.rndf((2 * F,), P.dev, g)
     desc = f"geglu v{v} M={M} C={C} F={F}"

@@ -367,7 +367,7 @@ def test_tile_table_matches_the_kernel_dispatch():
     variant to: rows = 16 * MB * WGM, columns = 32 * NB, stages = NSTG, waves = 2 * WGM."""
     import os
     import re
-    from svd_xtend_amd.ops import GEGLU_TWO_PER_CU, TILE_OF_VARIANT
+    from svd_xtend_amd.ops import GEGLU_TWO_PER_CU, STAGED_TILES, TILE_OF_VARIANT
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "svd_xtend_amd", "csrc", "gemm.hip")).read()
     seen = {}
     for line in src.splitlines():
@@ -379,7 +379,8 @@ def test_tile_table_matches_the_kernel_dispatch():
         assert tiles, line
         for v in variants:
             seen[v] = tiles
-    for v, (bm, bn, stages, waves) in TILE_OF_VARIANT.items():
+    assert not set(STAGED_TILES) & set(TILE_OF_VARIANT)
+    for v, (bm, bn, stages, waves) in list(TILE_OF_VARIANT.items()) + list(STAGED_TILES.items()):
         if v < 16:
             continue                                   # 6 / 7 / 8: the two-stage four-wave defaults of launch_gemm_v4<T, NB, MB>
         geo = {(16 * mb * wgm, 32 * nb, nstg, 2 * wgm) for nb, mb, wgm, nstg in seen[v]}
