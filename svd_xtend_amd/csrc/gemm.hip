@@ -1516,12 +1516,17 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
                 //   25:  96x160, 4 stages, four waves    24:  96x128, 4 stages, four waves   (M = 2240, N = 1280, short K: 240 tiles, not 180)
                 //   26: 192x128, TWO stages, eight waves: 80 KB of LDS and 114 VGPRs, so TWO workgroups share a CU -- the tile under the GEGLU
                 //       epilogues, where main loop, GELU polynomial and 275-366 MB of stores run one after the other inside a workgroup
+                //   29: 192x320, two stages, eight waves, one per CU (128 KB): the whole width of an N = 320 output in one tile -- 120 flop per staged
+                //       byte where 160x160 has 80 (the K-loop is bound by the ~24 B/clk a CU pulls into LDS: profiles/r1_gemm_ingest_probe.txt), and
+                //       M = 35840 is 187 tiles in ONE round on 256 CUs; tuner candidate
                 //   28: 128x160, 27: 128x128, TWO stages, eight waves (72 / 64 KB of LDS: two workgroups per CU): candidates of the in-situ
                 //       tuner for the short-K linears, not yet in the cost model (no measured rate)
                 // A 160-wide request on an N that 160 does not divide (or with the GEGLU-forward epilogue) takes the 128-wide sibling;
                 // 256-wide tiles need N % 256 == 0 (their GEGLU epilogues have no partial column tile).
                 const int n_cols = epilogue == SVDX_EPI_GEGLU_FWD ? 2 * aux_dim : N;
                 switch (variant) {
+                    case 29: if (n_cols % 320 == 0 && epilogue == SVDX_EPI_NONE) return launch_gemm_v4<T, 10, 3, 4, 2>(p, st);
+                             return nb5 ? launch_gemm_v4<T, 5, 3, 4, 3>(p, st) : launch_gemm_v4<T, 4, 3, 4, 3>(p, st);   // else: the 192-row ring tiles
                     case 18: if (n_cols % 256 == 0) return launch_gemm_v4<T, 8, 4, 4, 2>(p, st);   // else: fall through to 256 x 128
                     case 16: case 17: return nb5 ? launch_gemm_v4<T, 5, 4, 4, 3>(p, st) : launch_gemm_v4<T, 4, 4, 4, 3>(p, st);
                     case 20: case 21: return nb5 ? launch_gemm_v4<T, 5, 4, 2, 4>(p, st) : launch_gemm_v4<T, 4, 4, 2, 4>(p, st);

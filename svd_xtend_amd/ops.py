@@ -154,7 +154,7 @@ TILE_OF_VARIANT = {7: (128, 160, 2, 4), 6: (160, 160, 2, 4), 8: (128, 128, 2, 4)
                    16: (256, 160, 3, 8), 17: (256, 128, 3, 8), 18: (256, 256, 2, 8), 20: (128, 160, 4, 4), 21: (128, 128, 4, 4),
                    23: (192, 160, 3, 8), 22: (192, 128, 3, 8), 25: (96, 160, 4, 4), 24: (96, 128, 4, 4)}
 # instantiated in csrc/gemm.hip and offered to the in-situ tuner (bench.py --tune), but without a measured rate: the cost model never picks them
-STAGED_TILES = {27: (128, 128, 2, 8), 28: (128, 160, 2, 8)}
+STAGED_TILES = {27: (128, 128, 2, 8), 28: (128, 160, 2, 8), 29: (192, 320, 2, 8)}
 # TFLOP/s one CU sustains on a variant's K-loop when the CU is full (8192^3 runs of tools/ring_check.py divided by 256 CUs, trimmed by
 # the in-situ sweeps of bench.py --tune): the two-stage four-wave tiles need two workgroups per CU for it
 _TILE_RATE = {6: 4.05, 7: 3.5, 8: 3.5, 16: 4.4, 17: 4.0, 18: 3.6, 20: 2.75, 21: 2.5, 22: 3.8, 23: 3.8, 24: 2.4, 25: 2.05}
@@ -205,6 +205,8 @@ def _nt_candidates(M: int, N: int, Kd: int, splittable: bool, fused_epilogue: bo
             continue
         if bn == 256 and N % 256:
             continue
+        if bn == 320 and (N % 320 or fused_epilogue):
+            continue
         if waves == 8 and M < 2 * bm:
             continue
         tiles = -(-M // bm) * -(-N // bn)
@@ -249,6 +251,12 @@ def choose_geglu_variant(M: int, N: int, Kd: int, fwd: bool = True) -> int:
     the 256 x 256 tile keeps the forward at the 32x20 level (80.3 against 80.9), ring tiles the 8x5 level (M = 560)."""
     if not fwd and N % 128:
         return 4                                             # the backward epilogue takes whole column tiles: 160-wide ones here (N % 160 == 0)
+    if os.environ.get("SVDX_GEGLU_TILE") == "sweep":        # developer knob for A/B runs: the in-situ sweep's winners among the one-per-CU tiles
+        if fwd:
+            return 18 if (M >= 4096 and N % 256 == 0) else (17 if M >= 512 else 4)
+        if M >= 16384 and N % 256 == 0:
+            return 18
+        return 4 if M >= 1024 else 21
     if M < 1024:
         return (17 if M >= 512 else 4) if fwd else 21
     if fwd and 4096 <= M < 16384 and N % 256 == 0:

@@ -21,7 +21,7 @@ def groups(P, dt):
            "optim": lambda: kc.check_optim(P, dt)}
     for v in (17, 18, 21, 26, 27):
         fns[f"gemm_geglu_v{v}"] = lambda v=v: kc.check_gemm_geglu(P, dt, v)
-    for v in (1, 4, 6, 16, 18, 20, 23, 25, 27, 28):
+    for v in (1, 4, 6, 16, 18, 20, 23, 25, 27, 28, 29):
         fns[f"gemm_plain_v{v}"] = lambda v=v: kc.check_gemm_plain(P, dt, v)
         fns[f"gemm_gather_v{v}"] = lambda v=v: kc.check_gemm_gather(P, dt, v)
     return fns

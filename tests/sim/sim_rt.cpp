@@ -441,6 +441,14 @@ void sim_block_barrier(bool fence_vm) {
 
 void sim_dma(char* lds_dst, const void* src, int size) {
     if (size > 16 || size <= 0) die("LDS-DMA piece larger than 16 bytes");
+    // SVDX_SIM_DMA=eager: the other legal extreme -- the piece lands the moment it is issued, so a stage that is refilled while a slower
+    // wave still reads it (a write-after-read race the late landing cannot show) gives wrong data
+    static const bool eager = getenv("SVDX_SIM_DMA") && getenv("SVDX_SIM_DMA")[0] == 'e';
+    if (eager) {
+        if (src) memcpy(lds_dst, src, size);
+        else memset(lds_dst, 0, size);
+        return;
+    }
     Fiber* f = g_run->cur;
     DmaEntry e;
     e.dst = lds_dst;
