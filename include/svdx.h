@@ -76,7 +76,7 @@ int         svdx_device_ok(void);
  * (four waves, 4 stages),  23 / 22 = 192x160 / 192x128 (eight waves, 3 stages),  25 / 24 = 96x160 / 96x128 (four waves, 4 stages);
  * 26 = 192x128, eight waves, TWO stages (80 KB of LDS: two workgroups per CU -- the tile under the GEGLU epilogues).
  * 28 / 27 = 128x160 / 128x128, eight waves, two stages (72 / 64 KB: two workgroups per CU; tuner candidates).
- * 29 = 192x320, eight waves, two stages (128 KB, one per CU; N % 320 == 0 and no fused epilogue, else the 192-row ring tiles; tuner candidate).
+ * 29 = 192x320, eight waves, two stages (128 KB, one per CU; N % 320 == 0, else the 192-row ring tiles; tuner candidate).
  * A 160-wide variant takes its 128-wide sibling when N % 160 != 0 or under the GEGLU-forward epilogue; 18 needs N % 256 == 0 (else 17).
  * The host side picks per problem (svd_xtend_amd/ops.py: choose_cfg). */
 int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,

@@ -1525,7 +1525,7 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
                 // 256-wide tiles need N % 256 == 0 (their GEGLU epilogues have no partial column tile).
                 const int n_cols = epilogue == SVDX_EPI_GEGLU_FWD ? 2 * aux_dim : N;
                 switch (variant) {
-                    case 29: if (n_cols % 320 == 0 && epilogue == SVDX_EPI_NONE) return launch_gemm_v4<T, 10, 3, 4, 2>(p, st);
+                    case 29: if (n_cols % 320 == 0 && N % 320 == 0) return launch_gemm_v4<T, 10, 3, 4, 2>(p, st);
                              return nb5 ? launch_gemm_v4<T, 5, 3, 4, 3>(p, st) : launch_gemm_v4<T, 4, 3, 4, 3>(p, st);   // else: the 192-row ring tiles
                     case 18: if (n_cols % 256 == 0) return launch_gemm_v4<T, 8, 4, 4, 2>(p, st);   // else: fall through to 256 x 128
                     case 16: case 17: return nb5 ? launch_gemm_v4<T, 5, 4, 4, 3>(p, st) : launch_gemm_v4<T, 4, 4, 4, 3>(p, st);

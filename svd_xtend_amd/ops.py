@@ -205,7 +205,7 @@ def _nt_candidates(M: int, N: int, Kd: int, splittable: bool, fused_epilogue: bo
             continue
         if bn == 256 and N % 256:
             continue
-        if bn == 320 and (N % 320 or fused_epilogue):
+        if bn == 320 and N % 320:
             continue
         if waves == 8 and M < 2 * bm:
             continue

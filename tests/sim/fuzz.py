@@ -131,8 +131,8 @@ def fuzz_tn(P, dt, rng, g):
 
 
 def fuzz_geglu(P, dt, rng, g):
-    v = rng.choice((4, 6, 8, 16, 17, 18, 20, 21, 22, 24, 26, 27))
-    M, C, F = pick_dim(rng, 1, 600), 64 * rng.randint(1, 6), 64 * rng.randint(1, 10)
+    v = rng.choice((4, 6, 8, 16, 17, 18, 20, 21, 22, 24, 26, 27, 29, 29))
+    M, C, F = pick_dim(rng, 1, 600), 64 * rng.randint(1, 6), rng.choice((64 * rng.randint(1, 10), 160 * rng.randint(1, 4) * 2))
     x, W1, b1 = kc.rnd((M, C), dt, P.dev, g), kc.rnd((2 * F, C), dt, P.dev, g, C ** -0.5), kc.rndf((2 * F,), P.dev, g)
     desc = f"geglu v{v} M={M} C={C} F={F}"
     o1, o2 = P.run("gemm", lambda o: ((x, W1, o["pre"], M, 2 * F, C, C, C, 2 * F), dict(bias=b1, variant=v, epilogue=K.EPI_GEGLU_FWD, aux_out=o["h"], aux_dim=F)),

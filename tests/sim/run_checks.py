@@ -19,7 +19,7 @@ def groups(P, dt):
            "attention": lambda: kc.check_attention(P, dt), "temporal_attention": lambda: kc.check_temporal_attention(P, dt),
            "tsa": lambda: kc.check_tsa(P, dt), "encoders": lambda: kc.check_encoders(P, dt), "elementwise": lambda: kc.check_elementwise(P, dt),
            "optim": lambda: kc.check_optim(P, dt)}
-    for v in (17, 18, 21, 26, 27):
+    for v in (17, 18, 21, 26, 27, 29):
         fns[f"gemm_geglu_v{v}"] = lambda v=v: kc.check_gemm_geglu(P, dt, v)
     for v in (1, 4, 6, 16, 18, 20, 23, 25, 27, 28, 29):
         fns[f"gemm_plain_v{v}"] = lambda v=v: kc.check_gemm_plain(P, dt, v)

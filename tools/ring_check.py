@@ -17,7 +17,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 from svd_xtend_amd import kernels as K  # noqa: E402
-from svd_xtend_amd.ops import TILE_OF_VARIANT  # noqa: E402
+from svd_xtend_amd.ops import STAGED_TILES  # noqa: E402
+from svd_xtend_amd.ops import TILE_OF_VARIANT as _COST_MODEL_TILES  # noqa: E402
+
+TILE_OF_VARIANT = {**_COST_MODEL_TILES, **STAGED_TILES}      # the staged tuner candidates are screened and timed like the rest
 
 dev = torch.device("cuda")
 be = K.backend()
@@ -115,7 +118,7 @@ def do_race():
         torch.cuda.synchronize()
         for v in TILE_OF_VARIANT:
             bm, bn = TILE_OF_VARIANT[v][:2]
-            if (bn == 160 and N % 160) or (bn == 256 and N % 256):
+            if (bn == 160 and N % 160) or (bn == 256 and N % 256) or (bn == 320 and N % 320):
                 continue
             nbad = 0
             for rep in range(4):
@@ -157,7 +160,7 @@ def do_time():
         kt = Kd // 64
         res = {}
         for v, (bm, bn, st, waves) in TILE_OF_VARIANT.items():
-            if (bn == 160 and N % 160) or (bn == 256 and N % 256) or (bn == 128 and N % 128) or (waves == 8 and M < 2 * bm):
+            if (bn == 160 and N % 160) or (bn == 256 and N % 256) or (bn == 320 and N % 320) or (bn == 128 and N % 128) or (waves == 8 and M < 2 * bm):
                 continue
             tiles = -(-M // bm) * -(-N // bn)
             for sp in (1, 2, 3, 4, 6, 8, 12):
