@@ -108,7 +108,8 @@ int svdx_gemm_dual(const void* A, const void* B, void* C, int M, int N, int K, i
  * the rows in order -- a fixed summation order, so the bias gradient is run-to-run identical.  With split_k > 1 a_colsum needs the
  * slab mode.  stages selects the kernel: 0 / 2 = four waves, 128 x 128 output tiles, two LDS stages (two workgroups per CU, drained
  * every K-step); 3 / 4 = the same tile with 2 / 3 row tiles in flight across the barrier (one workgroup per CU); 18 = eight waves,
- * 256 x 256 output tiles, one workgroup per CU (outputs of >= 1024 x 512 that 180-256 such tiles x row slices cover). */
+ * 256 x 256 output tiles, one workgroup per CU (outputs of >= 1024 x 512 that 180-256 such tiles x row slices cover);
+ * 12 / 13 / 21 = eight waves, 128 x 256 / 128 x 384 / 256 x 128 output tiles (the 320-wide gradients of the 64x40 level; tuner candidates). */
 int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
                  float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, int dtype, void* stream);
 

@@ -1385,7 +1385,8 @@ int launch_gemm_tn8(GemmParams p, hipStream_t st) {
 extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
                             float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, int dtype, void* stream) {
     SVDX_CHECK_ARG(A && B && C && zero_page && R > 0 && N > 0 && K > 0, "svdx_gemm_tn: bad args");
-    SVDX_CHECK_ARG(stages == 0 || (stages >= 2 && stages <= 4) || stages == 18, "svdx_gemm_tn: stages=%d (0 = default, 2..4, 18)", stages);
+    SVDX_CHECK_ARG(stages == 0 || (stages >= 2 && stages <= 4) || stages == 18 || stages == 12 || stages == 13 || stages == 21,
+                   "svdx_gemm_tn: stages=%d (0 = default, 2..4 stages of the 128x128 tile, 18 / 12 / 13 / 21 = the 256x256 / 128x256 / 128x384 / 256x128 eight-wave tiles)", stages);
     // the unsplit / ADD modes read-modify-write a_colsum from every z slice: one slice only (SVDX_OUT_F32_SLAB keeps a row per slice)
     SVDX_CHECK_ARG(!a_colsum || split_k == 1 || out_mode == SVDX_OUT_F32_SLAB, "svdx_gemm_tn: a_colsum with split_k > 1 needs slab output");
     SVDX_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
@@ -1404,6 +1405,11 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
     p.slab_stride = (long)N * ldc;
     DISPATCH_DTYPE(dtype, {
         if (stages == 18) return launch_gemm_tn8<T, 2, 2, 2>(p, (hipStream_t)stream);
+        // eight-wave tiles for the 320-wide gradients of the 64x40 level (a 128x384 tile holds all 320 columns: 80 useful flop per staged
+        // byte where three 128x128 tiles have 53); tuner candidates (ops.gemm_tn_acc), not yet timed on hardware
+        if (stages == 12) return launch_gemm_tn8<T, 1, 2, 2>(p, (hipStream_t)stream);
+        if (stages == 13) return launch_gemm_tn8<T, 1, 3, 2>(p, (hipStream_t)stream);
+        if (stages == 21) return launch_gemm_tn8<T, 2, 1, 2>(p, (hipStream_t)stream);
         if (stages == 3) return launch_gemm_tn<T, 3>(p, (hipStream_t)stream);
         if (stages == 4) return launch_gemm_tn<T, 4>(p, (hipStream_t)stream);
         return launch_gemm_tn<T, 2>(p, (hipStream_t)stream);

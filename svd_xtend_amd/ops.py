@@ -481,6 +481,10 @@ class LinearOp:
         gemm_tn_acc(rt, dy, x, self.w_grad, M, self.N, self.Kdim, self.N, self.Kdim, a_colsum=self.b_grad, write_once=True)
 
 
+# eight-wave weight-gradient tiles instantiated in csrc/gemm.hip and offered to the in-situ tuner only (no hardware timing yet): `stages` code -> tile
+STAGED_TN_TILES = {12: (128, 256), 13: (128, 384), 21: (256, 128)}
+
+
 def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tensor, M: int, N: int, Kd: int, lda: int, ldb: int,
                 a_colsum: Optional[torch.Tensor] = None, write_once: bool = False) -> None:
     """dst[N, Kd] (float, contiguous) += dy[:, :N]^T x[:, :Kd] over M rows (row pitches lda / ldb); a_colsum += colsum(dy).
@@ -504,13 +508,14 @@ def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tenso
                             colsum_out=a_colsum)
 
     TN_TILES = {2: (128, 128), 18: (256, 256)}     # svdx_gemm_tn `stages`: output tile (rows of dst, columns)
+    ALL_TN_TILES = {**TN_TILES, **STAGED_TN_TILES}
 
     def tiles_of(v):
-        tm, tk = TN_TILES[v]
+        tm, tk = ALL_TN_TILES[v]
         return -(-N // tm) * -(-Kd // tk)
 
     def cands():
-        return [(s, v) for v in TN_TILES if v == 2 or (N >= 2 * TN_TILES[v][0] - 128 and Kd >= 2 * TN_TILES[v][1] - 128)
+        return [(s, v) for v in ALL_TN_TILES if v == 2 or (N >= 2 * ALL_TN_TILES[v][0] - 128 and Kd >= 2 * ALL_TN_TILES[v][1] - 128)
                 for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 96)
                 if s == 1 or (tiles_of(v) * s <= (2048 if v == 2 else 768) and rtiles // s >= 2 and -(-rtiles // s) * (s - 1) < rtiles)]
 
