@@ -187,7 +187,7 @@ TN_SHAPES = [(35840, 2560, 320), (35840, 320, 1280), (35840, 960, 320), (35840, 
 def do_tn_time():
     """weight-gradient shapes of the step (R rows, output N x K) over (kernel variant, row slices)"""
     dt = torch.float16
-    tiles_of = {2: (128, 128), 18: (256, 256)}
+    tiles_of = {2: (128, 128), 18: (256, 256), 12: (128, 256), 13: (128, 384), 21: (256, 128)}
     for (R, N, Kd) in TN_SHAPES:
         A = torch.randn(R, N, device=dev).to(dt)
         B = torch.randn(R, Kd, device=dev).to(dt)
