@@ -21,7 +21,8 @@ CSRC = os.environ.get("SVDX_SIM_CSRC") or os.path.join(ROOT, "svd_xtend_amd", "c
 OUT = os.environ.get("SVDX_SIM_OUT") or os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libsvdx_sim.so")
 CXX = os.environ.get("SVDX_SIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-FLAGS = ["-std=c++17", "-O1", "-g", "-fPIC", "-pthread", "-Wno-unused-value", "-Wno-pass-failed", "-Wno-unknown-pragmas", "-Wno-deprecated-declarations",
+OPT = os.environ.get("SVDX_SIM_OPT", "-O0")      # kernel sources: -O0 compiles gemm.hip's instantiations in seconds (-O1: most of a minute); the scheduler is -O2
+FLAGS = ["-std=c++17", "-fPIC", "-pthread", "-Wno-unused-value", "-Wno-pass-failed", "-Wno-unknown-pragmas", "-Wno-deprecated-declarations",
          "-ffp-contract=off", "-I", HERE]
 
 SUBS = [
@@ -69,7 +70,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     def cc(src):
         o = os.path.join(OUT, os.path.splitext(os.path.basename(src))[0] + ".o")
         if force or not os.path.exists(o) or any(os.path.getmtime(d) > os.path.getmtime(o) for d in deps):
-            cmd = [CXX] + FLAGS + ["-c", src, "-o", o]
+            cmd = [CXX] + FLAGS + ["-O2" if os.path.basename(src) == "sim_rt.cpp" else OPT] + ["-c", src, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)

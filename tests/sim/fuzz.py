@@ -3,7 +3,7 @@ are the UNet's; a drop-in library has to be right on every shape its argument ch
 
     python tests/sim/fuzz.py [family ...] [--n 60] [--seed 0] [--bf16]
 
-Families: gemm, gather, tn, geglu, norm, lnbwd, attn, tattn, tsa.  Prints every failing case with the arguments that reproduce it."""
+Families: gemm, gather, tn, geglu, norm, lnbwd, attn, tattn, tsa, small, rows, optim.  Prints every failing case with the arguments that reproduce it."""
 import math
 import os
 import random
@@ -261,8 +261,83 @@ def fuzz_lnbwd(P, dt, rng, g):
     return desc, e, kc.tol_for(dt)
 
 
+def fuzz_small(P, dt, rng, g):
+    M, N, Kd = rng.randint(1, 30), pick_dim(rng, 1, 1500), 8 * rng.randint(1, 200)
+    X, W, b = kc.rndf((M, Kd), P.dev, g), kc.rnd((N, Kd), dt, P.dev, g, Kd ** -0.5), kc.rndf((N,), P.dev, g)
+    silu_in, acc = rng.randint(0, 1), rng.randint(0, 1)
+    desc = f"small_linear M={M} N={N} K={Kd} silu={silu_in} acc={acc}"
+    o1, o2 = P.run("small_linear", lambda o: ((X, W, b, o["Y"], M, N, Kd, Kd), dict(trans=0, silu_in=silu_in, accumulate=acc)), dict(Y=torch.ones(M, N, device=P.dev)))
+    e = kc.relerr(o1["Y"], o2["Y"])
+    dY = kc.rndf((M, N), P.dev, g)
+    o1, o2 = P.run("small_linear", lambda o: ((dY, W, None, o["Y"], M, N, Kd, Kd), dict(trans=1)), dict(Y=torch.zeros(M, Kd, device=P.dev)))
+    e = max(e, kc.relerr(o1["Y"], o2["Y"]))
+    o1, o2 = P.run("outer_acc", lambda o: ((dY, X, o["W"], M, N, Kd), dict(scale=0.5)), dict(W=torch.ones(N, Kd, device=P.dev)))
+    e = max(e, kc.relerr(o1["W"], o2["W"]))
+    return desc, e * 20, kc.tol_for(dt)          # float kernels: held to 1e-4 (fp16 bar / 20)
+
+
+def fuzz_rows(P, dt, rng, g):
+    """row-vector / column-sum / transpose / concat kernels on ragged sizes"""
+    rows, C = pick_dim(rng, 1, 2500), 8 * rng.randint(1, 80)
+    ng = rng.randint(1, 6)
+    x = kc.rnd((rows, C), dt, P.dev, g)
+    vec = kc.rndf((ng, 2 * C), P.dev, g)
+    rpg, mod = ((rows + ng - 1) // ng, 0) if rng.random() < 0.5 else (0, ng)
+    desc = f"rows rows={rows} C={C} groups={ng} rpg={rpg} mod={mod}"
+    o1, o2 = P.run("add_rowvec", lambda o: ((x, vec[:, C:], o["y"], rows, C, 2 * C, rpg, mod), {}), dict(y=torch.zeros_like(x)))
+    e = kc.relerr(o1["y"], o2["y"])
+    acc = rng.randint(0, 1)
+    scr = torch.full((K.colsum_slabs(rows, rpg, mod) * ng * C,), float("nan"), device=P.dev) if rng.random() < 0.7 else None
+    o1, o2 = P.run("colsum", lambda o: ((x, o["s"], rows, C, C, ng, rpg, mod), dict(accumulate=acc, scratch=scr)), dict(s=torch.ones(ng, C, device=P.dev)))
+    e = max(e, 2 * kc.relerr(o1["s"], o2["s"]))
+    r, c = pick_dim(rng, 1, 400), pick_dim(rng, 1, 400)
+    xx = kc.rnd((r, c + 8), dt, P.dev, g)
+    ldo = (r + 63) // 64 * 64
+    o1, o2 = P.run("transpose", lambda o: ((xx, c + 8, o["t"], ldo, r, c), {}), dict(t=torch.full((c, ldo), 3.0, dtype=dt, device=P.dev)))
+    e = max(e, 1e3 * kc.relerr(o1["t"], o2["t"]))
+    wf = kc.rndf((r, c), P.dev, g)
+    o1, o2 = P.run("cast_transpose_from_f32", lambda o: ((wf, o["t"], r, c), {}), dict(t=torch.zeros(c, r, dtype=dt, device=P.dev)))
+    e = max(e, 1e3 * kc.relerr(o1["t"], o2["t"]))
+    ca, cb = 8 * rng.randint(1, 40), 8 * rng.randint(1, 40)
+    a2, b2 = kc.rnd((rows, ca), dt, P.dev, g), kc.rnd((rows, cb), dt, P.dev, g)
+    o1, o2 = P.run("concat2", lambda o: ((a2, ca, b2, cb, o["c"], rows), {}), dict(c=torch.zeros(rows, ca + cb, dtype=dt, device=P.dev)))
+    e = max(e, 1e3 * kc.relerr(o1["c"], o2["c"]))
+    cat = o2["c"]
+    o1, o2 = P.run("split2", lambda o: ((cat, o["a"], ca, o["b"], cb, rows), {}), dict(a=torch.zeros(rows, ca, dtype=dt, device=P.dev), b=torch.zeros(rows, cb, dtype=dt, device=P.dev)))
+    e = max(e, 1e3 * kc.relerr(o1["a"], o2["a"]), 1e3 * kc.relerr(o1["b"], o2["b"]))
+    return desc, e, kc.tol_for(dt)
+
+
+def fuzz_optim(P, dt, rng, g):
+    n = 4 * rng.randint(1, 6000)
+    p, gr = kc.rndf((n,), P.dev, g), kc.rndf((n,), P.dev, g, 100.0)
+    m, v = kc.rndf((n,), P.dev, g, 0.1), kc.rndf((n,), P.dev, g).abs()
+    found = rng.random() < 0.25
+    if found:
+        gr[rng.randrange(n)] = float("inf") if rng.random() < 0.5 else float("nan")
+    sched = rng.choice(([0, 0, 0, 0, 0, 0, 0], [1, 10, 0, 0, 0, 0, 1], [2, 2, 40, 0, 0, 0, 2], [3, 1, 20, 0.5, 0, 0, 1], [4, 1, 20, 3, 0, 0, 2], [5, 2, 30, 0, 2.0, 1e-2, 1]))
+    st0 = torch.tensor([rng.randint(0, 9), 1024.0, rng.randint(0, 9), 0, 1, 1, 1, 0, 1.0] + sched, dtype=torch.float32, device=P.dev)
+    outs = dict(st=st0, p=p, m=m, v=v, pa=torch.zeros(n, dtype=dt, device=P.dev))
+
+    def seq(be, o):
+        be.check_finite(gr, n, o["st"])
+        be.optim_prep(o["st"], 0.9, 0.999, 2.0, 0.5, 7, 1)
+        be.adamw(o["p"], gr, o["m"], o["v"], n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0.5, o["st"], o["pa"])
+    o1 = {k_: t.clone() for k_, t in outs.items()}
+    o2 = {k_: t.clone() for k_, t in outs.items()}
+    seq(P.impl, o1)
+    seq(P.ref, o2)
+    desc = f"optim n={n} found_inf={found} sched={sched}"
+    e = max(kc.relerr(o1["st"], o2["st"]), kc.relerr(o1["p"], o2["p"]), kc.relerr(o1["m"], o2["m"]), kc.relerr(o1["v"], o2["v"])) * 100
+    e = max(e, kc.relerr(o1["pa"], o2["pa"]))
+    sh, w = kc.rndf((n + 3,), P.dev, g), kc.rndf((n + 3,), P.dev, g)
+    o1, o2 = P.run("ema_lerp", lambda o: ((o["s"], w, n + 3, 0.013), {}), dict(s=sh))
+    e = max(e, 1e3 * kc.relerr(o1["s"], o2["s"]))
+    return desc, e, kc.tol_for(dt)
+
+
 FAMILIES = {"gemm": fuzz_gemm, "gather": fuzz_gather, "tn": fuzz_tn, "geglu": fuzz_geglu, "norm": fuzz_norm, "lnbwd": fuzz_lnbwd,
-            "attn": fuzz_attn, "tattn": fuzz_tattn, "tsa": fuzz_tsa}
+            "attn": fuzz_attn, "tattn": fuzz_tattn, "tsa": fuzz_tsa, "small": fuzz_small, "rows": fuzz_rows, "optim": fuzz_optim}
 
 
 def run(P, dt, families, n, seed, verbose=True):

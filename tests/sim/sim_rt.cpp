@@ -255,9 +255,7 @@ void fiber_entry() {
 void run_block(BlockRun* r, const std::function<void()>& body, dim3 grid, dim3 block, dim3 bidx, size_t shmem) {
     const int nt = (int)(block.x * block.y * block.z);
     if ((int)r->fibers.size() < nt) {
-        const size_t old = r->fibers.size();
-        r->fibers.resize(nt);
-        for (size_t i = 0; i < old; ++i) (void)i;
+        r->fibers.resize(nt);                    // (no fiber is live between workgroups, so moving the records is safe)
         for (Fiber& f : r->fibers)
             if (!f.stack) {
                 f.stack = (char*)mmap(nullptr, STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);

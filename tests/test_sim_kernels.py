@@ -62,6 +62,41 @@ def test_train_step_on_simulator_matches_oracle_tiny():
     assert got["loss_rel"] <= 1e-3 and got["grad_cos_min"] >= 0.99, got
 
 
+@pytest.mark.skipif(not FULL, reason="SVDX_SIM_FULL=1 (about two minutes)")
+def test_lora_step_and_replay_on_simulator():
+    """Reference config 5's path (adapters through the dual-operand GEMM loop, zero-padded rank 8) against the CPU oracle, and two runs of
+    two bf16 optimizer steps ending in identical bits -- the GPU suite's LoRA and determinism tests, on the simulated kernels."""
+    import e2e_checks
+    from backend import SimBackend
+    from svd_xtend_amd import kernels as K
+    prev = K._backend
+    K._set_backend_for_tests(SimBackend())
+    try:
+        dev = torch.device("cpu")
+        for key, r in e2e_checks.run_lora(dev=dev, ranks=(8,)).items():
+            e2e_checks.assert_parity(key, r)
+        a = e2e_checks.run_steps(dev=dev, dtype=torch.bfloat16, steps=2)
+        b = e2e_checks.run_steps(dev=dev, dtype=torch.bfloat16, steps=2)
+        assert a["loss"] == b["loss"] and all(torch.equal(a[k], b[k]) for k in ("p", "m", "v"))
+    finally:
+        K._set_backend_for_tests(prev)
+
+
+@pytest.mark.skipif(not FULL, reason="SVDX_SIM_FULL=1 (about a minute)")
+def test_drop_in_autograd_route_on_simulator():
+    """INTEGRATION.md's minimal-change route -- `unet(...).sample`, `loss.backward()` through `_UNetFn` on autograd's worker thread, the
+    host's own torch.optim.AdamW, `refresh_trainable()` -- on the simulated kernels against the oracle's step."""
+    import e2e_checks
+    from backend import SimBackend
+    from svd_xtend_amd import kernels as K
+    prev = K._backend
+    K._set_backend_for_tests(SimBackend())
+    try:
+        e2e_checks.assert_parity("autograd route", e2e_checks.autograd_route(dev=torch.device("cpu"), dtype=torch.float16))
+    finally:
+        K._set_backend_for_tests(prev)
+
+
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 def test_random_shapes_on_simulator(sim_pair, dt):
     """tests/sim/fuzz.py: seeded random shapes, strides, epilogue modes, tile variants and split factors of every kernel family against
