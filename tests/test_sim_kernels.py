@@ -3,7 +3,7 @@
 emulation and the same CPU oracle the `-m gpu` tests use.  This checks the kernels' LOGIC -- fragment layouts, swizzles, tile maps,
 barrier and wait placement -- on a box without a GPU; it says nothing about speed, and the GPU tests remain the parity tests proper.
 
-SVDX_SIM_FULL=1 adds every kernel group in both dtypes (about four minutes on eight cores) and the mutation tests that show the
+SVDX_SIM_FULL=1 adds every kernel group in both dtypes (about nine minutes on eight cores) and the mutation tests that show the
 simulator notices a missing wait / barrier."""
 import math
 import os
