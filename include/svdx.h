@@ -128,6 +128,31 @@ int svdx_small_linear(const float* X, const void* W, const float* bias, float* Y
                       int ldw, int trans, int silu_in, int accumulate, int dtype, void* stream);
 /* dW[n*K+k] += scale * sum_m dY[m,n] X[m,k]   (all float; weight-grad of a skinny linear) */
 int svdx_outer_acc(const float* dY, const float* X, float* dW, int M, int N, int K, float scale, void* stream);
+/* The same skinny kernels over a table of jobs in ONE launch (the KV-length-1 cross-attention of the 32 transformer blocks is a chain of
+ * 64 + 16 skinny linears and 48 outer products per step, each ~5 us of launch latency: diffusers Attention.to_v / to_out[0] behind
+ * src/unet_spatio_temporal_condition.py:170-192, 219-234).  `jobs` is a HOST array: it is copied into the kernel arguments
+ * (SVDX_BATCH_MAX_JOBS per launch; longer tables take several launches), so a captured hipGraph owns its copy.  Every job computes
+ * exactly what the single-job entry computes, bit for bit; all jobs of a call share M, trans and dtype.  Jobs of one call must not
+ * depend on each other. */
+#define SVDX_BATCH_MAX_JOBS 48
+typedef struct svdx_lin_job {
+    const float* X;    /* [M, K] (trans = 0) or [M, N] (trans = 1), float */
+    const void* W;     /* [N, ldw] in dtype */
+    const float* bias; /* [N] or NULL (trans = 0 only) */
+    float* Y;          /* [M, N] (trans = 0) or [M, K] (trans = 1) */
+    int N, K, ldw;
+    int flags;         /* bit 0: SiLU on the input (trans = 0 only); bit 1: accumulate into Y */
+} svdx_lin_job;
+int svdx_small_linear_batch(const svdx_lin_job* jobs, int n_jobs, int M, int trans, int dtype, void* stream);
+typedef struct svdx_outer_job {
+    const float* dY;   /* [M, N] */
+    const float* X;    /* [M, K]; NULL with K = 1: a column of ones (bias gradient) */
+    float* dW;         /* [N, K], accumulated into */
+    int N, K;
+    float scale;
+    int reserved;
+} svdx_outer_job;
+int svdx_outer_acc_batch(const svdx_outer_job* jobs, int n_jobs, int M, void* stream);
 /* out[i, :] = [cos(t_i f_j), sin(t_i f_j)], f_j = exp(-ln(1e4) j / (dim/2))  (diffusers Timesteps,
  * flip_sin_to_cos=True, shift 0; src/unet_spatio_temporal_condition.py:138,143) */
 int svdx_timestep_embed(const float* t, float* out, int n, int dim, void* stream);
@@ -157,8 +182,21 @@ int svdx_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, f
 /* dx = LN'(dy) (+ add) (+ add2_scale * add2);  dgamma/dbeta (float, accumulated into, may both be NULL).  scratch: NULL (block sums go in by
  * float atomics) or SVDX_LN_PARTIAL_ROWS*2*C floats of workspace (per-block partial rows + a reducing pass: ~4x faster). */
 #define SVDX_LN_PARTIAL_ROWS 2048
+/* defer_reduce (needs scratch): the reducing pass is NOT launched -- scratch then holds svdx_ln_bwd_blocks(rows, C) partial rows of 2*C floats
+ * (dgamma | dbeta) that svdx_ln_param_reduce_batch adds into dgamma / dbeta later, many LayerNorms per launch (a backward sweep of
+ * train_svd.py's trainable set has 48 of them, train_svd.py:761-766). */
 int svdx_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* add, const void* add2,
-                float add2_scale, void* dx, float* dgamma, float* dbeta, float* scratch, int rows, int C, int dtype, void* stream);
+                float add2_scale, void* dx, float* dgamma, float* dbeta, float* scratch, int rows, int C, int defer_reduce, int dtype,
+                void* stream);
+int svdx_ln_bwd_blocks(int rows, int C);
+typedef struct svdx_lnred_job {
+    const float* partial; /* [nblk][2*C] left by svdx_ln_bwd(defer_reduce = 1) */
+    float* dgamma;        /* [C], accumulated into */
+    float* dbeta;         /* [C], accumulated into */
+    int nblk, C;
+} svdx_lnred_job;
+/* jobs: HOST array (copied into the kernel arguments, SVDX_BATCH_MAX_JOBS per launch) */
+int svdx_ln_param_reduce_batch(const svdx_lnred_job* jobs, int n_jobs, void* stream);
 
 /* ---- spatial self-attention (head_dim 64), flash form; replaces F.scaled_dot_product_attention in
  *      diffusers AttnProcessor2_0.  q,k,v element (n,s,h,d) at (n*S+s)*ld + h*64 + d; o at pitch ld_o.

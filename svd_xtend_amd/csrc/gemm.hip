@@ -1129,10 +1129,10 @@ __global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
 
 // ---- skinny linear: one wave per output column, lanes split K (trans = 0); MT rows of X per pass ------------------
 template <typename T, int MT>
-__global__ __launch_bounds__(256) void small_linear_nt(const float* __restrict__ X, const T* __restrict__ W, const float* __restrict__ bias,
-                                                       float* Y, int M, int N, int K, int ldw, int silu_in, int accumulate) {
+__device__ __forceinline__ void small_linear_nt_body(const float* __restrict__ X, const T* __restrict__ W, const float* __restrict__ bias,
+                                                     float* Y, int M, int N, int K, int ldw, int silu_in, int accumulate, int blk) {
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = blk * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const T* w = W + (size_t)n * ldw;
     for (int mb = 0; mb < M; mb += MT) {
@@ -1167,15 +1167,21 @@ __global__ __launch_bounds__(256) void small_linear_nt(const float* __restrict__
     }
 }
 
+template <typename T, int MT>
+__global__ __launch_bounds__(256) void small_linear_nt(const float* __restrict__ X, const T* __restrict__ W, const float* __restrict__ bias,
+                                                       float* Y, int M, int N, int K, int ldw, int silu_in, int accumulate) {
+    small_linear_nt_body<T, MT>(X, W, bias, Y, M, N, K, ldw, silu_in, accumulate, blockIdx.x);
+}
+
 // trans = 1: Y[m,k] (+)= sum_n X[m,n] W[n,k].  The op is a GEMV over a matrix of a few MB: latency-shaped.  A block owns 64
 // output columns (8 chunks of 8) x 32 row lanes; a thread walks the rows n = nl, nl + 32, ... with four 16-byte loads in flight and
 // the 32 partial sums of a column are then added in a fixed order -- no atomics, so the result is run-to-run identical (the
 // gradient of the cross-attention value path depends on it).
 template <typename T>
-__global__ __launch_bounds__(256) void small_linear_nn(const float* X, const T* W, float* Y, int M, int N, int K, int ldw, int accumulate) {
-    __shared__ float part[32][65];
+__device__ __forceinline__ void small_linear_nn_body(const float* X, const T* W, float* Y, int M, int N, int K, int ldw, int accumulate,
+                                                     int blk, float (*part)[65]) {
     const int kc = threadIdx.x & 7, nl = threadIdx.x >> 3;
-    const int k8 = blockIdx.x * 8 + kc;
+    const int k8 = blk * 8 + kc;
     const int m = blockIdx.y;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (k8 * 8 < K) {
@@ -1207,7 +1213,7 @@ __global__ __launch_bounds__(256) void small_linear_nn(const float* X, const T* 
     for (int j = 0; j < 8; ++j) part[nl][kc * 8 + j] = acc[j];
     __syncthreads();
     if (threadIdx.x < 64) {
-        const int k = blockIdx.x * 64 + threadIdx.x;
+        const int k = blk * 64 + threadIdx.x;
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 32; ++r) sum += part[r][threadIdx.x];
@@ -1216,6 +1222,42 @@ __global__ __launch_bounds__(256) void small_linear_nn(const float* X, const T* 
             *y = accumulate ? *y + sum : sum;
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void small_linear_nn(const float* X, const T* W, float* Y, int M, int N, int K, int ldw, int accumulate) {
+    __shared__ float part[32][65];
+    small_linear_nn_body<T>(X, W, Y, M, N, K, ldw, accumulate, blockIdx.x, part);
+}
+
+// ---- the same two kernels over a PACK of jobs in one launch: the per-clip vector chain of the KV-length-1 cross-attention is ~5 us of
+// launch latency per linear and there are 64 of them per forward sweep (v and out of 32 blocks).  The job table travels in the kernel
+// arguments (graph-capturable, no device-side table to keep alive); a workgroup finds its job by scanning the block prefix.
+struct LinPack {
+    svdx_lin_job job[SVDX_BATCH_MAX_JOBS];
+    int start[SVDX_BATCH_MAX_JOBS + 1];        // first workgroup of job j; start[n_jobs] = grid size
+    int n_jobs;
+};
+
+__device__ __forceinline__ int pack_find(const int* start, int n_jobs, int blk) {
+    int j = 0;
+    while (j + 1 < n_jobs && blk >= start[j + 1]) ++j;
+    return j;
+}
+
+template <typename T, int MT>
+__global__ __launch_bounds__(256) void small_linear_nt_batch(const LinPack pk, int M) {
+    const int j = pack_find(pk.start, pk.n_jobs, blockIdx.x);
+    const svdx_lin_job& q = pk.job[j];
+    small_linear_nt_body<T, MT>(q.X, (const T*)q.W, q.bias, q.Y, M, q.N, q.K, q.ldw, q.flags & 1, (q.flags >> 1) & 1, blockIdx.x - pk.start[j]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void small_linear_nn_batch(const LinPack pk, int M) {
+    __shared__ float part[32][65];
+    const int j = pack_find(pk.start, pk.n_jobs, blockIdx.x);
+    const svdx_lin_job& q = pk.job[j];
+    small_linear_nn_body<T>(q.X, (const T*)q.W, q.Y, M, q.N, q.K, q.ldw, (q.flags >> 1) & 1, blockIdx.x - pk.start[j], part);
 }
 
 // split-K epilogue: v = sum over `nsplit` float slabs (+ bias + rowvec + res);  C = (dtype)v, or Cf += v (weight grads)
@@ -1268,13 +1310,30 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const float* __restr
     }
 }
 
-__global__ void outer_acc_kernel(const float* dY, const float* X, float* dW, int M, int N, int K, float scale) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// X == nullptr: a column of ones (the bias gradient, K = 1)
+__device__ __forceinline__ void outer_acc_body(const float* dY, const float* X, float* dW, int M, int N, int K, float scale, size_t blk) {
+    const size_t idx = blk * blockDim.x + threadIdx.x;
     if (idx >= (size_t)N * K) return;
     const int n = (int)(idx / K), k = (int)(idx - (size_t)n * K);
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += dY[(size_t)m * N + n] * X[(size_t)m * K + k];
+    for (int m = 0; m < M; ++m) s += dY[(size_t)m * N + n] * (X ? X[(size_t)m * K + k] : 1.f);
     dW[idx] += scale * s;
+}
+
+__global__ void outer_acc_kernel(const float* dY, const float* X, float* dW, int M, int N, int K, float scale) {
+    outer_acc_body(dY, X, dW, M, N, K, scale, blockIdx.x);
+}
+
+struct OuterPack {
+    svdx_outer_job job[SVDX_BATCH_MAX_JOBS];
+    int start[SVDX_BATCH_MAX_JOBS + 1];
+    int n_jobs;
+};
+
+__global__ void outer_acc_batch_kernel(const OuterPack pk, int M) {
+    const int j = pack_find(pk.start, pk.n_jobs, blockIdx.x);
+    const svdx_outer_job& q = pk.job[j];
+    outer_acc_body(q.dY, q.X, q.dW, M, q.N, q.K, q.scale, (size_t)(blockIdx.x - pk.start[j]));
 }
 
 __global__ void timestep_embed_kernel(const float* t, float* out, int n, int dim) {
@@ -1619,6 +1678,62 @@ extern "C" int svdx_outer_acc(const float* dY, const float* X, float* dW, int M,
     const size_t n = (size_t)N * K;
     hipLaunchKernelGGL(outer_acc_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dY, X, dW, M, N, K, scale);
     SVDX_LAUNCH_CHECK("svdx_outer_acc");
+    return 0;
+}
+
+extern "C" int svdx_small_linear_batch(const svdx_lin_job* jobs, int n_jobs, int M, int trans, int dtype, void* stream) {
+    SVDX_CHECK_ARG(jobs && n_jobs > 0 && M > 0, "svdx_small_linear_batch: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    for (int j0 = 0; j0 < n_jobs; j0 += SVDX_BATCH_MAX_JOBS) {
+        LinPack pk;
+        pk.n_jobs = std::min(n_jobs - j0, SVDX_BATCH_MAX_JOBS);
+        int blocks = 0;
+        for (int j = 0; j < pk.n_jobs; ++j) {
+            const svdx_lin_job& q = jobs[j0 + j];
+            SVDX_CHECK_ARG(q.X && q.W && q.Y && q.N > 0 && q.K > 0, "svdx_small_linear_batch: job %d: bad args", j0 + j);
+            SVDX_CHECK_ARG(q.K % 8 == 0 && q.ldw % 8 == 0 && ((uintptr_t)q.W & 15) == 0,
+                           "svdx_small_linear_batch: job %d: K/ldw must be multiples of 8", j0 + j);
+            if (trans == 0)
+                SVDX_CHECK_ARG(((uintptr_t)q.X & 15) == 0, "svdx_small_linear_batch: job %d: X must be 16-byte aligned", j0 + j);
+            else
+                SVDX_CHECK_ARG(!q.bias && !(q.flags & 1), "svdx_small_linear_batch: trans=1 takes no bias/activation");
+            pk.job[j] = q;
+            pk.start[j] = blocks;
+            blocks += trans == 0 ? cdiv(q.N, 4) : cdiv(q.K / 8, 8);
+        }
+        for (int j = pk.n_jobs; j <= SVDX_BATCH_MAX_JOBS; ++j) pk.start[j] = blocks;
+        DISPATCH_DTYPE(dtype, {
+            if (trans == 0) {
+                if (M == 1) hipLaunchKernelGGL((small_linear_nt_batch<T, 1>), dim3(blocks), dim3(256), 0, st, pk, M);
+                else if (M <= 4) hipLaunchKernelGGL((small_linear_nt_batch<T, 4>), dim3(blocks), dim3(256), 0, st, pk, M);
+                else hipLaunchKernelGGL((small_linear_nt_batch<T, 8>), dim3(blocks), dim3(256), 0, st, pk, M);
+            } else {
+                hipLaunchKernelGGL((small_linear_nn_batch<T>), dim3(blocks, M), dim3(256), 0, st, pk, M);
+            }
+        });
+        SVDX_LAUNCH_CHECK("svdx_small_linear_batch");
+    }
+    return 0;
+}
+
+extern "C" int svdx_outer_acc_batch(const svdx_outer_job* jobs, int n_jobs, int M, void* stream) {
+    SVDX_CHECK_ARG(jobs && n_jobs > 0 && M > 0, "svdx_outer_acc_batch: bad args");
+    for (int j0 = 0; j0 < n_jobs; j0 += SVDX_BATCH_MAX_JOBS) {
+        OuterPack pk;
+        pk.n_jobs = std::min(n_jobs - j0, SVDX_BATCH_MAX_JOBS);
+        long blocks = 0;
+        for (int j = 0; j < pk.n_jobs; ++j) {
+            const svdx_outer_job& q = jobs[j0 + j];
+            SVDX_CHECK_ARG(q.dY && q.dW && q.N > 0 && q.K > 0 && (q.X || q.K == 1), "svdx_outer_acc_batch: job %d: bad args", j0 + j);
+            pk.job[j] = q;
+            pk.start[j] = (int)blocks;
+            blocks += cdiv((size_t)q.N * q.K, 256);
+            SVDX_CHECK_ARG(blocks < (1l << 31), "svdx_outer_acc_batch: too many workgroups");
+        }
+        for (int j = pk.n_jobs; j <= SVDX_BATCH_MAX_JOBS; ++j) pk.start[j] = (int)blocks;
+        hipLaunchKernelGGL(outer_acc_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk, M);
+        SVDX_LAUNCH_CHECK("svdx_outer_acc_batch");
+    }
     return 0;
 }
 

@@ -518,11 +518,10 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const T* __restrict__ dy
 }
 
 // dgamma[c] += sum_b partial[b][c], dbeta[c] += sum_b partial[b][C + c]: 64 columns x 16 row groups per block.
-__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partial, int nblk, int C,
-                                                               float* dgamma, float* dbeta) {
-    __shared__ float sm[16][64];
+__device__ __forceinline__ void ln_param_reduce_body(const float* __restrict__ partial, int nblk, int C, float* dgamma, float* dbeta,
+                                                     int blk, float (*sm)[64]) {
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cl;
+    const int col = blk * 64 + cl;
     float s = 0.f;
     if (col < 2 * C) {
 #pragma unroll 8
@@ -538,7 +537,59 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
     }
 }
 
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                               float* dgamma, float* dbeta) {
+    __shared__ float sm[16][64];
+    ln_param_reduce_body(partial, nblk, C, dgamma, dbeta, blockIdx.x, sm);
+}
+
+// the reductions of MANY LayerNorm backwards in one launch (svdx_ln_bwd with defer_reduce leaves the partial rows; the 48 trainable
+// LayerNorms of a backward sweep otherwise pay 48 launches of ~5 us for a few hundred KB each); job table in the kernel arguments
+struct LnRedPack {
+    svdx_lnred_job job[SVDX_BATCH_MAX_JOBS];
+    int start[SVDX_BATCH_MAX_JOBS + 1];
+    int n_jobs;
+};
+
+__global__ __launch_bounds__(1024) void ln_param_reduce_batch_kernel(const LnRedPack pk) {
+    __shared__ float sm[16][64];
+    int j = 0;
+    while (j + 1 < pk.n_jobs && (int)blockIdx.x >= pk.start[j + 1]) ++j;
+    const svdx_lnred_job& q = pk.job[j];
+    ln_param_reduce_body(q.partial, q.nblk, q.C, q.dgamma, q.dbeta, blockIdx.x - pk.start[j], sm);
+}
+
+// workgroups (= partial rows left in scratch) of the affine-gradient form of svdx_ln_bwd
+static int ln_bwd_affine_blocks(int rows, int C) {
+    const int cc = C / 8;
+    const int lanes = cc <= 48 ? 16 : (cc <= 96 ? 32 : 64);
+    const int groups = 256 / lanes;
+    return max(1, min(cdiv(rows, 2 * groups), SVDX_LN_PARTIAL_ROWS));
+}
+
 }  // namespace
+
+extern "C" int svdx_ln_bwd_blocks(int rows, int C) { return rows > 0 && C > 0 && C % 8 == 0 ? ln_bwd_affine_blocks(rows, C) : 0; }
+
+extern "C" int svdx_ln_param_reduce_batch(const svdx_lnred_job* jobs, int n_jobs, void* stream) {
+    SVDX_CHECK_ARG(jobs && n_jobs > 0, "svdx_ln_param_reduce_batch: bad args");
+    for (int j0 = 0; j0 < n_jobs; j0 += SVDX_BATCH_MAX_JOBS) {
+        LnRedPack pk;
+        pk.n_jobs = min(n_jobs - j0, SVDX_BATCH_MAX_JOBS);
+        int blocks = 0;
+        for (int j = 0; j < pk.n_jobs; ++j) {
+            const svdx_lnred_job& q = jobs[j0 + j];
+            SVDX_CHECK_ARG(q.partial && q.dgamma && q.dbeta && q.nblk > 0 && q.C > 0, "svdx_ln_param_reduce_batch: job %d: bad args", j0 + j);
+            pk.job[j] = q;
+            pk.start[j] = blocks;
+            blocks += cdiv(2 * q.C, 64);
+        }
+        for (int j = pk.n_jobs; j <= SVDX_BATCH_MAX_JOBS; ++j) pk.start[j] = blocks;
+        hipLaunchKernelGGL(ln_param_reduce_batch_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, pk);
+        SVDX_LAUNCH_CHECK("svdx_ln_param_reduce_batch");
+    }
+    return 0;
+}
 
 extern "C" int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int C, int G, int prezeroed, int dtype, void* stream) {
     GnGeom q; int threads;
@@ -617,8 +668,8 @@ extern "C" int svdx_ln_fwd(const void* x, const float* gamma, const float* beta,
 }
 
 extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, const void* add, const void* add2,
-                           float add2_scale, void* dx, float* dgamma, float* dbeta, float* scratch, int rows, int C, int dtype,
-                           void* stream) {
+                           float add2_scale, void* dx, float* dgamma, float* dbeta, float* scratch, int rows, int C, int defer_reduce,
+                           int dtype, void* stream) {
     SVDX_CHECK_ARG(rows > 0 && C % 8 == 0 && C / 8 <= 64 * LN_MAXCH_LIMIT, "svdx_ln_bwd: C=%d unsupported", C);
     SVDX_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "svdx_ln_bwd: dgamma/dbeta must come together");
     hipStream_t st = (hipStream_t)stream;
@@ -630,8 +681,9 @@ extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, co
     const int groups = 256 / lanes;
     // affine grads: with scratch, up to SVDX_LN_PARTIAL_ROWS blocks each leave one [2C] partial row; without, every block ends with
     // 2*C float atomics, so keep one block per CU there
+    SVDX_CHECK_ARG(!defer_reduce || (dgamma && scratch), "svdx_ln_bwd: defer_reduce needs dgamma/dbeta and scratch");
     int blocks = min(cdiv(rows, groups), 2048);
-    if (dgamma) blocks = scratch ? max(1, min(cdiv(rows, 2 * groups), SVDX_LN_PARTIAL_ROWS)) : min(blocks, 256);
+    if (dgamma) blocks = scratch ? ln_bwd_affine_blocks(rows, C) : min(blocks, 256);
     const size_t sh = dgamma ? sizeof(float) * groups * C : 0;
     SVDX_CHECK_ARG(sh <= 64 * 1024, "svdx_ln_bwd: C=%d too wide for the affine-gradient slab", C);
 #define LN_BWD(L, N)                                                                                                                  \
@@ -650,7 +702,7 @@ extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, co
     });
 #undef LN_BWD
     SVDX_LAUNCH_CHECK("svdx_ln_bwd");
-    if (dgamma && scratch) {
+    if (dgamma && scratch && !defer_reduce) {
         hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, st, scratch, blocks, C, dgamma, dbeta);
         SVDX_LAUNCH_CHECK("svdx_ln_bwd(param reduce)");
     }

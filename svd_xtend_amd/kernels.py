@@ -34,6 +34,21 @@ class SvdxError(RuntimeError):
     pass
 
 
+class _LinJobC(ctypes.Structure):            # include/svdx.h: svdx_lin_job
+    _fields_ = [("X", ctypes.c_void_p), ("W", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("Y", ctypes.c_void_p),
+                ("N", ctypes.c_int), ("K", ctypes.c_int), ("ldw", ctypes.c_int), ("flags", ctypes.c_int)]
+
+
+class _OuterJobC(ctypes.Structure):          # include/svdx.h: svdx_outer_job
+    _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p),
+                ("N", ctypes.c_int), ("K", ctypes.c_int), ("scale", ctypes.c_float), ("reserved", ctypes.c_int)]
+
+
+class _LnRedJobC(ctypes.Structure):          # include/svdx.h: svdx_lnred_job
+    _fields_ = [("partial", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
+                ("nblk", ctypes.c_int), ("C", ctypes.c_int)]
+
+
 class _GatherC(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in
                 ("mode", "n_img", "hi", "wi", "ho", "wo", "cin", "stride", "ups", "t", "hw", "lda")]
@@ -68,13 +83,16 @@ _SIGS = {
     "svdx_gemm_finalize": "pil" "pi" "iii" "pp" "iii" "pi" "ppi" "ip",
     "svdx_small_linear": "pppp" "iiii" "iii" "ip",
     "svdx_outer_acc": "ppp" "iii" "f" "p",
+    "svdx_small_linear_batch": "p" "iii" "ip",
+    "svdx_outer_acc_batch": "p" "ii" "p",
+    "svdx_ln_param_reduce_batch": "p" "i" "p",
     "svdx_timestep_embed": "pp" "ii" "p",
     "svdx_gn_stats": "pp" "iiii" "i" "ip",
     "svdx_gn_apply": "ppppp" "iiii" "fi" "ip",
     "svdx_gn_bwd_stats": "pppppp" "iiii" "fi" "i" "ip",
     "svdx_gn_bwd_apply": "pppppppp" "iiii" "fi" "ip",
     "svdx_ln_fwd": "ppppp" "ii" "f" "ip",
-    "svdx_ln_bwd": "pppppp" "f" "pppp" "ii" "ip",
+    "svdx_ln_bwd": "pppppp" "f" "pppp" "iii" "ip",
     "svdx_attn_fwd": "ppppp" "iiiii" "f" "ip",
     "svdx_attn_bwd_prep": "ppp" "iii" "i" "ip",
     "svdx_attn_bwd_dkv": "pppppppp" "iiiiii" "f" "ip",
@@ -114,7 +132,8 @@ _SIGS = {
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "l": ctypes.c_int64, "z": ctypes.c_size_t}
 
-EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band")
+EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band", "svdx_ln_bwd_blocks")
+BATCH_MAX_JOBS = 48            # include/svdx.h SVDX_BATCH_MAX_JOBS: jobs of a *_batch entry that share one launch
 TSA_MAX_C, TSA_MAX_T, TSA_BAND_ROWS = 320, 16, 144
 
 
@@ -126,6 +145,13 @@ def colsum_slabs(rows: int, rpg: int, mod: int) -> int:
     """Row slabs of svdx_colsum (its deterministic form wants float[slabs][n_groups][C] of scratch)."""
     maxcnt = -(-rows // mod) if mod else min(rpg, rows)
     return -(-maxcnt // COLSUM_SLAB)
+
+
+def ln_bwd_blocks(rows: int, C: int) -> int:
+    """include/svdx.h svdx_ln_bwd_blocks: partial rows the affine-gradient form of svdx_ln_bwd leaves in its scratch."""
+    cc = C // 8
+    lanes = 16 if cc <= 48 else (32 if cc <= 96 else 64)
+    return max(1, min(-(-rows // (2 * (256 // lanes))), LN_PARTIAL_ROWS))
 
 
 def tsa_pixels_per_band(T: int, HW: int) -> int:
@@ -147,6 +173,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         fn.restype = ctypes.c_int
     lib.svdx_tsa_pixels_per_band.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.svdx_tsa_pixels_per_band.restype = ctypes.c_int
+    lib.svdx_ln_bwd_blocks.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.svdx_ln_bwd_blocks.restype = ctypes.c_int
     lib.svdx_version.restype = ctypes.c_int
     lib.svdx_device_ok.restype = ctypes.c_int
     lib.svdx_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
@@ -245,6 +273,18 @@ class HipBackend:
     def outer_acc(self, dY, X, dW, M, N, K, scale=1.0):
         self._call("svdx_outer_acc", _f32(dY), _f32(X), _f32(dW), M, N, K, float(scale), self._stream())
 
+    def small_linear_batch(self, jobs, M, trans=0):
+        """jobs: sequence of (X, W, bias, Y, N, K, ldw, silu_in, accumulate) -- each what `small_linear` takes; ONE launch per
+        BATCH_MAX_JOBS jobs.  The jobs of a call must be independent of each other."""
+        arr = (_LinJobC * len(jobs))(*[_LinJobC(_f32(X), _p(W), _f32(b), _f32(Y), N, Kd, ldw, int(bool(si)) | int(bool(acc)) << 1)
+                                       for X, W, b, Y, N, Kd, ldw, si, acc in jobs])
+        self._call("svdx_small_linear_batch", ctypes.cast(arr, ctypes.c_void_p), len(jobs), M, trans, _dt(jobs[0][1]), self._stream())
+
+    def outer_acc_batch(self, jobs, M):
+        """jobs: sequence of (dY, X or None (a column of ones: bias gradient, K = 1), dW, N, K, scale)."""
+        arr = (_OuterJobC * len(jobs))(*[_OuterJobC(_f32(dY), _f32(X), _f32(dW), N, Kd, float(sc), 0) for dY, X, dW, N, Kd, sc in jobs])
+        self._call("svdx_outer_acc_batch", ctypes.cast(arr, ctypes.c_void_p), len(jobs), M, self._stream())
+
     def timestep_embed(self, t, out, n, dim):
         self._call("svdx_timestep_embed", _f32(t), _f32(out), n, dim, self._stream())
 
@@ -268,11 +308,17 @@ class HipBackend:
         self._call("svdx_ln_fwd", _p(x), _f32(gamma), _f32(beta), _p(y), _f32(stats), rows, C, float(eps),
                    _dt(x), self._stream())
 
-    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C, scratch=None, add2=None, add2_scale=1.0):
+    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C, scratch=None, add2=None, add2_scale=1.0, defer_reduce=False):
+        """defer_reduce: scratch (>= ln_bwd_blocks(rows, C) * 2 * C floats) keeps the partial rows for `ln_param_reduce_batch`."""
         if scratch is not None:
-            assert scratch.dtype == torch.float32 and scratch.numel() >= LN_PARTIAL_ROWS * 2 * C
+            assert scratch.dtype == torch.float32 and scratch.numel() >= (ln_bwd_blocks(rows, C) if defer_reduce else LN_PARTIAL_ROWS) * 2 * C
         self._call("svdx_ln_bwd", _p(dy), _p(x), _f32(stats), _f32(gamma), _p(add), _p(add2), float(add2_scale), _p(dx),
-                   _f32(dgamma), _f32(dbeta), _f32(scratch), rows, C, _dt(x), self._stream())
+                   _f32(dgamma), _f32(dbeta), _f32(scratch), rows, C, int(defer_reduce), _dt(x), self._stream())
+
+    def ln_param_reduce_batch(self, jobs):
+        """jobs: sequence of (partial, dgamma, dbeta, nblk, C): the deferred reductions of `ln_bwd(..., defer_reduce=True)`."""
+        arr = (_LnRedJobC * len(jobs))(*[_LnRedJobC(_f32(pt), _f32(dg), _f32(db), nblk, C) for pt, dg, db, nblk, C in jobs])
+        self._call("svdx_ln_param_reduce_batch", ctypes.cast(arr, ctypes.c_void_p), len(jobs), self._stream())
 
     # ---- attention --------------------------------------------------------------------------------
     def attn_fwd(self, q, k, v, o, lse, nb, heads, S, ld, ld_o, scale):

@@ -90,8 +90,46 @@ class Runtime:
         self.arenas = [None, None]
         self.arena_cap = 1 << 20    # floats
         self.arena_cur, self.arena_pos = None, 0
+        # launches of a few us whose results nothing in the sweep reads (skinny weight gradients of the cross-attention value path,
+        # the affine-gradient reductions of LayerNorm) are queued and run as table-driven launches when the sweep -- or, with gradient
+        # buckets, the transformer block -- ends; SVDX_BATCH_SMALL=0: developer knob for A/B runs (one launch each, as before)
+        self.batch_small = os.environ.get("SVDX_BATCH_SMALL", "1") != "0"
+        self._q_nn, self._q_outer, self._q_outer2, self._q_ln, self._q_M = [], [], [], [], None
         self.p_flat = None          # flat float master buffer of the trainables (ops.flatten_trainables)
         self.w16_flat = None        # same layout in the activation dtype, written by svdx_adamw / one cast per refresh
+
+    # ---- deferred skinny launches (the queued jobs hold their tensors alive until the flush) -------------------------------------
+    def _q_rows(self, M: int) -> None:
+        if self._q_M is not None and self._q_M != M:
+            self.flush_deferred()
+        self._q_M = M
+
+    def defer_nn(self, job, M: int) -> None:
+        """job of kernels.small_linear_batch(trans=1)"""
+        self._q_rows(M)
+        self._q_nn.append(job)
+
+    def defer_outer(self, job, M: int, after_nn: bool = False) -> None:
+        """job of kernels.outer_acc_batch; after_nn: it reads the result of a queued defer_nn job"""
+        self._q_rows(M)
+        (self._q_outer2 if after_nn else self._q_outer).append(job)
+
+    def defer_ln_reduce(self, job) -> None:
+        """job of kernels.ln_param_reduce_batch"""
+        self._q_ln.append(job)
+
+    def flush_deferred(self) -> None:
+        k, M = self.k, self._q_M
+        if self._q_nn:
+            k.small_linear_batch(self._q_nn, M, 1)
+        if self._q_outer or self._q_outer2:
+            k.outer_acc_batch(self._q_outer + self._q_outer2, M)
+        if self._q_ln:
+            k.ln_param_reduce_batch(self._q_ln)
+        self.drop_deferred()
+
+    def drop_deferred(self) -> None:
+        self._q_nn, self._q_outer, self._q_outer2, self._q_ln, self._q_M = [], [], [], [], None
 
     def begin_pass(self, which: int) -> None:
         """Start of a forward (0) or backward (1) sweep: re-zero that sweep's statistics arena with ONE memset (GroupNorm
@@ -929,6 +967,13 @@ class LayerNormOp:
         dx = rt.empty(M, self.C)
         dg = self.mod.weight.grad if self.trainable else None
         db = self.mod.bias.grad if self.trainable else None
+        if self.trainable and rt.batch_small:        # the partial rows wait for the sweep's one reducing launch (Runtime.flush_deferred)
+            nblk = K.ln_bwd_blocks(M, self.C)
+            scratch = rt.f32(nblk * 2 * self.C)
+            rt.k.ln_bwd(dy, x, stats, self.mod.weight.data, add, dx, dg, db, M, self.C, scratch=scratch, add2=add2,
+                        add2_scale=add2_scale, defer_reduce=True)
+            rt.defer_ln_reduce((scratch, dg, db, nblk, self.C))
+            return dx
         scratch = rt.f32(K.LN_PARTIAL_ROWS * 2 * self.C) if self.trainable else None
         rt.k.ln_bwd(dy, x, stats, self.mod.weight.data, add, dx, dg, db, M, self.C, scratch=scratch, add2=add2,
                     add2_scale=add2_scale)

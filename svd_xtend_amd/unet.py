@@ -215,7 +215,12 @@ class _Attention(nn.Module):
 
     # KV-length-1 cross attention: softmax over one key == 1, so attn2(x, ctx) = to_out(to_v(ctx)) for every
     # query row; to_q / to_k (and the LayerNorm feeding to_q) receive exactly zero gradient.
+    _pre = None       # (out, saved) left by UNet..._cross_precompute for the next cross_vec of this sweep
+
     def cross_vec(self, rt, ctx, Bn):
+        if self._pre is not None:                    # all blocks' to_v / to_out ran in two launches at the head of the sweep
+            pre, self._pre = self._pre, None
+            return pre
         v = self.v.fwd(rt, ctx, Bn)
         va = self.v_lora.fwd(rt, ctx, v, Bn) if self.v_lora is not None else None
         out = self.o.fwd(rt, v, Bn)
@@ -228,6 +233,18 @@ class _Attention(nn.Module):
 
     def cross_vec_bwd(self, rt, dvec, saved, ctx, Bn):
         v, va, oa = saved
+        if rt.batch_small and self.v_lora is None and self.o_lora is None:
+            # nothing downstream of the sweep reads these gradients: queue the chain (d(v) = dvec W_o, then the three outer products) and
+            # run every block's share together when the sweep -- or the gradient bucket -- ends (Runtime.flush_deferred)
+            if self.o.trainable:
+                rt.defer_outer((dvec, v, self.o.weight.grad, self.o.N, self.o.Kdim, 1.0), Bn)
+                if self.o.bias is not None:
+                    rt.defer_outer((dvec, None, self.o.bias.grad, self.o.N, 1, 1.0), Bn)
+            if self.v.trainable:
+                dv = rt.f32(Bn, self.o.Kdim)
+                rt.defer_nn((dvec, self.o.w, None, dv, self.o.N, self.o.Kdim, self.o.Kdim, 0, 0), Bn)
+                rt.defer_outer((dv, ctx, self.v.weight.grad, self.v.N, self.v.Kdim, 1.0), Bn, after_nn=True)
+            return
         need_dv = self.v.trainable or (self.v_lora is not None and self.v_lora.trainable)
         dv = self.o.bwd(rt, dvec, v, Bn, need_dx=need_dv)
         if self.o_lora is not None and self.o_lora.trainable:
@@ -1127,6 +1144,8 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         k.small_linear(emb, self._temb_w, self._temb_b, temb_all, B, self._temb_total, emb.shape[1], emb.shape[1],
                        0, 1, 0)
         ctx = ehs.to(device=dev, dtype=torch.float32).reshape(B, -1).contiguous()     # [B, 1, D] -> [B, D]
+        if rt.batch_small:
+            self._cross_precompute(rt, ctx, B)
 
         # 2. conv_in on channels-last rows (input channels zero-padded to a multiple of 64)
         x0 = rt.empty(g.M, self.cin_pad)
@@ -1168,6 +1187,28 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         self._fwd_state = dict(g0=g, x_last=x, st_last=st, cat_info=cat_info)
         return y
 
+    def _cross_precompute(self, rt, ctx, B):
+        """The KV-length-1 cross-attention of EVERY transformer block, up front: out_i = to_out_i(to_v_i(ctx)) depends on nothing but
+        the clip's CLIP embed, so the 2 x 32 skinny linears of a sweep run as two table-driven launches (svdx_small_linear_batch)
+        instead of 64 launches of ~5 us strung between the GEMMs.  Blocks with adapters on the value path keep their own launches."""
+        atts = [blk.attn2 for kind, m in self.steps if kind == "attn"
+                for blk in list(m.transformer_blocks) + list(m.temporal_transformer_blocks)]
+        atts = [a for a in atts if a.v_lora is None and a.o_lora is None]
+        if not atts:
+            return
+        vbuf = rt.f32(B * sum(a.v.N for a in atts))
+        obuf = rt.f32(B * sum(a.o.N for a in atts))
+        jobs_v, jobs_o, vo, oo = [], [], 0, 0
+        for a in atts:
+            v = vbuf[vo:vo + B * a.v.N].view(B, a.v.N)
+            o = obuf[oo:oo + B * a.o.N].view(B, a.o.N)
+            vo, oo = vo + B * a.v.N, oo + B * a.o.N
+            jobs_v.append((ctx, a.v.w, None if a.v.bias is None else a.v.bias.data, v, a.v.N, a.v.Kdim, a.v.Kdim, 0, 0))
+            jobs_o.append((v, a.o.w, None if a.o.bias is None else a.o.bias.data, o, a.o.N, a.o.Kdim, a.o.Kdim, 0, 0))
+            a._pre = (o, (v, None, None))
+        rt.k.small_linear_batch(jobs_v, B, 0)
+        rt.k.small_linear_batch(jobs_o, B, 0)
+
     def _backward_impl(self, d_out):
         """d_out: float [B,T,out_channels,h,w] (gradient of `.sample`)."""
         rt = self.rt
@@ -1181,6 +1222,7 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         """dy: [B*T*h*w, rup(out_channels,64)] channels-last gradient of the prediction rows (zero padded)."""
         rt = self.rt
         rt.grad_overwrite, rt.grads_fresh = rt.grads_fresh, False
+        rt.drop_deferred()                      # leftovers of a sweep that raised
         try:
             return self._backward_rows(dy)
         finally:
@@ -1241,6 +1283,7 @@ class UNetSpatioTemporalConditionModel(nn.Module):
             if kind == "res" or kind == "attn":
                 dx = m.bwd(rt, dx, cur)
                 if kind == "attn" and self.grads_ready_cb is not None:
+                    rt.flush_deferred()             # the queued skinny gradient launches of this block belong to its bucket
                     self.grads_ready_cb(m)          # this block's weight gradients are final: the trainer may start reducing them
             elif kind == "up":
                 low = level_geoms[lvl]
@@ -1259,4 +1302,5 @@ class UNetSpatioTemporalConditionModel(nn.Module):
                 skip_grads.append(db_ if self._skip_needs_grad[skip_no] else None)
             cur = level_geoms[lvl]
         # the conv_in skip (index 0) and conv_in itself carry no trainable parameters upstream
+        rt.flush_deferred()
         return None

@@ -178,11 +178,45 @@ def run_steps(dev=None, dtype=torch.float16, steps=3, seed=5):
     m.load_state_dict(orc.state_dict(), strict=True)
     m.to(dev)
     tr = Trainer(m, dtype=dtype, lr=1e-3)
-    for _ in range(steps):
+    for _ in range(steps - 1):
         tr.step(batch)
+    tr.rt.k.launch_log = log = []              # entry names of the last step's launches
+    try:
+        tr.step(batch)
+    finally:
+        tr.rt.k.launch_log = None
     if dev.type == "cuda":
         torch.cuda.synchronize()
-    return dict(p=tr.p_flat.clone(), m=tr.m_flat.clone(), v=tr.v_flat.clone(), loss=float(tr.last_loss()))
+    return dict(p=tr.p_flat.clone(), m=tr.m_flat.clone(), v=tr.v_flat.clone(), loss=float(tr.last_loss()), launches=[e[0] for e in log])
+
+
+def batched_vs_single_small_launches(dev=None, dtype=torch.float16, steps=2):
+    """The table-driven skinny launches (Runtime.batch_small: the cross-attention vector chain up front, its gradient chain and the
+    LayerNorm affine-gradient reductions at the end of the sweep) against one launch each (SVDX_BATCH_SMALL=0): identical bits after
+    `steps` optimizer steps, and the launches they save.  Returns (batched, single) run_steps results."""
+    import os
+    prev = os.environ.get("SVDX_BATCH_SMALL")
+    try:
+        os.environ["SVDX_BATCH_SMALL"] = "1"
+        a = run_steps(dev=dev, dtype=dtype, steps=steps)
+        os.environ["SVDX_BATCH_SMALL"] = "0"
+        b = run_steps(dev=dev, dtype=dtype, steps=steps)
+    finally:
+        if prev is None:
+            os.environ.pop("SVDX_BATCH_SMALL", None)
+        else:
+            os.environ["SVDX_BATCH_SMALL"] = prev
+    return a, b
+
+
+def assert_batched_equals_single(a, b):
+    assert a["loss"] == b["loss"] and all(torch.equal(a[k], b[k]) for k in ("p", "m", "v")), "batched skinny launches changed the step's bits"
+    na, nb = a["launches"], b["launches"]
+    assert na.count("svdx_small_linear_batch") == 3 and na.count("svdx_outer_acc_batch") == 1 and na.count("svdx_ln_param_reduce_batch") == 1, \
+        {n: na.count(n) for n in set(na) if "batch" in n}
+    assert not any("batch" in n for n in nb)
+    assert na.count("svdx_outer_acc") == 0 and nb.count("svdx_outer_acc") > 0
+    assert len(na) < len(nb), (len(na), len(nb))
 
 
 def resume_vs_straight(tmpdir, dev=None, dtype=torch.float16, steps=4, cut=2):

@@ -237,6 +237,15 @@ class EmuBackend:
     def outer_acc(self, dY, X, dW, M, N, Kd, scale=1.0):
         V(dW, N, Kd, Kd).add_(scale * (V(dY, M, N, N).t() @ V(X, M, Kd, Kd)))
 
+    def small_linear_batch(self, jobs, M, trans=0):
+        for X, W, b, Y, N, Kd, ldw, si, acc in jobs:
+            self.small_linear(X, W, b, Y, M, N, Kd, ldw, trans, int(bool(si)), int(bool(acc)))
+
+    def outer_acc_batch(self, jobs, M):
+        for dY, X, dW, N, Kd, sc in jobs:
+            x = X if X is not None else torch.ones(M, 1, dtype=torch.float32, device=dY.device)
+            self.outer_acc(dY, x, dW, M, N, Kd, sc)
+
     def timestep_embed(self, t, out, n, dim):
         half = dim // 2
         f = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
@@ -306,7 +315,7 @@ class EmuBackend:
         st[:, 1:2] = rstd
         V(y, rows, C, C).copy_((((xf - mean) * rstd) * V1(gamma, C) + V1(beta, C)).to(y.dtype))
 
-    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C, scratch=None, add2=None, add2_scale=1.0):
+    def ln_bwd(self, dy, x, stats, gamma, add, dx, dgamma, dbeta, rows, C, scratch=None, add2=None, add2_scale=1.0, defer_reduce=False):
         xf = V(x, rows, C, C).float()
         st = V(stats, rows, 2, 2)
         xhat = (xf - st[:, 0:1]) * st[:, 1:2]
@@ -318,10 +327,23 @@ class EmuBackend:
         if add2 is not None:
             out = out + add2_scale * V(add2, rows, C, C).float()
         V(dx, rows, C, C).copy_(out.to(dx.dtype))
+        if defer_reduce:                       # partial rows [nblk][2C] for ln_param_reduce_batch: the totals in row 0, zeros below
+            assert dgamma is not None and dbeta is not None and scratch is not None
+            pt = V(scratch, K.ln_bwd_blocks(rows, C), 2 * C, 2 * C)
+            pt.zero_()
+            pt[0, :C] = (d * xhat).sum(0)
+            pt[0, C:] = d.sum(0)
+            return
         if dgamma is not None:
             V1(dgamma, C).add_((d * xhat).sum(0))
         if dbeta is not None:
             V1(dbeta, C).add_(d.sum(0))
+
+    def ln_param_reduce_batch(self, jobs):
+        for pt, dg, db, nblk, C in jobs:
+            t = V(pt, nblk, 2 * C, 2 * C).sum(0)
+            V1(dg, C).add_(t[:C])
+            V1(db, C).add_(t[C:])
 
     # ---- spatial attention ----
     @staticmethod

@@ -278,6 +278,48 @@ def check_small(P, dt):
         res.append((f"small_linear nn {M}x{N}x{Kd}", relerr(o1["Y"], o2["Y"]), 1e-4))
         o1, o2 = P.run("outer_acc", lambda o: ((dY, X, o["W"], M, N, Kd), dict(scale=0.5)), dict(W=torch.ones(N, Kd, device=P.dev)))
         res.append((f"outer_acc {M}x{N}x{Kd}", relerr(o1["W"], o2["W"]), 1e-4))
+    # table-driven launches (svdx_small_linear_batch / svdx_outer_acc_batch): every job must equal its single-job launch BIT FOR BIT
+    # (the deferred cross-attention chain of the step relies on it) and the emulation to tolerance; 50 jobs also cross the 48-job pack
+    for M, shapes in ((1, [(320, 1024), (640, 1024), (1280, 1024), (1280, 320), (96, 64), (320, 320)]), (3, [(640, 1024), (64, 64), (1280, 1280)]),
+                      (6, [(96, 64)] * 50)):
+        Xs = [rndf((M, Kd), P.dev, g) for N, Kd in shapes]
+        Ws = [rnd((N, Kd), dt, P.dev, g, Kd ** -0.5) for N, Kd in shapes]
+        bs = [rndf((N,), P.dev, g) if i % 2 == 0 else None for i, (N, Kd) in enumerate(shapes)]
+        dYs = [rndf((M, N), P.dev, g) for N, Kd in shapes]
+        fl = [(i % 3 == 1, i % 2 == 1) for i in range(len(shapes))]           # (silu_in, accumulate)
+        for trans in (0, 1):
+            single = [torch.ones(M, Kd if trans else N, device=P.dev) for N, Kd in shapes]
+            batch = [t.clone() for t in single]
+            refo = [t.clone() for t in single]
+            for i, (N, Kd) in enumerate(shapes):
+                if trans == 0:
+                    P.impl.small_linear(Xs[i], Ws[i], bs[i], single[i], M, N, Kd, Kd, 0, int(fl[i][0]), int(fl[i][1]))
+                else:
+                    P.impl.small_linear(dYs[i], Ws[i], None, single[i], M, N, Kd, Kd, 1, 0, int(fl[i][1]))
+            jobs = lambda outs: [((Xs[i], Ws[i], bs[i], outs[i], N, Kd, Kd, fl[i][0], fl[i][1]) if trans == 0 else
+                                  (dYs[i], Ws[i], None, outs[i], N, Kd, Kd, False, fl[i][1])) for i, (N, Kd) in enumerate(shapes)]
+            P.impl.small_linear_batch(jobs(batch), M, trans)
+            P.ref.small_linear_batch(jobs(refo), M, trans)
+            if P.dev.type == "cuda":
+                torch.cuda.synchronize()
+            res.append((f"small_linear_batch trans={trans} M={M} x{len(shapes)} == single launches", 0.0 if all(torch.equal(a, b) for a, b in zip(single, batch)) else 1.0, 0.0))
+            res.append((f"small_linear_batch trans={trans} M={M} x{len(shapes)}", max(relerr(a, b) for a, b in zip(batch, refo)), 1e-4))
+        single = [torch.ones(N, Kd if i % 3 else 1, device=P.dev) for i, (N, Kd) in enumerate(shapes)]
+        batch = [t.clone() for t in single]
+        refo = [t.clone() for t in single]
+        ones = torch.ones(M, 1, device=P.dev)
+        for i, (N, Kd) in enumerate(shapes):
+            if i % 3:
+                P.impl.outer_acc(dYs[i], Xs[i], single[i], M, N, Kd, 0.5)
+            else:
+                P.impl.outer_acc(dYs[i], ones, single[i], M, N, 1, 0.5)
+        jobs = lambda outs: [(dYs[i], Xs[i] if i % 3 else None, outs[i], N, Kd if i % 3 else 1, 0.5) for i, (N, Kd) in enumerate(shapes)]
+        P.impl.outer_acc_batch(jobs(batch), M)
+        P.ref.outer_acc_batch(jobs(refo), M)
+        if P.dev.type == "cuda":
+            torch.cuda.synchronize()
+        res.append((f"outer_acc_batch M={M} x{len(shapes)} == single launches", 0.0 if all(torch.equal(a, b) for a, b in zip(single, batch)) else 1.0, 0.0))
+        res.append((f"outer_acc_batch M={M} x{len(shapes)}", max(relerr(a, b) for a, b in zip(batch, refo)), 1e-4))
     t = torch.tensor([0.0, 0.31, -1.7, 127.0, 7.0, 24.0], device=P.dev)
     for dim in (320, 256, 64):
         o1, o2 = P.run("timestep_embed", lambda o: ((t, o["E"], 6, dim), {}), dict(E=torch.zeros(6, dim, device=P.dev)))
@@ -339,6 +381,34 @@ def check_layernorm(P, dt):
             if affine:
                 res.append((f"ln_bwd {rows}x{C} affine={affine} dgamma", relerr(o1["dg"], o2["dg"]), 2e-3))
                 res.append((f"ln_bwd {rows}x{C} affine={affine} dbeta", relerr(o1["db"], o2["db"]), 2e-3))
+    # deferred affine-gradient reduction: svdx_ln_bwd(defer_reduce) x 5 + ONE svdx_ln_param_reduce_batch == the five immediate forms, bit for bit
+    cases = [(100, 64), (777, 320), (3000, 640), (50, 1280), (9001, 320)]
+    imm, dfr, jobs, keep = [], [], [], []
+    for (rows, C) in cases:
+        x = (rnd((rows, C), dt, P.dev, g) * 2 + 0.5).to(dt)
+        dy = rnd((rows, C), dt, P.dev, g)
+        gamma, beta = 1 + 0.1 * rndf((C,), P.dev, g), 0.1 * rndf((C,), P.dev, g)
+        y, st = torch.zeros_like(x), torch.zeros(rows, 2, device=P.dev)
+        P.impl.ln_fwd(x, gamma, beta, y, st, rows, C, 1e-5)
+        a = dict(dx=torch.zeros_like(x), dg=torch.ones(C, device=P.dev), db=torch.ones(C, device=P.dev))
+        b = {k_: v.clone() for k_, v in a.items()}
+        P.impl.ln_bwd(dy, x, st, gamma, None, a["dx"], a["dg"], a["db"], rows, C,
+                      scratch=torch.full((K.LN_PARTIAL_ROWS * 2 * C,), float("nan"), device=P.dev))
+        nblk = K.ln_bwd_blocks(rows, C)
+        scr = torch.full((nblk * 2 * C,), float("nan"), device=P.dev)
+        P.impl.ln_bwd(dy, x, st, gamma, None, b["dx"], b["dg"], b["db"], rows, C, scratch=scr, defer_reduce=True)
+        jobs.append((scr, b["dg"], b["db"], nblk, C))
+        imm.append(a)
+        dfr.append(b)
+        keep.append((x, dy, st))
+    P.impl.ln_param_reduce_batch(jobs)
+    if P.dev.type == "cuda":
+        torch.cuda.synchronize()
+    same = all(torch.equal(a[k_], b[k_]) for a, b in zip(imm, dfr) for k_ in ("dx", "dg", "db"))
+    res.append(("ln_bwd defer_reduce + ln_param_reduce_batch == immediate reduction", 0.0 if same else 1.0, 0.0))
+    if hasattr(P.impl, "lib"):
+        ok = all(P.impl.lib.svdx_ln_bwd_blocks(r, c) == K.ln_bwd_blocks(r, c) for r in (1, 9, 100, 777, 9001, 35840, 10 ** 6) for c in (64, 320, 640, 768, 1280))
+        res.append(("svdx_ln_bwd_blocks == kernels.ln_bwd_blocks", 0.0 if ok else 1.0, 0.0))
     return res
 
 

@@ -50,6 +50,18 @@ def test_same_seed_twice_gives_identical_bits():
 
 
 @gpu
+def test_batched_skinny_launches_equal_single_launches():
+    """The table-driven launches of the cross-attention vector chain / LayerNorm affine-gradient reductions (Runtime.batch_small,
+    svdx_*_batch) against one launch each: identical weights, Adam moments and loss after two optimizer steps, both dtypes."""
+    import torch
+
+    import e2e_checks
+    for dt in (torch.float16, torch.bfloat16):
+        a, b = e2e_checks.batched_vs_single_small_launches(dtype=dt)
+        e2e_checks.assert_batched_equals_single(a, b)
+
+
+@gpu
 def test_lora_train_step_matches_oracle_tiny():
     """Reference config 5 (bf16 LoRA, r = 64; r = 8 exercises the zero-padded rank)."""
     import e2e_checks

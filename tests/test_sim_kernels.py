@@ -62,6 +62,21 @@ def test_train_step_on_simulator_matches_oracle_tiny():
     assert got["loss_rel"] <= 1e-3 and got["grad_cos_min"] >= 0.99, got
 
 
+def test_batched_skinny_launches_equal_single_launches_on_simulator():
+    """Two fp16 optimizer steps of the tiny topology with the table-driven skinny launches and with one launch each end in identical
+    bits (the GPU suite runs the same comparison on the hardware)."""
+    import e2e_checks
+    from backend import SimBackend
+    from svd_xtend_amd import kernels as K
+    prev = K._backend
+    K._set_backend_for_tests(SimBackend())
+    try:
+        a, b = e2e_checks.batched_vs_single_small_launches(dev=torch.device("cpu"))
+    finally:
+        K._set_backend_for_tests(prev)
+    e2e_checks.assert_batched_equals_single(a, b)
+
+
 @pytest.mark.skipif(not FULL, reason="SVDX_SIM_FULL=1 (about two minutes)")
 def test_lora_step_and_replay_on_simulator():
     """Reference config 5's path (adapters through the dual-operand GEMM loop, zero-padded rank 8) against the CPU oracle, and two runs of
