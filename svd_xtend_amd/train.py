@@ -192,19 +192,23 @@ class Trainer:
                    self.loss_slot, dpred, B, T, m.out_channels, h * w, self.opt_state)
         self._dpred = dpred
 
-    def backward(self, on_block=None):
+    def backward(self, on_block=None, block_grads_final: bool = True):
         """Backward sweep of the last `forward_loss`.  On the last micro-batch of a multi-rank step every transformer block's
         gradient slice starts its all-reduce the moment the sweep leaves the block (`allreduce_grads` then only waits).
-        `on_block(module)` replaces that hook (GraphedStep cuts its graph segments there)."""
+        `on_block(module)` replaces that hook (GraphedStep cuts its graph segments there); `block_grads_final=False` tells the sweep
+        that the hook does not read the block's gradients, so the queued skinny gradient launches (Runtime.flush_deferred) may wait
+        for the end of the sweep."""
         m = self.model
         dpred, self._dpred = self._dpred, None
         last = self.micro + 1 == self.grad_accum
         m.grads_ready_cb = on_block if on_block is not None else (
             self._reduce_bucket if (self.world > 1 and self.overlap and last) else None)
+        m.grads_ready_flush = block_grads_final
         try:
             m.backward_rows(dpred)
         finally:
             m.grads_ready_cb = None
+            m.grads_ready_flush = True
         self.micro += 1
 
     def _reduce_bucket(self, module) -> None:
@@ -225,7 +229,7 @@ class Trainer:
         while n < max_steps:
             self.zero_grad()
             self.forward_loss(**batch)
-            self.backward(on_block=lambda m: None)      # no gradient all-reduce here: these sweeps are measurements, not steps
+            self.backward(on_block=lambda m: None, block_grads_final=False)      # no gradient all-reduce here: these sweeps are measurements, not steps
             self.micro = 0
             n += 1
             if self.rt.tuner.end_step():
@@ -398,9 +402,9 @@ class GraphedStep:
             tr.zero_grad()
             for b in batches[:-1]:
                 tr.forward_loss(**b)
-                tr.backward(on_block=lambda m: None)
+                tr.backward(on_block=lambda m: None, block_grads_final=False)
             tr.forward_loss(**batches[-1])
-            tr.backward(on_block=on_last_block)
+            tr.backward(on_block=on_last_block, block_grads_final=cut_blocks)    # a segment cut is followed by the block's collective
 
         with torch.cuda.stream(s):                       # warm-up on the capture stream (allocator, lazy module state)
             sweep(lambda m: None)

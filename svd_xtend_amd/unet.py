@@ -1025,6 +1025,7 @@ class UNetSpatioTemporalConditionModel(nn.Module):
             rt.wt16_flat = torch.empty(rt.p_flat.numel(), dtype=dtype, device=dev)     # transposed twins (ops.LinearOp.pack)
         self.steps = self._steps()
         self.grads_ready_cb = None       # callable(module) invoked by backward_rows after each transformer block (gradient overlap)
+        self.grads_ready_flush = True    # the callback consumes the block's gradients: run the queued skinny gradient launches first
         # which modules need an input gradient: only those executed after the first trainable parameter
         seen = False
         skip_flags = [seen]                       # conv_in output
@@ -1283,7 +1284,8 @@ class UNetSpatioTemporalConditionModel(nn.Module):
             if kind == "res" or kind == "attn":
                 dx = m.bwd(rt, dx, cur)
                 if kind == "attn" and self.grads_ready_cb is not None:
-                    rt.flush_deferred()             # the queued skinny gradient launches of this block belong to its bucket
+                    if self.grads_ready_flush:
+                        rt.flush_deferred()         # the queued skinny gradient launches of this block belong to its bucket
                     self.grads_ready_cb(m)          # this block's weight gradients are final: the trainer may start reducing them
             elif kind == "up":
                 low = level_geoms[lvl]

@@ -419,3 +419,40 @@ def test_attention_processor_plumbing_and_forward_chunking():
     with pytest.raises(ValueError, match="either 0 or 1"):
         m.enable_forward_chunking(dim=2)
     assert list(m.state_dict()) == keys_before
+
+
+def test_deferred_skinny_gradients_are_final_at_the_block_hook(emu_backend):
+    """Runtime.flush_deferred: the skinny gradient launches of a transformer block (cross-attention value path, LayerNorm affine
+    reductions) are queued; when the per-block hook consumes the block's gradients (gradient buckets, graph cuts) they run before
+    it, otherwise they wait for the end of the sweep -- same gradients either way."""
+    orc, m = build_pair(3)
+    batch = make_synthetic_batch(1, 2, 16, 16, 9, cross_dim=64)
+    unet_in, ts, ehs, ids, noisy, _ = edm_inputs(batch)
+    tr = Trainer(m, dtype=torch.float32, lr=1e-3)
+    assert tr.rt.batch_small
+    args = (unet_in, ts, ehs, ids, noisy, batch["latents"], batch["sigmas"])
+    tr.zero_grad()
+    tr.forward_backward(*args)
+    final = tr.g_flat.clone()
+    watched = [n for n, p in m.named_parameters() if p.requires_grad and ("attn2.to_v" in n or "attn2.to_out" in n or ".norm1." in n)]
+    params = dict(m.named_parameters())
+    off = {id(p): o for p, o in zip(tr.params, tr.offsets)}
+    seen = {}
+
+    def hook(flushed):
+        def cb(module):
+            ids_ = {id(p) for p in module.parameters()}
+            for n in watched:
+                p = params[n]
+                if id(p) in ids_:
+                    seen[(flushed, n)] = torch.equal(p.grad.reshape(-1), final[off[id(p)]:off[id(p)] + p.numel()])
+        return cb
+    for flushed in (True, False):
+        tr.zero_grad()
+        tr.micro = 0
+        tr.forward_loss(*args)
+        tr.backward(on_block=hook(flushed), block_grads_final=flushed)
+        assert torch.equal(tr.g_flat, final)
+        assert not tr.rt._q_nn and not tr.rt._q_outer and not tr.rt._q_outer2 and not tr.rt._q_ln
+    assert watched and all(seen[(True, n)] for n in watched)                       # final when the hook says it reads them
+    assert not all(seen[(False, n)] for n in watched)                              # still queued otherwise
