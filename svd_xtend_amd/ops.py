@@ -94,6 +94,9 @@ class Runtime:
         # the affine-gradient reductions of LayerNorm) are queued and run as table-driven launches when the sweep -- or, with gradient
         # buckets, the transformer block -- ends; SVDX_BATCH_SMALL=0: developer knob for A/B runs (one launch each, as before)
         self.batch_small = os.environ.get("SVDX_BATCH_SMALL", "1") != "0"
+        # at one clip per rank the gradient of a temporal block's cross-attention vector IS colsum(d(h1)) = the bias gradient the
+        # attn1.to_out weight-gradient GEMM already computes on the matrix pipe: no svdx_colsum pass.  SVDX_DVEC_FROM_DW=0: A/B knob
+        self.dvec_from_dw = os.environ.get("SVDX_DVEC_FROM_DW", "1") != "0"
         self._q_nn, self._q_outer, self._q_outer2, self._q_ln, self._q_M = [], [], [], [], None
         self.p_flat = None          # flat float master buffer of the trainables (ops.flatten_trainables)
         self.w16_flat = None        # same layout in the activation dtype, written by svdx_adamw / one cast per refresh
@@ -512,11 +515,14 @@ class LinearOp:
         gemm_act(rt, dy, self.wt, dx, M, self.Kdim, self.N, self.N, self.N, self.Kdim, dual=dual)
         return dx
 
-    def bwd_dw(self, rt: Runtime, dy: torch.Tensor, x: torch.Tensor, M: int) -> None:
-        """w.grad += dy^T x ; b.grad += colsum(dy).  TN GEMM straight from the row-major dy [M,N] and x [M,K]."""
+    def bwd_dw(self, rt: Runtime, dy: torch.Tensor, x: torch.Tensor, M: int, colsum_to: Optional[torch.Tensor] = None) -> None:
+        """w.grad += dy^T x ; b.grad += colsum(dy).  TN GEMM straight from the row-major dy [M,N] and x [M,K].
+        colsum_to (float [N], zeroed): receives colsum(dy) instead of b.grad -- the caller wants the column sums themselves and adds
+        them to b.grad on its own (TemporalBasicTransformerBlock.bwd: they are also d(cross-attention vector))."""
         if not self.trainable:
             return
-        gemm_tn_acc(rt, dy, x, self.w_grad, M, self.N, self.Kdim, self.N, self.Kdim, a_colsum=self.b_grad, write_once=True)
+        gemm_tn_acc(rt, dy, x, self.w_grad, M, self.N, self.Kdim, self.N, self.Kdim,
+                    a_colsum=self.b_grad if colsum_to is None else colsum_to, write_once=True)
 
 
 # eight-wave weight-gradient tiles instantiated in csrc/gemm.hip and offered to the in-situ tuner only (no hardware timing yet): `stages` code -> tile

@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from . import kernels as K
 from .lora import LoraLinear, base_linear, inject
+from .ops import _ones as ops_ones
 from .ops import (ConvOp, GroupNormOp, LayerNormOp, LinearOp, LoraOp, Runtime, SmallLinearOp, SmallLoraOp, choose_geglu_variant, geglu_candidates, choose_split, flatten_trainables, tuned_call,
                   rup)
 
@@ -446,14 +447,29 @@ class TemporalBasicTransformerBlock(nn.Module):
         dn3 = self.ff.bwd(rt, dout, n3, pre, gg, M)
         dh1 = self.ln3.bwd(rt, dn3, h1, st3, M, add=dout)
         del dn3, pre, gg, n3, h1
-        if self.attn2.cross_trainable:
+        # d(cross-attention vector) = the sum of d(h1) over the rows of each clip.  With one clip that is colsum(d(h1)), which the
+        # attn1.to_out weight-gradient GEMM computes anyway (its bias gradient, four MFMAs per K-half on a fragment of ones): the
+        # GEMM leaves it in `dvec`, and `dvec` is then added to the bias gradient by a skinny job -- no pass over d(h1) of its own
+        dvec_from_dw = (rt.dvec_from_dw and self.attn2.cross_trainable and g.B == 1 and self.attn1.o.trainable
+                        and self.attn1.o.b_grad is not None)
+        if self.attn2.cross_trainable and not dvec_from_dw:
             rv = self._rv(g)
             dvec = rt.f32(g.B, C)
             k.colsum(dh1, dvec, M, C, C, g.B, rv["rv_rpg"], rv["rv_mod"],
                      scratch=rt.f32(K.colsum_slabs(M, rv["rv_rpg"], rv["rv_mod"]) * g.B * C))
             self.attn2.cross_vec_bwd(rt, dvec, cv, tctx, g.B)
         d_o = _proj_bwd_dx(rt, self.attn1.o, self.attn1.o_lora, dh1, C, o, xs_o, M)
-        if self.attn1.o.trainable:
+        if dvec_from_dw:
+            dvec, zeroed = rt.take_zeroed(C)
+            if not zeroed:
+                k.zero(dvec)
+            self.attn1.o.bwd_dw(rt, dh1, o, M, colsum_to=dvec)
+            if rt.batch_small:
+                rt.defer_outer((dvec, None, self.attn1.o.b_grad, C, 1, 1.0), 1)
+            else:
+                k.outer_acc(dvec.view(1, C), ops_ones(rt), self.attn1.o.b_grad.view(C, 1), 1, C, 1, 1.0)
+            self.attn2.cross_vec_bwd(rt, dvec.view(1, C), cv, tctx, 1)
+        elif self.attn1.o.trainable:
             self.attn1.o.bwd_dw(rt, dh1, o, M)
         dqkv = rt.empty(M, 3 * C)
         k.tattn_bwd(qkv, qkv[:, C:], qkv[:, 2 * C:], d_o, dqkv, dqkv[:, C:], dqkv[:, 2 * C:], g.B, g.T, g.HW,

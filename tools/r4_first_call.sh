@@ -14,6 +14,7 @@ timeout 540 python tools/ring_check.py race time tn > $O/r4a_ring_race_time.txt 
 bash tools/ab_env.sh SVDX_GEGLU_TILE=default SVDX_GEGLU_TILE=sweep > $O/r4a_ab_geglu_tile.txt 2>&1; cat $O/r4a_ab_geglu_tile.txt
 timeout 300 python -m pytest tests/test_kernels_gpu.py tests/test_e2e_gpu.py -q -k "small or layernorm or batched_skinny" > $O/r4a_batch_small_checks.txt 2>&1; tail -n 3 $O/r4a_batch_small_checks.txt
 bash tools/ab_env.sh SVDX_BATCH_SMALL=1 SVDX_BATCH_SMALL=0 > $O/r4a_ab_batch_small.txt 2>&1; cat $O/r4a_ab_batch_small.txt
+bash tools/ab_env.sh SVDX_DVEC_FROM_DW=1 SVDX_DVEC_FROM_DW=0 > $O/r4a_ab_dvec_from_dw.txt 2>&1; cat $O/r4a_ab_dvec_from_dw.txt
 timeout 600 python bench.py --tune --tune-rounds 2 --steps 40 --warmup 3 --no-cpu-baseline > $O/r4a_bench_tuned.json 2> $O/r4a_bench_tuned.err; grep -o '"ms_per_step": [0-9.]*' $O/r4a_bench_tuned.json | head -1
 cp $O/gemm_tuned.json $O/r4a_gemm_tuned.json 2>/dev/null
 python bench.py --steps 40 --warmup 3 --no-cpu-baseline | grep -o '"ms_per_step": [0-9.]*' | head -1
