@@ -3,7 +3,7 @@ are the UNet's; a drop-in library has to be right on every shape its argument ch
 
     python tests/sim/fuzz.py [family ...] [--n 60] [--seed 0] [--bf16]
 
-Families: gemm, gather, tn, geglu, norm, lnbwd, attn, tattn, tsa, small, rows, optim.  Prints every failing case with the arguments that reproduce it."""
+Families: gemm, gather, tn, geglu, norm, lnbwd, attn, tattn, tsa, small, batch, rows, optim.  Prints every failing case with the arguments that reproduce it."""
 import math
 import os
 import random
@@ -276,6 +276,61 @@ def fuzz_small(P, dt, rng, g):
     return desc, e * 20, kc.tol_for(dt)          # float kernels: held to 1e-4 (fp16 bar / 20)
 
 
+def fuzz_batch(P, dt, rng, g):
+    """table-driven skinny launches: random job tables (1..60 jobs: the 48-job pack boundary included) -- each job must equal its
+    single-job launch bit for bit; and svdx_ln_bwd(defer_reduce) + svdx_ln_param_reduce_batch against the immediate reduction"""
+    M, nj = rng.randint(1, 12), rng.choice((1, 2, 3, 5, 17, 47, 48, 49, 60))
+    shapes = [(pick_dim(rng, 1, 400), 8 * rng.randint(1, 40)) for _ in range(nj)]
+    kind = rng.choice(("nt", "nn", "outer", "lnred"))
+    desc = f"batch {kind} M={M} jobs={nj} first={shapes[:3]}"
+    if kind == "lnred":
+        nj = min(nj, 6)
+        jobs, pairs = [], []
+        for _ in range(nj):
+            rows, C = pick_dim(rng, 1, 3000), 64 * rng.randint(1, 20)
+            x = (kc.rnd((rows, C), dt, P.dev, g) * 2 + 0.5).to(dt)
+            dy = kc.rnd((rows, C), dt, P.dev, g)
+            gamma, beta = 1 + 0.1 * kc.rndf((C,), P.dev, g), 0.1 * kc.rndf((C,), P.dev, g)
+            y, st = torch.zeros_like(x), torch.zeros(rows, 2, device=P.dev)
+            P.impl.ln_fwd(x, gamma, beta, y, st, rows, C, 1e-5)
+            a = [torch.zeros_like(x), torch.ones(C, device=P.dev), torch.ones(C, device=P.dev)]
+            b = [t.clone() for t in a]
+            P.impl.ln_bwd(dy, x, st, gamma, None, a[0], a[1], a[2], rows, C, scratch=torch.full((K.LN_PARTIAL_ROWS * 2 * C,), float("nan"), device=P.dev))
+            nblk = K.ln_bwd_blocks(rows, C)
+            scr = torch.full((nblk * 2 * C,), float("nan"), device=P.dev)
+            P.impl.ln_bwd(dy, x, st, gamma, None, b[0], b[1], b[2], rows, C, scratch=scr, defer_reduce=True)
+            jobs.append((scr, b[1], b[2], nblk, C))
+            pairs.append((a, b))
+        P.impl.ln_param_reduce_batch(jobs)
+        same = all(torch.equal(u, v) for a, b in pairs for u, v in zip(a, b))
+        return desc, 0.0 if same else 1.0, 0.0
+    Xs = [kc.rndf((M, Kd), P.dev, g) for N, Kd in shapes]
+    Ws = [kc.rnd((N, Kd), dt, P.dev, g, Kd ** -0.5) for N, Kd in shapes]
+    bs = [kc.rndf((N,), P.dev, g) if rng.random() < 0.5 else None for N, Kd in shapes]
+    dYs = [kc.rndf((M, N), P.dev, g) for N, Kd in shapes]
+    fl = [(rng.random() < 0.3, rng.random() < 0.5) for _ in shapes]
+    if kind == "outer":
+        ones_col = [rng.random() < 0.3 for _ in shapes]
+        single = [torch.ones(N, 1 if oc else Kd, device=P.dev) for (N, Kd), oc in zip(shapes, ones_col)]
+        batch = [t.clone() for t in single]
+        ones = torch.ones(M, 1, device=P.dev)
+        for i, (N, Kd) in enumerate(shapes):
+            P.impl.outer_acc(dYs[i], ones if ones_col[i] else Xs[i], single[i], M, N, 1 if ones_col[i] else Kd, 0.25)
+        P.impl.outer_acc_batch([(dYs[i], None if ones_col[i] else Xs[i], batch[i], N, 1 if ones_col[i] else Kd, 0.25) for i, (N, Kd) in enumerate(shapes)], M)
+    else:
+        trans = int(kind == "nn")
+        single = [torch.ones(M, Kd if trans else N, device=P.dev) for N, Kd in shapes]
+        batch = [t.clone() for t in single]
+        for i, (N, Kd) in enumerate(shapes):
+            if trans:
+                P.impl.small_linear(dYs[i], Ws[i], None, single[i], M, N, Kd, Kd, 1, 0, int(fl[i][1]))
+            else:
+                P.impl.small_linear(Xs[i], Ws[i], bs[i], single[i], M, N, Kd, Kd, 0, int(fl[i][0]), int(fl[i][1]))
+        P.impl.small_linear_batch([((dYs[i], Ws[i], None, batch[i], N, Kd, Kd, False, fl[i][1]) if trans else
+                                    (Xs[i], Ws[i], bs[i], batch[i], N, Kd, Kd, fl[i][0], fl[i][1])) for i, (N, Kd) in enumerate(shapes)], M, trans)
+    return desc, 0.0 if all(torch.equal(a, b) for a, b in zip(single, batch)) else 1.0, 0.0
+
+
 def fuzz_rows(P, dt, rng, g):
     """row-vector / column-sum / transpose / concat kernels on ragged sizes"""
     rows, C = pick_dim(rng, 1, 2500), 8 * rng.randint(1, 80)
@@ -337,7 +392,7 @@ def fuzz_optim(P, dt, rng, g):
 
 
 FAMILIES = {"gemm": fuzz_gemm, "gather": fuzz_gather, "tn": fuzz_tn, "geglu": fuzz_geglu, "norm": fuzz_norm, "lnbwd": fuzz_lnbwd,
-            "attn": fuzz_attn, "tattn": fuzz_tattn, "tsa": fuzz_tsa, "small": fuzz_small, "rows": fuzz_rows, "optim": fuzz_optim}
+            "attn": fuzz_attn, "tattn": fuzz_tattn, "tsa": fuzz_tsa, "small": fuzz_small, "batch": fuzz_batch, "rows": fuzz_rows, "optim": fuzz_optim}
 
 
 def run(P, dt, families, n, seed, verbose=True):
