@@ -97,7 +97,7 @@ class Runtime:
         # at one clip per rank the gradient of a temporal block's cross-attention vector IS colsum(d(h1)) = the bias gradient the
         # attn1.to_out weight-gradient GEMM already computes on the matrix pipe: no svdx_colsum pass.  SVDX_DVEC_FROM_DW=0: A/B knob
         self.dvec_from_dw = os.environ.get("SVDX_DVEC_FROM_DW", "1") != "0"
-        self._q_nn, self._q_outer, self._q_outer2, self._q_ln, self._q_M = [], [], [], [], None
+        self._q_nn, self._q_outer, self._q_ln, self._q_M = [], [], [], None
         self.p_flat = None          # flat float master buffer of the trainables (ops.flatten_trainables)
         self.w16_flat = None        # same layout in the activation dtype, written by svdx_adamw / one cast per refresh
 
@@ -107,15 +107,17 @@ class Runtime:
             self.flush_deferred()
         self._q_M = M
 
-    def defer_nn(self, job, M: int) -> None:
-        """job of kernels.small_linear_batch(trans=1)"""
+    def defer_nn(self, job, M: int, stage: int = 0) -> None:
+        """job of kernels.small_linear_batch(trans=1); a job may read what jobs of LOWER stages wrote (one launch per stage)"""
         self._q_rows(M)
-        self._q_nn.append(job)
+        while len(self._q_nn) <= stage:
+            self._q_nn.append([])
+        self._q_nn[stage].append(job)
 
-    def defer_outer(self, job, M: int, after_nn: bool = False) -> None:
-        """job of kernels.outer_acc_batch; after_nn: it reads the result of a queued defer_nn job"""
+    def defer_outer(self, job, M: int) -> None:
+        """job of kernels.outer_acc_batch; runs after every queued defer_nn stage"""
         self._q_rows(M)
-        (self._q_outer2 if after_nn else self._q_outer).append(job)
+        self._q_outer.append(job)
 
     def defer_ln_reduce(self, job) -> None:
         """job of kernels.ln_param_reduce_batch"""
@@ -123,16 +125,21 @@ class Runtime:
 
     def flush_deferred(self) -> None:
         k, M = self.k, self._q_M
-        if self._q_nn:
-            k.small_linear_batch(self._q_nn, M, 1)
-        if self._q_outer or self._q_outer2:
-            k.outer_acc_batch(self._q_outer + self._q_outer2, M)
+        for jobs in self._q_nn:
+            if jobs:
+                k.small_linear_batch(jobs, M, 1)
+        if self._q_outer:
+            k.outer_acc_batch(self._q_outer, M)
         if self._q_ln:
             k.ln_param_reduce_batch(self._q_ln)
         self.drop_deferred()
 
     def drop_deferred(self) -> None:
-        self._q_nn, self._q_outer, self._q_outer2, self._q_ln, self._q_M = [], [], [], [], None
+        self._q_nn, self._q_outer, self._q_ln, self._q_M = [], [], [], None
+
+    @property
+    def deferred_pending(self) -> bool:
+        return bool(any(self._q_nn) or self._q_outer or self._q_ln)
 
     def begin_pass(self, which: int) -> None:
         """Start of a forward (0) or backward (1) sweep: re-zero that sweep's statistics arena with ONE memset (GroupNorm

@@ -232,19 +232,45 @@ class _Attention(nn.Module):
     def cross_trainable(self):
         return self.o.trainable or self.v.trainable or self.lora_trainable
 
+    def cross_batchable(self) -> bool:
+        """the table-driven launches carry no adapter scale: peft's lora_alpha == r (scale 1) is what the reference uses"""
+        return all(l is None or l.s == 1.0 for l in (self.v_lora, self.o_lora))
+
     def cross_vec_bwd(self, rt, dvec, saved, ctx, Bn):
         v, va, oa = saved
-        if rt.batch_small and self.v_lora is None and self.o_lora is None:
-            # nothing downstream of the sweep reads these gradients: queue the chain (d(v) = dvec W_o, then the three outer products) and
-            # run every block's share together when the sweep -- or the gradient bucket -- ends (Runtime.flush_deferred)
-            if self.o.trainable:
-                rt.defer_outer((dvec, v, self.o.weight.grad, self.o.N, self.o.Kdim, 1.0), Bn)
-                if self.o.bias is not None:
-                    rt.defer_outer((dvec, None, self.o.bias.grad, self.o.N, 1, 1.0), Bn)
-            if self.v.trainable:
-                dv = rt.f32(Bn, self.o.Kdim)
-                rt.defer_nn((dvec, self.o.w, None, dv, self.o.N, self.o.Kdim, self.o.Kdim, 0, 0), Bn)
-                rt.defer_outer((dv, ctx, self.v.weight.grad, self.v.N, self.v.Kdim, 1.0), Bn, after_nn=True)
+        if rt.batch_small and self.cross_batchable():
+            # nothing downstream of the sweep reads these gradients: queue the chain and run every block's share together when the
+            # sweep -- or the gradient bucket -- ends (Runtime.flush_deferred).  Transposed linears in dependency stages (d(v) from
+            # to_out and its adapter's B | the adapter's A into d(v) | d(v) through to_v's adapter B), then ALL outer products.
+            def nn(op, dy, dx, stage, acc=False):
+                rt.defer_nn((dy, op.w, None, dx, op.N, op.Kdim, op.Kdim, 0, int(acc)), Bn, stage)
+
+            def outer(op, dy, x):
+                if op.trainable:
+                    rt.defer_outer((dy, x, op.weight.grad, op.N, op.Kdim, 1.0), Bn)
+                    if op.bias is not None:
+                        rt.defer_outer((dy, None, op.bias.grad, op.N, 1, 1.0), Bn)
+            ol = self.o_lora if self.o_lora is not None and self.o_lora.trainable else None
+            vl = self.v_lora if self.v_lora is not None and self.v_lora.trainable else None
+            need_dv = self.v.trainable or vl is not None
+            outer(self.o, dvec, v)
+            dv = rt.f32(Bn, self.o.Kdim) if need_dv else None
+            if need_dv:
+                nn(self.o, dvec, dv, 0)
+            if ol is not None:                       # y += B (A v): d(Av) = dvec B, dB += dvec^T (Av), dA += d(Av)^T v, d(v) += d(Av) A
+                dxa = rt.f32(Bn, ol.b.Kdim)
+                outer(ol.b, dvec, oa)
+                nn(ol.b, dvec, dxa, 0)
+                outer(ol.a, dxa, v)
+                if need_dv:
+                    nn(ol.a, dxa, dv, 1, acc=True)
+            if need_dv:
+                outer(self.v, dv, ctx)
+            if vl is not None:
+                dxa = rt.f32(Bn, vl.b.Kdim)
+                outer(vl.b, dv, va)
+                nn(vl.b, dv, dxa, 2)
+                outer(vl.a, dxa, ctx)
             return
         need_dv = self.v.trainable or (self.v_lora is not None and self.v_lora.trainable)
         dv = self.o.bwd(rt, dvec, v, Bn, need_dx=need_dv)
@@ -1207,24 +1233,34 @@ class UNetSpatioTemporalConditionModel(nn.Module):
     def _cross_precompute(self, rt, ctx, B):
         """The KV-length-1 cross-attention of EVERY transformer block, up front: out_i = to_out_i(to_v_i(ctx)) depends on nothing but
         the clip's CLIP embed, so the 2 x 32 skinny linears of a sweep run as two table-driven launches (svdx_small_linear_batch)
-        instead of 64 launches of ~5 us strung between the GEMMs.  Blocks with adapters on the value path keep their own launches."""
+        instead of 64 launches of ~5 us strung between the GEMMs.  With adapters on the value path (config 5: y += B (A x)) the chain
+        has four dependency stages -- [v = W_v ctx, A_v ctx] [v += B_v ..] [out = W_o v + b, A_o v] [out += B_o ..] -- one launch each
+        instead of six per block."""
         atts = [blk.attn2 for kind, m in self.steps if kind == "attn"
                 for blk in list(m.transformer_blocks) + list(m.temporal_transformer_blocks)]
-        atts = [a for a in atts if a.v_lora is None and a.o_lora is None]
-        if not atts:
-            return
-        vbuf = rt.f32(B * sum(a.v.N for a in atts))
-        obuf = rt.f32(B * sum(a.o.N for a in atts))
-        jobs_v, jobs_o, vo, oo = [], [], 0, 0
+        stages = [[], [], [], []]
+
+        def lin(op, x, stage, y=None):
+            acc = y is not None
+            y = y if acc else rt.f32(B, op.N)
+            stages[stage].append((x, op.w, None if op.bias is None else op.bias.data, y, op.N, op.Kdim, op.Kdim, 0, int(acc)))
+            return y
         for a in atts:
-            v = vbuf[vo:vo + B * a.v.N].view(B, a.v.N)
-            o = obuf[oo:oo + B * a.o.N].view(B, a.o.N)
-            vo, oo = vo + B * a.v.N, oo + B * a.o.N
-            jobs_v.append((ctx, a.v.w, None if a.v.bias is None else a.v.bias.data, v, a.v.N, a.v.Kdim, a.v.Kdim, 0, 0))
-            jobs_o.append((v, a.o.w, None if a.o.bias is None else a.o.bias.data, o, a.o.N, a.o.Kdim, a.o.Kdim, 0, 0))
-            a._pre = (o, (v, None, None))
-        rt.k.small_linear_batch(jobs_v, B, 0)
-        rt.k.small_linear_batch(jobs_o, B, 0)
+            if not a.cross_batchable():
+                continue
+            v = lin(a.v, ctx, 0)
+            va = oa = None
+            if a.v_lora is not None:
+                va = lin(a.v_lora.a, ctx, 0)
+                lin(a.v_lora.b, va, 1, y=v)
+            o = lin(a.o, v, 2)
+            if a.o_lora is not None:
+                oa = lin(a.o_lora.a, v, 2)
+                lin(a.o_lora.b, oa, 3, y=o)
+            a._pre = (o, (v, va, oa))
+        for jobs in stages:
+            if jobs:
+                rt.k.small_linear_batch(jobs, B, 0)
 
     def _backward_impl(self, d_out):
         """d_out: float [B,T,out_channels,h,w] (gradient of `.sample`)."""

@@ -164,8 +164,9 @@ def graphed_vs_eager(dev=None, dtype=torch.float16, steps=3):
                 param_abs_max=float(e["p"].abs().max()), opt_steps=(e["state"][0], g["state"][0]), segments=g["segments"])
 
 
-def run_steps(dev=None, dtype=torch.float16, steps=3, seed=5):
-    """`steps` eager optimizer steps of the tiny topology from seeded weights on a seeded batch; returns the final state."""
+def run_steps(dev=None, dtype=torch.float16, steps=3, seed=5, lora_r=0):
+    """`steps` eager optimizer steps of the tiny topology from seeded weights on a seeded batch; returns the final state.
+    lora_r: config 5's trainable set (adapters on the attention projections, B randomised so that every gradient is non-zero)."""
     dev = dev or torch.device("cuda")
     cfg = TINY_CONFIG
     orc = UNetSpatioTemporalConditionOracle(**cfg)
@@ -176,6 +177,14 @@ def run_steps(dev=None, dtype=torch.float16, steps=3, seed=5):
                                            target=b["latents"], sigmas=b["sigmas"]).items()}
     m = UNetSpatioTemporalConditionModel(**cfg)
     m.load_state_dict(orc.state_dict(), strict=True)
+    if lora_r:
+        from svd_xtend_amd.lora import LoraConfig
+        torch.manual_seed(seed + 5)
+        m.add_adapter(LoraConfig(r=lora_r, lora_alpha=lora_r, init_lora_weights="gaussian"))
+        gen = torch.Generator().manual_seed(seed + 17)
+        for n, p in m.named_parameters():
+            if ".lora_B." in n:
+                p.data.copy_(torch.randn(p.shape, generator=gen) * 0.05)
     m.to(dev)
     tr = Trainer(m, dtype=dtype, lr=1e-3)
     for _ in range(steps - 1):
@@ -190,7 +199,7 @@ def run_steps(dev=None, dtype=torch.float16, steps=3, seed=5):
     return dict(p=tr.p_flat.clone(), m=tr.m_flat.clone(), v=tr.v_flat.clone(), loss=float(tr.last_loss()), launches=[e[0] for e in log])
 
 
-def batched_vs_single_small_launches(dev=None, dtype=torch.float16, steps=2):
+def batched_vs_single_small_launches(dev=None, dtype=torch.float16, steps=2, lora_r=0):
     """The table-driven skinny launches (Runtime.batch_small: the cross-attention vector chain up front, its gradient chain and the
     LayerNorm affine-gradient reductions at the end of the sweep) against one launch each (SVDX_BATCH_SMALL=0): identical bits after
     `steps` optimizer steps, and the launches they save.  Returns (batched, single) run_steps results."""
@@ -198,9 +207,9 @@ def batched_vs_single_small_launches(dev=None, dtype=torch.float16, steps=2):
     prev = os.environ.get("SVDX_BATCH_SMALL")
     try:
         os.environ["SVDX_BATCH_SMALL"] = "1"
-        a = run_steps(dev=dev, dtype=dtype, steps=steps)
+        a = run_steps(dev=dev, dtype=dtype, steps=steps, lora_r=lora_r)
         os.environ["SVDX_BATCH_SMALL"] = "0"
-        b = run_steps(dev=dev, dtype=dtype, steps=steps)
+        b = run_steps(dev=dev, dtype=dtype, steps=steps, lora_r=lora_r)
     finally:
         if prev is None:
             os.environ.pop("SVDX_BATCH_SMALL", None)
@@ -209,10 +218,13 @@ def batched_vs_single_small_launches(dev=None, dtype=torch.float16, steps=2):
     return a, b
 
 
-def assert_batched_equals_single(a, b):
+def assert_batched_equals_single(a, b, lora=False):
     assert a["loss"] == b["loss"] and all(torch.equal(a[k], b[k]) for k in ("p", "m", "v")), "batched skinny launches changed the step's bits"
     na, nb = a["launches"], b["launches"]
-    assert na.count("svdx_small_linear_batch") == 3 and na.count("svdx_outer_acc_batch") == 1 and na.count("svdx_ln_param_reduce_batch") == 1, \
+    # base training: 2 forward stages + 1 transposed stage, the outer products, the LayerNorm reductions; adapters (frozen LayerNorms):
+    # 4 forward stages + 3 transposed stages, the outer products
+    want = (7, 1, 0) if lora else (3, 1, 1)
+    assert (na.count("svdx_small_linear_batch"), na.count("svdx_outer_acc_batch"), na.count("svdx_ln_param_reduce_batch")) == want, \
         {n: na.count(n) for n in set(na) if "batch" in n}
     assert not any("batch" in n for n in nb)
     assert na.count("svdx_outer_acc") == 0 and nb.count("svdx_outer_acc") > 0

@@ -59,6 +59,8 @@ def test_batched_skinny_launches_equal_single_launches():
     for dt in (torch.float16, torch.bfloat16):
         a, b = e2e_checks.batched_vs_single_small_launches(dtype=dt)
         e2e_checks.assert_batched_equals_single(a, b)
+    a, b = e2e_checks.batched_vs_single_small_launches(dtype=torch.bfloat16, lora_r=8)      # config 5: adapters on to_v / to_out
+    e2e_checks.assert_batched_equals_single(a, b, lora=True)
 
 
 @gpu

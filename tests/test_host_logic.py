@@ -453,6 +453,6 @@ def test_deferred_skinny_gradients_are_final_at_the_block_hook(emu_backend):
         tr.forward_loss(*args)
         tr.backward(on_block=hook(flushed), block_grads_final=flushed)
         assert torch.equal(tr.g_flat, final)
-        assert not tr.rt._q_nn and not tr.rt._q_outer and not tr.rt._q_outer2 and not tr.rt._q_ln
+        assert not tr.rt.deferred_pending
     assert watched and all(seen[(True, n)] for n in watched)                       # final when the hook says it reads them
     assert not all(seen[(False, n)] for n in watched)                              # still queued otherwise

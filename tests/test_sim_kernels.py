@@ -72,9 +72,12 @@ def test_batched_skinny_launches_equal_single_launches_on_simulator():
     K._set_backend_for_tests(SimBackend())
     try:
         a, b = e2e_checks.batched_vs_single_small_launches(dev=torch.device("cpu"))
+        la, lb = e2e_checks.batched_vs_single_small_launches(dev=torch.device("cpu"), dtype=torch.bfloat16, steps=1, lora_r=8) if FULL else (None, None)
     finally:
         K._set_backend_for_tests(prev)
     e2e_checks.assert_batched_equals_single(a, b)
+    if FULL:                                                   # config 5's adapters on the cross-attention value path: four + three stages
+        e2e_checks.assert_batched_equals_single(la, lb, lora=True)
 
 
 @pytest.mark.skipif(not FULL, reason="SVDX_SIM_FULL=1 (about two minutes)")
