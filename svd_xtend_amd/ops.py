@@ -75,6 +75,7 @@ class Runtime:
         # the level qualifies (csrc/tsa.hip); SVDX_FUSE_TSA=0: developer knob for A/B runs
         self.fuse_tsa = os.environ.get("SVDX_FUSE_TSA", "1") != "0"
         self.fuse_dual = os.environ.get("SVDX_LORA_FUSED", "1") != "0"   # developer knob for A/B runs: adapter term as its own launch
+        self.lora_stack_da = os.environ.get("SVDX_LORA_STACK_DA", "1") != "0"   # A/B knob: dA of fused q/k/v adapters as one TN GEMM
         self.tuner = None           # GemmTuner (Trainer.tune_gemms): measured tile / split-K per GEMM problem
         # transposed 16-bit twins ([K,N], operand of the data-grad GEMM) of the trainable nn.Linear weights live in one arena so
         # that the tiled AdamW kernel can write them (wt_map: id(weight) -> (element offset of W^T[0, n0], row pitch))
@@ -775,6 +776,15 @@ class LoraOp:
                     gemm_tn_acc(rt, dyj, xs[:, j * rp:], tmp, M, n, rp, lddy, J * rp)
                     m.B.grad.add_(tmp[:, :r])
             off += n
+        # dA_j = d(xA_j^T)^T x: the J factors' gradients are adjacent in the flat buffer (ops._layout_order), so they are ONE
+        # [J*r, in] TN GEMM on the stacked d(xA^T) -- a third of the launches (and of their slab finalizes), and output tiles that
+        # are not three-quarters padding
+        a_grads = [m.A.grad for m in self.mods]
+        stacked = (LinearOp._flat_view(a_grads) if J > 1 and r == rp and rt.lora_stack_da and all(m.A.requires_grad for m in self.mods)
+                   and all(g is not None for g in a_grads) else None)
+        if stacked is not None:
+            gemm_tn_acc(rt, dxa, x, stacked.view(J * rp, self.in_f), M, J * rp, self.in_f, J * rp, self.in_f, write_once=True)
+            return dxa
         for j, m in enumerate(self.mods):
             if m.A.requires_grad:
                 if r == rp:
