@@ -758,10 +758,17 @@ class LoraOp:
             return (xs, self.Bst, self.rp, w, self.rp, self.outs[0] if self.J > 1 else 0)
         return (xs, self.Bbd, w, w, w)
 
-    def bwd(self, rt: Runtime, dy: torch.Tensor, lddy: int, x: torch.Tensor, xs: torch.Tensor, M: int) -> torch.Tensor:
+    def can_colsum(self) -> bool:
+        """the dB GEMM of a single-projection adapter can hand out colsum(dy) (`bwd(colsum_to=...)`)"""
+        return self.J == 1 and self.r == self.rp and self.mods[0].B.requires_grad
+
+    def bwd(self, rt: Runtime, dy: torch.Tensor, lddy: int, x: torch.Tensor, xs: torch.Tensor, M: int,
+            colsum_to: Optional[torch.Tensor] = None) -> torch.Tensor:
         """dy [M, sum N_j] (row pitch lddy); accumulates A_j.grad / B_j.grad and returns dxa = s * dy B [M, J*rp]; hand
-        `self.bwd_dual(dxa)` to the base projection's `bwd_dx` for the dx term."""
+        `self.bwd_dual(dxa)` to the base projection's `bwd_dx` for the dx term.  colsum_to (float [N], zeroed; needs `can_colsum()`):
+        += colsum(dy), computed by the dB GEMM on the side (the transformer blocks' d(cross-attention vector) at one clip per rank)."""
         k, r, rp, J = rt.k, self.r, self.rp, self.J
+        assert colsum_to is None or self.can_colsum()
         dxa = rt.empty(M, J * rp)
         off = 0
         for j, n in enumerate(self.outs):
@@ -770,7 +777,7 @@ class LoraOp:
             m = self.mods[j]
             if m.B.requires_grad:
                 if r == rp:
-                    gemm_tn_acc(rt, dyj, xs[:, j * rp:], m.B.grad, M, n, rp, lddy, J * rp, write_once=True)
+                    gemm_tn_acc(rt, dyj, xs[:, j * rp:], m.B.grad, M, n, rp, lddy, J * rp, a_colsum=colsum_to, write_once=True)
                 else:
                     tmp = rt.zeros_f32(n, rp)
                     gemm_tn_acc(rt, dyj, xs[:, j * rp:], tmp, M, n, rp, lddy, J * rp)

@@ -292,13 +292,27 @@ def _proj_fwd(rt, lin, lora, x, M, **kw):
     return lin.fwd(rt, x, M, dual=lora.fwd_dual(xs), **kw), xs
 
 
-def _proj_bwd_dx(rt, lin, lora, dy, lddy, x, xs, M, need_dx=True):
+def _proj_bwd_dx(rt, lin, lora, dy, lddy, x, xs, M, need_dx=True, colsum_to=None):
     """Adapter gradients (when there is an adapter) and d(input) of the adapted projection, the adapter's share riding on the
-    base data-grad GEMM."""
-    dxa = lora.bwd(rt, dy, lddy, x, xs, M) if lora is not None else None
+    base data-grad GEMM.  colsum_to: see LoraOp.bwd."""
+    dxa = lora.bwd(rt, dy, lddy, x, xs, M, colsum_to=colsum_to) if lora is not None else None
     if not need_dx:
         return None
     return lin.bwd_dx(rt, dy, M, dual=lora.bwd_dual(dxa) if lora is not None else None)
+
+
+def _zeroed_vec(rt, n):
+    """n zeroed floats (a slice of the sweep's pre-zeroed statistics arena when it has room)"""
+    t, zeroed = rt.take_zeroed(n)
+    if not zeroed:
+        rt.k.zero(t)
+    return t
+
+
+def _dvec_from_lora(rt, attn1, attn2, g) -> bool:
+    """config 5: d(cross-attention vector) = colsum(d(h)) rides on the dB GEMM of attn1.to_out's adapter (one clip per rank)"""
+    return (rt.dvec_from_dw and attn2.cross_trainable and g.B == 1 and attn1.o_lora is not None and attn1.o_lora.trainable
+            and attn1.o_lora.can_colsum())
 
 
 # ==================================================================================================
@@ -361,11 +375,15 @@ class BasicTransformerBlock(nn.Module):
         dn3 = self.ff.bwd(rt, dh3, None, pre, None, M)
         dh2 = self.ln3.bwd(rt, dn3, h2, st3, M, add=dh3)
         del dn3, pre, h2
-        if self.attn2.cross_trainable:               # adapters on the cross-attention's to_v / to_out (per-clip vectors)
+        cs_lora = _dvec_from_lora(rt, self.attn1, self.attn2, g)
+        if self.attn2.cross_trainable and not cs_lora:   # adapters on the cross-attention's to_v / to_out (per-clip vectors)
             dvec = rt.f32(g.B, C)
             k.colsum(dh2, dvec, M, C, C, g.B, g.T * g.HW, 0, scratch=rt.f32(K.colsum_slabs(M, g.T * g.HW, 0) * g.B * C))
             self.attn2.cross_vec_bwd(rt, dvec, cv, ctx, g.B)
-        d_o = _proj_bwd_dx(rt, self.attn1.o, self.attn1.o_lora, dh2, C, o, xs_o, M)
+        dvec = _zeroed_vec(rt, C) if cs_lora else None
+        d_o = _proj_bwd_dx(rt, self.attn1.o, self.attn1.o_lora, dh2, C, o, xs_o, M, colsum_to=dvec)
+        if cs_lora:
+            self.attn2.cross_vec_bwd(rt, dvec.view(1, C), cv, ctx, 1)
         D = rt.f32(g.N * self.heads * S)
         k.attn_bwd_prep(o, d_o, D, g.N, self.heads, S, C)
         dqkv = rt.empty(M, 3 * C)
@@ -478,17 +496,18 @@ class TemporalBasicTransformerBlock(nn.Module):
         # GEMM leaves it in `dvec`, and `dvec` is then added to the bias gradient by a skinny job -- no pass over d(h1) of its own
         dvec_from_dw = (rt.dvec_from_dw and self.attn2.cross_trainable and g.B == 1 and self.attn1.o.trainable
                         and self.attn1.o.b_grad is not None)
-        if self.attn2.cross_trainable and not dvec_from_dw:
+        cs_lora = not dvec_from_dw and _dvec_from_lora(rt, self.attn1, self.attn2, g)
+        if self.attn2.cross_trainable and not (dvec_from_dw or cs_lora):
             rv = self._rv(g)
             dvec = rt.f32(g.B, C)
             k.colsum(dh1, dvec, M, C, C, g.B, rv["rv_rpg"], rv["rv_mod"],
                      scratch=rt.f32(K.colsum_slabs(M, rv["rv_rpg"], rv["rv_mod"]) * g.B * C))
             self.attn2.cross_vec_bwd(rt, dvec, cv, tctx, g.B)
-        d_o = _proj_bwd_dx(rt, self.attn1.o, self.attn1.o_lora, dh1, C, o, xs_o, M)
+        dvec = _zeroed_vec(rt, C) if (dvec_from_dw or cs_lora) else None
+        d_o = _proj_bwd_dx(rt, self.attn1.o, self.attn1.o_lora, dh1, C, o, xs_o, M, colsum_to=dvec if cs_lora else None)
+        if cs_lora:
+            self.attn2.cross_vec_bwd(rt, dvec.view(1, C), cv, tctx, 1)
         if dvec_from_dw:
-            dvec, zeroed = rt.take_zeroed(C)
-            if not zeroed:
-                k.zero(dvec)
             self.attn1.o.bwd_dw(rt, dh1, o, M, colsum_to=dvec)
             if rt.batch_small:
                 rt.defer_outer((dvec, None, self.attn1.o.b_grad, C, 1, 1.0), 1)
