@@ -90,8 +90,9 @@ class _FeedForward(nn.Module):
         self.p2.pack(rt)
 
     def refresh(self, rt):
-        self.p1.refresh(rt)
-        self.p2.refresh(rt)
+        for op in (self.p1, self.p2):        # frozen projections (config 5: only adapters train) keep the copies packed at prepare()
+            if op.trainable:
+                op.refresh(rt)
 
     def _fusable(self, rt, M):
         F = self.inner
