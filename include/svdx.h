@@ -131,8 +131,8 @@ int svdx_outer_acc(const float* dY, const float* X, float* dW, int M, int N, int
 /* The same skinny kernels over a table of jobs in ONE launch (the KV-length-1 cross-attention of the 32 transformer blocks is a chain of
  * 64 + 16 skinny linears and 48 outer products per step, each ~5 us of launch latency: diffusers Attention.to_v / to_out[0] behind
  * src/unet_spatio_temporal_condition.py:170-192, 219-234).  `jobs` is a HOST array: it is copied into the kernel arguments
- * (SVDX_BATCH_MAX_JOBS per launch; longer tables take several launches), so a captured hipGraph owns its copy.  Every job computes
- * exactly what the single-job entry computes, bit for bit; all jobs of a call share M, trans and dtype.  Jobs of one call must not
+ * (SVDX_BATCH_MAX_JOBS per launch; longer tables take several launches), so a captured hipGraph owns its copy.  Every job runs
+ * the device function of the single-job entry (same arithmetic in the same order); all jobs of a call share M, trans and dtype.  Jobs of one call must not
  * depend on each other. */
 #define SVDX_BATCH_MAX_JOBS 48
 typedef struct svdx_lin_job {

@@ -218,8 +218,17 @@ def batched_vs_single_small_launches(dev=None, dtype=torch.float16, steps=2, lor
     return a, b
 
 
-def assert_batched_equals_single(a, b, lora=False):
-    assert a["loss"] == b["loss"] and all(torch.equal(a[k], b[k]) for k in ("p", "m", "v")), "batched skinny launches changed the step's bits"
+def assert_batched_equals_single(a, b, lora=False, exact=True):
+    """exact: bit equality (the simulator compiles both forms from the same device function without contraction; on the GPU the two
+    kernels inline the same function too, but nothing in the product depends on the compiler scheduling them identically, so the
+    hardware test holds them to rounding level instead)."""
+    if exact:
+        assert a["loss"] == b["loss"] and all(torch.equal(a[k], b[k]) for k in ("p", "m", "v")), "batched skinny launches changed the step's bits"
+    else:
+        assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(b["loss"]), (a["loss"], b["loss"])
+        for k in ("p", "m", "v"):
+            d = float((a[k] - b[k]).abs().max())
+            assert d <= 1e-5 * float(b[k].abs().max()) + 1e-12, (k, d)
     na, nb = a["launches"], b["launches"]
     # base training: 2 forward stages + 1 transposed stage, the outer products, the LayerNorm reductions; adapters (frozen LayerNorms):
     # 4 forward stages + 3 transposed stages, the outer products

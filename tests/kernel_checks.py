@@ -263,6 +263,19 @@ def check_gemm_gather(P, dt, variant):
     return res
 
 
+def same_or_err(xs, ys):
+    """0.0 when the two lists of tensors are bit-identical, else their largest relative difference"""
+    if all(torch.equal(a, b) for a, b in zip(xs, ys)):
+        return 0.0
+    return max(max(relerr(a.float(), b.float()) for a, b in zip(xs, ys)), 1e-30)
+
+
+def EXACT_TOL(P):
+    """A table-driven launch against its single-job launches: bit equality on the simulator (same device function, no contraction);
+    on hardware the two kernels are separate compilations of that function and are held to rounding level."""
+    return 0.0 if P.dev.type == "cpu" else 2e-6
+
+
 def check_small(P, dt):
     g = torch.Generator().manual_seed(3)
     res = []
@@ -302,7 +315,7 @@ def check_small(P, dt):
             P.ref.small_linear_batch(jobs(refo), M, trans)
             if P.dev.type == "cuda":
                 torch.cuda.synchronize()
-            res.append((f"small_linear_batch trans={trans} M={M} x{len(shapes)} == single launches", 0.0 if all(torch.equal(a, b) for a, b in zip(single, batch)) else 1.0, 0.0))
+            res.append((f"small_linear_batch trans={trans} M={M} x{len(shapes)} == single launches", same_or_err(single, batch), EXACT_TOL(P)))
             res.append((f"small_linear_batch trans={trans} M={M} x{len(shapes)}", max(relerr(a, b) for a, b in zip(batch, refo)), 1e-4))
         single = [torch.ones(N, Kd if i % 3 else 1, device=P.dev) for i, (N, Kd) in enumerate(shapes)]
         batch = [t.clone() for t in single]
@@ -318,7 +331,7 @@ def check_small(P, dt):
         P.ref.outer_acc_batch(jobs(refo), M)
         if P.dev.type == "cuda":
             torch.cuda.synchronize()
-        res.append((f"outer_acc_batch M={M} x{len(shapes)} == single launches", 0.0 if all(torch.equal(a, b) for a, b in zip(single, batch)) else 1.0, 0.0))
+        res.append((f"outer_acc_batch M={M} x{len(shapes)} == single launches", same_or_err(single, batch), EXACT_TOL(P)))
         res.append((f"outer_acc_batch M={M} x{len(shapes)}", max(relerr(a, b) for a, b in zip(batch, refo)), 1e-4))
     t = torch.tensor([0.0, 0.31, -1.7, 127.0, 7.0, 24.0], device=P.dev)
     for dim in (320, 256, 64):
@@ -404,8 +417,8 @@ def check_layernorm(P, dt):
     P.impl.ln_param_reduce_batch(jobs)
     if P.dev.type == "cuda":
         torch.cuda.synchronize()
-    same = all(torch.equal(a[k_], b[k_]) for a, b in zip(imm, dfr) for k_ in ("dx", "dg", "db"))
-    res.append(("ln_bwd defer_reduce + ln_param_reduce_batch == immediate reduction", 0.0 if same else 1.0, 0.0))
+    res.append(("ln_bwd defer_reduce + ln_param_reduce_batch == immediate reduction",
+                same_or_err([a[k_] for a in imm for k_ in ("dx", "dg", "db")], [b[k_] for b in dfr for k_ in ("dx", "dg", "db")]), EXACT_TOL(P)))
     if hasattr(P.impl, "lib"):
         ok = all(P.impl.lib.svdx_ln_bwd_blocks(r, c) == K.ln_bwd_blocks(r, c) for r in (1, 9, 100, 777, 9001, 35840, 10 ** 6) for c in (64, 320, 640, 768, 1280))
         res.append(("svdx_ln_bwd_blocks == kernels.ln_bwd_blocks", 0.0 if ok else 1.0, 0.0))
