@@ -34,6 +34,87 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16, /opt/skills/guides/MI355X_MICR
 STEP_TFLOP_C2 = 24.80          # 2x fwd (10.707 T) + dW of the trainable set, 14x512x320, B=1
 
 
+class ClockSampler:
+    """Shader clock / socket power of the benched GPU while the timed region runs (box-to-box spread is +-5 %: a slow box shows as a
+    lower sustained sclk).  Reads the amdgpu sysfs nodes of the device (`pp_dpm_sclk`: the level marked `*`; hwmon `power1_average` /
+    `power1_input`, microwatts) from a background thread every 0.5 s; when sysfs has no such node, ONE `rocm-smi --showclocks
+    --showpower` call in the middle of the region."""
+
+    def __init__(self, index: int):
+        import glob
+        import threading
+        self.samples, self.power, self.source = [], [], None
+        self._stop = threading.Event()
+        # the box holds other GPUs (other tenants): find THIS device's node by its PCI address, not by card number
+        self.node = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cand = f"/sys/bus/pci/devices/{addr}/pp_dpm_sclk"
+            self.node = cand if os.path.exists(cand) else None
+            self.pci = addr
+        except Exception:  # noqa: BLE001
+            self.pci = None
+        self.pnode = None
+        if self.node:
+            hw = glob.glob(os.path.join(os.path.dirname(self.node), "hwmon", "hwmon*", "power1_average")) + \
+                 glob.glob(os.path.join(os.path.dirname(self.node), "hwmon", "hwmon*", "power1_input"))
+            self.pnode = hw[0] if hw else None
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _read_sysfs(self):
+        try:
+            for line in open(self.node):
+                if line.rstrip().endswith("*"):
+                    self.samples.append(float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()))
+                    self.source = "sysfs pp_dpm_sclk"
+            if self.pnode:
+                self.power.append(float(open(self.pnode).read()) / 1e6)
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _read_smi(self):
+        import re
+        import subprocess
+        try:
+            out = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+            m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+            if m:
+                self.samples.append(float(m.group(1)))
+                self.source = "rocm-smi --showclocks"
+            m = re.search(r"(?:Socket|Average) Graphics Package Power \(W\): ([0-9.]+)", out)
+            if m:
+                self.power.append(float(m.group(1)))
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _run(self):
+        if self.node:
+            while not self._stop.wait(0.5):
+                self._read_sysfs()
+        if not self.samples and not self._stop.wait(1.0):
+            self._read_smi()
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._t.join(timeout=25)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        out = {"sclk_mhz_median": v[len(v) // 2], "sclk_mhz_min": v[0], "sclk_mhz_max": v[-1], "samples": len(v), "source": self.source,
+               "pci": self.pci, "max_sclk_mhz": 2400}
+        if self.power:
+            w = sorted(self.power)
+            out["power_w_median"] = w[len(w) // 2]
+        return out
+
+
 def init_weights_(model: torch.nn.Module, seed: int) -> None:
     """Random init with O(1) activations (same law as oracle.unet.scaled_init_, drawn on device)."""
     g = torch.Generator(device=next(model.parameters()).device).manual_seed(seed)
@@ -176,9 +257,9 @@ def main():
     ap.add_argument("--grad-accum", type=int, default=1,
                     help="micro-batches per optimizer step (reference config 4 runs gradient_accumulation_steps = 2); gradients are "
                          "reduced over ranks on the last one only")
-    ap.add_argument("--overlap", default="buckets", choices=["buckets", "single", "vae"],
-                    help="N > 1, how the gradient sum over ranks is scheduled: `buckets` = one all-reduce per transformer block started "
-                         "during the backward sweep (default); `single` = ONE all-reduce of the flat buffer after the sweep; `vae` = that "
+    ap.add_argument("--overlap", default="single", choices=["buckets", "single", "vae"],
+                    help="N > 1, how the gradient sum over ranks is scheduled: `single` (default) = ONE all-reduce of the flat buffer after the sweep; "
+                         "`buckets` = one all-reduce per transformer block started during the backward sweep; `vae` = that "
                          "one all-reduce with the VAE encode of the NEXT micro-batch (train_svd.py:948) replayed beside it and AdamW after "
                          "the wait -- north_star's schedule; reported as a second field next to the UNet-only headline, with the part of "
                          "the collective that stayed exposed")
@@ -301,13 +382,18 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    sampler = ClockSampler(local_rank) if rank == 0 and os.environ.get("SVDX_NO_CLOCK_SAMPLER") != "1" else None
     t0 = time.perf_counter()
+    if sampler is not None:
+        sampler.__enter__()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.__exit__()
     if world > 1:
         te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -435,8 +521,24 @@ def main():
             Bq, Tq, HWq, Cq = a[16], a[17], a[18], a[19]
             band.append((e0, e1, 8.0 * Bq * Tq * HWq * Cq * Cq + 4.0 * Bq * Tq * HWq * Tq * Cq))
 
+        # the temporal self-attention OP (north_star's "temporal-attention kernel"; SURVEY 8d: LN + q/k/v + core + out-projection is the
+        # only definition under which an MFMA fraction means anything): every launch between the region marks of
+        # TemporalBasicTransformerBlock.fwd / .bwd, per block, bracketed by events
+        regions, open_ev = [], {}
+
+        def on_region(name, info, begin):
+            if begin:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                open_ev[name] = e0
+            else:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                regions.append((name, dict(info), open_ev.pop(name), e1))
+
         if rank == 0:
             k.gemm, k.gemm_tn = timed_gemm, timed_gemm_tn
+            trainer.rt.on_region = on_region
             if orig_tsa is not None:
                 k.tsa_fwd = timed_tsa
         try:
@@ -449,6 +551,7 @@ def main():
             torch.cuda.synchronize()
         finally:
             k.gemm, k.gemm_tn = orig, orig_tn
+            trainer.rt.on_region = None
             if rank == 0:
                 k.__dict__.pop("tsa_fwd", None)
         trainer.allreduce_grads()
@@ -487,12 +590,47 @@ def main():
                                      "of this command, tools/pmc_traffic.py; NOT a counter of this run)"
                 except Exception:  # noqa: BLE001
                     traffic = None
+            tsa_op = None
+            if regions:
+                lv = {}
+                for name, info, e0, e1 in regions:
+                    M_, C_, T_ = info["M"], info["C"], info["T"]
+                    fwd = name.endswith(".fwd")
+                    # fwd: q/k/v 6MC^2 + out 2MC^2 + core (QK^T, PV) 4MTC;  bwd: data-grads 8MC^2 + weight-grads 8MC^2 + core (S again, dP, dV, dQ, dK) 10MTC
+                    fl = (8.0 * M_ * C_ * C_ + 4.0 * M_ * T_ * C_) if fwd else (16.0 * M_ * C_ * C_ + 10.0 * M_ * T_ * C_)
+                    d = lv.setdefault((M_, C_), {"rows": M_, "channels": C_, "frames": T_, "fwd": [0, 0.0, 0.0], "bwd": [0, 0.0, 0.0]})
+                    a = d["fwd" if fwd else "bwd"]
+                    a[0] += 1
+                    a[1] += e0.elapsed_time(e1)
+                    a[2] += fl
+                tot = {"fwd": [0.0, 0.0], "bwd": [0.0, 0.0]}
+                levels = []
+                for key in sorted(lv, reverse=True):
+                    d = lv[key]
+                    row = {"rows": d["rows"], "channels": d["channels"], "frames": d["frames"]}
+                    for w in ("fwd", "bwd"):
+                        n, ms_, fl = d[w]
+                        tot[w][0] += ms_
+                        tot[w][1] += fl
+                        row[w] = {"blocks": n, "ms": ms_, "tflops": fl / (ms_ * 1e-3) / 1e12 if ms_ else None,
+                                  "frac_of_mfma_peak": fl / (ms_ * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if ms_ else None}
+                    levels.append(row)
+                allms, allfl = tot["fwd"][0] + tot["bwd"][0], tot["fwd"][1] + tot["bwd"][1]
+                tsa_op = {"what": "temporal self-attention op of every TemporalBasicTransformerBlock (norm1 -> q/k/v -> attention over frames -> "
+                                  "out-projection + residual; backward: both data-grads, both weight-grads, the core, norm1): algorithmic FLOPs / "
+                                  "summed duration of ALL launches between the region marks (events on the launch stream, one instrumented eager step)",
+                          "flops": "fwd 8MC^2 + 4MTC, bwd 16MC^2 + 10MTC", "levels": levels,
+                          "fwd_frac_of_mfma_peak": tot["fwd"][1] / (tot["fwd"][0] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if tot["fwd"][0] else None,
+                          "bwd_frac_of_mfma_peak": tot["bwd"][1] / (tot["bwd"][0] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if tot["bwd"][0] else None,
+                          "op_frac_of_mfma_peak": allfl / (allms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if allms else None,
+                          "ms_per_step": allms, "north_star_target": 0.40}
             roof = {"bound": "mfma", "kernel": "MFMA GEMM family (NT + implicit conv, TN weight-grad)", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "launches": len(recs),
                     "flops_per_step": fl, "kernel_ms_per_step": t_ms,
                     "band_kernels": ({"what": "fused temporal self-attention launches (their projections are not in the family above)", "launches": len(band), "flops_per_step": sum(f for _, _, f in band),
                                       "kernel_ms_per_step": sum(a.elapsed_time(b) for a, b, _ in band)} if band else None),
-                    "algorithmic_bytes_per_launch": sum(b for _, _, _, b in recs_bytes) / max(len(recs_bytes), 1)}
+                    "algorithmic_bytes_per_launch": sum(b for _, _, _, b in recs_bytes) / max(len(recs_bytes), 1),
+                    "temporal_self_attention": tsa_op}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -520,7 +658,7 @@ def main():
                                           "one collective after backward, under the next clip's VAE encode" if args.overlap == "vae" else
                                           "per-transformer-block buckets overlapped with the backward sweep"),
                        "ranks_seen": ranks_seen, "allreduce_ms": allreduce_ms, "allreduce_bytes": trainer.n_total * 4,
-                       "exec": exec_mode, "gemm_tuning_sweeps": tune_sweeps,
+                       "exec": exec_mode, "gemm_tuning_sweeps": tune_sweeps, "gpu_clock": sampler.summary() if sampler is not None else None,
                        "gemm_variant": args.gemm_variant, "loss": loss, "loss_scale": state[1], "opt_steps": state[0],
                        "step_tflops_per_gpu": (STEP_TFLOP_C2 * args.grad_accum / (ms * 1e-3) if full else None),
                        "step_frac_of_mfma_peak": (STEP_TFLOP_C2 * args.grad_accum / (ms * 1e-3) / MFMA_PEAK_TFLOPS if full else None)},

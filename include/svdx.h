@@ -60,6 +60,9 @@ typedef struct svdx_gather {
     int lda;        /* row stride of the source tensor in elements                         */
 } svdx_gather;
 
+/* ABI revision of this header: bumped whenever an entry changes its argument list or meaning (100 = rounds 1-3; 400 = round 4).
+ * svdx_version() returns the value the library was built with; the ctypes binding refuses a library whose number differs. */
+#define SVDX_VERSION 400
 int         svdx_version(void);
 int         svdx_last_error(char* buf, size_t n);
 /* 1 when the binary was built for gfx950 and a device is usable */
@@ -70,13 +73,12 @@ int         svdx_device_ok(void);
  * g(m) = rv_mod ? m % rv_mod : m / rv_rows_per_group.   B is [N,K] row-major (ldb).
  * out_mode ACT: C[m*ldc+n] = (dtype)v ; F32: float store ; F32_ATOMIC: atomicAdd (split_k >= 1).
  * epilogue (variant >= 2): SVDX_EPI_GEGLU_FWD / _BWD fuse diffusers' GEGLU (attention.py) into the projection GEMMs, aux_dim = F.
- * variant = output tile of the launch (rows x columns, LDS stages of the K-loop, waves):  0 / 1 the plain 128x128 kernels (1: operands
- * beyond the 2 GiB buffer reach);  4 heuristic among 6 / 7 / 8 = 160x160 / 128x160 / 128x128, two stages, four waves, two workgroups per CU;
+ * variant = output tile of the launch (rows x columns, LDS stages of the K-loop, waves):  0 / 1 the plain 128x128 kernel with 64-bit addressing
+ * (operands beyond the 2 GiB buffer reach);  4 heuristic among 6 / 7 / 8 = 160x160 / 128x160 / 128x128, two stages, four waves, two workgroups per CU;
  * ring-staged, one workgroup per CU:  16 / 17 / 18 = 256x160 / 256x128 / 256x256 (eight waves; 3, 3, 2 stages),  20 / 21 = 128x160 / 128x128
  * (four waves, 4 stages),  23 / 22 = 192x160 / 192x128 (eight waves, 3 stages),  25 / 24 = 96x160 / 96x128 (four waves, 4 stages);
  * 26 = 192x128, eight waves, TWO stages (80 KB of LDS: two workgroups per CU -- the tile under the GEGLU epilogues).
  * 28 / 27 = 128x160 / 128x128, eight waves, two stages (72 / 64 KB: two workgroups per CU; tuner candidates).
- * 29 = 192x320, eight waves, two stages (128 KB, one per CU; N % 320 == 0, else the 192-row ring tiles; tuner candidate).
  * A 160-wide variant takes its 128-wide sibling when N % 160 != 0 or under the GEGLU-forward epilogue; 18 needs N % 256 == 0 (else 17).
  * The host side picks per problem (svd_xtend_amd/ops.py: choose_cfg). */
 int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -84,6 +86,17 @@ int svdx_gemm(const void* A, const void* B, void* C, int M, int N, int K, int ld
               const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
               int out_mode, float alpha, int split_k, int variant, int epilogue, const void* aux_in, void* aux_out, int aux_dim,
               int dtype, void* stream);
+
+/* svdx_gemm with activation output, PLUS the GroupNorm statistics of the tensor it writes: gn_stats (the opaque buffer of svdx_gn_stats,
+ * zeroed by the caller) receives sum / sum of squares of the ROUNDED results per (sample, group), sample = m / gn_rows, group =
+ * n / gn_cg (M = whole samples, N = whole groups; G = N / gn_cg, n_s = M / gn_rows) -- the svdx_gn_stats pass over C that the consuming
+ * ResnetBlock2D / TemporalResnetBlock / TransformerSpatioTemporalModel norm would need is gone.  Same fixed-point
+ * integer sums as svdx_gn_stats: run-to-run identical.  Needs a variant-4 tile whose width divides N (the statistics are taken in the
+ * coalesced store loop), ldc % 8 == 0, a tile that touches <= 8 samples and <= 36 groups; no split-K, no fused epilogue. */
+int svdx_gemm_gn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                 const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
+                 const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
+                 float alpha, int variant, float* gn_stats, int gn_rows, int gn_cg, int dtype, void* stream);
 
 /* Same GEMM with a second, plain operand pair reduced into the same accumulators before the epilogue:
  *   C = alpha * (gather(A) B^T + A2 B2^T) (+ bias + rowvec + res),  A2 [M, K2] row pitch lda2, B2 [N, K2] row pitch ldb2.
@@ -108,8 +121,7 @@ int svdx_gemm_dual(const void* A, const void* B, void* C, int M, int N, int K, i
  * the rows in order -- a fixed summation order, so the bias gradient is run-to-run identical.  With split_k > 1 a_colsum needs the
  * slab mode.  stages selects the kernel: 0 / 2 = four waves, 128 x 128 output tiles, two LDS stages (two workgroups per CU, drained
  * every K-step); 3 / 4 = the same tile with 2 / 3 row tiles in flight across the barrier (one workgroup per CU); 18 = eight waves,
- * 256 x 256 output tiles, one workgroup per CU (outputs of >= 1024 x 512 that 180-256 such tiles x row slices cover);
- * 12 / 13 / 21 = eight waves, 128 x 256 / 128 x 384 / 256 x 128 output tiles (the 320-wide gradients of the 64x40 level; tuner candidates). */
+ * 256 x 256 output tiles, one workgroup per CU (outputs of >= 1024 x 512 that 180-256 such tiles x row slices cover). */
 int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
                  float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, int dtype, void* stream);
 
@@ -120,6 +132,13 @@ int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, in
 int svdx_gemm_finalize(const float* acc, int nsplit, int64_t slab_stride, void* C, int c_is_f32_accumulate, int M, int N, int ldc,
                        const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
                        const void* res, int ldres, const float* colsum_slabs, float* colsum_out, int colsum_n, int dtype, void* stream);
+
+/* svdx_gemm_finalize with activation output, PLUS the GroupNorm statistics of the tensor it writes (see svdx_gemm_gn; the split-K
+ * convolutions of the 16x10 / 8x5 levels end here).  N * gn_rows >= 1024 (a block's 1024 consecutive elements touch <= 2 samples),
+ * N / gn_cg <= 64 groups. */
+int svdx_gemm_finalize_gn(const float* acc, int nsplit, int64_t slab_stride, void* C, int M, int N, int ldc, const float* bias,
+                          const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod, const void* res, int ldres,
+                          float* gn_stats, int gn_rows, int gn_cg, int dtype, void* stream);
 
 /* Skinny linears (M <= 64): time/added-id embedding MLPs, time_emb_proj, time_pos_embed, the KV-length-1
  * cross-attention.  X, Y float; W in dtype.
@@ -147,7 +166,7 @@ int svdx_small_linear_batch(const svdx_lin_job* jobs, int n_jobs, int M, int tra
 typedef struct svdx_outer_job {
     const float* dY;   /* [M, N] */
     const float* X;    /* [M, K]; NULL with K = 1: a column of ones (bias gradient) */
-    float* dW;         /* [N, K], accumulated into */
+    float* dW;         /* [N, K], accumulated into WITHOUT atomics: the jobs of one call run concurrently, so their dW must be distinct */
     int N, K;
     float scale;
     int reserved;

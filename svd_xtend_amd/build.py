@@ -22,7 +22,7 @@ def _stale(out: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "svdx.h")]
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(HERE, "..", "include", "svdx.h")]
     objs = []
 
     def compile_one(src):

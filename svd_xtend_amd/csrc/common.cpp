@@ -14,7 +14,7 @@ void svdx_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int svdx_version(void) { return 100; }
+extern "C" int svdx_version(void) { return SVDX_VERSION; }
 
 extern "C" int svdx_last_error(char* buf, size_t n) {
     if (!buf || n == 0) return -1;

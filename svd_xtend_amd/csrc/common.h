@@ -122,6 +122,17 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return g.cdf + g.pdf_x;
 }
 
+// Fixed-point scales of the GroupNorm statistics (see the banner in norm.hip; shared with the GEMM epilogue that produces them):
+// mode 0 = (sum, sum of squares) of the activations, mode 1 = the two backward sums; cnt = rows x channels of one group.
+__host__ __device__ __forceinline__ void gn_fixed_scales(long cnt, int mode, int& k0, int& k1) {
+    int lg = 0;
+    while ((1L << lg) < cnt) ++lg;
+    const int b0 = mode == 0 ? 16 : 18, b1 = mode == 0 ? 24 : 26;
+    k0 = 62 - b0 - lg; k1 = 62 - b1 - lg;
+    k0 = k0 < 0 ? 0 : (k0 > 40 ? 40 : k0);
+    k1 = k1 < 0 ? 0 : (k1 > 40 ? 40 : k1);
+}
+
 #define DISPATCH_DTYPE(dtype, ...)                                   \
     if ((dtype) == SVDX_F16) { typedef f16 T; __VA_ARGS__; }         \
     else if ((dtype) == SVDX_BF16) { typedef bf16 T; __VA_ARGS__; }  \

@@ -8,9 +8,9 @@
 // rows of that tile are fetched from the tap's shifted pixel (or from a zero page outside the image).
 //
 // Kernels in this file (variant argument of svdx_gemm):
-//   variant 0  gemm_kernel<GLDS=false>: 128x128x64, global -> VGPR -> ds_write_b128 staging (reference structure)
-//   variant 1  gemm_kernel<GLDS=true> : same with global_load_lds_dwordx4 (LDS-DMA), swizzle on the per-lane SOURCE address;
-//              also the fallback when a buffer exceeds the 2 GiB range of variant 4's 32-bit offsets
+//   variant 0 / 1  gemm_kernel: 128x128x64, global_load_lds_dwordx4 (LDS-DMA) with 64-bit pointers, swizzle on the per-lane SOURCE
+//              address -- the fallback when a buffer exceeds the 2 GiB range of variant 4's 32-bit offsets (round 1's register-staged
+//              variant 0 was removed in round 4: it now runs this kernel too)
 //   variant 4  gemm_v4_kernel         : production (see its banner): 128x160 tiles, lean buffer_load...lds loop, coalesced epilogue
 //   gemm_tn_kernel                    : weight gradients straight from row-major dY / X via ds_read_b64_tr_b16
 // Common: 256 threads = 4 waves (2x2); LDS rows of 128 B with the 16-byte chunk index XOR-swizzled by (row & 7) so the
@@ -38,7 +38,12 @@ struct GemmParams {
     // variant 4, second operand pair: acc += A2 [M, K2] B2^T [N, K2] after the main reduction (the LoRA term of a projection)
     const void* A2; const void* B2; int K2, lda2, ldb2, a2_bytes, b2_bytes;
     int a2_seg;   // > 0: output columns [j * a2_seg, (j + 1) * a2_seg) read A2 columns [j * K2, (j + 1) * K2) (fused q/k/v adapters)
+    // variant 4, activation output: GroupNorm statistics of the tensor this launch writes (sum, sum of squares per (sample, group) of the
+    // ROUNDED values, in the fixed-point replica slots svdx_gn_apply reads) -- the norm that consumes C needs no pass of its own over it
+    unsigned long long* gn_stats; int gn_rows, gn_cg; float gn_m0, gn_m1;
 };
+constexpr int GN_MAX_S = 8, GN_MAX_G = 36;               // samples / groups one output tile may touch (else the host runs svdx_gn_stats)
+constexpr int GN_LDS = GN_MAX_S * GN_MAX_G * 2 * 8;
 
 struct RowInfo { int a, b, base; };   // per gathered A row (meaning depends on gather mode)
 
@@ -187,7 +192,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
 }
 
-template <typename T, bool GLDS>
+template <typename T>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
@@ -246,24 +251,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
             pb[i] = b_ptr[i] + k0;
         }
     };
-#define SVDX_LOAD_REGS(kt_)                                                               \
-    uint4 ra[4], rb[4];                                                                   \
-    {                                                                                     \
-        const T* pa[4]; const T* pb[4];                                                   \
-        stage_ptrs((kt_), pa, pb);                                                        \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(pa[i]); \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const uint4*>(pb[i]); \
-    }
-#define SVDX_WRITE_LDS(stage_)                                                            \
-    {                                                                                     \
-        char* As_ = smem + (stage_) * STAGE_BYTES;                                        \
-        char* Bs_ = As_ + BM * BK * 2;                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                   \
-            const int off = (i * 32 + ld_row) * 128 + pc * 16;                            \
-            *reinterpret_cast<uint4*>(As_ + off) = ra[i];                                 \
-            *reinterpret_cast<uint4*>(Bs_ + off) = rb[i];                                 \
-        }                                                                                 \
-    }
     auto issue_glds = [&](int kt, int stage) __attribute__((always_inline)) {
         const T* pa[4]; const T* pb[4];
         stage_ptrs(kt, pa, pb);
@@ -300,39 +287,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
         }
     };
 
-    if (GLDS) {
-        issue_glds(kt_begin, 0);
+    issue_glds(kt_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
+        issue_glds(kt + 1, cur ^ 1);
+        compute(cur);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int cur = 0;
-        for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
-            issue_glds(kt + 1, cur ^ 1);
-            compute(cur);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            cur ^= 1;
-        }
-        compute(cur);
-        __syncthreads();
-    } else {
-        {
-            SVDX_LOAD_REGS(kt_begin);
-            SVDX_WRITE_LDS(0);
-        }
-        __syncthreads();
-        int cur = 0;
-        for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
-            SVDX_LOAD_REGS(kt + 1);     // global loads in flight during the MFMA phase
-            compute(cur);
-            SVDX_WRITE_LDS(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
-        }
-        compute(cur);
-        __syncthreads();
+        cur ^= 1;
     }
-#undef SVDX_LOAD_REGS
-#undef SVDX_WRITE_LDS
+    compute(cur);
+    __syncthreads();
 
     gemm_epilogue<T>(p, acc, smem, m0, n0, z, tid, lane, wm, wn);
 }
@@ -946,6 +913,10 @@ __global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
         (n0 + BN3 <= p.N || p.epi == SVDX_EPI_GEGLU_FWD)) {
         constexpr int PITCH = (BN3 + 8) * 2;              // bytes per staged row (multiple of 16)
         __syncthreads();
+        if (p.gn_stats) {                                  // the statistics table sits behind the parked tile; every wave has left the K-loop
+            unsigned long long* gacc = reinterpret_cast<unsigned long long*>(smem + ((BM4 * PITCH + 15) & ~15));
+            for (int i = tid; i < GN_MAX_S * GN_MAX_G * 2; i += NT) gacc[i] = 0ull;
+        }
         {
             const bool lead0 = (z == 0);
             const int nb0 = n0 + wn * WN3 + fg * 4;
@@ -1029,6 +1000,70 @@ __global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
         }
         T* Ct2 = reinterpret_cast<T*>(p.C);
         const T* R2 = (z == 0) ? reinterpret_cast<const T*>(p.res) : nullptr;
+        if (p.gn_stats) {
+            // Same stores, with every thread on ONE fixed 16-byte column chunk (threads beyond the last whole row of a pass idle) so that the
+            // statistics of its 8 channels stay in registers while it walks down the tile's rows.  Rows ascend, so the GroupNorm sample
+            // (frame or clip) of a thread changes monotonically: on a change, and at the end, the 8 channel sums are merged into their
+            // groups and added to the tile's [sample][group] table in LDS as 64-bit fixed-point integers (integer addition is
+            // associative: the statistics do not depend on the order of the atomics -- run-to-run identical, like svdx_gn_stats);
+            // the table's nonzero entries then go to the replica slots in HBM, one atomic each.
+            constexpr int RPS = NT / CPR;
+            unsigned long long* gacc = reinterpret_cast<unsigned long long*>(smem + ((BM4 * PITCH + 15) & ~15));
+            const int c = tid % CPR;
+            const int s_first = m0 / p.gn_rows, g_first = n0 / p.gn_cg;
+            float a0[8], a1[8];
+            int cur_s = -1;
+            auto flush = [&](int sl) __attribute__((always_inline)) {
+                int cur = (n0 + c * 8) / p.gn_cg;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int g = (n0 + c * 8 + e) / p.gn_cg;
+                    if (g != cur) {
+                        atomicAdd(&gacc[(sl * GN_MAX_G + cur - g_first) * 2], (unsigned long long)__float2ll_rn(s0 * p.gn_m0));
+                        atomicAdd(&gacc[(sl * GN_MAX_G + cur - g_first) * 2 + 1], (unsigned long long)__float2ll_rn(s1 * p.gn_m1));
+                        cur = g; s0 = 0.f; s1 = 0.f;
+                    }
+                    s0 += a0[e]; s1 += a1[e];
+                }
+                atomicAdd(&gacc[(sl * GN_MAX_G + cur - g_first) * 2], (unsigned long long)__float2ll_rn(s0 * p.gn_m0));
+                atomicAdd(&gacc[(sl * GN_MAX_G + cur - g_first) * 2 + 1], (unsigned long long)__float2ll_rn(s1 * p.gn_m1));
+            };
+            if (tid < RPS * CPR) {
+                for (int row = tid / CPR; row < BM4; row += RPS) {
+                    const int m = m0 + row;
+                    if (m >= p.M) break;
+                    Vec8<T> o8 = *reinterpret_cast<const Vec8<T>*>(smem + row * PITCH + c * 16);
+                    const size_t co = (size_t)m * p.ldc + n0 + c * 8;
+                    if (R2) {
+                        const Vec8<T> r8 = *reinterpret_cast<const Vec8<T>*>(R2 + (size_t)m * p.ldres + n0 + c * 8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o8.v[e] = from_f<T>(to_f<T>(o8.v[e]) + to_f<T>(r8.v[e]));
+                    }
+                    *reinterpret_cast<Vec8<T>*>(Ct2 + co) = o8;
+                    const int sl = m / p.gn_rows - s_first;
+                    if (sl != cur_s) {
+                        if (cur_s >= 0) flush(cur_s);
+                        cur_s = sl;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float v = to_f<T>(o8.v[e]); a0[e] += v; a1[e] += v * v; }
+                }
+                if (cur_s >= 0) flush(cur_s);
+            }
+            __syncthreads();
+            const int ns_t = (min(m0 + BM4, p.M) - 1) / p.gn_rows - s_first + 1, ng_t = (min(n0 + BN3, p.N) - 1) / p.gn_cg - g_first + 1;
+            const int n_s = p.M / p.gn_rows, G = p.N / p.gn_cg;
+            unsigned long long* out = p.gn_stats + (size_t)((pid_m + pid_n) % SVDX_GN_REPLICAS) * n_s * G * 2;
+            for (int i = tid; i < ns_t * ng_t * 2; i += NT) {
+                const int w = i & 1, gl = (i >> 1) % ng_t, sl = (i >> 1) / ng_t;
+                const unsigned long long v = gacc[(sl * GN_MAX_G + gl) * 2 + w];
+                if (v) atomicAdd(out + ((size_t)(s_first + sl) * G + g_first + gl) * 2 + w, v);
+            }
+            return;
+        }
 #pragma unroll 2
         for (int id = tid; id < BM4 * CPR; id += NT) {
             const int row = id / CPR, c = id - row * CPR;
@@ -1261,12 +1296,18 @@ __global__ __launch_bounds__(256) void small_linear_nn_batch(const LinPack pk, i
 }
 
 // split-K epilogue: v = sum over `nsplit` float slabs (+ bias + rowvec + res);  C = (dtype)v, or Cf += v (weight grads)
-template <typename T>
+// GN: also the GroupNorm statistics of the activation tensor it writes (see svdx_gemm_gn): a block's 256 pieces of 4 consecutive
+// channels are 1024 consecutive elements of C -- at most two samples -- whose (sample, group) sums meet in a small LDS table of 64-bit
+// fixed-point integers before they go to the replica slots, one atomic per touched entry.
+struct FinGn { unsigned long long* stats; int rows, cg; float m0, m1; };
+constexpr int FIN_GN_G = 64;
+template <typename T, bool GN>
 __global__ __launch_bounds__(256) void gemm_finalize_kernel(const float* __restrict__ acc, int nsplit, long slab_stride, T* __restrict__ C,
                                                             float* __restrict__ Cf, int f32_store, int M, int N, int ldc,
                                                             const float* __restrict__ bias, const float* __restrict__ rowvec,
                                                             int rv_ld, int rv_rpg, int rv_mod, const T* __restrict__ res, int ldres,
-                                                            const float* __restrict__ cs_slabs, float* cs_out, int cs_n) {
+                                                            const float* __restrict__ cs_slabs, float* cs_out, int cs_n, FinGn gn) {
+    __shared__ unsigned long long gacc[GN ? 2 * FIN_GN_G * 2 : 1];
     if (cs_slabs) {                            // bias gradient: the row slices' column sums, added in slice order (spread over the grid)
         for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < cs_n; n += gridDim.x * blockDim.x) {
             float t = 0.f;
@@ -1275,37 +1316,74 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const float* __restr
         }
     }
     const long total4 = (long)M * N / 4;       // N % 4 == 0
-    for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
-        const long i = i4 * 4;
-        const int m = (int)(i / N), n = (int)(i - (long)m * N);
-        f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(acc + i));       // slabs: written once, read once
-        for (int z = 1; z < nsplit; ++z) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(acc + (size_t)z * slab_stride + i));
-        if (bias) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bias[n + e];
+    for (long b4 = (long)blockIdx.x * blockDim.x; b4 < total4; b4 += (long)gridDim.x * blockDim.x) {
+        const long i4 = b4 + threadIdx.x;
+        if (GN) {
+            for (int t = threadIdx.x; t < 2 * FIN_GN_G * 2; t += 256) gacc[t] = 0ull;
+            __syncthreads();
         }
-        if (rowvec) {
-            const float* rv = rowvec + (size_t)(rv_mod ? m % rv_mod : m / rv_rpg) * rv_ld + n;
+        if (i4 < total4) {
+            const long i = i4 * 4;
+            const int m = (int)(i / N), n = (int)(i - (long)m * N);
+            f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(acc + i));       // slabs: written once, read once
+            for (int z = 1; z < nsplit; ++z) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(acc + (size_t)z * slab_stride + i));
+            if (bias) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += rv[e];
-        }
-        if (res) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += to_f<T>(res[(size_t)m * ldres + n + e]);
-        }
-        if (Cf) {
-            float* o = Cf + (size_t)m * ldc + n;
-            if (f32_store) {             // a weight gradient: next read by the optimizer, a whole backward sweep later
-                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o));
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += v[e];
+                for (int e = 0; e < 4; ++e) v[e] += bias[n + e];
             }
-        } else {
-            Vec4<T> o;
+            if (rowvec) {
+                const float* rv = rowvec + (size_t)(rv_mod ? m % rv_mod : m / rv_rpg) * rv_ld + n;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(v[e]);
-            *reinterpret_cast<Vec4<T>*>(C + (size_t)m * ldc + n) = o;
+                for (int e = 0; e < 4; ++e) v[e] += rv[e];
+            }
+            if (res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += to_f<T>(res[(size_t)m * ldres + n + e]);
+            }
+            if (Cf) {
+                float* o = Cf + (size_t)m * ldc + n;
+                if (f32_store) {             // a weight gradient: next read by the optimizer, a whole backward sweep later
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += v[e];
+                }
+            } else {
+                Vec4<T> o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.v[e] = from_f<T>(v[e]);
+                *reinterpret_cast<Vec4<T>*>(C + (size_t)m * ldc + n) = o;
+                if (GN) {
+                    const int sl = m / gn.rows - (int)((b4 * 4) / N) / gn.rows;      // 0 or 1 (host: N * rows >= 1024)
+                    int cur = n / gn.cg;
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int g = (n + e) / gn.cg;
+                        if (g != cur) {
+                            atomicAdd(&gacc[(sl * FIN_GN_G + cur) * 2], (unsigned long long)__float2ll_rn(s0 * gn.m0));
+                            atomicAdd(&gacc[(sl * FIN_GN_G + cur) * 2 + 1], (unsigned long long)__float2ll_rn(s1 * gn.m1));
+                            cur = g; s0 = 0.f; s1 = 0.f;
+                        }
+                        const float x = to_f<T>(o.v[e]);
+                        s0 += x; s1 += x * x;
+                    }
+                    atomicAdd(&gacc[(sl * FIN_GN_G + cur) * 2], (unsigned long long)__float2ll_rn(s0 * gn.m0));
+                    atomicAdd(&gacc[(sl * FIN_GN_G + cur) * 2 + 1], (unsigned long long)__float2ll_rn(s1 * gn.m1));
+                }
+            }
+        }
+        if (GN) {
+            __syncthreads();
+            const int G = N / gn.cg, n_s = M / gn.rows;
+            const int s_first = (int)((b4 * 4) / N) / gn.rows;              // sample of the block's first element
+            unsigned long long* out = gn.stats + (size_t)(blockIdx.x % SVDX_GN_REPLICAS) * n_s * G * 2;
+            for (int t = threadIdx.x; t < 2 * G * 2; t += 256) {
+                const int w = t & 1, g = (t >> 1) % G, s2 = (t >> 1) / G;
+                const unsigned long long a = gacc[(s2 * FIN_GN_G + g) * 2 + w];
+                if (a && s_first + s2 < n_s) atomicAdd(out + ((size_t)(s_first + s2) * G + g) * 2 + w, a);
+            }
+            __syncthreads();
         }
     }
 }
@@ -1347,16 +1425,16 @@ __global__ void timestep_embed_kernel(const float* t, float* out, int n, int dim
     out[(size_t)i * dim + half + j] = sinf(a);
 }
 
-template <typename T, bool GLDS>
+template <typename T>
 int launch_gemm(const GemmParams& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, GLDS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
         attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
-    hipLaunchKernelGGL((gemm_kernel<T, GLDS>), grid, dim3(NTHREADS), 2 * STAGE_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_kernel<T>), grid, dim3(NTHREADS), 2 * STAGE_BYTES, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm");
     return 0;
 }
@@ -1364,7 +1442,7 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
 template <typename T, int NB, int MB, int WGM = 2, int NSTG = 2>
 int launch_gemm_v4(GemmParams p, hipStream_t st) {
     constexpr int BMT = 16 * MB * WGM, BNT = 32 * NB;
-    constexpr int LDS_STG = NSTG * (BMT + BNT) * BK * 2, LDS_EPI = BMT * (BNT + 8) * 2;      // K-loop stages | the rounded output tile parked for the coalesced stores
+    constexpr int LDS_STG = NSTG * (BMT + BNT) * BK * 2, LDS_EPI = ((BMT * (BNT + 8) * 2 + 15) & ~15) + GN_LDS;      // K-loop stages | the rounded output tile parked for the coalesced stores (+ the GroupNorm statistics table behind it)
     constexpr int LDS = LDS_STG > LDS_EPI ? LDS_STG : LDS_EPI;
     static_assert(LDS <= 160 * 1024, "stages (and the epilogue tile parked in them) must fit the 160 KiB LDS");
     constexpr bool HAS_DUAL = WGM == 2 && NSTG == 2;            // the LoRA second-operand loop is only instantiated for the round-1 tiles
@@ -1376,6 +1454,12 @@ int launch_gemm_v4(GemmParams p, hipStream_t st) {
         attr_set = true;
     }
     if (p.K2 > 0 && !HAS_DUAL) { svdx_set_error("svdx_gemm_dual: this tile variant has no second-operand loop"); return -2; }
+    if (p.gn_stats) {
+        // the statistics are taken in the coalesced store loop, which handles whole column tiles of 16-byte-aligned rows only
+        const bool ok = p.N % BNT == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && (!p.res || (p.ldres % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
+                        (BMT - 1) / p.gn_rows + 2 <= GN_MAX_S && (BNT - 1) / p.gn_cg + 2 <= GN_MAX_G;
+        if (!ok) { svdx_set_error("svdx_gemm_gn: N=%d / ldc=%d / rows=%d / cg=%d do not fit the %dx%d tile's statistics path", p.N, p.ldc, p.gn_rows, p.gn_cg, BMT, BNT); return -2; }
+    }
     p.tiles_m = cdiv(p.M, BMT);
     p.tiles_n = p.epi == SVDX_EPI_GEGLU_FWD ? cdiv(p.aux_dim, 16 * NB) : cdiv(p.N, BNT);
     p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 15) == 0));
@@ -1444,8 +1528,8 @@ int launch_gemm_tn8(GemmParams p, hipStream_t st) {
 extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
                             float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, int dtype, void* stream) {
     SVDX_CHECK_ARG(A && B && C && zero_page && R > 0 && N > 0 && K > 0, "svdx_gemm_tn: bad args");
-    SVDX_CHECK_ARG(stages == 0 || (stages >= 2 && stages <= 4) || stages == 18 || stages == 12 || stages == 13 || stages == 21,
-                   "svdx_gemm_tn: stages=%d (0 = default, 2..4 stages of the 128x128 tile, 18 / 12 / 13 / 21 = the 256x256 / 128x256 / 128x384 / 256x128 eight-wave tiles)", stages);
+    SVDX_CHECK_ARG(stages == 0 || (stages >= 2 && stages <= 4) || stages == 18,
+                   "svdx_gemm_tn: stages=%d (0 = default, 2..4 stages of the 128x128 tile, 18 = the 256x256 eight-wave tile)", stages);
     // the unsplit / ADD modes read-modify-write a_colsum from every z slice: one slice only (SVDX_OUT_F32_SLAB keeps a row per slice)
     SVDX_CHECK_ARG(!a_colsum || split_k == 1 || out_mode == SVDX_OUT_F32_SLAB, "svdx_gemm_tn: a_colsum with split_k > 1 needs slab output");
     SVDX_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
@@ -1459,16 +1543,12 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
     p.bias = nullptr; p.rowvec = nullptr; p.rv_ld = 0; p.rv_rpg = 0; p.rv_mod = 0; p.res = nullptr; p.ldres = 0;
     p.g = svdx_gather{}; p.zero_page = zero_page; p.out_mode = out_mode; p.alpha = 1.f; p.split_k = split_k;
     p.epi = 0; p.aux_in = nullptr; p.aux_out = nullptr; p.aux_dim = 0; p.a_bytes = 0; p.b_bytes = 0; p.a_colsum = a_colsum;
+    p.gn_stats = nullptr; p.gn_rows = p.gn_cg = 0; p.gn_m0 = p.gn_m1 = 0.f;
     p.tiles_m = cdiv(N, BM); p.tiles_n = cdiv(K, BN);
     p.vec_ok = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) && (K % 8 == 0);
     p.slab_stride = (long)N * ldc;
     DISPATCH_DTYPE(dtype, {
         if (stages == 18) return launch_gemm_tn8<T, 2, 2, 2>(p, (hipStream_t)stream);
-        // eight-wave tiles for the 320-wide gradients of the 64x40 level (a 128x384 tile holds all 320 columns: 80 useful flop per staged
-        // byte where three 128x128 tiles have 53); tuner candidates (ops.gemm_tn_acc), not yet timed on hardware
-        if (stages == 12) return launch_gemm_tn8<T, 1, 2, 2>(p, (hipStream_t)stream);
-        if (stages == 13) return launch_gemm_tn8<T, 1, 3, 2>(p, (hipStream_t)stream);
-        if (stages == 21) return launch_gemm_tn8<T, 2, 1, 2>(p, (hipStream_t)stream);
         if (stages == 3) return launch_gemm_tn<T, 3>(p, (hipStream_t)stream);
         if (stages == 4) return launch_gemm_tn<T, 4>(p, (hipStream_t)stream);
         return launch_gemm_tn<T, 2>(p, (hipStream_t)stream);
@@ -1479,8 +1559,15 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
                       const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
                       const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
                       int out_mode, float alpha, int split_k, int variant, int epilogue, const void* aux_in, void* aux_out,
-                      int aux_dim, const void* A2, const void* B2, int K2, int lda2, int ldb2, int a2_seg, int dtype, void* stream) {
+                      int aux_dim, const void* A2, const void* B2, int K2, int lda2, int ldb2, int a2_seg, float* gn_stats, int gn_rows,
+                      int gn_cg, int dtype, void* stream) {
     SVDX_CHECK_ARG(A && B && C, "svdx_gemm: null operand");
+    if (gn_stats) {
+        SVDX_CHECK_ARG(variant >= 2 && out_mode == SVDX_OUT_ACT && split_k == 1 && epilogue == SVDX_EPI_NONE && K2 <= 0,
+                       "svdx_gemm_gn: statistics ride on an unsplit variant-4 launch with activation output and no fused epilogue");
+        SVDX_CHECK_ARG(gn_rows > 0 && gn_cg > 0 && M % gn_rows == 0 && N % gn_cg == 0 && ((uintptr_t)gn_stats & 7) == 0,
+                       "svdx_gemm_gn: M=%d must be whole samples of %d rows, N=%d whole groups of %d channels", M, gn_rows, N, gn_cg);
+    }
     if (K2 > 0) {
         SVDX_CHECK_ARG(A2 && B2 && K2 % BK == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && lda2 >= K2 && ldb2 >= K2 &&
                            (((uintptr_t)A2 | (uintptr_t)B2) & 15) == 0, "svdx_gemm_dual: second operand pair misaligned (K2=%d)", K2);
@@ -1512,6 +1599,12 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
     p.out_mode = out_mode; p.alpha = alpha; p.split_k = split_k; p.slab_stride = (long)M * ldc;
     p.epi = epilogue; p.aux_in = aux_in; p.aux_out = aux_out; p.aux_dim = aux_dim; p.a_colsum = nullptr;
     p.A2 = A2; p.B2 = B2; p.K2 = K2 > 0 ? K2 : 0; p.lda2 = lda2; p.ldb2 = ldb2; p.a2_bytes = p.b2_bytes = 0; p.a2_seg = K2 > 0 ? a2_seg : 0;
+    p.gn_stats = reinterpret_cast<unsigned long long*>(gn_stats); p.gn_rows = gn_rows; p.gn_cg = gn_cg; p.gn_m0 = p.gn_m1 = 0.f;
+    if (gn_stats) {
+        int k0, k1;
+        gn_fixed_scales((long)gn_rows * gn_cg, 0, k0, k1);
+        p.gn_m0 = exp2f((float)k0); p.gn_m1 = exp2f((float)k1);
+    }
     if (gather && gather->mode != SVDX_GATHER_PLAIN) {
         p.g = *gather;
         SVDX_CHECK_ARG(p.g.cin % BK == 0, "svdx_gemm: gather cin=%d must be a multiple of %d", p.g.cin, BK);
@@ -1581,17 +1674,12 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
                 //   25:  96x160, 4 stages, four waves    24:  96x128, 4 stages, four waves   (M = 2240, N = 1280, short K: 240 tiles, not 180)
                 //   26: 192x128, TWO stages, eight waves: 80 KB of LDS and 114 VGPRs, so TWO workgroups share a CU -- the tile under the GEGLU
                 //       epilogues, where main loop, GELU polynomial and 275-366 MB of stores run one after the other inside a workgroup
-                //   29: 192x320, two stages, eight waves, one per CU (128 KB): the whole width of an N = 320 output in one tile -- 120 flop per staged
-                //       byte where 160x160 has 80 (the K-loop is bound by the ~24 B/clk a CU pulls into LDS: profiles/r1_gemm_ingest_probe.txt), and
-                //       M = 35840 is 187 tiles in ONE round on 256 CUs; tuner candidate
                 //   28: 128x160, 27: 128x128, TWO stages, eight waves (72 / 64 KB of LDS: two workgroups per CU): candidates of the in-situ
                 //       tuner for the short-K linears, not yet in the cost model (no measured rate)
                 // A 160-wide request on an N that 160 does not divide (or with the GEGLU-forward epilogue) takes the 128-wide sibling;
                 // 256-wide tiles need N % 256 == 0 (their GEGLU epilogues have no partial column tile).
                 const int n_cols = epilogue == SVDX_EPI_GEGLU_FWD ? 2 * aux_dim : N;
                 switch (variant) {
-                    case 29: if (n_cols % 320 == 0 && N % 320 == 0) return launch_gemm_v4<T, 10, 3, 4, 2>(p, st);
-                             return nb5 ? launch_gemm_v4<T, 5, 3, 4, 3>(p, st) : launch_gemm_v4<T, 4, 3, 4, 3>(p, st);   // else: the 192-row ring tiles
                     case 18: if (n_cols % 256 == 0) return launch_gemm_v4<T, 8, 4, 4, 2>(p, st);   // else: fall through to 256 x 128
                     case 16: case 17: return nb5 ? launch_gemm_v4<T, 5, 4, 4, 3>(p, st) : launch_gemm_v4<T, 4, 4, 4, 3>(p, st);
                     case 20: case 21: return nb5 ? launch_gemm_v4<T, 5, 4, 2, 4>(p, st) : launch_gemm_v4<T, 4, 4, 2, 4>(p, st);
@@ -1606,7 +1694,8 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
             return nb5 ? launch_gemm_v4<T, 5, 4>(p, st) : launch_gemm_v4<T, 4, 4>(p, st);
         }
         if (epilogue != SVDX_EPI_NONE) { svdx_set_error("svdx_gemm: fused epilogue unavailable (buffer too large for variant 4)"); return -2; }
-        return variant == 0 ? launch_gemm<T, false>(p, st) : launch_gemm<T, true>(p, st);
+        if (gn_stats) { svdx_set_error("svdx_gemm_gn: statistics unavailable (buffer too large for variant 4)"); return -2; }
+        return launch_gemm<T>(p, st);
     });
 }
 
@@ -1616,7 +1705,16 @@ extern "C" int svdx_gemm(const void* A, const void* B, void* C, int M, int N, in
                          int out_mode, float alpha, int split_k, int variant, int epilogue, const void* aux_in, void* aux_out,
                          int aux_dim, int dtype, void* stream) {
     return gemm_entry(A, B, C, M, N, K, lda, ldb, ldc, bias, rowvec, rv_ld, rv_rows_per_group, rv_mod, res, ldres, gather, zero_page,
-                      out_mode, alpha, split_k, variant, epilogue, aux_in, aux_out, aux_dim, nullptr, nullptr, 0, 0, 0, 0, dtype, stream);
+                      out_mode, alpha, split_k, variant, epilogue, aux_in, aux_out, aux_dim, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, 0, dtype, stream);
+}
+
+extern "C" int svdx_gemm_gn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                            const float* bias, const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod,
+                            const void* res, int ldres, const svdx_gather* gather, const void* zero_page,
+                            float alpha, int variant, float* gn_stats, int gn_rows, int gn_cg, int dtype, void* stream) {
+    SVDX_CHECK_ARG(gn_stats, "svdx_gemm_gn: gn_stats must not be NULL");
+    return gemm_entry(A, B, C, M, N, K, lda, ldb, ldc, bias, rowvec, rv_ld, rv_rows_per_group, rv_mod, res, ldres, gather, zero_page,
+                      SVDX_OUT_ACT, alpha, 1, variant, SVDX_EPI_NONE, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, gn_stats, gn_rows, gn_cg, dtype, stream);
 }
 
 extern "C" int svdx_gemm_dual(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -1626,7 +1724,7 @@ extern "C" int svdx_gemm_dual(const void* A, const void* B, void* C, int M, int 
                               int a2_seg_n, int dtype, void* stream) {
     SVDX_CHECK_ARG(K2 > 0, "svdx_gemm_dual: K2 must be positive");
     return gemm_entry(A, B, C, M, N, K, lda, ldb, ldc, bias, rowvec, rv_ld, rv_rows_per_group, rv_mod, res, ldres, gather, zero_page,
-                      out_mode, alpha, 1, variant, SVDX_EPI_NONE, nullptr, nullptr, 0, A2, B2, K2, lda2, ldb2, a2_seg_n, dtype, stream);
+                      out_mode, alpha, 1, variant, SVDX_EPI_NONE, nullptr, nullptr, 0, A2, B2, K2, lda2, ldb2, a2_seg_n, nullptr, 0, 0, dtype, stream);
 }
 
 extern "C" int svdx_small_linear(const float* X, const void* W, const float* bias, float* Y, int M, int N, int K,
@@ -1665,11 +1763,34 @@ extern "C" int svdx_gemm_finalize(const float* acc, int nsplit, int64_t slab_str
                    "svdx_gemm_finalize: N/ld must be multiples of 4");
     SVDX_CHECK_ARG(!rowvec || rv_mod > 0 || rv_rows_per_group > 0, "svdx_gemm_finalize: rowvec needs a grouping");
     const int blocks = (int)std::min<long>(((long)M * N / 4 + 255) / 256, 4096);
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_finalize_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, nsplit,
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_finalize_kernel<T, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, nsplit,
                                              (long)slab_stride, c_is_f32_accumulate ? (T*)nullptr : (T*)C,
                                              c_is_f32_accumulate ? (float*)C : (float*)nullptr, c_is_f32_accumulate == 2, M, N, ldc, bias, rowvec, rv_ld,
-                                             rv_rows_per_group, rv_mod, (const T*)res, ldres, colsum_slabs, colsum_out, colsum_n));
+                                             rv_rows_per_group, rv_mod, (const T*)res, ldres, colsum_slabs, colsum_out, colsum_n, FinGn{}));
     SVDX_LAUNCH_CHECK("svdx_gemm_finalize");
+    return 0;
+}
+
+extern "C" int svdx_gemm_finalize_gn(const float* acc, int nsplit, int64_t slab_stride, void* C, int M, int N, int ldc, const float* bias,
+                                     const float* rowvec, int rv_ld, int rv_rows_per_group, int rv_mod, const void* res, int ldres,
+                                     float* gn_stats, int gn_rows, int gn_cg, int dtype, void* stream) {
+    SVDX_CHECK_ARG(acc && C && gn_stats && M > 0 && N > 0 && nsplit >= 1, "svdx_gemm_finalize_gn: bad args");
+    SVDX_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && slab_stride % 4 == 0 && (!res || ldres % 4 == 0) && (!rowvec || rv_ld % 4 == 0),
+                   "svdx_gemm_finalize_gn: N/ld must be multiples of 4");
+    SVDX_CHECK_ARG(!rowvec || rv_mod > 0 || rv_rows_per_group > 0, "svdx_gemm_finalize_gn: rowvec needs a grouping");
+    SVDX_CHECK_ARG(gn_rows > 0 && gn_cg > 0 && M % gn_rows == 0 && N % gn_cg == 0 && N / gn_cg <= FIN_GN_G && (long)N * gn_rows >= 1024 &&
+                       ((uintptr_t)gn_stats & 7) == 0,
+                   "svdx_gemm_finalize_gn: M=%d whole samples of %d rows (N x rows >= 1024), N=%d whole groups of %d channels (<= %d groups)", M, gn_rows, N, gn_cg, FIN_GN_G);
+    FinGn gn;
+    gn.stats = reinterpret_cast<unsigned long long*>(gn_stats); gn.rows = gn_rows; gn.cg = gn_cg;
+    int k0, k1;
+    gn_fixed_scales((long)gn_rows * gn_cg, 0, k0, k1);
+    gn.m0 = exp2f((float)k0); gn.m1 = exp2f((float)k1);
+    const int blocks = (int)std::min<long>(((long)M * N / 4 + 255) / 256, 4096);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gemm_finalize_kernel<T, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, nsplit,
+                                             (long)slab_stride, (T*)C, (float*)nullptr, 0, M, N, ldc, bias, rowvec, rv_ld,
+                                             rv_rows_per_group, rv_mod, (const T*)res, ldres, (const float*)nullptr, (float*)nullptr, 0, gn));
+    SVDX_LAUNCH_CHECK("svdx_gemm_finalize_gn");
     return 0;
 }
 

@@ -24,14 +24,6 @@ struct GnGeom {
 // the worst case 2^32: eight more fraction bits, which clip-wide norms over 8 x 576 x 1024 rows need for groups of small activations
 // (with the worst-case scale a block partial was rounded to 1/32 there; a group with an rms of 4096 has left fp16 training long
 // before).  Backward: |dz gamma| <= 2^18, |xhat| <= 2^8.  A block's float partial converts exactly (24 significant bits).
-__host__ __device__ __forceinline__ void gn_fixed_scales(long cnt, int mode, int& k0, int& k1) {
-    int lg = 0;
-    while ((1L << lg) < cnt) ++lg;
-    const int b0 = mode == 0 ? 16 : 18, b1 = mode == 0 ? 24 : 26;
-    k0 = 62 - b0 - lg; k1 = 62 - b1 - lg;
-    k0 = k0 < 0 ? 0 : (k0 > 40 ? 40 : k0);
-    k1 = k1 < 0 ? 0 : (k1 > 40 ? 40 : k1);
-}
 __device__ __forceinline__ void group_sums(const float* stats, int n_s, int n, int G, int g, float i0, float i1, float& s, float& ss) {
     long long a = 0, b = 0;
     const long long* st = reinterpret_cast<const long long*>(stats);

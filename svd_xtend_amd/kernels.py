@@ -26,6 +26,7 @@ LN_PARTIAL_ROWS = 2048
 GN_REPLICAS = 8
 GN_STAT_FLOATS = 4             # floats of storage per (replica, sample, group) of a GroupNorm statistics buffer: two int64
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3, GATHER_CONV3X3_PAD0 = 0, 1, 2, 3, 4
+ABI_VERSION = 400              # include/svdx.h: SVDX_VERSION this binding was written against
 OPT_STATE_FLOATS = 16          # include/svdx.h: layout of the optimizer / loss-scale / schedule state
 SCHED_KINDS = {"constant": 0, "constant_with_warmup": 1, "linear": 2, "cosine": 3, "cosine_with_restarts": 4, "polynomial": 5}
 
@@ -79,8 +80,10 @@ class Gather:
 _SIGS = {
     "svdx_gemm": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifii" "ippi" "ip",
     "svdx_gemm_dual": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifi" "pp" "iiii" "ip",
+    "svdx_gemm_gn": "ppp" "iiiiii" "p" "piii" "pi" "pp" "fi" "pii" "ip",
     "svdx_gemm_tn": "ppp" "iiiiii" "pp" "iii" "ip",
     "svdx_gemm_finalize": "pil" "pi" "iii" "pp" "iii" "pi" "ppi" "ip",
+    "svdx_gemm_finalize_gn": "pil" "p" "iii" "pp" "iii" "pi" "pii" "ip",
     "svdx_small_linear": "pppp" "iiii" "iii" "ip",
     "svdx_outer_acc": "ppp" "iii" "f" "p",
     "svdx_small_linear_batch": "p" "iii" "ip",
@@ -179,6 +182,9 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.svdx_device_ok.restype = ctypes.c_int
     lib.svdx_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     lib.svdx_last_error.restype = ctypes.c_int
+    if lib.svdx_version() != ABI_VERSION:
+        raise SvdxError(f"{path} was built from another revision of include/svdx.h (library {lib.svdx_version()}, binding {ABI_VERSION}): "
+                        "rebuild it with `python __graft_entry__.py`")
     return lib
 
 
@@ -235,11 +241,19 @@ class HipBackend:
     # ---- GEMM family ------------------------------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
              res=None, ldres=0, gather: Optional[Gather] = None, out_mode=OUT_ACT, alpha=1.0, split_k=1,
-             variant=0, epilogue=EPI_NONE, aux_in=None, aux_out=None, aux_dim=0, dual=None):
-        """dual = (A2, B2, K2, lda2, ldb2[, a2_seg_n]): second operand pair reduced into the same accumulators (svdx_gemm_dual)."""
+             variant=0, epilogue=EPI_NONE, aux_in=None, aux_out=None, aux_dim=0, dual=None, gn=None):
+        """dual = (A2, B2, K2, lda2, ldb2[, a2_seg_n]): second operand pair reduced into the same accumulators (svdx_gemm_dual).
+        gn = (stats, rows, cg): also leave the GroupNorm statistics of C in `stats` (svdx_gemm_gn; zeroed buffer, activation output)."""
         g = gather.to_c() if gather is not None else None
         if self.launch_log is not None and gather is not None:
             self._log_extra = [gather.mode, gather.cin, gather.stride, gather.ups]
+        if gn is not None:
+            assert dual is None and split_k == 1 and epilogue == EPI_NONE and out_mode == OUT_ACT
+            self._call("svdx_gemm_gn", _p(A), _p(B), _p(C), M, N, K, lda, ldb, ldc, _f32(bias),
+                       _f32(rowvec), rv_ld, rv_rpg, rv_mod, _p(res), ldres,
+                       ctypes.cast(ctypes.pointer(g), ctypes.c_void_p) if g is not None else None,
+                       _p(self._zero_page), float(alpha), variant, _f32(gn[0]), gn[1], gn[2], _dt(A), self._stream())
+            return
         if dual is not None:
             A2, B2, K2, lda2, ldb2 = dual[:5]
             seg = dual[5] if len(dual) > 5 else 0
@@ -260,8 +274,14 @@ class HipBackend:
                    _dt(A), self._stream())
 
     def gemm_finalize(self, acc, nsplit, slab_stride, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
-                      res=None, ldres=0, accumulate_f32=False, dtype=None, colsum_slabs=None, colsum_out=None):
+                      res=None, ldres=0, accumulate_f32=False, dtype=None, colsum_slabs=None, colsum_out=None, gn=None):
+        """gn = (stats, rows, cg): also leave the GroupNorm statistics of C in `stats` (svdx_gemm_finalize_gn; activation output)."""
         dt = F16 if dtype == torch.float16 else BF16 if dtype == torch.bfloat16 else _dt(C)
+        if gn is not None:
+            assert not accumulate_f32 and colsum_slabs is None
+            self._call("svdx_gemm_finalize_gn", _f32(acc), nsplit, slab_stride, _p(C), M, N, ldc, _f32(bias), _f32(rowvec), rv_ld, rv_rpg, rv_mod,
+                       _p(res), ldres, _f32(gn[0]), gn[1], gn[2], dt, self._stream())
+            return
         self._call("svdx_gemm_finalize", _f32(acc), nsplit, slab_stride, _p(C), int(accumulate_f32), M, N, ldc, _f32(bias),
                    _f32(rowvec), rv_ld, rv_rpg, rv_mod, _p(res), ldres, _f32(colsum_slabs), _f32(colsum_out),
                    colsum_out.numel() if colsum_out is not None else 0, dt, self._stream())

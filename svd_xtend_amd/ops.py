@@ -9,7 +9,10 @@ temporal ops address rows with stride HW.
 """
 from __future__ import annotations
 
+import contextlib
+import functools
 import os
+from types import SimpleNamespace
 from typing import List, Optional, Sequence
 
 import torch
@@ -98,9 +101,27 @@ class Runtime:
         # at one clip per rank the gradient of a temporal block's cross-attention vector IS colsum(d(h1)) = the bias gradient the
         # attn1.to_out weight-gradient GEMM already computes on the matrix pipe: no svdx_colsum pass.  SVDX_DVEC_FROM_DW=0: A/B knob
         self.dvec_from_dw = os.environ.get("SVDX_DVEC_FROM_DW", "1") != "0"
-        self._q_nn, self._q_outer, self._q_ln, self._q_M = [], [], [], None
+        self._q_nn, self._q_outer, self._q_ln, self._q_M, self._q_outer_dst = [], [], [], None, set()
+        # GroupNorm statistics of a tensor come from the store loop of the GEMM that writes it (svdx_gemm_gn) instead of a pass of their
+        # own over it; SVDX_FUSE_GN_STATS=0: developer knob for A/B runs
+        self.fuse_gn_stats = os.environ.get("SVDX_FUSE_GN_STATS", "1") != "0"
         self.p_flat = None          # flat float master buffer of the trainables (ops.flatten_trainables)
         self.w16_flat = None        # same layout in the activation dtype, written by svdx_adamw / one cast per refresh
+
+    # ---- measurement aid: named regions of the sweep (bench.py brackets them with events to report an OP made of several launches) ----
+    on_region = None              # callable(name, info dict, begin: bool) or None
+
+    @contextlib.contextmanager
+    def region(self, name: str, **info):
+        cb = self.on_region
+        if cb is None:
+            yield
+            return
+        cb(name, info, True)
+        try:
+            yield
+        finally:
+            cb(name, info, False)
 
     # ---- deferred skinny launches (the queued jobs hold their tensors alive until the flush) -------------------------------------
     def _q_rows(self, M: int) -> None:
@@ -116,8 +137,15 @@ class Runtime:
         self._q_nn[stage].append(job)
 
     def defer_outer(self, job, M: int) -> None:
-        """job of kernels.outer_acc_batch; runs after every queued defer_nn stage"""
+        """job of kernels.outer_acc_batch; runs after every queued defer_nn stage.  The jobs of one table run concurrently and add
+        into their destination without atomics, so a destination may be queued ONCE per table: a second job on the same gradient
+        (tied weights, a second sweep queued before a flush) first flushes what is queued."""
         self._q_rows(M)
+        dst = job[2].data_ptr()
+        if dst in self._q_outer_dst:
+            self.flush_deferred()
+            self._q_M = M
+        self._q_outer_dst.add(dst)
         self._q_outer.append(job)
 
     def defer_ln_reduce(self, job) -> None:
@@ -136,7 +164,7 @@ class Runtime:
         self.drop_deferred()
 
     def drop_deferred(self) -> None:
-        self._q_nn, self._q_outer, self._q_ln, self._q_M = [], [], [], None
+        self._q_nn, self._q_outer, self._q_ln, self._q_M, self._q_outer_dst = [], [], [], None, set()
 
     @property
     def deferred_pending(self) -> bool:
@@ -203,7 +231,7 @@ TILE_OF_VARIANT = {7: (128, 160, 2, 4), 6: (160, 160, 2, 4), 8: (128, 128, 2, 4)
                    16: (256, 160, 3, 8), 17: (256, 128, 3, 8), 18: (256, 256, 2, 8), 20: (128, 160, 4, 4), 21: (128, 128, 4, 4),
                    23: (192, 160, 3, 8), 22: (192, 128, 3, 8), 25: (96, 160, 4, 4), 24: (96, 128, 4, 4)}
 # instantiated in csrc/gemm.hip and offered to the in-situ tuner (bench.py --tune), but without a measured rate: the cost model never picks them
-STAGED_TILES = {27: (128, 128, 2, 8), 28: (128, 160, 2, 8), 29: (192, 320, 2, 8)}
+STAGED_TILES = {27: (128, 128, 2, 8), 28: (128, 160, 2, 8)}
 # TFLOP/s one CU sustains on a variant's K-loop when the CU is full (8192^3 runs of tools/ring_check.py divided by 256 CUs, trimmed by
 # the in-situ sweeps of bench.py --tune): the two-stage four-wave tiles need two workgroups per CU for it
 _TILE_RATE = {6: 4.05, 7: 3.5, 8: 3.5, 16: 4.4, 17: 4.0, 18: 3.6, 20: 2.75, 21: 2.5, 22: 3.8, 23: 3.8, 24: 2.4, 25: 2.05}
@@ -254,8 +282,6 @@ def _nt_candidates(M: int, N: int, Kd: int, splittable: bool, fused_epilogue: bo
             continue
         if bn == 256 and N % 256:
             continue
-        if bn == 320 and N % 320:
-            continue
         if waves == 8 and M < 2 * bm:
             continue
         tiles = -(-M // bm) * -(-N // bn)
@@ -273,13 +299,19 @@ def _dual_candidates(M: int, N: int, Kd: int):
 
 def choose_cfg(rt: "Runtime", M: int, N: int, Kd: int, ldc: int, cin: int = 0, dual: bool = False):
     """(split, variant) without a measurement: the candidate with the smallest `estimate_gemm_us`.  dual: the launch carries a
-    second operand pair (LoRA), which only the unsplit two-stage four-wave tiles implement."""
+    second operand pair (LoRA), which only the unsplit two-stage four-wave tiles implement.  Memoised on the problem: the search
+    walks ~100 (split, tile) candidates (0.16 ms of Python), and an eager step asks ~600 times."""
     if rt.gemm_variant != 4:
         return (1 if dual else choose_split(rt, M, N, Kd, ldc)), rt.gemm_variant
-    splittable = rt.split_k and N % 4 == 0 and ldc % 4 == 0
+    return _choose_cfg_v4(bool(rt.split_k), M, N, Kd, ldc, cin, bool(dual))
+
+
+@functools.lru_cache(maxsize=None)
+def _choose_cfg_v4(split_k: bool, M: int, N: int, Kd: int, ldc: int, cin: int, dual: bool):
+    splittable = split_k and N % 4 == 0 and ldc % 4 == 0
     cands = _dual_candidates(M, N, Kd) if dual else _nt_candidates(M, N, Kd, splittable)
     if not cands:
-        return choose_split(rt, M, N, Kd, ldc), 4
+        return choose_split(SimpleNamespace(split_k=split_k), M, N, Kd, ldc), 4
     return min(cands, key=lambda c: estimate_gemm_us(M, N, Kd, c[0], c[1], cin))
 
 
@@ -293,6 +325,11 @@ def geglu_candidates(M: int, N: int, Kd: int, fwd: bool = True):
 
 
 def choose_geglu_variant(M: int, N: int, Kd: int, fwd: bool = True) -> int:
+    return _choose_geglu_variant(M, N, Kd, fwd, os.environ.get("SVDX_GEGLU_TILE"))
+
+
+@functools.lru_cache(maxsize=None)
+def _choose_geglu_variant(M: int, N: int, Kd: int, fwd: bool, rule) -> int:
     """Tile variant of a GEMM with a fused GEGLU epilogue (no split-K there) without a measurement.  Under these epilogues a
     workgroup runs its main loop, the GELU polynomial and its 200-400 KB of stores one after the other, so two workgroups per CU
     matter more than the main loop: the two-stage eight-wave 192 x 128 tile is the default (isolated, us: forward M = 35840
@@ -300,7 +337,7 @@ def choose_geglu_variant(M: int, N: int, Kd: int, fwd: bool = True) -> int:
     the 256 x 256 tile keeps the forward at the 32x20 level (80.3 against 80.9), ring tiles the 8x5 level (M = 560)."""
     if not fwd and N % 128:
         return 4                                             # the backward epilogue takes whole column tiles: 160-wide ones here (N % 160 == 0)
-    if os.environ.get("SVDX_GEGLU_TILE") == "sweep":        # developer knob for A/B runs: the in-situ sweep's winners among the one-per-CU tiles
+    if rule == "sweep":        # developer knob for A/B runs: the in-situ sweep's winners among the one-per-CU tiles
         if fwd:
             return 18 if (M >= 4096 and N % 256 == 0) else (17 if M >= 512 else 4)
         if M >= 16384 and N % 256 == 0:
@@ -384,31 +421,51 @@ def tuned_call(rt: "Runtime", key, make_cands, fallback, run) -> None:
     run(cfg if cfg is not None else fallback())
 
 
+def gn_tile_ok(variant: int, N: int, rows: int, cg: int) -> bool:
+    """Can the tile `variant` take GroupNorm statistics in its store loop (svdx_gemm_gn)?  Whole column tiles, and a tile that touches
+    at most 8 samples and 36 groups (csrc/gemm.hip: GN_MAX_S / GN_MAX_G)."""
+    t = TILE_OF_VARIANT.get(variant) or STAGED_TILES.get(variant)
+    if t is None:
+        return False
+    bm, bn = t[0], t[1]
+    return N % bn == 0 and (bm - 1) // rows + 2 <= 8 and (bn - 1) // cg + 2 <= 36
+
+
 def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
-             res=None, ldres=0, gather=None, dual=None, alpha: float = 1.0) -> None:
+             res=None, ldres=0, gather=None, dual=None, alpha: float = 1.0, gn=None) -> bool:
     """Activation-dtype GEMM.  Tile shape and split-K factor come from the GemmTuner table when the model was tuned
     (Trainer.tune_gemms), else from a formula: the 10x16 / 5x8 latent levels (M = 2240 / 560 rows against K up to 23040)
     cannot fill 256 CUs with output tiles alone, so the reduction is split across blocks -- partial sums go to float slabs
     that a small epilogue kernel reduces, applying bias/row-vector/residual.
     dual = (A2, B2, K2, lda2, ldb2): out also gets A2 B2^T (the LoRA term) -- inside the same launch when the reduction is not
-    split, by a second accumulate launch when it is."""
+    split, by a second accumulate launch when it is.
+    gn = (stats, rows, cg): the GroupNorm that consumes `out` wants its statistics (zeroed opaque buffer of svdx_gn_stats; sample =
+    `rows` consecutive rows, group = `cg` consecutive channels).  Returns True when the launch left them there (unsplit launch of a
+    tile whose store loop can take them); False: the caller runs svdx_gn_stats as before."""
     k = rt.k
     splittable = rt.split_k and N % 4 == 0 and ldc % 4 == 0
     key = ("nt", M, N, Kd, lda, ldc, 0 if gather is None else (gather.mode, gather.stride, gather.ups, gather.cin),
            bias is not None, rowvec is not None, res is not None) + (() if dual is None else (("dual", dual[2]),))
     assert alpha == 1.0 or dual is None
 
+    done = [False]
+
     def run(cfg):
         split, variant = cfg
         fused = dual if (split == 1 and rt.fuse_dual) else None
         if split == 1:
+            take = gn if (gn is not None and dual is None and rt.fuse_gn_stats and ldc % 8 == 0 and gn_tile_ok(_tile_launched(variant, M, N), N, gn[1], gn[2])) else None
+            done[0] = take is not None
             k.gemm(A, B, out, M, N, Kd, lda, ldb, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod,
-                   res=res, ldres=ldres, gather=gather, variant=variant, dual=fused, alpha=alpha)
+                   res=res, ldres=ldres, gather=gather, variant=variant, dual=fused, alpha=alpha, gn=take)
         else:
             acc = rt.f32(split, M, N)
             k.gemm(A, B, acc, M, N, Kd, lda, ldb, N, gather=gather, out_mode=K.OUT_F32_SLAB, split_k=split, variant=variant, alpha=alpha)
+            # the reducing launch writes the tensor: the statistics ride there (a block's 1024 consecutive elements: <= 2 samples)
+            take = gn if (gn is not None and rt.fuse_gn_stats and N * gn[1] >= 1024 and N // gn[2] <= 64) else None
+            done[0] = take is not None
             k.gemm_finalize(acc, split, M * N, out, M, N, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg,
-                            rv_mod=rv_mod, res=res, ldres=ldres)
+                            rv_mod=rv_mod, res=res, ldres=ldres, gn=take)
         if dual is not None and fused is None:
             A2, B2, K2, lda2, ldb2 = dual[:5]
             seg = dual[5] if len(dual) > 5 and dual[5] else N
@@ -418,6 +475,23 @@ def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowve
 
     tuned_call(rt, key, lambda: _nt_candidates(M, N, Kd, splittable and dual is None, staged=True) if dual is None else _dual_candidates(M, N, Kd),
                lambda: choose_cfg(rt, M, N, Kd, ldc, 0 if gather is None else gather.cin, dual is not None and rt.fuse_dual), run)
+    return done[0]
+
+
+def _tile_launched(variant: int, M: int, N: int) -> int:
+    """The tile svdx_gemm resolves `variant` to (csrc/gemm.hip: variant 4 is a rule among 6 / 7 / 8; a 160-wide request on an N that 160
+    does not divide takes the 128-wide sibling, 256-wide tiles need N % 256 == 0)."""
+    if variant == 4:
+        if N % 160:
+            return 8
+        t128, t160 = -(-M // 128) * (N // 160), -(-M // 160) * (N // 160)
+        return 6 if (-(-t128 // 512) * 4 > -(-t160 // 512) * 5 and t160 >= 384) else 7
+    sib = {16: 17, 23: 22, 25: 24, 20: 21, 28: 27, 7: 8, 6: 8}
+    if variant in sib and N % 160:
+        return sib[variant]
+    if variant == 18 and N % 256:
+        return 17
+    return variant
 
 
 # --------------------------------------------------------------------------------------------------
@@ -511,12 +585,13 @@ class LinearOp:
     # ---- compute ----
     def fwd(self, rt: Runtime, x: torch.Tensor, M: int, res: Optional[torch.Tensor] = None,
             rowvec: Optional[torch.Tensor] = None, rv_ld: int = 0, rv_rpg: int = 0, rv_mod: int = 0,
-            out: Optional[torch.Tensor] = None, dual=None) -> torch.Tensor:
+            out: Optional[torch.Tensor] = None, dual=None, gn=None):
+        """gn: see gemm_act; with it the return value is (y, statistics taken)."""
         y = out if out is not None else rt.empty(M, self.N)
-        gemm_act(rt, x, self.w, y, M, self.N, self.Kdim, self.Kdim, self.Kdim, self.N, bias=self.b,
-                 rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod, res=res,
-                 ldres=self.N if res is not None else 0, dual=dual)
-        return y
+        took = gemm_act(rt, x, self.w, y, M, self.N, self.Kdim, self.Kdim, self.Kdim, self.N, bias=self.b,
+                        rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod, res=res,
+                        ldres=self.N if res is not None else 0, dual=dual, gn=gn)
+        return y if gn is None else (y, took)
 
     def bwd_dx(self, rt: Runtime, dy: torch.Tensor, M: int, out: Optional[torch.Tensor] = None, dual=None) -> torch.Tensor:
         dx = out if out is not None else rt.empty(M, self.Kdim)
@@ -533,8 +608,32 @@ class LinearOp:
                     a_colsum=self.b_grad if colsum_to is None else colsum_to, write_once=True)
 
 
-# eight-wave weight-gradient tiles instantiated in csrc/gemm.hip and offered to the in-situ tuner only (no hardware timing yet): `stages` code -> tile
-STAGED_TN_TILES = {12: (128, 256), 13: (128, 384), 21: (256, 128)}
+# Round 4 timed eight-wave 128 x 256 / 128 x 384 / 256 x 128 weight-gradient tiles (two and three stages) inside the step: the four-wave
+# 128 x 128 tile with two workgroups per CU won every problem by 5-40 % (profiles/r4_tn_tile_sweep.txt); they were removed again.
+STAGED_TN_TILES = {}
+
+
+@functools.lru_cache(maxsize=None)
+def _tn_formula(M: int, N: int, Kd: int):
+    """(row slices, `stages` code) of a weight-gradient GEMM without a measurement."""
+    rtiles = (M + 63) // 64
+
+    def tiles_of(tm, tk):
+        return -(-N // tm) * -(-Kd // tk)
+    # 256 x 256 eight-wave tiles when (with a few row slices) they cover the output in one round of <= 256 workgroups: the
+    # 16x10 / 32x20-level feed-forward gradients (10240 x 1280 over 2240 rows: 98 against 107 us in the step; 5120 x 640 over 8960)
+    if N >= 1024 and Kd >= 512 and rtiles >= 16:
+        t18 = tiles_of(256, 256)
+        sk = max(1, min(256 // t18, rtiles // 32))
+        if 180 <= t18 * sk <= 256:
+            return sk, 18
+    tiles = tiles_of(128, 128)
+    sk = 1
+    if tiles < 256 and rtiles >= 16:
+        sk = max(1, min(512 // tiles, rtiles // 4, 128 if tiles <= 4 else 32))
+        while sk > 1 and (rtiles + sk - 1) // sk * (sk - 1) >= rtiles:
+            sk -= 1
+    return sk, 2
 
 
 def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tensor, M: int, N: int, Kd: int, lda: int, ldb: int,
@@ -567,27 +666,11 @@ def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tenso
         return -(-N // tm) * -(-Kd // tk)
 
     def cands():
-        return [(s, v) for v in ALL_TN_TILES if v == 2 or (N >= 2 * ALL_TN_TILES[v][0] - 128 and Kd >= 2 * ALL_TN_TILES[v][1] - 128)
+        return [(s, v) for v in ALL_TN_TILES if v == 2 or (N >= ALL_TN_TILES[v][0] and Kd > ALL_TN_TILES[v][1] - 128)
                 for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 96)
                 if s == 1 or (tiles_of(v) * s <= (2048 if v == 2 else 768) and rtiles // s >= 2 and -(-rtiles // s) * (s - 1) < rtiles)]
 
-    def formula():
-        # 256 x 256 eight-wave tiles when (with a few row slices) they cover the output in one round of <= 256 workgroups: the
-        # 16x10 / 32x20-level feed-forward gradients (10240 x 1280 over 2240 rows: 98 against 107 us in the step; 5120 x 640 over 8960)
-        if N >= 1024 and Kd >= 512 and rtiles >= 16:
-            t18 = tiles_of(18)
-            sk = max(1, min(256 // t18, rtiles // 32))
-            if 180 <= t18 * sk <= 256:
-                return sk, 18
-        tiles = tiles_of(2)
-        sk = 1
-        if tiles < 256 and rtiles >= 16:
-            sk = max(1, min(512 // tiles, rtiles // 4, 128 if tiles <= 4 else 32))
-            while sk > 1 and (rtiles + sk - 1) // sk * (sk - 1) >= rtiles:
-                sk -= 1
-        return sk, 2
-
-    tuned_call(rt, ("tn", M, N, Kd, lda, ldb), cands, formula, run)
+    tuned_call(rt, ("tn", M, N, Kd, lda, ldb), cands, lambda: _tn_formula(M, N, Kd), run)
 
 
 _ONES = {}
@@ -906,7 +989,7 @@ class ConvOp:
 
     def fwd(self, rt: Runtime, x: torch.Tensor, n_img: int, h: int, w: int, T: int = 0,
             res: Optional[torch.Tensor] = None, rowvec=None, rv_ld=0, rv_rpg=0, ldc: Optional[int] = None,
-            out: Optional[torch.Tensor] = None):
+            out: Optional[torch.Tensor] = None, gn=None):
         """x: [n_img*h*w, cin_p] (t3: n_img = B, rows = B*T*h*w).  Returns ([M, cout], ho, wo); `out` [M, ldc]: write the cout
         columns into the caller's (wider) rows instead of a fresh tensor."""
         ho, wo = self.out_hw(h, w)
@@ -919,8 +1002,8 @@ class ConvOp:
         ldc = ldc or self.cout
         y = out if out is not None else rt.empty(M, ldc)
         Kd = self.taps * self.cin_p
-        gemm_act(rt, x, self.w, y, M, self.cout, Kd, self.cin_p, Kd, ldc, bias=self.b, rowvec=rowvec, rv_ld=rv_ld,
-                 rv_rpg=rv_rpg, res=res, ldres=self.cout if res is not None else 0, gather=g)
+        self.took_gn = gemm_act(rt, x, self.w, y, M, self.cout, Kd, self.cin_p, Kd, ldc, bias=self.b, rowvec=rowvec, rv_ld=rv_ld,
+                                rv_rpg=rv_rpg, res=res, ldres=self.cout if res is not None else 0, gather=g, gn=gn)
         return y, ho, wo
 
     def bwd_dx(self, rt: Runtime, dy: torch.Tensor, n_img: int, h: int, w: int, T: int = 0) -> torch.Tensor:
@@ -962,9 +1045,27 @@ class GroupNormOp:
         if mod.weight.requires_grad:
             raise NotImplementedError("GroupNorm affine grads are outside this round's trainable set")
 
-    def fwd(self, rt: Runtime, x: torch.Tensor, n_s: int, rows: int):
+    def want(self, rt: Runtime, n_s: int, rows: int):
+        """-> (stats, rows, cg): what the GEMM that writes this norm's input gets as `gn` (ops.gemm_act) so that the statistics are
+        there when `fwd(..., pre=)` runs.  The buffer is a zeroed slice of the sweep's arena; None when the fusion is switched off."""
+        if not rt.fuse_gn_stats:
+            return None
         stats, pz = rt.take_zeroed(K.GN_REPLICAS * n_s * GN_GROUPS * K.GN_STAT_FLOATS)
+        if not pz:
+            rt.k.zero(stats)
+        return stats, rows, self.C // GN_GROUPS
+
+    def fwd(self, rt: Runtime, x: torch.Tensor, n_s: int, rows: int, pre=None):
+        """pre = (stats buffer from `want`, filled): filled -- the GEMM that wrote x took the statistics; not filled -- the (zeroed)
+        buffer is used for the pass over x here.  None: a buffer of this norm's own."""
         y = rt.empty(n_s * rows, self.C)
+        if pre is not None:
+            stats, filled = pre
+            if not filled:
+                rt.k.gn_stats(x, stats, n_s, rows, self.C, GN_GROUPS, prezeroed=1)
+            rt.k.gn_apply(x, stats, self.mod.weight.data, self.mod.bias.data, y, n_s, rows, self.C, GN_GROUPS, self.eps, self.silu)
+            return y, stats
+        stats, pz = rt.take_zeroed(K.GN_REPLICAS * n_s * GN_GROUPS * K.GN_STAT_FLOATS)
         rt.k.gn_stats(x, stats, n_s, rows, self.C, GN_GROUPS, prezeroed=pz)
         rt.k.gn_apply(x, stats, self.mod.weight.data, self.mod.bias.data, y, n_s, rows, self.C, GN_GROUPS,
                       self.eps, self.silu)

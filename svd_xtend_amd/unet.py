@@ -463,19 +463,21 @@ class TemporalBasicTransformerBlock(nn.Module):
         keep_n = self.trainable and self.ff.p1.trainable            # the weight gradients of the feed-forwards read the normalised rows
         h, pre0, g0, n0, st0 = self.ff_in.fwd_ln(rt, self.ln0, x, M, res=x, need_n=keep_n)
         cvec, cv = self.attn2.cross_vec(rt, tctx, g.B)
-        if self._tsa_fused(rt, g):
-            n1 = rt.empty(M, C) if self.trainable else None
-            st1, qkv, o, h1 = rt.f32(M, 2), rt.empty(M, 3 * C), rt.empty(M, C), rt.empty(M, C)
-            rv = self._rv(g)
-            k.tsa_fwd(h, self.norm1.weight.data, self.norm1.bias.data, self.norm1.eps, self.attn1.qkv.w, self.attn1.o.w, self.attn1.o.b,
-                      cvec, C, rv["rv_rpg"], rv["rv_mod"], n1, st1, qkv, o, h1, g.B, g.T, g.HW, C, self.heads, HEAD_DIM ** -0.5)
-            xs_qkv = xs_o = None
-        else:
-            n1, st1 = self.ln1.fwd(rt, h, M)
-            qkv, xs_qkv = _proj_fwd(rt, self.attn1.qkv, self.attn1.qkv_lora, n1, M)
-            o = rt.empty(M, C)
-            k.tattn_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], o, g.B, g.T, g.HW, self.heads, 3 * C, C, HEAD_DIM ** -0.5)
-            h1, xs_o = _proj_fwd(rt, self.attn1.o, self.attn1.o_lora, o, M, res=h, rowvec=cvec, rv_ld=C, **self._rv(g))
+        # the temporal self-attention OP (north_star's kernel): norm1 -> q/k/v -> attention over the frames -> out-projection + residual
+        with rt.region("temporal_self_attention.fwd", M=M, C=C, T=g.T):
+            if self._tsa_fused(rt, g):
+                n1 = rt.empty(M, C) if self.trainable else None
+                st1, qkv, o, h1 = rt.f32(M, 2), rt.empty(M, 3 * C), rt.empty(M, C), rt.empty(M, C)
+                rv = self._rv(g)
+                k.tsa_fwd(h, self.norm1.weight.data, self.norm1.bias.data, self.norm1.eps, self.attn1.qkv.w, self.attn1.o.w, self.attn1.o.b,
+                          cvec, C, rv["rv_rpg"], rv["rv_mod"], n1, st1, qkv, o, h1, g.B, g.T, g.HW, C, self.heads, HEAD_DIM ** -0.5)
+                xs_qkv = xs_o = None
+            else:
+                n1, st1 = self.ln1.fwd(rt, h, M)
+                qkv, xs_qkv = _proj_fwd(rt, self.attn1.qkv, self.attn1.qkv_lora, n1, M)
+                o = rt.empty(M, C)
+                k.tattn_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], o, g.B, g.T, g.HW, self.heads, 3 * C, C, HEAD_DIM ** -0.5)
+                h1, xs_o = _proj_fwd(rt, self.attn1.o, self.attn1.o_lora, o, M, res=h, rowvec=cvec, rv_ld=C, **self._rv(g))
         out, pre, gg, n3, st3 = self.ff.fwd_ln(rt, self.ln3, h1, M, res=h1, need_n=keep_n)
         if not self.trainable:
             n0 = g0 = n1 = n3 = gg = None
@@ -505,6 +507,8 @@ class TemporalBasicTransformerBlock(nn.Module):
                      scratch=rt.f32(K.colsum_slabs(M, rv["rv_rpg"], rv["rv_mod"]) * g.B * C))
             self.attn2.cross_vec_bwd(rt, dvec, cv, tctx, g.B)
         dvec = _zeroed_vec(rt, C) if (dvec_from_dw or cs_lora) else None
+        region = rt.region("temporal_self_attention.bwd", M=M, C=C, T=g.T)     # ... to the norm1 backward; the skinny cross-attention
+        region.__enter__()                                                      # gradient launches in between belong to attn2
         d_o = _proj_bwd_dx(rt, self.attn1.o, self.attn1.o_lora, dh1, C, o, xs_o, M, colsum_to=dvec if cs_lora else None)
         if cs_lora:
             self.attn2.cross_vec_bwd(rt, dvec.view(1, C), cv, tctx, 1)
@@ -526,6 +530,7 @@ class TemporalBasicTransformerBlock(nn.Module):
             self.attn1.qkv.bwd_dw(rt, dqkv, n1, M)
         del dqkv, n1
         dh = self.ln1.bwd(rt, dn1, h, st1, M, add=dh1)
+        region.__exit__(None, None, None)
         del dn1, dh1, h
         dn0 = self.ff_in.bwd(rt, dh, n0, pre0, g0, M)
         if not need_dx and not self.ln0.trainable:
@@ -580,11 +585,17 @@ class TransformerSpatioTemporalModel(nn.Module):
             if b.trainable:
                 b.refresh(rt)
 
-    def fwd(self, rt: Runtime, x, g: Geom, ctx):
+    def first_norm(self, g: Geom):
+        """(GroupNormOp, samples, rows per sample) of the norm that reads this module's input"""
+        return self.gn, g.N, g.HW
+
+    def fwd(self, rt: Runtime, x, g: Geom, ctx, pre=None, want_out=None):
         """x [M, C]; ctx float [B, cross_dim] (the CLIP embed of each clip; identical for all its frames, so
-        the first-frame `time_context` of the temporal blocks is the same tensor)."""
+        the first-frame `time_context` of the temporal blocks is the same tensor).
+        pre: GroupNorm statistics of x left by the GEMM that wrote it (GroupNormOp.fwd); want_out: `gn` operand for the GEMM that writes
+        the result (GroupNormOp.want of the consumer).  Returns (out, statistics of out taken)."""
         k, C, M = rt.k, self.C, g.M
-        xn, st = self.gn.fwd(rt, x, g.N, g.HW)
+        xn, st = self.gn.fwd(rt, x, g.N, g.HW, pre=pre)
         h = self.pin.fwd(rt, xn, M)
         del xn
         # frame position embedding e[t] = time_pos_embed(Timesteps(C)(arange(T))), one row vector per frame.  It depends only on
@@ -604,9 +615,12 @@ class TransformerSpatioTemporalModel(nn.Module):
             h2 = rt.empty(M, C)
             k.blend(h, hm, self.time_mixer.mix_factor.data, h2, M * C)
             h = h2
-        out = self.pout.fwd(rt, h, M, res=x)
+        if want_out is not None:
+            out, took = self.pout.fwd(rt, h, M, res=x, gn=want_out)
+        else:
+            out, took = self.pout.fwd(rt, h, M, res=x), False
         self.sv = (x, st)
-        return out
+        return out, took
 
     def bwd(self, rt: Runtime, dout, g: Geom):
         k, C, M = rt.k, self.C, g.M
@@ -678,18 +692,21 @@ class _ResnetHalf(nn.Module):
         # GroupNorm sample: a frame for the 2-D block, the whole clip (all frames) for the 3-D block
         return (g.B, g.T * g.HW) if self.temporal else (g.N, g.HW)
 
-    def fwd(self, rt: Runtime, x, g: Geom, temb_all):
+    def fwd(self, rt: Runtime, x, g: Geom, temb_all, pre=None, want_out=None):
+        """pre / want_out: GroupNorm statistics from the producing GEMM's store loop -- of x (already taken) and of the result (asked
+        of conv2) -- see TransformerSpatioTemporalModel.fwd.  Returns (out, statistics of out taken)."""
         n_s, rows = self._ns(g)
-        a1, st1 = self.gn1.fwd(rt, x, n_s, rows)
+        a1, st1 = self.gn1.fwd(rt, x, n_s, rows, pre=pre)
         off, ld = self.temb_slice
         ni = g.B if self.temporal else g.N
-        h1, _, _ = self.c1.fwd(rt, a1, ni, g.h, g.w, T=g.T, rowvec=temb_all[:, off:], rv_ld=ld, rv_rpg=g.T * g.HW)
+        w2 = self.gn2.want(rt, n_s, rows)
+        h1, _, _ = self.c1.fwd(rt, a1, ni, g.h, g.w, T=g.T, rowvec=temb_all[:, off:], rv_ld=ld, rv_rpg=g.T * g.HW, gn=w2)
         del a1
-        a2, st2 = self.gn2.fwd(rt, h1, n_s, rows)
+        a2, st2 = self.gn2.fwd(rt, h1, n_s, rows, pre=None if w2 is None else (w2[0], self.c1.took_gn))
         sc = x if self.sc is None else self.sc.fwd(rt, x, ni, g.h, g.w, T=g.T)[0]
-        out, _, _ = self.c2.fwd(rt, a2, ni, g.h, g.w, T=g.T, res=sc)
+        out, _, _ = self.c2.fwd(rt, a2, ni, g.h, g.w, T=g.T, res=sc, gn=want_out)
         self.sv = (x, st1, h1, st2)
-        return out
+        return out, (want_out is not None and self.c2.took_gn)
 
     def bwd(self, rt: Runtime, dout, g: Geom, add=None):
         """returns dx (+ add).  The identity/1x1 shortcut gradient is folded into the last GroupNorm backward."""
@@ -741,9 +758,14 @@ class SpatioTemporalResBlock(nn.Module):
         self.spatial_res_block.pack(rt, self.need_dx)
         self.temporal_res_block.pack(rt, self.need_dx, out_scale=one_minus_a)
 
-    def fwd(self, rt: Runtime, x, g: Geom, temb_all):
-        s = self.spatial_res_block.fwd(rt, x, g, temb_all)
-        return self.temporal_res_block.fwd(rt, s, g, temb_all)
+    def first_norm(self, g: Geom):
+        return self.spatial_res_block.gn1, g.N, g.HW
+
+    def fwd(self, rt: Runtime, x, g: Geom, temb_all, pre=None, want_out=None):
+        t = self.temporal_res_block
+        ws = t.gn1.want(rt, *t._ns(g))            # the temporal half's first norm reads the spatial half's output (clip-wide groups)
+        s, took = self.spatial_res_block.fwd(rt, x, g, temb_all, pre=pre, want_out=ws)
+        return t.fwd(rt, s, g, temb_all, pre=None if ws is None else (ws[0], took), want_out=want_out)
 
     def bwd(self, rt: Runtime, dout, g: Geom):
         if not self.need_dx:
@@ -1166,6 +1188,15 @@ class UNetSpatioTemporalConditionModel(nn.Module):
                 for b in list(m.transformer_blocks) + list(m.temporal_transformer_blocks):
                     b.sv = None
         self._fwd_state = None
+        self._clear_cross_pre()
+
+    def _clear_cross_pre(self):
+        """Drop cross-attention vectors a previous sweep precomputed and never consumed (a forward that raised, a knob that
+        flipped between sweeps): the next cross_vec must not read results of an older context."""
+        for kind, m in self.steps:
+            if kind == "attn":
+                for b in list(m.transformer_blocks) + list(m.temporal_transformer_blocks):
+                    b.attn2._pre = None
 
     def _forward_impl(self, sample, timestep, ehs, added_time_ids):
         out_rows = self.forward_rows(sample, timestep, ehs, added_time_ids)
@@ -1180,6 +1211,7 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         rt = self.rt
         k = rt.k
         rt.begin_pass(0)
+        self._clear_cross_pre()
         B, T, Cin, h, w = sample.shape
         mult = 2 ** sum(1 for kind, _ in self.steps if kind == "down")
         if h % mult or w % mult:
@@ -1214,28 +1246,48 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         x0 = rt.empty(g.M, self.cin_pad)
         k.nchw_to_rows(sample.reshape(g.N, Cin, h, w).to(torch.float32).contiguous(), x0, g.N, Cin, h, w,
                        self.cin_pad, 1.0)
-        x, _, _ = self.cin_op.fwd(rt, x0, g.N, h, w)
+        # GroupNorm statistics ride on the GEMM that writes the normalised tensor (svdx_gemm_gn): `consumer(i, geom)` is the `gn` operand
+        # for the producer at step i -- the first norm of the next module when that module reads the tensor as it stands (a skip
+        # connection is concatenated first: its norm spans both inputs and takes its own pass), the output norm after the last step
+        steps = self.steps
+
+        def consumer(i, geom):
+            j = i + 1
+            while j < len(steps) and steps[j][0] == "push":
+                j += 1
+            if j == len(steps):
+                return self.gn_out.want(rt, geom.N, geom.HW)
+            if steps[j][0] in ("res", "attn"):
+                op, n_s, rows = steps[j][1].first_norm(geom)
+                return op.want(rt, n_s, rows)
+            return None
+        want = consumer(-1, g)
+        x, _, _ = self.cin_op.fwd(rt, x0, g.N, h, w, gn=want)
+        pre = None if want is None else (want[0], self.cin_op.took_gn)      # (statistics buffer, filled) of x for the next first norm
         del x0
 
         skips: List[Tuple[torch.Tensor, Geom]] = [(x, g)]
         geoms = [g]
         cur = g
         cat_info = []
-        for kind, m in self.steps:
-            if kind == "res":
-                x = m.fwd(rt, x, cur, temb_all)
-            elif kind == "attn":
-                x = m.fwd(rt, x, cur, ctx)
+        for i, (kind, m) in enumerate(steps):
+            if kind == "res" or kind == "attn":
+                want = consumer(i, cur)
+                x, took = m.fwd(rt, x, cur, temb_all if kind == "res" else ctx, pre=pre, want_out=want)
+                pre = None if want is None else (want[0], took)
             elif kind == "push":
                 skips.append((x, cur))
-            elif kind == "down":
-                x, ho, wo = m.op.fwd(rt, x, cur.N, cur.h, cur.w)
-                cur = Geom(B, T, ho, wo)
-                geoms.append(cur)
-            elif kind == "up":
-                x, ho, wo = m.op.fwd(rt, x, cur.N, cur.h, cur.w)
-                cur = Geom(B, T, ho, wo)
+            elif kind == "down" or kind == "up":
+                ho, wo = m.op.out_hw(cur.h, cur.w)
+                nxt = Geom(B, T, ho, wo)
+                want = consumer(i, nxt)
+                x, ho, wo = m.op.fwd(rt, x, cur.N, cur.h, cur.w, gn=want)
+                pre = None if want is None else (want[0], m.op.took_gn)
+                cur = nxt
+                if kind == "down":
+                    geoms.append(cur)
             elif kind == "pop_cat":
+                pre = None
                 s, sg = skips.pop()
                 assert sg.h == cur.h and sg.w == cur.w
                 Ca, Cb = x.shape[1], s.shape[1]
@@ -1245,7 +1297,7 @@ class UNetSpatioTemporalConditionModel(nn.Module):
                 x = cat
         assert not skips
         # 3. out: GroupNorm + SiLU + conv_out
-        a, st = self.gn_out.fwd(rt, x, cur.N, cur.HW)
+        a, st = self.gn_out.fwd(rt, x, cur.N, cur.HW, pre=pre)
         y, _, _ = self.cout_op.fwd(rt, a, cur.N, cur.h, cur.w)
         self._fwd_state = dict(g0=g, x_last=x, st_last=st, cat_info=cat_info)
         return y

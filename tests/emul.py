@@ -114,8 +114,9 @@ class EmuBackend:
     # ---- GEMM family ----
     def gemm(self, A, B, C, M, N, Kd, lda, ldb, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
              res=None, ldres=0, gather=None, out_mode=K.OUT_ACT, alpha=1.0, split_k=1, variant=0, epilogue=0, aux_in=None,
-             aux_out=None, aux_dim=0, dual=None):
+             aux_out=None, aux_dim=0, dual=None, gn=None):
         assert Kd % 64 == 0, "GEMM K must be a multiple of 64"
+        assert gn is None or (dual is None and split_k == 1 and epilogue == 0 and out_mode == K.OUT_ACT)
         if gather is None or gather.mode == K.GATHER_PLAIN:
             a = V(A, M, Kd, lda).float()
         else:
@@ -173,6 +174,11 @@ class EmuBackend:
         else:
             assert C.dtype == torch.float32 or out_mode == K.OUT_ACT
             c.copy_(v.to(C.dtype))
+            if gn is not None:           # svdx_gemm_gn: statistics of the ROUNDED tensor, added to the (zeroed) buffer
+                stats, rows, cg = gn
+                assert M % rows == 0 and N % cg == 0
+                xf = c.float().reshape(M // rows, rows, N // cg, cg)
+                gn_encode_add(stats, M // rows, N // cg, rows * cg, 0, xf.sum((1, 3)), (xf * xf).sum((1, 3)))
 
     def gemm_tn(self, A, B, C, R, N, Kd, lda, ldb, ldc, out_mode=K.OUT_F32_ADD, split_k=1, a_colsum=None, stages=0):
         a, b = V(A, R, N, lda).float(), V(B, R, Kd, ldb).float()
@@ -196,7 +202,8 @@ class EmuBackend:
             c += v
 
     def gemm_finalize(self, acc, nsplit, slab_stride, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
-                      res=None, ldres=0, accumulate_f32=False, dtype=None, colsum_slabs=None, colsum_out=None):
+                      res=None, ldres=0, accumulate_f32=False, dtype=None, colsum_slabs=None, colsum_out=None, gn=None):
+        assert gn is None or (not accumulate_f32 and colsum_slabs is None)
         if colsum_slabs is not None:
             n = colsum_out.numel()
             V1(colsum_out, n).add_(V(colsum_slabs, nsplit, n, n).sum(0))
@@ -215,6 +222,11 @@ class EmuBackend:
             V(C, M, N, ldc).add_(v)
         else:                                        # 0: activation store, 2: float store
             V(C, M, N, ldc).copy_(v.to(C.dtype))
+            if gn is not None:                       # svdx_gemm_finalize_gn: statistics of the rounded tensor
+                stats, rows, cg = gn
+                assert M % rows == 0 and N % cg == 0 and N * rows >= 1024 and N // cg <= 64
+                xf = V(C, M, N, ldc).float().reshape(M // rows, rows, N // cg, cg)
+                gn_encode_add(stats, M // rows, N // cg, rows * cg, 0, xf.sum((1, 3)), (xf * xf).sum((1, 3)))
 
     def small_linear(self, X, W, bias, Y, M, N, Kd, ldw, trans=0, silu_in=0, accumulate=0):
         w = V(W, N, Kd, ldw).float()

@@ -340,6 +340,57 @@ def check_small(P, dt):
     return res
 
 
+def check_gemm_gn(P, dt, variant):
+    """svdx_gemm_gn: the GEMM result against the emulation, and the GroupNorm statistics it leaves against a statistics pass (emulated)
+    over the tensor THE LAUNCH ITSELF wrote -- same rounded values, so only the fp32 summation order differs."""
+    from svd_xtend_amd.ops import TILE_OF_VARIANT, STAGED_TILES, _tile_launched, gn_tile_ok
+    g = torch.Generator().manual_seed(11)
+    res = []
+    # (samples, rows per sample, N, channels per group, K, gather?)   -- 2-D norms over frames shorter / longer than a tile, a clip-wide norm
+    cases = [(6, 40, 320, 10, 128), (2, 400, 640, 20, 192), (1, 700, 1280, 40, 64), (14, 160, 1280, 40, 128), (3, 96, 640, 20, 64), (2, 2560, 320, 10, 64)]
+    for (n_s, rows, N, cg, Kd) in cases:
+        M, G = n_s * rows, N // cg
+        tile = _tile_launched(variant, M, N)
+        if not gn_tile_ok(tile, N, rows, cg):
+            continue
+        A, B = rnd((M, Kd), dt, P.dev, g), rnd((N, Kd), dt, P.dev, g, Kd ** -0.5)
+        bias, R = rndf((N,), P.dev, g), rnd((M, N), dt, P.dev, g)
+        rv = rndf((n_s, N), P.dev, g)
+        for mode in ("plain", "bias_res", "rowvec"):
+            kw = dict(variant=variant)
+            if mode == "bias_res":
+                kw.update(bias=bias, res=R, ldres=N)
+            elif mode == "rowvec":
+                kw.update(bias=bias, rowvec=rv, rv_ld=N, rv_rpg=rows)
+            outs = dict(C=torch.zeros(M, N, dtype=dt, device=P.dev), st=torch.zeros(K.GN_REPLICAS, n_s, G, K.GN_STAT_FLOATS, device=P.dev))
+            o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, N, Kd, Kd, Kd, N), dict(kw, gn=(o["st"], rows, cg))), outs)
+            res.append((f"gemm_gn v{variant} {n_s}x{rows}x{N} cg={cg} K={Kd} {mode} C", relerr(o1["C"], o2["C"]), tol_for(dt)))
+            own = torch.zeros_like(outs["st"])
+            P.ref.gn_stats(o1["C"], own, n_s, rows, N, G, prezeroed=1)
+            res.append((f"gemm_gn v{variant} {n_s}x{rows}x{N} cg={cg} K={Kd} {mode} stats",
+                        relerr(emul.gn_decode(o1["st"], n_s, G, rows * cg, 0).view(-1, 2), emul.gn_decode(own, n_s, G, rows * cg, 0).view(-1, 2)), 1e-4))
+    # split-K form: the statistics come from the reducing launch
+    for (n_s, rows, N, cg, Kd, sk) in [(14, 40, 1280, 40, 256, 3), (3, 160, 640, 20, 128, 2), (1, 300, 320, 10, 128, 2), (5, 8, 1280, 40, 128, 2)]:
+        M, G = n_s * rows, N // cg
+        A, B = rnd((M, Kd), dt, P.dev, g), rnd((N, Kd), dt, P.dev, g, Kd ** -0.5)
+        bias, R = rndf((N,), P.dev, g), rnd((M, N), dt, P.dev, g)
+
+        def splitk(be, o, st):
+            acc = torch.zeros(sk, M, N, device=P.dev)
+            be.gemm(A, B, acc, M, N, Kd, Kd, Kd, N, out_mode=K.OUT_F32_SLAB, split_k=sk, variant=variant)
+            be.gemm_finalize(acc, sk, M * N, o, M, N, N, bias=bias, res=R, ldres=N, gn=(st, rows, cg))
+        c1, c2 = torch.zeros(M, N, dtype=dt, device=P.dev), torch.zeros(M, N, dtype=dt, device=P.dev)
+        s1, s2 = (torch.zeros(K.GN_REPLICAS, n_s, G, K.GN_STAT_FLOATS, device=P.dev) for _ in range(2))
+        splitk(P.impl, c1, s1)
+        splitk(P.ref, c2, s2)
+        res.append((f"gemm_finalize_gn v{variant} {n_s}x{rows}x{N} split {sk} C", relerr(c1, c2), tol_for(dt)))
+        own = torch.zeros_like(s1)
+        P.ref.gn_stats(c1, own, n_s, rows, N, G, prezeroed=1)
+        res.append((f"gemm_finalize_gn v{variant} {n_s}x{rows}x{N} split {sk} stats",
+                    relerr(emul.gn_decode(s1, n_s, G, rows * cg, 0).view(-1, 2), emul.gn_decode(own, n_s, G, rows * cg, 0).view(-1, 2)), 1e-4))
+    return res
+
+
 def check_groupnorm(P, dt):
     g = torch.Generator().manual_seed(4)
     res = []
@@ -718,6 +769,8 @@ def run_all(impl, dev, dtypes=DTYPES, verbose=True):
             checks += [(f"gemm_plain_v{v}", lambda v=v: check_gemm_plain(P, dt, v)), (f"gemm_gather_v{v}", lambda v=v: check_gemm_gather(P, dt, v))]
         checks += [("gemm_tn", lambda: check_gemm_tn(P, dt)), ("gemm_tn_s3", lambda: check_gemm_tn(P, dt, 3)), ("gemm_tn_s4", lambda: check_gemm_tn(P, dt, 4)),
                    ("gemm_tn_v18", lambda: check_gemm_tn(P, dt, 18)),
+                   ("gemm_gn_v4", lambda: check_gemm_gn(P, dt, 4)), ("gemm_gn_v6", lambda: check_gemm_gn(P, dt, 6)), ("gemm_gn_v23", lambda: check_gemm_gn(P, dt, 23)),
+                   ("gemm_gn_v18", lambda: check_gemm_gn(P, dt, 18)), ("gemm_gn_v24", lambda: check_gemm_gn(P, dt, 24)), ("gemm_gn_v26", lambda: check_gemm_gn(P, dt, 26)),
                    ("gemm_geglu", lambda: check_gemm_geglu(P, dt))]
         checks += [(f"gemm_geglu_v{v}", lambda v=v: check_gemm_geglu(P, dt, v)) for v in (17, 18, 21, 26)]
         checks += [

@@ -18,7 +18,7 @@ import emul  # noqa: E402
 import kernel_checks as kc  # noqa: E402
 from svd_xtend_amd import kernels as K  # noqa: E402
 
-NT_VARIANTS = (1, 4, 6, 7, 8, 16, 17, 18, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29)
+NT_VARIANTS = (1, 4, 6, 7, 8, 16, 17, 18, 20, 21, 22, 23, 24, 25, 26, 27, 28)
 HEAD = 64
 
 
@@ -108,7 +108,7 @@ def fuzz_gather(P, dt, rng, g):
 
 
 def fuzz_tn(P, dt, rng, g):
-    stages = rng.choice((0, 3, 4, 18, 12, 13, 21))
+    stages = rng.choice((0, 3, 4, 18))
     R, N, Kd = pick_dim(rng, 1, 900), pick_dim(rng, 8, 600, 8), pick_dim(rng, 8, 600, 8)
     A, B = kc.rnd((R, N), dt, P.dev, g), kc.rnd((R, Kd), dt, P.dev, g, R ** -0.5)
     mode = rng.choice((K.OUT_F32, K.OUT_F32_ADD, K.OUT_F32_SLAB))
@@ -131,7 +131,7 @@ def fuzz_tn(P, dt, rng, g):
 
 
 def fuzz_geglu(P, dt, rng, g):
-    v = rng.choice((4, 6, 8, 16, 17, 18, 20, 21, 22, 24, 26, 27, 29, 29))
+    v = rng.choice((4, 6, 8, 16, 17, 18, 20, 21, 22, 24, 26, 27))
     M, C, F = pick_dim(rng, 1, 600), 64 * rng.randint(1, 6), rng.choice((64 * rng.randint(1, 10), 160 * rng.randint(1, 4) * 2))
     x, W1, b1 = kc.rnd((M, C), dt, P.dev, g), kc.rnd((2 * F, C), dt, P.dev, g, C ** -0.5), kc.rndf((2 * F,), P.dev, g)
     desc = f"geglu v{v} M={M} C={C} F={F}"

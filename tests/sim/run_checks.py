@@ -14,15 +14,16 @@ from backend import SimBackend  # noqa: E402
 
 def groups(P, dt):
     fns = {"gemm_tn": lambda: kc.check_gemm_tn(P, dt), "gemm_tn_s3": lambda: kc.check_gemm_tn(P, dt, 3), "gemm_tn_s4": lambda: kc.check_gemm_tn(P, dt, 4),
-           "gemm_tn_v18": lambda: kc.check_gemm_tn(P, dt, 18), "gemm_tn_v12": lambda: kc.check_gemm_tn(P, dt, 12), "gemm_tn_v13": lambda: kc.check_gemm_tn(P, dt, 13),
-           "gemm_tn_v21": lambda: kc.check_gemm_tn(P, dt, 21), "gemm_geglu": lambda: kc.check_gemm_geglu(P, dt),
+           "gemm_tn_v18": lambda: kc.check_gemm_tn(P, dt, 18), "gemm_geglu": lambda: kc.check_gemm_geglu(P, dt),
            "small": lambda: kc.check_small(P, dt), "groupnorm": lambda: kc.check_groupnorm(P, dt), "layernorm": lambda: kc.check_layernorm(P, dt),
            "attention": lambda: kc.check_attention(P, dt), "temporal_attention": lambda: kc.check_temporal_attention(P, dt),
            "tsa": lambda: kc.check_tsa(P, dt), "encoders": lambda: kc.check_encoders(P, dt), "elementwise": lambda: kc.check_elementwise(P, dt),
            "optim": lambda: kc.check_optim(P, dt)}
-    for v in (17, 18, 21, 26, 27, 29):
+    for v in (4, 6, 8, 16, 18, 22, 23, 24, 26):
+        fns[f"gemm_gn_v{v}"] = lambda v=v: kc.check_gemm_gn(P, dt, v)
+    for v in (17, 18, 21, 26, 27):
         fns[f"gemm_geglu_v{v}"] = lambda v=v: kc.check_gemm_geglu(P, dt, v)
-    for v in (1, 4, 6, 16, 18, 20, 23, 25, 27, 28, 29):
+    for v in (1, 4, 6, 16, 18, 20, 23, 25, 27, 28):
         fns[f"gemm_plain_v{v}"] = lambda v=v: kc.check_gemm_plain(P, dt, v)
         fns[f"gemm_gather_v{v}"] = lambda v=v: kc.check_gemm_gather(P, dt, v)
     return fns

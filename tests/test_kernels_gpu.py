@@ -9,8 +9,8 @@ gpu = pytest.mark.gpu
 RING = (16, 18, 20, 23, 25)  # ring-staged tile variants: between them every instantiation of gemm_v4_kernel (kernel_checks.RING_VARIANTS: N % 160 picks the 160- or 128-wide sibling)
 GROUPS = (["gemm_tn", "gemm_tn_s3", "gemm_tn_s4", "gemm_tn_v18", "gemm_geglu", "gemm_geglu_v17", "gemm_geglu_v18", "gemm_geglu_v21", "gemm_geglu_v26", "gemm_plain_v1"]
           + [f"gemm_{k}_v{v}" for v in (4, 6) + RING for k in ("plain", "gather")]
-          # staged tile variants (ops.STAGED_TILES: tuner candidates the simulator has verified and no GPU has run yet) join with SVDX_STAGED=1
-          + ([f"gemm_{k}_v{v}" for v in (27, 28, 29) for k in ("plain", "gather")] + ["gemm_geglu_v27", "gemm_geglu_v29", "gemm_tn_v12", "gemm_tn_v13", "gemm_tn_v21"] if os.environ.get("SVDX_STAGED") == "1" else [])
+          + [f"gemm_gn_v{v}" for v in (4, 6, 8, 16, 18, 22, 23, 24, 26)]     # svdx_gemm_gn: GroupNorm statistics from the store loop of every tile family
+          + [f"gemm_{k}_v{v}" for v in (27, 28) for k in ("plain", "gather")] + ["gemm_geglu_v27"]     # tuner candidates (ops.STAGED_TILES)
           + ["small", "groupnorm", "layernorm", "attention", "temporal_attention", "tsa", "encoders", "elementwise", "optim"])
 
 
@@ -34,11 +34,13 @@ def test_kernel_group(pair, group, dt):
            "temporal_attention": lambda: kc.check_temporal_attention(pair, dt),
            "tsa": lambda: kc.check_tsa(pair, dt), "encoders": lambda: kc.check_encoders(pair, dt),
            "elementwise": lambda: kc.check_elementwise(pair, dt), "optim": lambda: kc.check_optim(pair, dt)}
-    for v in (18, 12, 13, 21):
+    for v in (18,):
         fns[f"gemm_tn_v{v}"] = lambda v=v: kc.check_gemm_tn(pair, dt, v)
-    for v in (17, 18, 21, 26, 27, 29):
+    for v in (4, 6, 8, 16, 18, 22, 23, 24, 26):
+        fns[f"gemm_gn_v{v}"] = lambda v=v: kc.check_gemm_gn(pair, dt, v)
+    for v in (17, 18, 21, 26, 27):
         fns[f"gemm_geglu_v{v}"] = lambda v=v: kc.check_gemm_geglu(pair, dt, v)
-    for v in (4, 6, 27, 28, 29) + RING:
+    for v in (4, 6, 27, 28) + RING:
         fns[f"gemm_plain_v{v}"] = lambda v=v: kc.check_gemm_plain(pair, dt, v)
         fns[f"gemm_gather_v{v}"] = lambda v=v: kc.check_gemm_gather(pair, dt, v)
     bad = [(l, e, t) for l, e, t in fns[group]() if not (e <= t and math.isfinite(e))]

@@ -22,6 +22,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 F=$(ls $O/ev_FETCH_SIZE/*/*counter_collection.csv | head -1); W=$(ls $O/ev_WRITE_SIZE/*/*counter_collection.csv | head -1)
 python tools/pmc_traffic.py $F $W $O/${tag}_pmc_traffic.json > $O/${tag}_pmc_traffic.txt 2> $O/pmc_traffic.err
+python tools/pmc_traffic.py $F $W --by-grid --by-shape $O/launch_log.json > $O/${tag}_pmc_traffic_by_grid.txt 2>> $O/pmc_traffic.err
 rm -rf $O/ev_FETCH_SIZE $O/ev_WRITE_SIZE
 # 3. MFMA-pipe busy cycles per kernel symbol inside the step
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/ev_mfma -- python bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > /dev/null 2> $O/ev_mfma.err
