@@ -1,6 +1,8 @@
 // elementwise.hip -- HBM-bound glue kernels of the SVD UNet step for gfx950: GEGLU, AlphaBlender, broadcast
 // row-vector add / grouped column sums, transposes (weight-grad operands, head-transposed attention operands),
 // channel concat/split, nearest-x2 backward, dtype casts, NCHW<->rows.  All accesses are 16 B per lane.
+#include <algorithm>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -319,7 +321,7 @@ extern "C" int svdx_colsum(const void* x, float* out, int rows, int C, int ldx, 
     hipStream_t st = (hipStream_t)stream;
     const int maxcnt = mod ? cdiv(rows, mod) : std::min(rows_per_group, rows);
     const int nslab = cdiv(maxcnt, CS_SLAB);
-    if (!scratch && !accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * n_groups * C, st);
+    if (!scratch && !accumulate) { if (int rc = svdx_zero(out, sizeof(float) * n_groups * C, stream)) return rc; }     // a kernel: see svdx_zero
     dim3 grid(n_groups, nslab, cdiv(C, 256));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, out, rows, C, ldx,
                                              rows_per_group, mod, scratch));
@@ -415,9 +417,38 @@ extern "C" int svdx_zero_spans(float* base, const int* spans, int n_spans, void*
     return 0;
 }
 
+namespace {
+// 16 bytes per lane, grid-stride; the unaligned head / tail bytes (never more than 15 each) by single lanes
+__global__ __launch_bounds__(256) void zero_kernel(char* p, size_t bytes) {
+    const size_t head = min(bytes, (size_t)((16 - ((uintptr_t)p & 15)) & 15));
+    const size_t n16 = (bytes - head) / 16;
+    f32x4* q = reinterpret_cast<f32x4*>(p + head);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) q[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) p[threadIdx.x] = 0;
+        const size_t tail0 = head + n16 * 16;
+        if (tail0 + threadIdx.x < bytes && threadIdx.x < 16) p[tail0 + threadIdx.x] = 0;
+    }
+}
+}  // namespace
+
+// A kernel, not hipMemsetAsync.  Round 4 (MI355X, ROCm 7.2, torch 2.10; profiles/r4_graph_replay_hazard.txt): once the process has issued
+// ANY host <-> device copy or certain eager torch launches between two replays of a captured step, the hipMemsetAsync calls captured
+// in it (memset NODES of the hipGraph: the statistics arenas cleared at the head of every sweep) no longer take effect in order with the
+// kernel nodes around them -- every later replay computed with wrong GroupNorm statistics (loss 0.905 where the undisturbed replay and
+// the eager step give 0.988; sometimes NaN), silently and for good.  A training loop copies a new batch in before every replay, so this
+// hit any real use of GraphedStep; the fixed-batch bench and tests never saw it.  With a kernel in place of the memset the replays are
+// bit-identical whatever runs between them.  SVDX_ZERO_MEMSET=1 restores the memset (developer knob: tools/dbg_corrupt.py).
 extern "C" int svdx_zero(void* p, size_t bytes, void* stream) {
     if (bytes == 0) return 0;
-    hipError_t e = hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);
-    if (e != hipSuccess) { svdx_set_error("svdx_zero: %s", hipGetErrorString(e)); return -1; }
+    static const bool use_memset = getenv("SVDX_ZERO_MEMSET") && atoi(getenv("SVDX_ZERO_MEMSET")) == 1;
+    if (use_memset) {
+        hipError_t e = hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);
+        if (e != hipSuccess) { svdx_set_error("svdx_zero: %s", hipGetErrorString(e)); return -1; }
+        return 0;
+    }
+    const int blocks = (int)std::min<size_t>((bytes / 16 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (char*)p, bytes);
+    SVDX_LAUNCH_CHECK("svdx_zero");
     return 0;
 }

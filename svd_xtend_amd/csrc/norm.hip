@@ -587,7 +587,7 @@ extern "C" int svdx_gn_stats(const void* x, float* stats, int n_s, int rows, int
     GnGeom q; int threads;
     if (int rc = gn_geom(q, n_s, rows, C, G, threads, true)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (!prezeroed) (void)hipMemsetAsync(stats, 0, sizeof(long long) * 2 * n_s * G * SVDX_GN_REPLICAS, st);
+    if (!prezeroed) { if (int rc = svdx_zero(stats, sizeof(long long) * 2 * n_s * G * SVDX_GN_REPLICAS, stream)) return rc; }      // a kernel, not a memset node: see svdx_zero
     dim3 grid(n_s, cdiv(rows, q.slab));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_reduce_kernel<T, 0>), grid, dim3(threads), 0, st, (const T*)x,
                                              (const T*)nullptr, (const float*)nullptr, (const float*)nullptr,
@@ -614,7 +614,7 @@ extern "C" int svdx_gn_bwd_stats(const void* dy, const void* x, const float* sta
     GnGeom q; int threads;
     if (int rc = gn_geom(q, n_s, rows, C, G, threads, true)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (!prezeroed) (void)hipMemsetAsync(bstats, 0, sizeof(long long) * 2 * n_s * G * SVDX_GN_REPLICAS, st);
+    if (!prezeroed) { if (int rc = svdx_zero(bstats, sizeof(long long) * 2 * n_s * G * SVDX_GN_REPLICAS, stream)) return rc; }
     dim3 grid(n_s, cdiv(rows, q.slab));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_reduce_kernel<T, 1>), grid, dim3(threads), 0, st, (const T*)x,
                                              (const T*)dy, stats, gamma, beta, bstats, q, eps, silu));

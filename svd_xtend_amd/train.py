@@ -456,9 +456,6 @@ class GraphedStep:
                 self.g_opt.capture_end()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self.loss = None       # device scalar: mean loss of the last replayed step (what the reference logs, train_svd.py:1039-1040)
-        self.keep_loss = os.environ.get("SVDX_GRAPH_KEEP_LOSS", "1") != "0"      # developer knob (tools/dbg_timing.py)
-
     def __call__(self, side_work=None) -> None:
         """side_work: callable queued between the backward sweep and the optimizer, beside the gradient collective
         (`Trainer.finish_grads`) -- e.g. the replay of the next micro-batch's VAE-encode graph."""
@@ -471,13 +468,6 @@ class GraphedStep:
                     tr._pending.append(((lo, hi), dist.all_reduce(tr.g_flat[lo:hi], op=dist.ReduceOp.SUM, group=tr.pg, async_op=True)))
         tr.finish_grads(side_work)
         self.g_opt.replay()
-        # The step's loss as a fresh device scalar (the caller logs it when it likes; no host sync here) -- the reference reads its loss
-        # every step (train_svd.py:1039-1040).  This one ordinary, out-of-place ATen launch between two replays also matters for SPEED on
-        # MI355X / ROCm 7.2: a stream that sees nothing but hipGraph replays after the capture runs every kernel node ~3 us longer -- 7-10 %
-        # of the step, indefinitely (profiles/r4_graph_replay_prime.txt: 49.8 -> 44.7 ms/step; in-place ops, fills, copies, events and
-        # synchronizes do not change it, an out-of-place elementwise op does).  Rounds 1-3 benched in the slow state.
-        if self.keep_loss:
-            self.loss = tr.last_loss()
 
 
 def edm_prepare(latents, noise, cond_latents, sigmas):

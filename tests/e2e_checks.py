@@ -167,6 +167,41 @@ def graphed_vs_eager(dev=None, dtype=torch.float16, steps=3):
                 param_abs_max=float(e["p"].abs().max()), opt_steps=(e["state"][0], g["state"][0]), segments=g["segments"])
 
 
+def replays_with_traffic_between(dev=None, dtype=torch.float16, replays=4, disturb=True, cfg=None, geom=(1, 3, 16, 16)):
+    """`replays` replays of the captured step with -- when `disturb` -- the things a real training loop does between two replays: a new
+    batch copied into the captured input tensors (here: the same values, so the trajectory must not move), the loss read on the host,
+    ATen launches, a matmul.  Returns the flat parameters, the loss slot and the optimizer state."""
+    from svd_xtend_amd.train import GraphedStep
+    dev = dev or torch.device("cuda")
+    cfg = cfg or TINY_CONFIG
+    B, T, h, w = geom
+    orc = UNetSpatioTemporalConditionOracle(**cfg)
+    scaled_init_(orc, 5)
+    b = make_synthetic_batch(B, T, h, w, 77, cross_dim=cfg["cross_attention_dim"])
+    unet_in, ts, ehs, ids, noisy, _ = edm_inputs(b)
+    host = dict(unet_in=unet_in, timesteps=ts, ehs=ehs, added_time_ids=ids, noisy_latents=noisy, target=b["latents"], sigmas=b["sigmas"])
+    batch = {k: v.to(dev) for k, v in host.items()}
+    m = UNetSpatioTemporalConditionModel(**cfg)
+    m.load_state_dict(orc.state_dict(), strict=True)
+    m.to(dev)
+    tr = Trainer(m, dtype=dtype, lr=1e-3)
+    gs = GraphedStep(tr, batch)
+    losses = []
+    big = torch.ones(1 << 20, device=dev)
+    a = torch.ones(64, 64, device=dev, dtype=torch.float16)
+    for i in range(replays):
+        gs()
+        if disturb:
+            losses.append(float(tr.last_loss()))                 # an ATen launch + a D2H copy + a host sync
+            for k, v in host.items():
+                batch[k].copy_(v)                                # the next batch: H2D copies into the captured tensors
+            _ = big + 1                                          # eager launches with allocations of their own
+            _ = a @ a
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    return dict(p=tr.p_flat.clone(), loss=float(tr.loss_slot.cpu()), state=tr.opt_state.cpu().tolist(), losses=losses)
+
+
 def run_steps(dev=None, dtype=torch.float16, steps=3, seed=5, lora_r=0):
     """`steps` eager optimizer steps of the tiny topology from seeded weights on a seeded batch; returns the final state.
     lora_r: config 5's trainable set (adapters on the attention projections, B randomised so that every gradient is non-zero)."""

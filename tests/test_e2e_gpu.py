@@ -35,6 +35,23 @@ def test_graphed_step_follows_eager_trajectory():
 
 
 @gpu
+def test_graph_replays_survive_copies_and_eager_launches():
+    """A training loop copies the next batch into the captured tensors, reads the loss and launches whatever it likes between two
+    replays.  Round 4 found replays going off the trajectory -- for good -- after any such copy while libsvdx cleared its statistics
+    arenas with hipMemsetAsync (memset nodes of the captured graph lost their ordering: profiles/r4_graph_replay_hazard.txt); with
+    the zeroing kernel the disturbed replays must equal the undisturbed ones bit for bit.  Tiny topology and the 64x40-level block."""
+    import torch
+
+    import e2e_checks
+    for cfg, geom in ((None, (1, 3, 16, 16)), (e2e_checks.level_config(320, 5), (1, 14, 40, 64))):
+        quiet = e2e_checks.replays_with_traffic_between(disturb=False, cfg=cfg, geom=geom)
+        noisy = e2e_checks.replays_with_traffic_between(disturb=True, cfg=cfg, geom=geom)
+        assert quiet["state"][0] == noisy["state"][0] >= 5.0, (quiet["state"], noisy["state"])       # every replay took its optimizer step
+        assert quiet["loss"] == noisy["loss"], (quiet["loss"], noisy["loss"], noisy["losses"])
+        assert torch.equal(quiet["p"], noisy["p"]), float((quiet["p"] - noisy["p"]).abs().max())
+
+
+@gpu
 def test_same_seed_twice_gives_identical_bits():
     """SURVEY.md section 5 (deterministic replay): two runs of three optimizer steps from the same weights and batch end in
     identical weights, Adam moments and loss -- eager launches, both dtypes."""

@@ -121,7 +121,10 @@ def main():
         graphs[cfg]()
         torch.cuda.synchronize()
         undo()
-        print(f"# captured {cfg}: loss {float(tr.last_loss()):.6f}", flush=True)
+        # NB: no torch kernel may be launched between replays here (round 4 found that an out-of-place ATen op after a replay leaves
+        # every later replay of the graph with a non-finite loss on this runtime -- profiles/r4_graph_replay_prime.txt); the loss slot is
+        # read with a plain D2H copy
+        print(f"# captured {cfg}: loss {float(tr.loss_slot.cpu()):.6f}", flush=True)
 
     res = {c: [] for c in cfgs}
     for c in cfgs:                       # settle clocks: the first replays after capture run warm-up fast
@@ -138,6 +141,9 @@ def main():
             ms = (time.perf_counter() - t0) / args.steps * 1e3
             res[c].append(ms)
             print(f"[{c}] rep {rep}: {ms:.3f} ms/step", flush=True)
+    st = tr.opt_state.cpu().tolist()
+    lf = float(tr.loss_slot.cpu())
+    print(f"# after the timed replays: loss {lf:.6f}, optimizer steps {st[0]:.0f}, loss scale {st[1]:g}" + ("" if lf == lf and abs(lf) < 1e30 else "   <-- NON-FINITE: the timings above are void"))
     base = min(res[cfgs[0]])
     print("# summary (min / median over reps; delta of medians against the first CFG)")
     med0 = sorted(res[cfgs[0]])[len(res[cfgs[0]]) // 2]
