@@ -172,6 +172,22 @@ typedef struct svdx_outer_job {
     int reserved;
 } svdx_outer_job;
 int svdx_outer_acc_batch(const svdx_outer_job* jobs, int n_jobs, int M, void* stream);
+/* The float forms of svdx_gemm_finalize (c_is_f32_accumulate 1 / 2) over a table of jobs: dst[i] (+)= sum_z acc[z*slab_stride + i] for
+ * i < count, slice 0 first (the order svdx_gemm_finalize adds them in: same bits), and colsum_out[n] += sum_z colsum_slabs[z*colsum_n + n].
+ * Replaces the weight-grad half of autograd's Linear backward epilogues (train_svd.py:1044): the reducing launches of the row-sliced
+ * svdx_gemm_tn weight gradients of a sweep, none of which is read before the optimizer, run as one launch per 48.  The destinations of
+ * one call must be distinct. */
+typedef struct svdx_gradfin_job {
+    const float* acc;           /* [nsplit][slab_stride] float slabs */
+    float* dst;                 /* [count] floats, 16-byte aligned */
+    const float* colsum_slabs;  /* [nsplit][colsum_n] or NULL */
+    float* colsum_out;          /* [colsum_n], accumulated into */
+    int64_t slab_stride, count; /* floats; multiples of 4 */
+    int nsplit, colsum_n;
+    int store;                  /* 1: dst = sum (a gradient written once per step), 0: dst += sum */
+    int reserved;
+} svdx_gradfin_job;
+int svdx_grad_finalize_batch(const svdx_gradfin_job* jobs, int n_jobs, void* stream);
 /* out[i, :] = [cos(t_i f_j), sin(t_i f_j)], f_j = exp(-ln(1e4) j / (dim/2))  (diffusers Timesteps,
  * flip_sin_to_cos=True, shift 0; src/unet_spatio_temporal_condition.py:138,143) */
 int svdx_timestep_embed(const float* t, float* out, int n, int dim, void* stream);

@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
                         for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
                     }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float v = to_f<T>(o8.v[e]); a0[e] += v; a1[e] += v * v; }
+                        for (int e = 0; e < 8; ++e) { const float v = to_f<T>(o8.v[e]); a0[e] += v; a1[e] += v * v; }
                 }
                 if (cur_s >= 0) flush(cur_s);
             }
@@ -1385,6 +1385,36 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const float* __restr
             }
             __syncthreads();
         }
+    }
+}
+
+// ---- the float form of that epilogue over a PACK of jobs: the weight gradients of a backward sweep are not read before the optimizer,
+// so the reducing launches of their row-sliced TN GEMMs (96 per step at c2, a few us of launch latency each for a few hundred KB) wait
+// and run as one launch per 48 -- the same arithmetic in the same order per element (slice 0 first), so the bits do not change.
+struct GradFinPack {
+    svdx_gradfin_job job[SVDX_BATCH_MAX_JOBS];
+    int start[SVDX_BATCH_MAX_JOBS + 1];
+    int n_jobs;
+};
+__global__ __launch_bounds__(256) void grad_finalize_batch_kernel(const GradFinPack pk) {
+    const int j = pack_find(pk.start, pk.n_jobs, blockIdx.x);
+    const svdx_gradfin_job& q = pk.job[j];
+    const int blk = blockIdx.x - pk.start[j], nblk = pk.start[j + 1] - pk.start[j];
+    if (q.colsum_slabs) {                      // bias gradient: the row slices' column sums, added in slice order
+        for (int n = blk * 256 + threadIdx.x; n < q.colsum_n; n += nblk * 256) {
+            float t = 0.f;
+            for (int z = 0; z < q.nsplit; ++z) t += q.colsum_slabs[(size_t)z * q.colsum_n + n];
+            q.colsum_out[n] += t;
+        }
+    }
+    const long total4 = q.count / 4;
+    for (long i4 = (long)blk * 256 + threadIdx.x; i4 < total4; i4 += (long)nblk * 256) {
+        const long i = i4 * 4;
+        f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q.acc + i));
+        for (int z = 1; z < q.nsplit; ++z) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q.acc + (size_t)z * q.slab_stride + i));
+        f32x4* o = reinterpret_cast<f32x4*>(q.dst + i);
+        if (q.store) __builtin_nontemporal_store(v, o);
+        else *o = *o + v;
     }
 }
 
@@ -1854,6 +1884,28 @@ extern "C" int svdx_outer_acc_batch(const svdx_outer_job* jobs, int n_jobs, int 
         for (int j = pk.n_jobs; j <= SVDX_BATCH_MAX_JOBS; ++j) pk.start[j] = (int)blocks;
         hipLaunchKernelGGL(outer_acc_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk, M);
         SVDX_LAUNCH_CHECK("svdx_outer_acc_batch");
+    }
+    return 0;
+}
+
+extern "C" int svdx_grad_finalize_batch(const svdx_gradfin_job* jobs, int n_jobs, void* stream) {
+    SVDX_CHECK_ARG(jobs && n_jobs > 0, "svdx_grad_finalize_batch: bad args");
+    for (int j0 = 0; j0 < n_jobs; j0 += SVDX_BATCH_MAX_JOBS) {
+        GradFinPack pk;
+        pk.n_jobs = std::min(n_jobs - j0, SVDX_BATCH_MAX_JOBS);
+        long blocks = 0;
+        for (int j = 0; j < pk.n_jobs; ++j) {
+            const svdx_gradfin_job& q = jobs[j0 + j];
+            SVDX_CHECK_ARG(q.acc && q.dst && q.nsplit >= 1 && q.count > 0 && q.count % 4 == 0 && q.slab_stride % 4 == 0 &&
+                               (((uintptr_t)q.acc | (uintptr_t)q.dst) & 15) == 0 && (!q.colsum_slabs || (q.colsum_out && q.colsum_n > 0)),
+                           "svdx_grad_finalize_batch: job %d: bad args", j0 + j);
+            pk.job[j] = q;
+            pk.start[j] = (int)blocks;
+            blocks += std::min<long>(cdiv(q.count / 4, 256), 1024);
+        }
+        for (int j = pk.n_jobs; j <= SVDX_BATCH_MAX_JOBS; ++j) pk.start[j] = (int)blocks;
+        hipLaunchKernelGGL(grad_finalize_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk);
+        SVDX_LAUNCH_CHECK("svdx_grad_finalize_batch");
     }
     return 0;
 }

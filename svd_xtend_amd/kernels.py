@@ -45,6 +45,12 @@ class _OuterJobC(ctypes.Structure):          # include/svdx.h: svdx_outer_job
                 ("N", ctypes.c_int), ("K", ctypes.c_int), ("scale", ctypes.c_float), ("reserved", ctypes.c_int)]
 
 
+class _GradFinJobC(ctypes.Structure):        # include/svdx.h: svdx_gradfin_job
+    _fields_ = [("acc", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("colsum_slabs", ctypes.c_void_p), ("colsum_out", ctypes.c_void_p),
+                ("slab_stride", ctypes.c_int64), ("count", ctypes.c_int64), ("nsplit", ctypes.c_int), ("colsum_n", ctypes.c_int),
+                ("store", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
 class _LnRedJobC(ctypes.Structure):          # include/svdx.h: svdx_lnred_job
     _fields_ = [("partial", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
                 ("nblk", ctypes.c_int), ("C", ctypes.c_int)]
@@ -89,6 +95,7 @@ _SIGS = {
     "svdx_small_linear_batch": "p" "iii" "ip",
     "svdx_outer_acc_batch": "p" "ii" "p",
     "svdx_ln_param_reduce_batch": "p" "i" "p",
+    "svdx_grad_finalize_batch": "p" "i" "p",
     "svdx_timestep_embed": "pp" "ii" "p",
     "svdx_gn_stats": "pp" "iiii" "i" "ip",
     "svdx_gn_apply": "ppppp" "iiii" "fi" "ip",
@@ -304,6 +311,13 @@ class HipBackend:
         """jobs: sequence of (dY, X or None (a column of ones: bias gradient, K = 1), dW, N, K, scale)."""
         arr = (_OuterJobC * len(jobs))(*[_OuterJobC(_f32(dY), _f32(X), _f32(dW), N, Kd, float(sc), 0) for dY, X, dW, N, Kd, sc in jobs])
         self._call("svdx_outer_acc_batch", ctypes.cast(arr, ctypes.c_void_p), len(jobs), M, self._stream())
+
+    def grad_finalize_batch(self, jobs):
+        """jobs: sequence of (slabs, nsplit, slab_stride, dst, count, colsum_slabs or None, colsum_out or None, store) -- each what the
+        float forms of `gemm_finalize` take; ONE launch per BATCH_MAX_JOBS jobs, distinct destinations."""
+        arr = (_GradFinJobC * len(jobs))(*[_GradFinJobC(_f32(a), _f32(d), _f32(cs), _f32(co), st, cnt, ns, co.numel() if co is not None else 0, int(bool(sto)), 0)
+                                           for a, ns, st, d, cnt, cs, co, sto in jobs])
+        self._call("svdx_grad_finalize_batch", ctypes.cast(arr, ctypes.c_void_p), len(jobs), self._stream())
 
     def timestep_embed(self, t, out, n, dim):
         self._call("svdx_timestep_embed", _f32(t), _f32(out), n, dim, self._stream())

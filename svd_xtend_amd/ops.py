@@ -102,6 +102,10 @@ class Runtime:
         # attn1.to_out weight-gradient GEMM already computes on the matrix pipe: no svdx_colsum pass.  SVDX_DVEC_FROM_DW=0: A/B knob
         self.dvec_from_dw = os.environ.get("SVDX_DVEC_FROM_DW", "1") != "0"
         self._q_nn, self._q_outer, self._q_ln, self._q_M, self._q_outer_dst = [], [], [], None, set()
+        self._q_fin, self._q_fin_dst = [], set()
+        # the reducing launches of the row-sliced weight-gradient GEMMs wait for one table-driven launch at the end of the sweep (or of
+        # the transformer block, with gradient buckets); SVDX_DEFER_GRAD_FINALIZE=0: developer knob for A/B runs
+        self.defer_grad_finalize = os.environ.get("SVDX_DEFER_GRAD_FINALIZE", "1") != "0"
         # GroupNorm statistics of a tensor come from the store loop of the GEMM that writes it (svdx_gemm_gn) instead of a pass of their
         # own over it; SVDX_FUSE_GN_STATS=0: developer knob for A/B runs
         self.fuse_gn_stats = os.environ.get("SVDX_FUSE_GN_STATS", "1") != "0"
@@ -152,6 +156,17 @@ class Runtime:
         """job of kernels.ln_param_reduce_batch"""
         self._q_ln.append(job)
 
+    def defer_grad_finalize_job(self, job) -> None:
+        """job of kernels.grad_finalize_batch (the reducing launch of a row-sliced weight-gradient GEMM).  A destination may be queued
+        once per table (the jobs of a launch run concurrently): a second job on it first flushes what is queued."""
+        dst = job[3].data_ptr()
+        if dst in self._q_fin_dst or (job[6] is not None and job[6].data_ptr() in self._q_fin_dst):
+            self.flush_deferred()
+        self._q_fin_dst.add(dst)
+        if job[6] is not None:
+            self._q_fin_dst.add(job[6].data_ptr())
+        self._q_fin.append(job)
+
     def flush_deferred(self) -> None:
         k, M = self.k, self._q_M
         for jobs in self._q_nn:
@@ -161,14 +176,17 @@ class Runtime:
             k.outer_acc_batch(self._q_outer, M)
         if self._q_ln:
             k.ln_param_reduce_batch(self._q_ln)
+        if self._q_fin:
+            k.grad_finalize_batch(self._q_fin)
         self.drop_deferred()
 
     def drop_deferred(self) -> None:
         self._q_nn, self._q_outer, self._q_ln, self._q_M, self._q_outer_dst = [], [], [], None, set()
+        self._q_fin, self._q_fin_dst = [], set()
 
     @property
     def deferred_pending(self) -> bool:
-        return bool(any(self._q_nn) or self._q_outer or self._q_ln)
+        return bool(any(self._q_nn) or self._q_outer or self._q_ln or self._q_fin)
 
     def begin_pass(self, which: int) -> None:
         """Start of a forward (0) or backward (1) sweep: re-zero that sweep's statistics arena with ONE memset (GroupNorm
@@ -655,8 +673,13 @@ def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tenso
             slabs = rt.f32(sk, N, Kd)
             cs = rt.f32(sk, N) if a_colsum is not None else None       # per-slice column sums, added in slice order by the finalize
             k.gemm_tn(dy, x, slabs, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32_SLAB, split_k=sk, a_colsum=cs, stages=stages)
-            k.gemm_finalize(slabs, sk, N * Kd, dst, N, Kd, Kd, accumulate_f32=2 if store else 1, dtype=rt.dt, colsum_slabs=cs,
-                            colsum_out=a_colsum)
+            if rt.batch_small and rt.defer_grad_finalize and (N * Kd) % 4 == 0 and not _tuning(rt):
+                # nothing reads a weight gradient before the optimizer (or the block's gradient bucket): the reducing launch waits for
+                # the sweep's one table-driven launch (Runtime.flush_deferred); the slabs stay alive in the queue until then
+                rt.defer_grad_finalize_job((slabs, sk, N * Kd, dst, N * Kd, cs, a_colsum, store))
+            else:
+                k.gemm_finalize(slabs, sk, N * Kd, dst, N, Kd, Kd, accumulate_f32=2 if store else 1, dtype=rt.dt, colsum_slabs=cs,
+                                colsum_out=a_colsum)
 
     TN_TILES = {2: (128, 128), 18: (256, 256)}     # svdx_gemm_tn `stages`: output tile (rows of dst, columns)
     ALL_TN_TILES = {**TN_TILES, **STAGED_TN_TILES}
@@ -1072,9 +1095,12 @@ class GroupNormOp:
         return y, stats
 
     def bwd(self, rt: Runtime, dy, x, stats, n_s: int, rows: int, add: Optional[torch.Tensor] = None):
-        bst, pz = rt.take_zeroed(K.GN_REPLICAS * n_s * GN_GROUPS * K.GN_STAT_FLOATS)
+        """The backward statistics stay a pass of their own over (dy, x): round 4 built them into the store loop of the data-gradient GEMM that
+        writes dy (the norm's input x read beside it) and measured the step 0.12 ms SLOWER (profiles/r4_ab_in_step.txt) -- the pass
+        reads dy and x at 3 TB/s beside nothing else, the store loop read x through a workgroup that had just finished its K-loop."""
         dx = rt.empty(n_s * rows, self.C)
         g, b = self.mod.weight.data, self.mod.bias.data
+        bst, pz = rt.take_zeroed(K.GN_REPLICAS * n_s * GN_GROUPS * K.GN_STAT_FLOATS)
         rt.k.gn_bwd_stats(dy, x, stats, g, b, bst, n_s, rows, self.C, GN_GROUPS, self.eps, self.silu, prezeroed=pz)
         rt.k.gn_bwd_apply(dy, x, stats, bst, g, b, add, dx, n_s, rows, self.C, GN_GROUPS, self.eps, self.silu)
         return dx

@@ -228,6 +228,20 @@ class EmuBackend:
                 xf = V(C, M, N, ldc).float().reshape(M // rows, rows, N // cg, cg)
                 gn_encode_add(stats, M // rows, N // cg, rows * cg, 0, xf.sum((1, 3)), (xf * xf).sum((1, 3)))
 
+    def grad_finalize_batch(self, jobs):
+        for acc, nsplit, stride, dst, count, cs, co, store in jobs:
+            v = torch.zeros(count, device=acc.device)
+            for z in range(nsplit):
+                v = v + torch.as_strided(acc, (count,), (1,), acc.storage_offset() + z * stride)
+            d = V1(dst, count)
+            if store:
+                d.copy_(v)
+            else:
+                d.add_(v)
+            if cs is not None:
+                n = co.numel()
+                V1(co, n).add_(V(cs, nsplit, n, n).sum(0))
+
     def small_linear(self, X, W, bias, Y, M, N, Kd, ldw, trans=0, silu_in=0, accumulate=0):
         w = V(W, N, Kd, ldw).float()
         if trans == 0:

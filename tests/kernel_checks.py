@@ -183,6 +183,26 @@ def check_gemm_tn(P, dt, stages=0):
     o1, o2 = P.run("gemm_tn", lambda o: ((big[:, 128:], X, o["C"], 300, 128, 64, 384, 64, 64), dict(out_mode=K.OUT_F32, stages=stages)),
                    dict(C=torch.zeros(128, 64, device=P.dev)))
     res.append(("gemm_tn strided A", relerr(o1["C"], o2["C"]), tol_for(dt)))
+    if stages == 0:
+        # table-driven float finalize (svdx_grad_finalize_batch): store and accumulate forms, with and without bias-gradient slabs,
+        # bit-compared with one svdx_gemm_finalize launch each on the implementation under test
+        g2 = torch.Generator().manual_seed(77)
+        jobs, singles = [], []
+        for (n, kd, sk, store, with_cs) in [(320, 320, 5, True, True), (960, 320, 3, False, False), (64, 1280, 2, True, True), (1280, 64, 7, False, True)]:
+            slabs = rndf((sk, n, kd), P.dev, g2)
+            cs = rndf((sk, n), P.dev, g2) if with_cs else None
+            d0, c0 = rndf((n, kd), P.dev, g2), (rndf((n,), P.dev, g2) if with_cs else None)
+            jobs.append((slabs, sk, n * kd, d0.clone(), n * kd, cs, None if c0 is None else c0.clone(), store))
+            singles.append((slabs, sk, n, kd, d0.clone(), cs, None if c0 is None else c0.clone(), store))
+        for be, tag in ((P.impl, "impl"), (P.ref, "emul")):
+            jb = [(a, ns, st, d.clone(), cnt, cs, None if co is None else co.clone(), sto) for a, ns, st, d, cnt, cs, co, sto in jobs]
+            be.grad_finalize_batch(jb)
+            for (a, ns, st, d, cnt, cs, co, sto), (slabs, sk, n, kd, d1, cs1, c1, store) in zip(jb, singles):
+                d1, c1 = d1.clone(), (None if c1 is None else c1.clone())
+                be.gemm_finalize(slabs, sk, n * kd, d1, n, kd, kd, accumulate_f32=2 if store else 1, dtype=dt, colsum_slabs=cs1, colsum_out=c1)
+                res.append((f"grad_finalize_batch [{tag}] {n}x{kd} split {sk} store={store}", float((d - d1).abs().max()), 0.0))
+                if c1 is not None:
+                    res.append((f"grad_finalize_batch [{tag}] {n}x{kd} colsum", float((co - c1).abs().max()), 0.0))
     return res
 
 

@@ -43,7 +43,9 @@ def test_graph_replays_survive_copies_and_eager_launches():
     import torch
 
     import e2e_checks
-    for cfg, geom in ((None, (1, 3, 16, 16)), (e2e_checks.level_config(320, 5), (1, 14, 40, 64))):
+    from oracle.unet import SVD_CONFIG
+    # the full topology at the benched shape is where the hazard showed (tools/dbg_corrupt.py); the two small cases are quick guards
+    for cfg, geom in ((None, (1, 3, 16, 16)), (e2e_checks.level_config(320, 5), (1, 14, 40, 64)), (SVD_CONFIG, (1, 14, 40, 64))):
         quiet = e2e_checks.replays_with_traffic_between(disturb=False, cfg=cfg, geom=geom)
         noisy = e2e_checks.replays_with_traffic_between(disturb=True, cfg=cfg, geom=geom)
         assert quiet["state"][0] == noisy["state"][0] >= 5.0, (quiet["state"], noisy["state"])       # every replay took its optimizer step

@@ -41,7 +41,7 @@ def by_shape(fetch, write, log):
     """Fabric-side bytes per GEMM problem: the k-th dispatch of a kernel family in the step belongs to the k-th logged call of the
     entries that launch it (tools/step_trace.py's join).  Algorithmic bytes = each operand once + the result once (float slabs: 4 B x
     slices), activations of a convolution once (not once per tap) -- what bench.py's `algorithmic_bytes_per_launch` counts."""
-    fams = [(("gemm_v4", "gemm_kernel"), ("svdx_gemm", "svdx_gemm_dual")), (("gemm_tn",), ("svdx_gemm_tn",))]
+    fams = [(("gemm_v4", "gemm_kernel"), ("svdx_gemm", "svdx_gemm_dual", "svdx_gemm_gn")), (("gemm_tn",), ("svdx_gemm_tn",))]
     agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0])
     for keys, entries in fams:
         calls = [c for c in log if c[0] in entries]
@@ -60,10 +60,12 @@ def by_shape(fetch, write, log):
                 M, N, K = a[3], a[4], a[5]
                 dual = c[0] == "svdx_gemm_dual"
                 g = tuple(c[2]) if len(c) > 2 and c[2] else 0
-                sk, om, epi = (a[20], a[18], a[22]) if not dual else (1, a[18], 0)
+                sk, om, epi = (a[20], a[18], a[22]) if c[0] == "svdx_gemm" else (1, a[18], 0) if dual else (1, 0, 0)
                 taps = {0: 1, 1: 9, 2: 9, 3: 3, 4: 9}.get(g[0] if g else 0, 1)
                 osz = 4 * sk if om != 0 else 2
                 alg = 2.0 * M * K / taps + 2.0 * N * K + osz * M * N + (2.0 * M * N if a[14] is not None else 0.0)
+                if c[0] == "svdx_gemm_gn" and a[23] is not None:
+                    alg += 2.0 * M * N              # the backward-statistics form also reads the norm's input x [M, N]
                 if epi == 1:
                     alg += 2.0 * M * N / 2          # GEGLU forward also writes h [M, F]
                 elif epi == 2:

@@ -9,7 +9,7 @@ def main():
     cat = collections.defaultdict(lambda: [0, 0.0, 0.0])
     for r in d["calls"]:
         a, e = r["args"], r["entry"]
-        if e in ("svdx_gemm", "svdx_gemm_dual"):
+        if e in ("svdx_gemm", "svdx_gemm_dual", "svdx_gemm_gn"):
             M, N, K = a[3], a[4], a[5]
             lvl = {35840: "L0", 8960: "L1", 2240: "L2", 560: "L3"}.get(M, str(M))
             epi = a[22] if e == "svdx_gemm" else 0

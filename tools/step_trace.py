@@ -13,9 +13,9 @@ import sqlite3
 import sys
 
 FAMILIES = [   # (kernel-name regex, entries whose calls launch exactly one such kernel each, in call order)
-    (r"gemm_v4_kernel|[^_]gemm_kernel|gemm_v5", ["svdx_gemm", "svdx_gemm_dual"]),
+    (r"gemm_v4_kernel|[^_]gemm_kernel|gemm_v5", ["svdx_gemm", "svdx_gemm_dual", "svdx_gemm_gn"]),
     (r"gemm_tn", ["svdx_gemm_tn"]),
-    (r"gemm_finalize_kernel", ["svdx_gemm_finalize"]),
+    (r"gemm_finalize_kernel", ["svdx_gemm_finalize", "svdx_gemm_finalize_gn"]),
     (r"attn_fwd_kernel", ["svdx_attn_fwd"]), (r"attn_bwd_dkv_kernel", ["svdx_attn_bwd_dkv"]), (r"attn_bwd_dq_kernel", ["svdx_attn_bwd_dq"]),
     (r"attn_bwd_prep_kernel", ["svdx_attn_bwd_prep"]),
     (r"tattn_fwd_kernel", ["svdx_tattn_fwd"]), (r"tattn_bwd_kernel", ["svdx_tattn_bwd"]), (r"tsa_fwd_kernel", ["svdx_tsa_fwd"]),
@@ -69,11 +69,13 @@ def main():
     agg = {}
     for r in out:
         a = r["args"]
-        if r["entry"] in ("svdx_gemm", "svdx_gemm_dual"):
+        if r["entry"] in ("svdx_gemm", "svdx_gemm_dual", "svdx_gemm_gn"):
             M, N, K = a[3], a[4], a[5]
             dual = r["entry"] == "svdx_gemm_dual"
-            key = ("nt", M, N, K, tuple(r["extra"]) if r["extra"] else 0, a[20] if not dual else 1, a[21] if not dual else a[20], a[22] if not dual else 0,
-                   a[9] is not None, a[10] is not None, a[14] is not None, a[18])
+            gn = r["entry"] == "svdx_gemm_gn"            # ... gather, zero_page, alpha, variant, gn_stats, rows, cg, gn_bwd: unsplit, activation output
+            key = ("nt", M, N, K, tuple(r["extra"]) if r["extra"] else 0, 1 if (dual or gn) else a[20], a[19] if gn else (a[21] if not dual else a[20]),
+                   (3 if a[23] is not None else 4) if gn else (a[22] if not dual else 0),      # epi column: 4 = + GroupNorm statistics, 3 = + backward statistics
+                   a[9] is not None, a[10] is not None, a[14] is not None, 0 if gn else a[18])
             fl = 2.0 * M * N * K
         elif r["entry"] == "svdx_gemm_tn":
             R, N, K = a[3], a[4], a[5]
@@ -81,6 +83,9 @@ def main():
             fl = 2.0 * R * N * K
         elif r["entry"] == "svdx_gemm_finalize":
             key = ("fin", a[5], a[6], a[1], 0, 0, 0, 0, a[8] is not None, a[9] is not None, a[13] is not None, a[4])
+            fl = 0.0
+        elif r["entry"] == "svdx_gemm_finalize_gn":
+            key = ("fin", a[4], a[5], a[1], 0, 0, 0, 4, a[7] is not None, a[8] is not None, a[12] is not None, 0)
             fl = 0.0
         else:
             continue
@@ -95,7 +100,7 @@ def main():
     # everything else by entry
     other = {}
     for r in out:
-        if r["entry"] in ("svdx_gemm", "svdx_gemm_dual", "svdx_gemm_tn", "svdx_gemm_finalize"):
+        if r["entry"] in ("svdx_gemm", "svdx_gemm_dual", "svdx_gemm_gn", "svdx_gemm_tn", "svdx_gemm_finalize", "svdx_gemm_finalize_gn"):
             continue
         ints = tuple(x for x in r["args"] if isinstance(x, int) and 0 < x < (1 << 24))[:6]
         e = other.setdefault((r["entry"], r["kernel"][-40:], ints), [0, 0.0])
