@@ -489,81 +489,173 @@ def main():
         k = trainer.rt.k
         orig, orig_tn = k.gemm, k.gemm_tn
         recs, recs_bytes = [], []
+        # Two clocks.  `stamps` (one rank, graph mode): every launch of the family is bracketed by svdx_stamp -- a one-lane kernel that writes
+        # the device wall clock -- INSIDE a second capture of the step, so the durations are those of the replayed step (the kernel
+        # boundary a stamp adds is calibrated from back-to-back stamps and subtracted).  `events` (eager fallback, and the multi-rank
+        # path whose collectives cannot be captured): HIP events around each eager launch, which also time ~5 us of marker handling per
+        # launch -- round 3's method; its figure is reported beside the stamps' as `kernel_ms_per_step_events`.
+        use_stamps = world == 1 and exec_mode == "hipgraph" and hasattr(k, "stamp") and k.wall_clock_khz() > 0
+        slots = torch.zeros(16384, dtype=torch.int64, device=dev) if use_stamps else None
+        nslot = [0]
+
+        class Span:
+            """duration of what was enqueued between begin() and end(); ms() after the measurement"""
+            calib_ms, host = 0.0, None
+
+            def __init__(self):
+                self.h = None
+                if use_stamps:
+                    if torch.cuda.is_current_stream_capturing() and nslot[0] + 2 <= slots.numel():
+                        self.h = nslot[0]
+                        nslot[0] += 2
+                        k.stamp(slots, self.h)
+                else:
+                    self.h = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    self.h[0].record()
+
+            def end(self):
+                if self.h is None:
+                    return self
+                if use_stamps:
+                    k.stamp(slots, self.h + 1)
+                else:
+                    self.h[1].record()
+                return self
+
+            @property
+            def live(self):
+                return self.h is not None
+
+            def ms(self):
+                if use_stamps:
+                    return max(0.0, float(Span.host[self.h + 1] - Span.host[self.h]) / k.wall_clock_khz() - Span.calib_ms)
+                return self.h[0].elapsed_time(self.h[1])
 
         def timed_gemm(A, Bm, C, M, N, Kd, *a, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            sp = Span()
             orig(A, Bm, C, M, N, Kd, *a, **kw)
-            e1.record()
+            if not sp.end().live:
+                return
             g = kw.get("gather")
-            recs.append((e0, e1, 2.0 * M * N * Kd, ("nt", M, N, Kd, g.mode if g is not None else 0, kw.get("split_k", 1))))
-            taps = {0: 1, 1: 9, 2: 9, 3: 3}.get(g.mode if g is not None else 0, 1)
+            recs.append((sp, 2.0 * M * N * Kd, ("nt", M, N, Kd, g.mode if g is not None else 0, kw.get("split_k", 1))))
+            # algorithmic bytes of the launch: every operand once (the activations of a convolution once, not once per tap), the result
+            # once (float slabs: 4 B x slices), the residual it adds, and what a fused GEGLU epilogue moves besides the plain result
+            # (forward: h [M, F] beside pre [M, 2F]; backward: reads pre [M, 2F] and writes d(pre) [M, 2F] where the plain GEMM writes [M, F])
+            taps = {0: 1, 1: 9, 2: 9, 3: 3, 4: 9}.get(g.mode if g is not None else 0, 1)
             osz = 4 * kw.get("split_k", 1) if kw.get("out_mode", 0) != 0 else 2       # float slabs vs 16-bit activations
-            recs_bytes.append((0, 0, 0, 2.0 * M * Kd / taps + 2.0 * N * Kd + osz * M * N))
+            epi = kw.get("epilogue", 0)
+            recs_bytes.append(2.0 * M * Kd / taps + 2.0 * N * Kd + osz * M * N + (2.0 * M * N if kw.get("res") is not None else 0.0)
+                              + (1.0 * M * N if epi == 1 else 6.0 * M * N if epi == 2 else 0.0))
 
         def timed_gemm_tn(A, Bm, C, R, N, Kd, *a, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            sp = Span()
             orig_tn(A, Bm, C, R, N, Kd, *a, **kw)
-            e1.record()
-            recs.append((e0, e1, 2.0 * R * N * Kd, ("tn", N, Kd, R, 0, kw.get("split_k", 1))))
-            recs_bytes.append((0, 0, 0, 2.0 * R * N + 2.0 * R * Kd + 4.0 * N * Kd * max(2, kw.get("split_k", 1))))
+            if not sp.end().live:
+                return
+            recs.append((sp, 2.0 * R * N * Kd, ("tn", N, Kd, R, 0, kw.get("split_k", 1))))
+            recs_bytes.append(2.0 * R * N + 2.0 * R * Kd + 4.0 * N * Kd * max(1, kw.get("split_k", 1)))
         # the band kernel (fused temporal self-attention) carries projections that used to be launches of the family above; it is
         # timed beside it, not inside it
         orig_tsa = getattr(k, "tsa_fwd", None)
         band = []
 
         def timed_tsa(*a):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            sp = Span()
             orig_tsa(*a)
-            e1.record()
+            if not sp.end().live:
+                return
             Bq, Tq, HWq, Cq = a[16], a[17], a[18], a[19]
-            band.append((e0, e1, 8.0 * Bq * Tq * HWq * Cq * Cq + 4.0 * Bq * Tq * HWq * Tq * Cq))
+            band.append((sp, 8.0 * Bq * Tq * HWq * Cq * Cq + 4.0 * Bq * Tq * HWq * Tq * Cq))
 
         # the temporal self-attention OP (north_star's "temporal-attention kernel"; SURVEY 8d: LN + q/k/v + core + out-projection is the
         # only definition under which an MFMA fraction means anything): every launch between the region marks of
-        # TemporalBasicTransformerBlock.fwd / .bwd, per block, bracketed by events
-        regions, open_ev = [], {}
+        # TemporalBasicTransformerBlock.fwd / .bwd, per block
+        regions, open_sp = [], {}
 
         def on_region(name, info, begin):
             if begin:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                open_ev[name] = e0
+                open_sp[name] = Span()
             else:
-                e1 = torch.cuda.Event(enable_timing=True)
-                e1.record()
-                regions.append((name, dict(info), open_ev.pop(name), e1))
+                sp = open_sp.pop(name).end()
+                if sp.live:
+                    regions.append((name, dict(info), sp))
 
-        if rank == 0:
+        def install():
             k.gemm, k.gemm_tn = timed_gemm, timed_gemm_tn
             trainer.rt.on_region = on_region
             if orig_tsa is not None:
                 k.tsa_fwd = timed_tsa
-        try:
-            # The events must time kernels, not the host: an eager step is ~1900 launches + 1400 event records, and wherever the
-            # host falls behind (the 8x5 / 16x10 levels: 20 us kernels) the idle gap would land inside an event pair.  A spin kernel
-            # holds the stream for ~40 ms first, so the whole step is enqueued before its first kernel starts.
-            torch.cuda.synchronize()
-            torch.cuda._sleep(int(0.040 * 2.1e9))
-            fwd_bwd()
-            torch.cuda.synchronize()
-        finally:
+
+        def uninstall():
             k.gemm, k.gemm_tn = orig, orig_tn
             trainer.rt.on_region = None
+            k.__dict__.pop("tsa_fwd", None)
+
+        events_ms = None
+        if use_stamps:
+            # (1) round 3's eager + events figure, for continuity; (2) the stamped capture
+            use_stamps = False
+            install()
+            try:
+                torch.cuda.synchronize()
+                torch.cuda._sleep(int(0.040 * 2.1e9))
+                fwd_bwd()
+                torch.cuda.synchronize()
+            finally:
+                uninstall()
+            trainer.allreduce_grads()
+            opt_step()
+            torch.cuda.synchronize()
+            events_ms = sum(sp.ms() for sp, _, _ in recs)
+            recs.clear(), recs_bytes.clear(), band.clear(), regions.clear()
+            use_stamps = True
+            install()
+            try:
+                g2 = GraphedStep(trainer, batches)         # its warm-up sweep is eager (no stamps, nothing recorded); the capture is stamped
+            finally:
+                uninstall()
+            ncal = 32
+            c0 = nslot[0]
+            gc = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(gc, stream=side):
+                    for i in range(ncal):
+                        k.stamp(slots, c0 + 2 * i)
+                        k.stamp(slots, c0 + 2 * i + 1)
+            torch.cuda.current_stream().wait_stream(side)
+            for _ in range(3):
+                g2()
+                gc.replay()
+            torch.cuda.synchronize()
+            Span.host = slots.cpu().tolist()
+            cal = sorted(float(Span.host[c0 + 2 * i + 1] - Span.host[c0 + 2 * i]) / k.wall_clock_khz() for i in range(ncal))
+            Span.calib_ms = cal[ncal // 2]
+            del g2, gc
+        elif rank == 0 or world > 1:
             if rank == 0:
-                k.__dict__.pop("tsa_fwd", None)
-        trainer.allreduce_grads()
-        opt_step()
-        torch.cuda.synchronize()
+                install()
+            try:
+                # The events must time kernels, not the host: an eager step is ~1900 launches + 1400 event records, and wherever the
+                # host falls behind (the 8x5 / 16x10 levels: 20 us kernels) the idle gap would land inside an event pair.  A spin kernel
+                # holds the stream for ~40 ms first, so the whole step is enqueued before its first kernel starts.
+                torch.cuda.synchronize()
+                torch.cuda._sleep(int(0.040 * 2.1e9))
+                fwd_bwd()
+                torch.cuda.synchronize()
+            finally:
+                uninstall()
+            trainer.allreduce_grads()
+            opt_step()
+            torch.cuda.synchronize()
         if rank == 0:
             if args.gemm_table:
                 agg = {}
-                for a, b, f, key in recs:
+                for sp, f, key in recs:
                     e = agg.setdefault(key, [0, 0.0, 0.0])
                     e[0] += 1
-                    e[1] += a.elapsed_time(b)
+                    e[1] += sp.ms()
                     e[2] += f
                 rows = sorted(([list(kk) + [v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12] for kk, v in agg.items()]), key=lambda r: -r[7])
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -574,9 +666,8 @@ def main():
                     with open(os.path.join(ROOT, "gpurun_out", "gemm_tuned.json"), "w") as f:
                         json.dump([[repr(kk), repr(tn.table.get(kk)), [[c if not isinstance(c, tuple) else list(c), (st[0] / st[1]) if st[1] else None]
                                                                       for c, st in zip(tn.cands[kk], tn.stats[kk])]] for kk in tn.cands], f)
-            recs = [(a, b, f) for a, b, f, _ in recs]
-            t_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-            fl = sum(f for _, _, f in recs)
+            t_ms = sum(sp.ms() for sp, _, _ in recs)
+            fl = sum(f for _, f, _ in recs)
             ach = fl / (t_ms * 1e-3) / 1e12
             # HBM-side bytes per launch of the same kernel family: rocprofv3 FETCH_SIZE / WRITE_SIZE passes over this exact command
             # (tools/pmc_traffic.py, gfx950 FETCH_SIZE x2 correction), committed under profiles/ -- bench.py cannot run a profiler
@@ -593,32 +684,32 @@ def main():
             tsa_op = None
             if regions:
                 lv = {}
-                for name, info, e0, e1 in regions:
+                for name, info, sp in regions:
                     M_, C_, T_ = info["M"], info["C"], info["T"]
                     fwd = name.endswith(".fwd")
                     # fwd: q/k/v 6MC^2 + out 2MC^2 + core (QK^T, PV) 4MTC;  bwd: data-grads 8MC^2 + weight-grads 8MC^2 + core (S again, dP, dV, dQ, dK) 10MTC
-                    fl = (8.0 * M_ * C_ * C_ + 4.0 * M_ * T_ * C_) if fwd else (16.0 * M_ * C_ * C_ + 10.0 * M_ * T_ * C_)
+                    ofl = (8.0 * M_ * C_ * C_ + 4.0 * M_ * T_ * C_) if fwd else (16.0 * M_ * C_ * C_ + 10.0 * M_ * T_ * C_)
                     d = lv.setdefault((M_, C_), {"rows": M_, "channels": C_, "frames": T_, "fwd": [0, 0.0, 0.0], "bwd": [0, 0.0, 0.0]})
                     a = d["fwd" if fwd else "bwd"]
                     a[0] += 1
-                    a[1] += e0.elapsed_time(e1)
-                    a[2] += fl
+                    a[1] += sp.ms()
+                    a[2] += ofl
                 tot = {"fwd": [0.0, 0.0], "bwd": [0.0, 0.0]}
                 levels = []
                 for key in sorted(lv, reverse=True):
                     d = lv[key]
                     row = {"rows": d["rows"], "channels": d["channels"], "frames": d["frames"]}
                     for w in ("fwd", "bwd"):
-                        n, ms_, fl = d[w]
+                        n, ms_, ofl = d[w]
                         tot[w][0] += ms_
-                        tot[w][1] += fl
-                        row[w] = {"blocks": n, "ms": ms_, "tflops": fl / (ms_ * 1e-3) / 1e12 if ms_ else None,
-                                  "frac_of_mfma_peak": fl / (ms_ * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if ms_ else None}
+                        tot[w][1] += ofl
+                        row[w] = {"blocks": n, "ms": ms_, "tflops": ofl / (ms_ * 1e-3) / 1e12 if ms_ else None,
+                                  "frac_of_mfma_peak": ofl / (ms_ * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if ms_ else None}
                     levels.append(row)
                 allms, allfl = tot["fwd"][0] + tot["bwd"][0], tot["fwd"][1] + tot["bwd"][1]
                 tsa_op = {"what": "temporal self-attention op of every TemporalBasicTransformerBlock (norm1 -> q/k/v -> attention over frames -> "
                                   "out-projection + residual; backward: both data-grads, both weight-grads, the core, norm1): algorithmic FLOPs / "
-                                  "summed duration of ALL launches between the region marks (events on the launch stream, one instrumented eager step)",
+                                  "summed duration of ALL launches between the region marks (the `clock` of this roofline object)",
                           "flops": "fwd 8MC^2 + 4MTC, bwd 16MC^2 + 10MTC", "levels": levels,
                           "fwd_frac_of_mfma_peak": tot["fwd"][1] / (tot["fwd"][0] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if tot["fwd"][0] else None,
                           "bwd_frac_of_mfma_peak": tot["bwd"][1] / (tot["bwd"][0] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if tot["bwd"][0] else None,
@@ -627,9 +718,13 @@ def main():
             roof = {"bound": "mfma", "kernel": "MFMA GEMM family (NT + implicit conv, TN weight-grad)", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "launches": len(recs),
                     "flops_per_step": fl, "kernel_ms_per_step": t_ms,
-                    "band_kernels": ({"what": "fused temporal self-attention launches (their projections are not in the family above)", "launches": len(band), "flops_per_step": sum(f for _, _, f in band),
-                                      "kernel_ms_per_step": sum(a.elapsed_time(b) for a, b, _ in band)} if band else None),
-                    "algorithmic_bytes_per_launch": sum(b for _, _, _, b in recs_bytes) / max(len(recs_bytes), 1),
+                    "band_kernels": ({"what": "fused temporal self-attention launches (their projections are not in the family above)", "launches": len(band), "flops_per_step": sum(f for _, f in band),
+                                      "kernel_ms_per_step": sum(sp.ms() for sp, _ in band)} if band else None),
+                    "clock": ("svdx_stamp: device wall clock written by one-lane kernels around every launch of the family inside a second "
+                              f"capture of the step (replay conditions); calibrated kernel boundary {Span.calib_ms * 1e3:.2f} us subtracted per launch"
+                              if use_stamps else "HIP events around eager launches"),
+                    "kernel_ms_per_step_events": events_ms,
+                    "algorithmic_bytes_per_launch": sum(recs_bytes) / max(len(recs_bytes), 1),
                     "temporal_self_attention": tsa_op}
 
     cpu = None

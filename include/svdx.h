@@ -329,6 +329,10 @@ int svdx_attn_small_fwd(const void* qkv, void* out, int n_img, int S, int heads,
 /* base[off .. off+cnt) = 0 for each (off, cnt) pair of `spans` (int pairs; off and cnt multiples of 4): ONE launch for the scattered
  * gradient slots that are accumulated with atomics and so must start from zero (biases, LayerNorm, skinny cross-attention weights). */
 int svdx_zero_spans(float* base, const int* spans, int n_spans, void* stream);
+/* Measurement aid: *slot = the device's constant-rate wall clock (ticks of svdx_wall_clock_khz kHz), written by a one-lane kernel in stream
+ * order; capturable.  bench.py brackets the GEMM-family launches of a captured step with it. */
+int svdx_stamp(uint64_t* slot, void* stream);
+int svdx_wall_clock_khz(void);
 
 /* ---- EDM loss (train_svd.py:1025-1036) fused with its gradient.  pred rows [B*T*HW, ld]; noisy/target
  *      float NCHW-per-frame [B,T,4,H,W]; sigma[B].  loss (float, accumulated; zero it first) and

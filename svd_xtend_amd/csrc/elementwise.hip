@@ -432,6 +432,26 @@ __global__ __launch_bounds__(256) void zero_kernel(char* p, size_t bytes) {
 }
 }  // namespace
 
+namespace {
+__global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+}  // namespace
+
+// Device-side time stamp on the launch stream: one single-lane kernel writes the constant-rate wall clock (svdx_wall_clock_khz) to
+// *slot.  Two stamps around a launch, captured with it in a hipGraph, give that launch's duration under replay conditions -- bench.py's
+// `roofline` uses them (HIP events around eager launches add ~5 us of marker handling per launch; stamps cost one ~1.5 us kernel
+// boundary, calibrated from back-to-back stamps and subtracted).
+extern "C" int svdx_stamp(uint64_t* slot, void* stream) {
+    SVDX_CHECK_ARG(slot && ((uintptr_t)slot & 7) == 0, "svdx_stamp: slot must be 8-byte aligned");
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(slot));
+    SVDX_LAUNCH_CHECK("svdx_stamp");
+    return 0;
+}
+extern "C" int svdx_wall_clock_khz(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+    return khz;
+}
+
 // A kernel, not hipMemsetAsync.  Round 4 (MI355X, ROCm 7.2, torch 2.10; profiles/r4_graph_replay_hazard.txt): once the process has issued
 // ANY host <-> device copy or certain eager torch launches between two replays of a captured step, the hipMemsetAsync calls captured
 // in it (memset NODES of the hipGraph: the statistics arenas cleared at the head of every sweep) no longer take effect in order with the

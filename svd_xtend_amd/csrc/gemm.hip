@@ -331,21 +331,50 @@ __device__ __forceinline__ typename TT<T>::v8 tn_frag(const char* tile, int colb
     return __builtin_bit_cast(typename TT<T>::v8, r);
 }
 
+// ---- which (row slice z, output tile) a TN workgroup computes.  Workgroup ids go round-robin to the 8 XCDs (id & 7), each with a private
+// 4 MiB L2, and a TN workgroup streams ROWS of dY / X: everything that shares rows wants to sit on one XCD at the same time.
+//   * split_k a multiple of 8 (the 64x40-level gradients: 16-32 slices of 35840 rows): XCD x runs slices x, x + 8, ... -- ALL output
+//     tiles of a slice side by side, walking the slice's rows in step, so each row of dY and X comes over the fabric once (round 3 put
+//     the slices of one TILE on an XCD: they share nothing, and every operand row was fetched by up to 8 XCDs -- 344 MB where 115 MB are
+//     algorithmic on the 320 x 1280 gradient, profiles/r4c_pmc_traffic_by_shape.txt);
+//   * split_k in {1, 2, 4}: each slice owns 8 / split_k XCDs, arranged xm x xn over its tile grid so that the cheaper operand is the one
+//     re-fetched (host: tn_arrange -- the rule of launch_gemm_v4).
+// Grid: 8 * zsets * sub_m * sub_n workgroups in x; out-of-range ids exit.
+struct TnWho { int pid_m, pid_n, z; bool live; };
+__device__ __forceinline__ TnWho tn_who(const GemmParams& p) {
+    const int bid = blockIdx.x, xcd = bid & 7, l = bid >> 3;
+    const int per = p.sub_m * p.sub_n;
+    const int zs = l / per, r = l - zs * per;
+    TnWho w;
+    int xi_m = 0, xi_n = 0;
+    if (p.split_k >= 8 || 8 % p.split_k) {           // (a slice count that neither divides 8 nor is a multiple of it leaves XCDs idle: legal, slow)
+        w.z = zs * 8 + xcd;
+    } else {
+        const int xps = 8 / p.split_k, xi = xcd % xps;
+        w.z = xcd / xps;
+        xi_m = xi / p.xcd_n;
+        xi_n = xi - xi_m * p.xcd_n;
+    }
+    const int lm = r / p.sub_n;
+    w.pid_m = xi_m * p.sub_m + lm;
+    w.pid_n = xi_n * p.sub_n + (r - lm * p.sub_n);
+    w.live = w.z < p.split_k && w.pid_m < p.tiles_m && w.pid_n < p.tiles_n;
+    return w;
+}
+
 template <typename T, int NSTG>
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int pid_m = swz / p.tiles_n, pid_n = swz - pid_m * p.tiles_n;
+    const TnWho who = tn_who(p);
+    if (!who.live) return;
+    const int pid_m = who.pid_m, pid_n = who.pid_n;
     const int m0 = pid_m * BM, n0 = pid_n * BN;          // m0: first output row (a column of A), n0: first output col (a column of B)
     const int R = p.K;                                   // reduction length (rows of A and B)
     const int kt_total = (R + BK - 1) / BK;
-    const int z = blockIdx.y;
+    const int z = who.z;
     const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
     const int kt_begin = z * kt_per;
     const int kt_end = min(kt_total, kt_begin + kt_per);
@@ -500,15 +529,13 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
     constexpr int NPIECE = 2 * (PA + PB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WNN, wn = wave % WNN;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int pid_m = swz / p.tiles_n, pid_n = swz - pid_m * p.tiles_n;
+    const TnWho who = tn_who(p);
+    if (!who.live) return;
+    const int pid_m = who.pid_m, pid_n = who.pid_n;
     const int m0 = pid_m * TM, n0 = pid_n * TK;
     const int R = p.K;
     const int kt_total = (R + BK - 1) / BK;
-    const int z = blockIdx.y;
+    const int z = who.z;
     const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
     const int kt_begin = z * kt_per;
     const int kt_end = min(kt_total, kt_begin + kt_per);
@@ -1522,15 +1549,40 @@ int launch_gemm_v4(GemmParams p, hipStream_t st) {
     return 0;
 }
 
+// grid of the TN kernels (tn_who): fills p.xcd_n / sub_m / sub_n, returns the number of workgroups.  The host side asks for 1, 2, 4 or a
+// multiple of 8 row slices (ops._tn_formula); any other count runs with some XCDs idle.
+static long tn_arrange(GemmParams& p) {
+    if (p.split_k >= 8 || 8 % p.split_k) {
+        p.xcd_n = 1; p.sub_m = p.tiles_m; p.sub_n = p.tiles_n;
+        return 8L * cdiv(p.split_k, 8) * p.sub_m * p.sub_n;
+    }
+    const int xps = 8 / p.split_k;
+    const double a_bytes = 2.0 * p.K * p.M, b_bytes = 2.0 * p.K * p.N;          // dY [R, N_out] and X [R, K_out] of one call (p.M / p.N = output rows / columns)
+    int best_xn = 1;
+    double best_cost = 0, best_eff = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int xn = 1; xn <= xps; xn *= 2) {
+            const int xm = xps / xn, sm = cdiv(p.tiles_m, xm), sn = cdiv(p.tiles_n, xn);
+            const double eff = (double)p.tiles_m * p.tiles_n / ((double)xps * sm * sn);
+            if (pass == 0) { best_eff = eff > best_eff ? eff : best_eff; continue; }
+            const double cost = a_bytes * xn + b_bytes * xm;                     // every XCD column re-fetches dY, every XCD row re-fetches X
+            if (eff >= 0.9 * best_eff && (best_cost == 0 || cost < best_cost)) { best_xn = xn; best_cost = cost; }
+        }
+    p.xcd_n = best_xn;
+    p.sub_m = cdiv(p.tiles_m, xps / best_xn);
+    p.sub_n = cdiv(p.tiles_n, best_xn);
+    return 8L * p.sub_m * p.sub_n;
+}
+
 template <typename T, int NSTG>
-int launch_gemm_tn(const GemmParams& p, hipStream_t st) {
+int launch_gemm_tn(GemmParams p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   NSTG * STAGE_BYTES);
         attr_set = true;
     }
-    dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
+    dim3 grid((unsigned)tn_arrange(p));
     hipLaunchKernelGGL((gemm_tn_kernel<T, NSTG>), grid, dim3(NTHREADS), NSTG * STAGE_BYTES, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm_tn");
     return 0;
@@ -1547,7 +1599,7 @@ int launch_gemm_tn8(GemmParams p, hipStream_t st) {
     }
     p.tiles_m = cdiv(p.M, 128 * PA);
     p.tiles_n = cdiv(p.N, 128 * PB);
-    dim3 grid(p.tiles_m * p.tiles_n, p.split_k);
+    dim3 grid((unsigned)tn_arrange(p));
     hipLaunchKernelGGL((gemm_tn8_kernel<T, PA, PB, NSTG>), grid, dim3(512), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm_tn");
     return 0;

@@ -132,6 +132,7 @@ _SIGS = {
     "svdx_blur_axis": "pp" "iii" "p" "ii" "p",
     "svdx_bicubic_affine": "pp" "iiiiii" "pp" "p",
     "svdx_attn_small_fwd": "pp" "iiiii" "ll" "f" "ip",
+    "svdx_stamp": "pp",
     "svdx_zero_spans": "pp" "ip",
     "svdx_edm_loss": "pi" "ppppp" "iiii" "pp" "ip",
     "svdx_check_finite": "plpp",
@@ -142,7 +143,7 @@ _SIGS = {
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "l": ctypes.c_int64, "z": ctypes.c_size_t}
 
-EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band", "svdx_ln_bwd_blocks")
+EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_wall_clock_khz", "svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band", "svdx_ln_bwd_blocks")
 BATCH_MAX_JOBS = 48            # include/svdx.h SVDX_BATCH_MAX_JOBS: jobs of a *_batch entry that share one launch
 TSA_MAX_C, TSA_MAX_T, TSA_BAND_ROWS = 320, 16, 144
 
@@ -186,6 +187,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.svdx_ln_bwd_blocks.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.svdx_ln_bwd_blocks.restype = ctypes.c_int
     lib.svdx_version.restype = ctypes.c_int
+    lib.svdx_wall_clock_khz.restype = ctypes.c_int
     lib.svdx_device_ok.restype = ctypes.c_int
     lib.svdx_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     lib.svdx_last_error.restype = ctypes.c_int
@@ -477,6 +479,14 @@ class HipBackend:
         self._call("svdx_adamw", _f32(p), _f32(g), _f32(m), _f32(v), n, float(lr), float(beta1), float(beta2),
                    float(eps), float(wd), float(grad_mul), _f32(opt_state), _p(p_act),
                    _dt(p_act) if p_act is not None else F16, self._stream())
+
+    def stamp(self, slots, i):
+        """slots: int64 device tensor; slots[i] = the device wall clock when the stream reaches this point (svdx_stamp)"""
+        assert slots.dtype == torch.int64
+        self._call("svdx_stamp", slots.data_ptr() + 8 * i, self._stream())
+
+    def wall_clock_khz(self) -> int:
+        return int(self.lib.svdx_wall_clock_khz())
 
     def zero_spans(self, base, spans, n_spans):
         assert spans.dtype == torch.int32 and spans.is_contiguous()

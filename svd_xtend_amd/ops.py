@@ -642,16 +642,23 @@ def _tn_formula(M: int, N: int, Kd: int):
     # 16x10 / 32x20-level feed-forward gradients (10240 x 1280 over 2240 rows: 98 against 107 us in the step; 5120 x 640 over 8960)
     if N >= 1024 and Kd >= 512 and rtiles >= 16:
         t18 = tiles_of(256, 256)
-        sk = max(1, min(256 // t18, rtiles // 32))
+        sk = _tn_slices(max(1, min(256 // t18, rtiles // 32)))
         if 180 <= t18 * sk <= 256:
             return sk, 18
     tiles = tiles_of(128, 128)
     sk = 1
     if tiles < 256 and rtiles >= 16:
         sk = max(1, min(512 // tiles, rtiles // 4, 128 if tiles <= 4 else 32))
+        sk = _tn_slices(sk)
         while sk > 1 and (rtiles + sk - 1) // sk * (sk - 1) >= rtiles:
-            sk -= 1
+            sk = _tn_slices(sk - 1)
     return sk, 2
+
+
+def _tn_slices(sk: int) -> int:
+    """Row-slice counts the TN kernels place well on the 8 XCDs (csrc/gemm.hip tn_who): 1, 2, 4 (a slice owns 8 / sk XCDs) or a multiple of 8
+    (an XCD owns whole slices); the largest such count <= sk."""
+    return sk // 8 * 8 if sk >= 8 else (4 if sk >= 4 else 2 if sk >= 2 else 1)
 
 
 def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tensor, M: int, N: int, Kd: int, lda: int, ldb: int,
@@ -690,7 +697,7 @@ def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tenso
 
     def cands():
         return [(s, v) for v in ALL_TN_TILES if v == 2 or (N >= ALL_TN_TILES[v][0] and Kd > ALL_TN_TILES[v][1] - 128)
-                for s in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 96)
+                for s in (1, 2, 4, 8, 16, 24, 32, 40, 48, 64, 96)
                 if s == 1 or (tiles_of(v) * s <= (2048 if v == 2 else 768) and rtiles // s >= 2 and -(-rtiles // s) * (s - 1) < rtiles)]
 
     tuned_call(rt, ("tn", M, N, Kd, lda, ldb), cands, lambda: _tn_formula(M, N, Kd), run)

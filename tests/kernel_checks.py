@@ -178,6 +178,14 @@ def check_gemm_tn(P, dt, stages=0):
                                                            dict(accumulate_f32=2, dtype=dt, colsum_slabs=cs, colsum_out=o["b"])),
                                dict(W=torch.ones(N, Kd, device=P.dev), b=torch.ones(N, device=P.dev)))
                 res.append((f"gemm_finalize {N}x{Kd} of 3 slabs + colsum rows", max(relerr(o1["W"], o2["W"]), relerr(o1["b"], o2["b"])), 1e-5))
+    # the row-slice counts the host asks for (ops._tn_slices): 2 / 4 (a slice owns several XCDs, arranged over its tile grid) and
+    # multiples of 8 (an XCD owns whole slices); rectangular outputs so that both arrangements of the XCDs occur
+    for (R, N, Kd, sk) in [(2100, 320, 320, 2), (2100, 640, 128, 4), (2100, 128, 640, 4), (2100, 320, 320, 8), (4200, 320, 256, 16), (2100, 256, 320, 24)]:
+        A, B = rnd((R, N), dt, P.dev, g), rnd((R, Kd), dt, P.dev, g, R ** -0.5)
+        outs = dict(C=torch.zeros(sk, N, Kd, device=P.dev), cs=torch.full((sk, N), 7.0, device=P.dev))
+        o1, o2 = P.run("gemm_tn", lambda o: ((A, B, o["C"], R, N, Kd, N, Kd, Kd), dict(out_mode=K.OUT_F32_SLAB, split_k=sk, a_colsum=o["cs"], stages=stages)), outs)
+        res.append((f"gemm_tn s{stages} {R}x{N}x{Kd} {sk} slices", relerr(o1["C"].view(sk * N, Kd), o2["C"].view(sk * N, Kd)), tol_for(dt)))
+        res.append((f"gemm_tn s{stages} {R}x{N}x{Kd} {sk} slices colsum(A)", relerr(o1["cs"], o2["cs"]), 2e-3))
     big = rnd((300, 3 * 128), dt, P.dev, g)
     X = rnd((300, 64), dt, P.dev, g)
     o1, o2 = P.run("gemm_tn", lambda o: ((big[:, 128:], X, o["C"], 300, 128, 64, 384, 64, 64), dict(out_mode=K.OUT_F32, stages=stages)),

@@ -56,6 +56,9 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "simulator"; }
 template <typename F> inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+constexpr int hipDeviceAttributeWallClockRate = 1;
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 100000; return hipSuccess; }      // the simulator's wall clock: 100 MHz, a counter
+inline unsigned long long wall_clock64() { static unsigned long long t = 0; return t += 100; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { memset(p, 0, sizeof(*p)); strcpy(p->gcnArchName, "gfx950"); p->multiProcessorCount = 256; return hipSuccess; }
