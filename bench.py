@@ -593,6 +593,12 @@ def main():
 
         events_ms = None
         if use_stamps:
+            # the stamped capture needs a memory pool of its own (as large as the timed one: ~25 GB at c2, ~100 GB at config 4's shape):
+            # the timed graph has done its work -- give its pool and the allocator's cached eager blocks back first
+            import gc
+            step = step_graph = None        # noqa: F841
+            gc.collect()
+            torch.cuda.empty_cache()
             # (1) round 3's eager + events figure, for continuity; (2) the stamped capture
             use_stamps = False
             install()

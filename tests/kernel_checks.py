@@ -630,6 +630,45 @@ def check_encoders(P, dt):
     return res
 
 
+def check_large_offsets(P, dt):
+    """Tensors beyond 2^31 bytes (the temporal VAE decoder at the reference's 1024 x 576 validation size puts 2.4 GB in front of its last
+    up block; vae.decode no longer refuses such chunks): the non-GEMM kernels on that path against the emulation with VALUES compared --
+    a 32-bit offset that wraps would leave finite but wrong numbers in the tail rows.  GPU only (2.4 GB operands), fp16."""
+    res = []
+    if P.dev.type != "cuda":
+        return res
+    n_s, rows, C = 8, 576 * 1024, 256                   # 8 frames of the 1024 x 576 decode at 256 channels: 2.42 GB per tensor
+    g = torch.Generator(device=P.dev).manual_seed(3)
+    x = (torch.randn(n_s * rows, C, generator=g, device=P.dev, dtype=torch.float32) * 1.5 + 0.2).to(dt)
+    gamma, beta = torch.ones(C, device=P.dev), torch.zeros(C, device=P.dev)
+    st = torch.zeros(K.GN_REPLICAS, n_s, 32, K.GN_STAT_FLOATS, device=P.dev)
+    P.impl.gn_stats(x, st, n_s, rows, C, 32, prezeroed=1)
+    ref = torch.zeros_like(st)
+    for i in range(n_s):                                # the emulation sample by sample (float copies of 2.4 GB at once are not needed)
+        r1 = torch.zeros(K.GN_REPLICAS, 1, 32, K.GN_STAT_FLOATS, device=P.dev)
+        P.ref.gn_stats(x[i * rows:(i + 1) * rows], r1, 1, rows, C, 32, prezeroed=1)
+        emul.gn_view(ref, n_s, 32)[:, i] = emul.gn_view(r1, 1, 32)[:, 0]
+    cnt = rows * (C // 32)
+    res.append((f"gn_stats {n_s}x{rows}x{C} (2.4 GB)", relerr(emul.gn_decode(st, n_s, 32, cnt, 0).view(-1, 2), emul.gn_decode(ref, n_s, 32, cnt, 0).view(-1, 2)), 1e-4))
+    y = torch.empty_like(x)
+    P.impl.gn_apply(x, ref, gamma, beta, y, n_s, rows, C, 32, 1e-5, 1)
+    worst = 0.0
+    for i in (0, n_s - 1):                              # first and last sample: the last one lies wholly beyond 2^31 bytes
+        yr = torch.empty(rows, C, dtype=dt, device=P.dev)
+        r1 = torch.zeros(K.GN_REPLICAS, 1, 32, K.GN_STAT_FLOATS, device=P.dev)
+        emul.gn_view(r1, 1, 32)[:, 0] = emul.gn_view(ref, n_s, 32)[:, i]
+        P.ref.gn_apply(x[i * rows:(i + 1) * rows], r1, gamma, beta, yr, 1, rows, C, 32, 1e-5, 1)
+        worst = max(worst, relerr(y[i * rows:(i + 1) * rows], yr))
+    res.append((f"gn_apply {n_s}x{rows}x{C} (2.4 GB), first and last sample", worst, tol_for(dt)))
+    n = n_s * rows * C
+    b = x.flip(0)
+    out = torch.empty_like(x)
+    P.impl.add(x, b, out, n)
+    tail = slice((n_s - 1) * rows, n_s * rows)
+    res.append(("add over 2.4 GB operands, last sample", relerr(out[tail], (x[tail].float() + b[tail].float()).to(dt)), tol_for(dt)))
+    return res
+
+
 def check_elementwise(P, dt):
     g = torch.Generator().manual_seed(8)
     res = []

@@ -11,7 +11,7 @@ GROUPS = (["gemm_tn", "gemm_tn_s3", "gemm_tn_s4", "gemm_tn_v18", "gemm_geglu", "
           + [f"gemm_{k}_v{v}" for v in (4, 6) + RING for k in ("plain", "gather")]
           + [f"gemm_gn_v{v}" for v in (4, 6, 8, 16, 18, 22, 23, 24, 26)]     # svdx_gemm_gn: GroupNorm statistics from the store loop of every tile family
           + [f"gemm_{k}_v{v}" for v in (27, 28) for k in ("plain", "gather")] + ["gemm_geglu_v27"]     # tuner candidates (ops.STAGED_TILES)
-          + ["small", "groupnorm", "layernorm", "attention", "temporal_attention", "tsa", "encoders", "elementwise", "optim"])
+          + ["large_offsets", "small", "groupnorm", "layernorm", "attention", "temporal_attention", "tsa", "encoders", "elementwise", "optim"])
 
 
 @pytest.fixture(scope="module")
@@ -29,6 +29,7 @@ def test_kernel_group(pair, group, dt):
     import kernel_checks as kc
     fns = {"gemm_tn": lambda: kc.check_gemm_tn(pair, dt), "gemm_tn_s3": lambda: kc.check_gemm_tn(pair, dt, 3), "gemm_tn_s4": lambda: kc.check_gemm_tn(pair, dt, 4),
            "gemm_geglu": lambda: kc.check_gemm_geglu(pair, dt), "gemm_plain_v1": lambda: kc.check_gemm_plain(pair, dt, 1),
+           "large_offsets": lambda: kc.check_large_offsets(pair, dt) if dt == torch.float16 else [],
            "small": lambda: kc.check_small(pair, dt), "groupnorm": lambda: kc.check_groupnorm(pair, dt),
            "layernorm": lambda: kc.check_layernorm(pair, dt), "attention": lambda: kc.check_attention(pair, dt),
            "temporal_attention": lambda: kc.check_temporal_attention(pair, dt),
