@@ -705,11 +705,11 @@ def main():
                 for key in sorted(lv, reverse=True):
                     d = lv[key]
                     row = {"rows": d["rows"], "channels": d["channels"], "frames": d["frames"]}
-                    for w in ("fwd", "bwd"):
-                        n, ms_, ofl = d[w]
-                        tot[w][0] += ms_
-                        tot[w][1] += ofl
-                        row[w] = {"blocks": n, "ms": ms_, "tflops": ofl / (ms_ * 1e-3) / 1e12 if ms_ else None,
+                    for which in ("fwd", "bwd"):
+                        n, ms_, ofl = d[which]
+                        tot[which][0] += ms_
+                        tot[which][1] += ofl
+                        row[which] = {"blocks": n, "ms": ms_, "tflops": ofl / (ms_ * 1e-3) / 1e12 if ms_ else None,
                                   "frac_of_mfma_peak": ofl / (ms_ * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if ms_ else None}
                     levels.append(row)
                 allms, allfl = tot["fwd"][0] + tot["bwd"][0], tot["fwd"][1] + tot["bwd"][1]
