@@ -6,6 +6,7 @@
 // block.  GroupNorm "sample" = `rows` consecutive rows (a frame for the 2-D norms, a whole clip for the
 // TemporalResnetBlock norms whose groups span all frames).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -409,6 +410,8 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const T* __restrict__ dy
     constexpr int GROUPS = 256 / LANES;
     const int ll = threadIdx.x % LANES, grp = threadIdx.x / LANES;
     const int cc = C / 8;
+    // (four waves per SIMD -- launch bound 4, gamma re-read per row -- spills at three chunks per lane and ran 2-3x slower:
+    // profiles/r4_ln_bwd_sweep.txt)
     float gm[NCH][8], pg[AFFINE ? NCH : 1][8], pb[AFFINE ? NCH : 1][8];
     bool cv[NCH];
     int cl[NCH];
@@ -552,11 +555,22 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_batch_kernel(const LnRed
 }
 
 // workgroups (= partial rows left in scratch) of the affine-gradient form of svdx_ln_bwd
+static int ln_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+
 static int ln_bwd_affine_blocks(int rows, int C) {
     const int cc = C / 8;
     const int lanes = cc <= 48 ? 16 : (cc <= 96 ? 32 : 64);
     const int groups = 256 / lanes;
-    return max(1, min(cdiv(rows, 2 * groups), SVDX_LN_PARTIAL_ROWS));
+    // Two workgroups per CU (208 VGPRs) x 256 CUs: ONE resident round that strides over the rows, so that the per-block epilogue (two
+    // LDS reductions + the partial row) is paid 512 times and no round runs part-empty -- 35.1 -> 27.7 us at 35840 x 320, 22.3 -> 17.5
+    // at 8960 x 640 against the former rows / (2 groups) blocks (profiles/r4_ln_bwd_sweep.txt).  Developer knobs for that sweep
+    // (tools/norm_bench.py --ln-sweep; kernels.ln_bwd_blocks mirrors them): rows per row group and block, block cap.
+    const int per = max(1, ln_env_int("SVDX_LN_AFFINE_R", 1));
+    const int cap = max(1, min(ln_env_int("SVDX_LN_AFFINE_CAP", 512), SVDX_LN_PARTIAL_ROWS));
+    return max(1, min(cdiv(rows, per * groups), cap));
 }
 
 }  // namespace
@@ -678,14 +692,12 @@ extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, co
     if (dgamma) blocks = scratch ? ln_bwd_affine_blocks(rows, C) : min(blocks, 256);
     const size_t sh = dgamma ? sizeof(float) * groups * C : 0;
     SVDX_CHECK_ARG(sh <= 64 * 1024, "svdx_ln_bwd: C=%d too wide for the affine-gradient slab", C);
+#define LN_BWD_A(L, N, A)                                                                                                          \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, L, N, A>), dim3(blocks), dim3(256), sh, st, (const T*)dy, (const T*)x, stats, gamma,           \
+                       (const T*)add, (const T*)add2, add2_scale, (T*)dx, dgamma, dbeta, scratch, rows, C)
 #define LN_BWD(L, N)                                                                                                                  \
     {                                                                                                                                 \
-        if (dgamma)                                                                                                                   \
-            hipLaunchKernelGGL((ln_bwd_kernel<T, L, N, true>), dim3(blocks), dim3(256), sh, st, (const T*)dy, (const T*)x, stats, gamma, \
-                               (const T*)add, (const T*)add2, add2_scale, (T*)dx, dgamma, dbeta, scratch, rows, C);                    \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((ln_bwd_kernel<T, L, N, false>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, stats, gamma, \
-                               (const T*)add, (const T*)add2, add2_scale, (T*)dx, dgamma, dbeta, scratch, rows, C);                    \
+        if (dgamma) LN_BWD_A(L, N, true); else LN_BWD_A(L, N, false);                                                                   \
     }
     DISPATCH_DTYPE(dtype, {
         if (lanes == 16) { if (nch == 1) LN_BWD(16, 1) else if (nch == 2) LN_BWD(16, 2) else LN_BWD(16, 3) }
@@ -693,6 +705,7 @@ extern "C" int svdx_ln_bwd(const void* dy, const void* x, const float* stats, co
         else { if (nch <= 3) LN_BWD(64, 3) else LN_BWD(64, 4) }
     });
 #undef LN_BWD
+#undef LN_BWD_A
     SVDX_LAUNCH_CHECK("svdx_ln_bwd");
     if (dgamma && scratch && !defer_reduce) {
         hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, st, scratch, blocks, C, dgamma, dbeta);

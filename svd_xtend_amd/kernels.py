@@ -162,7 +162,9 @@ def ln_bwd_blocks(rows: int, C: int) -> int:
     """include/svdx.h svdx_ln_bwd_blocks: partial rows the affine-gradient form of svdx_ln_bwd leaves in its scratch."""
     cc = C // 8
     lanes = 16 if cc <= 48 else (32 if cc <= 96 else 64)
-    return max(1, min(-(-rows // (2 * (256 // lanes))), LN_PARTIAL_ROWS))
+    per = max(1, int(os.environ.get("SVDX_LN_AFFINE_R") or 1))                       # developer knobs, mirrored from csrc/norm.hip
+    cap = max(1, min(int(os.environ.get("SVDX_LN_AFFINE_CAP") or 512), LN_PARTIAL_ROWS))
+    return max(1, min(-(-rows // (per * (256 // lanes))), cap))
 
 
 def tsa_pixels_per_band(T: int, HW: int) -> int:

@@ -169,6 +169,10 @@ class Runtime:
 
     def flush_deferred(self) -> None:
         k, M = self.k, self._q_M
+        # the reducing launch FIRST: with `dvec_from_dw` the column sums it leaves (d(cross-attention vector) = the bias gradient of
+        # attn1.to_out's weight-gradient GEMM) are what the skinny gradient chain below reads
+        if self._q_fin:
+            k.grad_finalize_batch(self._q_fin)
         for jobs in self._q_nn:
             if jobs:
                 k.small_linear_batch(jobs, M, 1)
@@ -176,8 +180,6 @@ class Runtime:
             k.outer_acc_batch(self._q_outer, M)
         if self._q_ln:
             k.ln_param_reduce_batch(self._q_ln)
-        if self._q_fin:
-            k.grad_finalize_batch(self._q_fin)
         self.drop_deferred()
 
     def drop_deferred(self) -> None:

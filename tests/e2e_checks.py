@@ -167,10 +167,11 @@ def graphed_vs_eager(dev=None, dtype=torch.float16, steps=3):
                 param_abs_max=float(e["p"].abs().max()), opt_steps=(e["state"][0], g["state"][0]), segments=g["segments"])
 
 
-def replays_with_traffic_between(dev=None, dtype=torch.float16, replays=4, disturb=True, cfg=None, geom=(1, 3, 16, 16)):
+def replays_with_traffic_between(dev=None, dtype=torch.float16, replays=4, disturb=True, cfg=None, geom=(1, 3, 16, 16), lora_r=0):
     """`replays` replays of the captured step with -- when `disturb` -- the things a real training loop does between two replays: a new
     batch copied into the captured input tensors (here: the same values, so the trajectory must not move), the loss read on the host,
-    ATen launches, a matmul.  Returns the flat parameters, the loss slot and the optimizer state."""
+    ATen launches, a matmul.  Returns the flat parameters, the loss slot and the optimizer state.  lora_r: config 5's trainable set
+    (a rank below the K granule of 64 also captures the padded-rank re-layout of the adapters, ops.LoraOp.refresh)."""
     from svd_xtend_amd.train import GraphedStep
     dev = dev or torch.device("cuda")
     cfg = cfg or TINY_CONFIG
@@ -183,6 +184,14 @@ def replays_with_traffic_between(dev=None, dtype=torch.float16, replays=4, distu
     batch = {k: v.to(dev) for k, v in host.items()}
     m = UNetSpatioTemporalConditionModel(**cfg)
     m.load_state_dict(orc.state_dict(), strict=True)
+    if lora_r:
+        from svd_xtend_amd.lora import LoraConfig
+        torch.manual_seed(11)
+        m.add_adapter(LoraConfig(r=lora_r, lora_alpha=lora_r, init_lora_weights="gaussian"))
+        gen = torch.Generator().manual_seed(23)
+        for n, p in m.named_parameters():
+            if ".lora_B." in n:
+                p.data.copy_(torch.randn(p.shape, generator=gen) * 0.05)
     m.to(dev)
     tr = Trainer(m, dtype=dtype, lr=1e-3)
     gs = GraphedStep(tr, batch)

@@ -30,7 +30,7 @@ def test_state_dict_keys_and_shapes_match_diffusers_layout():
     assert m.add_embedding.linear_1.in_features == 3 * m.config.addition_time_embed_dim      # train_svd.py:887-889
 
 
-@pytest.mark.parametrize("B,T,h,w", [(1, 3, 16, 16), (2, 2, 16, 24)])
+@pytest.mark.parametrize("B,T,h,w", [(1, 3, 16, 16), (1, 4, 16, 16), (1, 4, 32, 32), (2, 2, 16, 24)])
 def test_fp32_train_step_matches_oracle(emu_backend, B, T, h, w):
     orc, m = build_pair(1)
     batch = make_synthetic_batch(B, T, h, w, 7, cross_dim=64)

@@ -36,12 +36,60 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / (2 * iters) * 1e3
 
 
+def ln_sweep(k, dev, dt, iters):
+    """us per launch of svdx_ln_bwd at the three widths of the benched shape: frozen form (dx only, with the two fan-in addends the
+    temporal blocks hand it) and trainable form (affine gradients through the partial slab, deferred reduce as in the step)."""
+    T = 14
+    for name, HW, C in (("L0", 2560, 320), ("L1", 640, 640), ("L2", 160, 1280)):
+        M = T * HW
+        nset = max(2, int(900e6 // (M * C * 2 * 5)))
+        xs, dys, a1, a2, ys = ([torch.randn(M, C, device=dev).to(dt) for _ in range(nset)] for _ in range(5))
+        gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        lst = torch.empty(M, 2, device=dev)
+        k.ln_fwd(xs[0], gamma, beta, ys[0], lst, M, C, 1e-5)
+        scr = torch.empty(K.LN_PARTIAL_ROWS * 2 * C, device=dev)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        it = [0]
+
+        def nxt():
+            it[0] = (it[0] + 1) % nset
+            return it[0]
+
+        def frozen():
+            i = nxt()
+            k.ln_bwd(dys[i], xs[i], lst, gamma, a1[i], ys[i], None, None, M, C)
+
+        def affine():
+            i = nxt()
+            k.ln_bwd(dys[i], xs[i], lst, gamma, a1[i], ys[i], dg, db, M, C, scratch=scr, defer_reduce=True)
+
+        def affine2():
+            i = nxt()
+            k.ln_bwd(dys[i], xs[i], lst, gamma, a1[i], ys[i], dg, db, M, C, scratch=scr, add2=a2[i], add2_scale=0.5, defer_reduce=True)
+        B1 = M * C * 2
+        us = timeit(frozen, iters)
+        print(json.dumps(dict(level=name, kernel="ln_bwd_frozen_add", us=round(us, 2), gbps=round(4 * B1 / us / 1e3))), flush=True)
+        for cap in ("2048", "1024", "512", "256"):
+            for r in ("1", "2", "4"):
+                os.environ["SVDX_LN_AFFINE_CAP"], os.environ["SVDX_LN_AFFINE_R"] = cap, r
+                blocks = K.ln_bwd_blocks(M, C)
+                us = timeit(affine, iters)
+                us2 = timeit(affine2, iters)
+                print(json.dumps(dict(level=name, kernel="ln_bwd_affine", cap=cap, r=r, blocks=blocks, us_add=round(us, 2), gbps_add=round(4 * B1 / us / 1e3),
+                                      us_add2=round(us2, 2), gbps_add2=round(5 * B1 / us2 / 1e3))), flush=True)
+        for kk in ("SVDX_LN_AFFINE_CAP", "SVDX_LN_AFFINE_R"):
+            os.environ.pop(kk)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--ln-sweep", action="store_true", help="LayerNorm backward only, over the developer knobs of csrc/norm.hip (block counts, occupancy)")
     args = ap.parse_args()
     dt, dev = torch.float16, torch.device("cuda")
     k = K.backend()
+    if args.ln_sweep:
+        return ln_sweep(k, dev, dt, args.iters)
     out = []
     T = 14
     for name, HW, C in (("L0", 2560, 320), ("L0cat", 2560, 640), ("L1", 640, 640), ("L2", 160, 1280), ("L3", 40, 1280)):
