@@ -33,6 +33,7 @@ struct GemmParams {
     svdx_gather g; const void* zero_page;
     int out_mode; float alpha; int split_k; int tiles_m, tiles_n; int vec_ok; long slab_stride; int a_bytes, b_bytes;
     int xcd_n, sub_m, sub_n;   // variant 4: the 8 XCDs form an (8/xcd_n) x xcd_n grid, each owning sub_m x sub_n tiles (0: balanced row-major split)
+    int z_xcd;                 // variant 4, split_k in {2, 4, 8}: K slice z owns 8 / split_k XCDs, arranged (8/split_k/xcd_n) x xcd_n over the tiles (1-D grid)
     int epi; const void* aux_in; void* aux_out; int aux_dim;   // fused GEGLU epilogues (variant 4)
     float* a_colsum;                                           // TN form: += column sums of A (the bias gradient), or null
     // variant 4, second operand pair: acc += A2 [M, K2] B2^T [N, K2] after the main reduction (the LoRA term of a projection)
@@ -734,9 +735,21 @@ __global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
     // rows its tiles touch, so the host picks an (8/xcd_n) x xcd_n arrangement of XCDs over the tile grid that minimises
     // A_bytes * xcd_n + B_bytes * (8 / xcd_n): row bands when A dominates (the 64x40 level: A = 23 MB x taps, B < 2 MB), column
     // bands when the weights dominate (10x16 / 5x8 levels: B = 30-60 MB, A = 1-6 MB; measured 8x weight re-fetch before).
+    // Split-K (round 4): the K slices of one tile share nothing, so a slice count of 2 / 4 / 8 gives every slice its OWN 8 / split_k XCDs
+    // (z_xcd): an XCD then streams half / a quarter / an eighth of K for its tiles instead of all of it -- 2240 x 1280 x 10240 in two slices
+    // fetched 197 MB where 72 MB are algorithmic with every XCD holding both slices of a 3 x 5 tile block; 144 MB with 2 x 2 XCDs per slice.
     const int bid = blockIdx.x;
-    int pid_m, pid_n;
-    if (p.xcd_n > 0) {
+    int pid_m, pid_n, z = blockIdx.y;
+    if (p.z_xcd) {
+        const int xcd = bid & 7, l = bid >> 3, xps = 8 / p.split_k;
+        z = xcd / xps;
+        const int xi = xcd - z * xps;
+        const int xi_m = xi / p.xcd_n, xi_n = xi - xi_m * p.xcd_n;
+        const int lm = l / p.sub_n;
+        pid_m = xi_m * p.sub_m + lm;
+        pid_n = xi_n * p.sub_n + (l - lm * p.sub_n);
+        if (lm >= p.sub_m || pid_m >= p.tiles_m || pid_n >= p.tiles_n) return;
+    } else if (p.xcd_n > 0) {
         const int xcd = bid & 7, l = bid >> 3;
         const int xi_m = xcd / p.xcd_n, xi_n = xcd - xi_m * p.xcd_n;
         const int lm = l / p.sub_n;
@@ -752,7 +765,6 @@ __global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
     }
     const int m0 = pid_m * BM4, n0 = pid_n * BN3;
     const int kt_total = p.K / KT;
-    const int z = blockIdx.y;
     const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
     const int kt_begin = z * kt_per;
     const int kt_end = min(kt_total, kt_begin + kt_per);
@@ -1536,13 +1548,35 @@ int launch_gemm_v4(GemmParams p, hipStream_t st) {
         }
     if (force_xn >= 0) best_xn = force_xn;
     p.xcd_n = best_xn;
-    int gx = p.tiles_m * p.tiles_n;
+    p.z_xcd = 0;
+    int gx = p.tiles_m * p.tiles_n, gy = p.split_k;
     if (best_xn > 0) {
         p.sub_m = cdiv(p.tiles_m, 8 / best_xn);
         p.sub_n = cdiv(p.tiles_n, best_xn);
         gx = 8 * p.sub_m * p.sub_n;
     }
-    dim3 grid(gx, p.split_k);
+    // K slices on XCDs of their own (see the kernel): among the arrangements of the 8 / split_k XCDs of a slice, the least re-fetch that keeps
+    // >= 90 % of the best balance; taken when it fetches less than the slice-agnostic arrangement and leaves no more workgroup slots empty
+    const char* zx_env = getenv("SVDX_ZXCD");                                               // developer knob, read per launch (tools/ab_inproc.py
+    const int zxcd_on = zx_env ? atoi(zx_env) : 1;                                           // toggles it between captures): 0 = every XCD holds all slices
+    if (zxcd_on && force_xn < 0 && best_xn > 0 && (p.split_k == 2 || p.split_k == 4 || p.split_k == 8)) {
+        const int xps = 8 / p.split_k;
+        int zb_xn = 0; double zb_cost = 0, zb_eff = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int xn = 1; xn <= xps; xn *= 2) {
+                const int xm = xps / xn, sm = cdiv(p.tiles_m, xm), sn = cdiv(p.tiles_n, xn);
+                const double eff = (double)p.tiles_m * p.tiles_n / ((double)xps * sm * sn);
+                if (pass == 0) { zb_eff = eff > zb_eff ? eff : zb_eff; continue; }
+                const double cost = a_bytes * xn + b_bytes * xm;
+                if (eff >= 0.9 * zb_eff && (zb_xn == 0 || cost < zb_cost)) { zb_xn = xn; zb_cost = cost; }
+            }
+        const int zsm = cdiv(p.tiles_m, xps / zb_xn), zsn = cdiv(p.tiles_n, zb_xn);
+        if (zb_cost < best_cost && zsm * zsn <= p.sub_m * p.sub_n * p.split_k) {
+            p.z_xcd = 1; p.xcd_n = zb_xn; p.sub_m = zsm; p.sub_n = zsn;
+            gx = 8 * zsm * zsn; gy = 1;
+        }
+    }
+    dim3 grid(gx, gy);
     if (p.K2 > 0) hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB, HAS_DUAL, WGM, NSTG>), grid, dim3(128 * WGM), LDS, st, p);
     else hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB, false, WGM, NSTG>), grid, dim3(128 * WGM), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm");

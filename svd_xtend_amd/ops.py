@@ -259,7 +259,9 @@ _ALONE, _FILL_STEPS, _EPI_US, _FIN_US, _FIN_BYTES_PER_US = 0.5, 1.5, 3.0, 12.0, 
 
 
 def _xcd_block_tiles(Tm: int, Tn: int, a_bytes: float, b_bytes: float) -> int:
-    """Tiles owned by the fullest XCD under launch_gemm_v4's arrangement of the 8 XCDs over the tile grid (csrc/gemm.hip)."""
+    """Tiles owned by the fullest XCD under launch_gemm_v4's arrangement of the 8 XCDs over the tile grid (csrc/gemm.hip).  (With 2 / 4 / 8
+    K slices the launcher may give every slice XCDs of its own -- `z_xcd`, round 4 -- which fills no worse by construction; the model
+    keeps the slice-agnostic count its rates were fitted with.)"""
     best_eff, best = 0.0, None
     for xn in (1, 2, 4, 8):
         sm, sn = -(-Tm // (8 // xn)), -(-Tn // xn)

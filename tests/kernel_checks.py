@@ -151,6 +151,13 @@ def check_gemm_plain(P, dt, variant):
     o1, o2 = P.run("gemm", lambda o: ((big[:, Kd:], B, o["C"][:, N:], M, N, Kd, 3 * Kd, Kd, 3 * N), dict(variant=variant)),
                    dict(C=outb))
     res.append((f"gemm v{variant} strided views", relerr(o1["C"], o2["C"]), tol_for(dt)))
+    # 2 / 4 / 8 K slices: every slice on XCDs of its own (launch_gemm_v4 `z_xcd`) -- ragged tile grids, every slab element written once
+    if variant >= 4:
+        for (M2, N2, K2, sk) in [(700, 640, 512, 2), (700, 640, 512, 4), (330, 1280, 512, 8), (900, 1280, 256, 2), (90, 320, 512, 8)]:
+            A2, B2 = rnd((M2, K2), dt, P.dev, g), rnd((N2, K2), dt, P.dev, g, K2 ** -0.5)
+            o1, o2 = P.run("gemm", lambda o: ((A2, B2, o["C"], M2, N2, K2, K2, K2, N2), dict(variant=variant, out_mode=K.OUT_F32_SLAB, split_k=sk)),
+                           dict(C=torch.full((sk, M2, N2), float("nan"), device=P.dev)))
+            res.append((f"gemm v{variant} {M2}x{N2}x{K2} slabs x{sk} (slices on their own XCDs)", relerr(o1["C"], o2["C"]), tol_for(dt)))
     return res
 
 
