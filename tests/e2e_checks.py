@@ -405,7 +405,8 @@ C2_LEVELS = {           # name: (C, heads, h, w) at T = 14
 }
 
 
-C4_LEVELS = {           # reference config 4 (25 frames of 1024 x 576, latent 72 x 128): its two deepest levels at T = 25
+C4_LEVELS = {           # reference config 4 (25 frames of 1024 x 576, latent 72 x 128) at T = 25: its two deepest levels, and -- opt-in, the CPU
+    "L1 640ch 36x64": (640, 10, 36, 64),          # oracle needs minutes and ~20 GB for it -- the 2304-pixel level (57,600 rows of 640 channels)
     "L2 1280ch 18x32": (1280, 20, 18, 32),
     "L3 1280ch 9x16": (1280, 20, 9, 16),
 }

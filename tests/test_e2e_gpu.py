@@ -1,4 +1,6 @@
 """`-m gpu`: train-step parity of the HIP UNet against the CPU oracle (loss rel err <= 1e-3 for fp16)."""
+import os
+
 import pytest
 
 gpu = pytest.mark.gpu
@@ -144,12 +146,15 @@ def test_c5_lora_level_blocks_match_oracle(level):
 
 
 @gpu
-@pytest.mark.parametrize("level,lora_r", [("L2", 0), ("L3", 0), ("L3", 64)])
+@pytest.mark.parametrize("level,lora_r", [("L2", 0), ("L3", 0), ("L3", 64),
+                                          pytest.param("L1", 0, marks=pytest.mark.skipif(os.environ.get("SVDX_BIG_PARITY") != "1",
+                                                                                        reason="the 2304-pixel level of config 4: minutes of CPU oracle; SVDX_BIG_PARITY=1"))])
 def test_c4_level_blocks_match_oracle(level, lora_r):
     """Reference config 4 (/root/reference/train_svd.py:318 --num_frames 25, 1024 x 576): the T = 25 path -- temporal attention with the
     frame axis padded 25 -> 32 and masked, no fused temporal self-attention (T > 16), Conv3d over 25 frames, 3-D GroupNorm over 25 x HW
     rows -- at the two deepest levels of that shape (576 and 144 pixels per frame, 1280 channels), one optimizer step against the CPU
-    oracle in fp16; the 144-pixel level also with LoRA r = 64 adapters (bf16, config 5's recipe on config 4's frame count)."""
+    oracle in fp16; the 144-pixel level also with LoRA r = 64 adapters (bf16, config 5's recipe on config 4's frame count).  Opt-in
+    (SVDX_BIG_PARITY=1; result of the round-4 run in profiles/r4_c4_level_2304px.txt): the 2304-pixel level, 57,600 rows of 640 channels."""
     import torch
 
     import e2e_checks
