@@ -6,3 +6,4 @@ hipcc $F -DTSA_STAMPS tools/probes/tsa_probe.hip svd_xtend_amd/csrc/common.cpp -
 hipcc $F -DTSA_STAMPS -DTSA_SKIP_QKV_STORE tools/probes/tsa_probe.hip svd_xtend_amd/csrc/common.cpp -o tools/probes/tsa_probe_nostore
 hipcc $F tools/probes/ingest_probe.hip -o tools/probes/ingest_probe
 hipcc $F tools/probes/regw_probe.hip -Lsvd_xtend_amd/csrc -lsvdx -Wl,-rpath,'$ORIGIN/../../svd_xtend_amd/csrc' -o tools/probes/regw_probe
+hipcc $F tools/probes/mfma_rate_probe.hip -o tools/probes/mfma_rate_probe
