@@ -71,7 +71,8 @@ int         svdx_device_ok(void);
 /* ---- GEMM family: nn.Linear / conv2d / conv3d fwd and data-grad, weight-grad (NT form) ------------
  * acc[m,n] = sum_k Aeff[m,k] * B[n,k];  v = alpha*acc + bias[n] + rowvec[g(m)*rv_ld + n] + res[m*ldres+n]
  * g(m) = rv_mod ? m % rv_mod : m / rv_rows_per_group.   B is [N,K] row-major (ldb).
- * out_mode ACT: C[m*ldc+n] = (dtype)v ; F32: float store ; F32_ATOMIC: atomicAdd (split_k >= 1).
+ * out_mode ACT: C[m*ldc+n] = (dtype)v ; F32: float store ; F32_ATOMIC: atomicAdd (split_k >= 1) ; F32_SLAB: slice z of the K-tiles (ceil(K/64/split_k)
+ * tiles each) to its own float slab -- a split_k whose last slices would own no K-tile is an argument error (their slabs would stay unwritten).
  * epilogue (variant >= 2): SVDX_EPI_GEGLU_FWD / _BWD fuse diffusers' GEGLU (attention.py) into the projection GEMMs, aux_dim = F.
  * variant = output tile of the launch (rows x columns, LDS stages of the K-loop, waves):  0 / 1 the plain 128x128 kernel with 64-bit addressing
  * (operands beyond the 2 GiB buffer reach);  4 heuristic among 6 / 7 / 8 = 160x160 / 128x160 / 128x128, two stages, four waves, two workgroups per CU;

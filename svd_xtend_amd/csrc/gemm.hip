@@ -1654,6 +1654,8 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
                        out_mode == SVDX_OUT_F32_ATOMIC, "svdx_gemm_tn: float output modes only");
     SVDX_CHECK_ARG(split_k >= 1 && (split_k == 1 || out_mode == SVDX_OUT_F32_SLAB || out_mode == SVDX_OUT_F32_ATOMIC),
                    "svdx_gemm_tn: split_k needs slab or atomic output");
+    SVDX_CHECK_ARG(out_mode != SVDX_OUT_F32_SLAB || (split_k - 1) * cdiv(cdiv(R, BK), split_k) < cdiv(R, BK),
+                   "svdx_gemm_tn: split_k=%d leaves slices without rows (R=%d): their slabs would stay unwritten", split_k, R);
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.M = N; p.N = K; p.K = R; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = nullptr; p.rowvec = nullptr; p.rv_ld = 0; p.rv_rpg = 0; p.rv_mod = 0; p.res = nullptr; p.ldres = 0;
@@ -1708,6 +1710,9 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
     SVDX_CHECK_ARG(split_k >= 1 && (split_k == 1 || out_mode == SVDX_OUT_F32_ATOMIC || out_mode == SVDX_OUT_F32_SLAB),
                    "svdx_gemm: split_k=%d needs atomic or slab output", split_k);
     SVDX_CHECK_ARG(!rowvec || rv_mod > 0 || rv_rows_per_group > 0, "svdx_gemm: rowvec needs a grouping");
+    // a slice without K-tiles would leave its slab unwritten (found by tests/sim/fuzz.py with NaN-filled slabs; ops.choose_cfg never asks for one)
+    SVDX_CHECK_ARG(out_mode != SVDX_OUT_F32_SLAB || (split_k - 1) * cdiv(K / BK, split_k) < K / BK,
+                   "svdx_gemm: split_k=%d leaves slices without K-tiles (K=%d): their slabs would stay unwritten", split_k, K);
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.rowvec = rowvec; p.rv_ld = rv_ld; p.rv_rpg = rv_rows_per_group; p.rv_mod = rv_mod;

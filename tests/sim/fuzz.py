@@ -3,7 +3,7 @@ are the UNet's; a drop-in library has to be right on every shape its argument ch
 
     python tests/sim/fuzz.py [family ...] [--n 60] [--seed 0] [--bf16]
 
-Families: gemm, gather, tn, geglu, norm, lnbwd, attn, tattn, tsa, small, batch, rows, optim.  Prints every failing case with the arguments that reproduce it."""
+Families: gemm, gemm_gn, gradfin, gather, tn, geglu, norm, lnbwd, attn, tattn, tsa, small, batch, rows, optim.  Prints every failing case with the arguments that reproduce it."""
 import math
 import os
 import random
@@ -58,12 +58,12 @@ def fuzz_gemm(P, dt, rng, g):
         kw.update(out_mode=K.OUT_F32_ADD)
         out = torch.ones(M, ldc, dtype=torch.float32, device=P.dev)
     elif mode == "slab":
-        sk = rng.randint(1, min(4, Kd // 64))
+        sk = rng.choice([x for x in (1, 2, 3, 4, 5, 8) if x <= Kd // 64])
         kw.update(out_mode=K.OUT_F32_SLAB, split_k=sk)
-        out = torch.zeros(sk, M, ldc, dtype=torch.float32, device=P.dev)
+        out = torch.full((sk, M, ldc), float("nan"), dtype=torch.float32, device=P.dev)        # every slab element has exactly one writer
     desc = f"gemm v{v} M={M} N={N} K={Kd} lda={lda} ldb={ldb} ldc={ldc} {mode} sk={sk}"
     o1, o2 = P.run("gemm", lambda o: ((A, B, o["C"], M, N, Kd, lda, ldb, ldc), kw), dict(C=out))
-    a, b = (o1["C"].sum(0), o2["C"].sum(0)) if mode == "slab" else (o1["C"], o2["C"])
+    a, b = o1["C"], o2["C"]          # slab mode: slice by slice (the emulation cuts K like the kernel; launch_gemm_v4 may give every slice XCDs of its own)
     return desc, kc.relerr(a[..., :N], b[..., :N]), kc.tol_for(dt)
 
 
@@ -391,7 +391,79 @@ def fuzz_optim(P, dt, rng, g):
     return desc, e, kc.tol_for(dt)
 
 
-FAMILIES = {"gemm": fuzz_gemm, "gather": fuzz_gather, "tn": fuzz_tn, "geglu": fuzz_geglu, "norm": fuzz_norm, "lnbwd": fuzz_lnbwd,
+def fuzz_gemm_gn(P, dt, rng, g):
+    """svdx_gemm_gn / svdx_gemm_finalize_gn: the result against the emulation, the statistics against a statistics pass over the tensor the
+    launch itself wrote (same rounded values: the 64-bit fixed-point sums must agree to the float decode's last bits)."""
+    from svd_xtend_amd.ops import _tile_launched, gn_tile_ok
+    v = rng.choice((4, 6, 7, 8, 16, 17, 18, 20, 21, 22, 23, 24, 25, 26))
+    cg = rng.choice((4, 8, 10, 20, 40, 80))
+    N = cg * rng.choice((8, 16, 32))
+    n_s, rows = rng.randint(1, 6), pick_dim(rng, 8, 400)
+    Kd = 64 * rng.randint(1, 6)
+    M, G = n_s * rows, N // cg
+    split = rng.random() < 0.35
+    A, B = kc.rnd((M, Kd), dt, P.dev, g), kc.rnd((N, Kd), dt, P.dev, g, Kd ** -0.5)
+    bias, R, rv = kc.rndf((N,), P.dev, g), kc.rnd((M, N), dt, P.dev, g), kc.rndf((n_s, N), P.dev, g)
+    mode = rng.choice(("plain", "bias_res", "rowvec"))
+    ep = dict(bias=bias, res=R, ldres=N) if mode == "bias_res" else dict(bias=bias, rowvec=rv, rv_ld=N, rv_rpg=rows) if mode == "rowvec" else {}
+    st1, st2 = (torch.zeros(K.GN_REPLICAS, n_s, G, K.GN_STAT_FLOATS, device=P.dev) for _ in range(2))
+    c1, c2 = (torch.zeros(M, N, dtype=dt, device=P.dev) for _ in range(2))
+    if split:
+        sk = rng.choice([x for x in (2, 3, 4, 8) if x <= max(2, Kd // 64)])
+        if sk > Kd // 64 or N * rows < 1024:
+            raise K.SvdxError("not a split-K statistics case")
+        for be, c, st in ((P.impl, c1, st1), (P.ref, c2, st2)):
+            acc = torch.zeros(sk, M, N, device=P.dev)
+            be.gemm(A, B, acc, M, N, Kd, Kd, Kd, N, out_mode=K.OUT_F32_SLAB, split_k=sk, variant=v)
+            be.gemm_finalize(acc, sk, M * N, c, M, N, N, gn=(st, rows, cg), **ep)
+        desc = f"gemm_finalize_gn v{v} n_s={n_s} rows={rows} N={N} cg={cg} K={Kd} sk={sk} {mode}"
+    else:
+        if not gn_tile_ok(_tile_launched(v, M, N), N, rows, cg):
+            raise K.SvdxError("tile does not take the statistics path")
+        P.impl.gemm(A, B, c1, M, N, Kd, Kd, Kd, N, variant=v, gn=(st1, rows, cg), **ep)
+        P.ref.gemm(A, B, c2, M, N, Kd, Kd, Kd, N, variant=v, gn=(st2, rows, cg), **ep)
+        desc = f"gemm_gn v{v} n_s={n_s} rows={rows} N={N} cg={cg} K={Kd} {mode}"
+    own = torch.zeros_like(st1)
+    P.ref.gn_stats(c1, own, n_s, rows, N, G, prezeroed=1)
+    e_st = kc.relerr(emul.gn_decode(st1, n_s, G, rows * cg, 0).view(-1, 2), emul.gn_decode(own, n_s, G, rows * cg, 0).view(-1, 2))
+    return desc, max(kc.relerr(c1, c2), e_st * (kc.tol_for(dt) / 1e-4)), kc.tol_for(dt)
+
+
+def fuzz_gradfin(P, dt, rng, g):
+    """svdx_grad_finalize_batch: random job tables (slices, sizes, store / accumulate, with and without column sums) against one
+    svdx_gemm_finalize launch per job -- BIT equality (the same additions in the same order)."""
+    jobs, singles = [], []
+    for _ in range(rng.randint(1, 60)):
+        sk, rows_, cols = rng.randint(1, 9), rng.randint(1, 40), 4 * rng.randint(1, 60)
+        n = rows_ * cols
+        acc = kc.rndf((sk, n), P.dev, g)
+        store = rng.random() < 0.5
+        d0 = kc.rndf((n,), P.dev, g)
+        if rng.random() < 0.4:
+            cs, co0 = kc.rndf((sk, rows_), P.dev, g), kc.rndf((rows_,), P.dev, g)
+        else:
+            cs, co0 = None, None
+        jobs.append((acc, sk, n, d0, cs, co0, store, rows_, cols))
+    outs = []
+    for be, batched in ((P.impl, True), (P.impl, False)):
+        ds = [j[3].clone() for j in jobs]
+        cos = [None if j[5] is None else j[5].clone() for j in jobs]
+        if batched:
+            be.grad_finalize_batch([(acc, sk, n, d, n, cs, co, store) for (acc, sk, n, _d, cs, _c, store, _r, _k), d, co in zip(jobs, ds, cos)])
+        else:
+            for (acc, sk, n, _d, cs, _c, store, rows_, cols), d, co in zip(jobs, ds, cos):
+                be.gemm_finalize(acc, sk, n, d, rows_, cols, cols, accumulate_f32=2 if store else 1, dtype=dt, colsum_slabs=cs, colsum_out=co)
+        outs.append((ds, cos))
+    same = all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0])) and all(a is None or torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+    # ... and the emulation agrees to rounding
+    ds = [j[3].clone() for j in jobs]
+    cos = [None if j[5] is None else j[5].clone() for j in jobs]
+    P.ref.grad_finalize_batch([(acc, sk, n, d, n, cs, co, store) for (acc, sk, n, _d, cs, _c, store, _r, _k), d, co in zip(jobs, ds, cos)])
+    e = max(kc.relerr(a, b) for a, b in zip(outs[0][0], ds))
+    return f"gradfin {len(jobs)} jobs", (e if same else float("inf")), 1e-5
+
+
+FAMILIES = {"gemm": fuzz_gemm, "gemm_gn": fuzz_gemm_gn, "gradfin": fuzz_gradfin, "gather": fuzz_gather, "tn": fuzz_tn, "geglu": fuzz_geglu, "norm": fuzz_norm, "lnbwd": fuzz_lnbwd,
             "attn": fuzz_attn, "tattn": fuzz_tattn, "tsa": fuzz_tsa, "small": fuzz_small, "batch": fuzz_batch, "rows": fuzz_rows, "optim": fuzz_optim}
 
 

@@ -305,6 +305,28 @@ def test_gemm_config_rules_for_the_c2_shapes():
     assert choose_cfg(rt, 2240, 1280, 11520, 1280)[1] == 1
 
 
+def test_split_rules_never_leave_an_empty_slice():
+    """svdx_gemm / svdx_gemm_tn refuse a slab split whose last slices own no K-tiles / rows (their slabs would stay unwritten and the
+    reducing launch would add uninitialised memory): the host rules must never ask for one, on any problem of configs 2, 4 and 5."""
+    from svd_xtend_amd.ops import _tn_formula, choose_cfg
+
+    class RT:
+        gemm_variant, split_k = 4, True
+    rt = RT()
+    rows = [35840, 8960, 2240, 560, 230400, 57600, 14400, 3600, 6144, 1536, 384, 96]
+    widths = [64, 128, 192, 256, 320, 640, 960, 1280, 1920, 2560, 3840, 5120, 10240, 2880, 5760, 8640, 11520, 17280, 23040]
+    for M in rows:
+        for N in widths:
+            for Kd in widths:
+                sk, _ = _tn_formula(M, N, Kd)
+                r = -(-M // 64)
+                assert sk == 1 or -(-r // sk) * (sk - 1) < r, ("tn", M, N, Kd, sk)
+                if N <= 10240:
+                    s, v = choose_cfg(rt, M, N, Kd, N)
+                    kt = Kd // 64
+                    assert s == 1 or -(-kt // s) * (s - 1) < kt, ("nt", M, N, Kd, s, v)
+
+
 def test_gemm_tuner_picks_fastest_candidate_per_problem():
     from svd_xtend_amd.ops import GemmTuner
     tn = GemmTuner(rounds=2)
