@@ -248,12 +248,118 @@ __global__ __launch_bounds__(512 + 64 * NPROD) void band2_kernel(const f16* __re
     }
 }
 
+// ---- third form: as band2, but 16-wide K-steps through FOUR 10 KB weight stages, the producers two steps ahead (counted vmcnt): a stage's load latency is no longer
+// exposed in every step
+__global__ __launch_bounds__(512 + 64 * NPROD) void band3_kernel(const f16* __restrict__ A, const f16* __restrict__ W, f16* __restrict__ C, int M, int N) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;
+    constexpr int ST3 = NC * 16 * 2;                                    // 10,240: [320 rows n][16 of K] = 32 B per row, FOUR stages (same 40 KB)
+    constexpr int KS = K / 16;                                          // 20 K-steps of 16 (v_mfma_f32_16x16x16_f16)
+    char* park = smem + A_BYTES + 4 * ST3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * BAND;
+    const int nchunks = N / NC, nsteps = nchunks * KS;                 // global K-step index s = chunk * 20 + ks, stage s & 3
+    // the band: all waves fetch it (no stores are outstanding yet, so everybody may wait for it)
+    for (int i = wave; i < BROWS * KC / 64; i += 8 + NPROD) {
+        const int q = i * 64 + lane, row = q / KC, pc = q - row * KC;
+        const int c = (pc & ~7) | ((pc ^ (row >> 1)) & 7);
+        const int grow = min(row0 + row, M - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)grow * K + c * 8),
+                                         (__attribute__((address_space(3))) void*)(As + (size_t)i * 1024), 16, 0, 0);
+    }
+    if (wave >= 8) {                                                    // ---- producers
+        const int pw = wave - 8;
+        auto issue_b = [&](int s) __attribute__((always_inline)) {      // 320 rows x 2 chunks = 640 chunks = 10 wave instructions: producers 0 / 1 issue 3, 2 / 3 issue 2
+            const int chunk = s / KS, ks = s - chunk * KS;
+            char* Bs = smem + A_BYTES + (s & 3) * ST3;
+            for (int i = pw; i < 10; i += NPROD) {
+                const int q = i * 64 + lane, n = q >> 1, pc = q & 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (size_t)(chunk * NC + n) * K + ks * 16 + pc * 8),
+                                                 (__attribute__((address_space(3))) void*)(Bs + (size_t)i * 1024), 16, 0, 0);
+            }
+        };
+        issue_b(0);
+        if (nsteps > 1) issue_b(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raw_barrier();                                                   // B0: band + steps 0, 1 have landed
+        for (int s = 0; s < nsteps; ++s) {
+            if (s + 2 < nsteps) {
+                issue_b(s + 2);                                          // two steps ahead, into the stage the consumers left two barriers ago
+                if (pw < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // step s + 1 has landed, step s + 2 (3 or 2 pieces of this wave) stays in flight
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            raw_barrier();                                               // end of step s
+            if ((s + 1) % KS == 0) {                                     // the consumers' epilogue barriers of this chunk (5 passes x 2)
+                for (int b = 0; b < 10; ++b) raw_barrier();
+            }
+        }
+        return;
+    }
+    // ---- consumers
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, g = lane >> 4;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's pieces of the band
+    raw_barrier();                                                       // B0
+#pragma unroll 1
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        f32x4 acc[5][5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int ks = 0; ks < KS; ++ks) {
+            const int s = chunk * KS + ks;
+            const char* Bs = smem + A_BYTES + (s & 3) * ST3;
+            f16x4 af[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {                                // lane (r, g): A[row][16 ks + 4 g .. + 4] = half (g & 1) of logical chunk 2 ks + (g >> 1)
+                const int row = wm * 80 + i * 16 + r;
+                const int lc = ks * 2 + (g >> 1), pc = (lc & ~7) | ((lc ^ (row >> 1)) & 7);
+                af[i] = *reinterpret_cast<const f16x4*>(As + (size_t)row * (K * 2) + pc * 16 + (g & 1) * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int n = wn * 80 + j * 16 + r;
+                const f16x4 bf = *reinterpret_cast<const f16x4*>(Bs + (size_t)n * 32 + g * 8);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x16f16(bf, af[i], acc[j][i], 0, 0, 0);
+            }
+            raw_barrier();                                               // end of step s
+        }
+        // epilogue: row tile i of both wave-row groups (32 rows) per pass through the park buffer; physical 16-byte chunk of (row lr, logical chunk c): (c & ~7) | ((c ^ (lr >> 1)) & 7)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int lr = wm * 16 + r;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int col = wn * 80 + j * 16 + 4 * g;               // 8-byte half of logical chunk col / 8
+                const int c = col >> 3, pc = (c & ~7) | ((c ^ (lr >> 1)) & 7);
+                f16x4 o = {(f16)acc[j][i][0], (f16)acc[j][i][1], (f16)acc[j][i][2], (f16)acc[j][i][3]};
+                *reinterpret_cast<f16x4*>(park + (size_t)lr * (NC * 2) + pc * 16 + (col & 4) * 2) = o;
+            }
+            raw_barrier();
+            for (int q = tid; q < 32 * (NC / 8); q += 512) {
+                const int lr2 = q / (NC / 8), c = q - lr2 * (NC / 8);
+                const int lrow = (lr2 >> 4) * 80 + i * 16 + (lr2 & 15);
+                const int pc = (c & ~7) | ((c ^ (lr2 >> 1)) & 7);
+                if (lrow < BAND && row0 + lrow < M)
+                    *reinterpret_cast<f16x8*>(C + (size_t)(row0 + lrow) * N + chunk * NC + c * 8) = *reinterpret_cast<const f16x8*>(park + (size_t)lr2 * (NC * 2) + pc * 16);
+            }
+            raw_barrier();
+        }
+    }
+}
+
 int main() {
     const int M = 35840;
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&band2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&band3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
     for (int N : {320, 960, 2560}) {
         const int NSET = N == 320 ? 8 : 3;
         std::vector<f16*> As(NSET), Cs(NSET);
@@ -320,6 +426,12 @@ int main() {
         {
             const double us = time_graph([&](int s) { hipLaunchKernelGGL(band2_kernel, dim3(M / BAND), dim3(512 + 64 * NPROD), LDS2_BYTES, st, As[s], W, Cs[s], M, N); });
             printf("N=%4d  A-stationary band, producer waves + park buffer %7.2f us   %6.1f TFLOP/s   %5.2f TB/s (A + C once)   max |err| %.2e\n", N, us, 2.0 * M * N * K / us / 1e6,
+                   bytes / us / 1e6, check());
+        }
+        {
+            for (int s = 0; s < NSET; ++s) hipMemsetAsync(Cs[s], 0xff, (size_t)M * N * 2, st);
+            const double us = time_graph([&](int s) { hipLaunchKernelGGL(band3_kernel, dim3(M / BAND), dim3(512 + 64 * NPROD), LDS2_BYTES, st, As[s], W, Cs[s], M, N); });
+            printf("N=%4d  A-stationary band, 4 stages of K = 16, producers 2 ahead %7.2f us   %6.1f TFLOP/s   %5.2f TB/s (A + C once)   max |err| %.2e\n", N, us, 2.0 * M * N * K / us / 1e6,
                    bytes / us / 1e6, check());
         }
         hipStreamDestroy(st);
