@@ -11,9 +11,15 @@ batch 1, random-init weights, synthetic latents already resident in HBM.
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
-  roofline     -- the dominant kernel (the MFMA GEMM / implicit-conv kernel): algorithmic FLOPs of all its launches
-                  in one step / their summed duration (HIP events on the launch stream, one instrumented step)
-  cpu_baseline -- the CPU oracle train step timed on the host cores on a bounded sample (c1': 8 frames 256x192)
+  roofline     -- the dominant kernel family (MFMA GEMM / implicit convolution / weight gradient): algorithmic FLOPs of all its launches in
+                  one step / their summed duration.  Clock at one rank under hipGraph: device timestamps written by one-lane `svdx_stamp`
+                  kernels around every launch inside a second capture of the step (replay conditions; `clock` says so); otherwise HIP
+                  events on the launch stream around the launches of one eager step (also reported as `kernel_ms_per_step_events`).
+                  `traffic` = fabric bytes per launch from profiles/pmc_traffic.json (rocprofv3 counter passes of this command);
+                  `temporal_self_attention` = the north-star op for all 16 temporal blocks, forward and backward
+  cpu_baseline -- the CPU oracle train step timed on the host cores on a bounded sample (c1': 8 frames 256x192), plus one oracle step at
+                  the benched shape when the host allows; both batches also go through the HIP path (parity_full_model / parity_c2)
+  config.gpu_clock -- shader clock and socket power of THIS device sampled during the timed region (a slow box is recognisable)
 """
 from __future__ import annotations
 
