@@ -199,9 +199,16 @@ def cpu_baseline(dev=None, dtype=torch.float16, c2=True):
             prod.forward_backward(unet_in.to(dev), ts.to(dev), ehs.to(dev), ids.to(dev), noisy.to(dev), b["latents"].to(dev),
                                   b["sigmas"].to(dev))
             lg = float(prod.last_loss())
-            return {"loss_oracle_fp32": float(loss_ref), "loss_hip": lg, "loss_rel_err": abs(lg - float(loss_ref)) / abs(float(loss_ref)),
-                    "pred_rel_l2": float((pred - pred_ref).norm() / pred_ref.norm()),
-                    "tolerance": 1e-3 if dtype == torch.float16 else 8e-3, "dtype": str(dtype).split(".")[-1]}
+            # two bars, each next to the number it applies to: north_star's metric is the LOSS (noise-prediction MSE, <= 1e-3 relative
+            # in fp16); the prediction tensor itself -- 16-bit storage through ~100 chained layers -- is held to the bar of
+            # tests/e2e_checks.assert_parity (a quarter above the worst case ever measured)
+            fp16 = dtype == torch.float16
+            loss_rel = abs(lg - float(loss_ref)) / abs(float(loss_ref))
+            pred_rel = float((pred - pred_ref).norm() / pred_ref.norm())
+            loss_tol, pred_bar = (1e-3, 2.5e-3) if fp16 else (8e-3, 2e-2)
+            return {"loss_oracle_fp32": float(loss_ref), "loss_hip": lg, "loss_rel_err": loss_rel, "loss_rel_tolerance": loss_tol,
+                    "pred_rel_l2": pred_rel, "pred_rel_l2_bar": pred_bar, "within_tolerance": loss_rel <= loss_tol and pred_rel <= pred_bar,
+                    "dtype": str(dtype).split(".")[-1]}
         except Exception as e:  # noqa: BLE001
             return {"error": repr(e)[:200]}
 
@@ -235,6 +242,74 @@ def cpu_baseline(dev=None, dtype=torch.float16, c2=True):
     del prod
     if dev is not None:
         torch.cuda.empty_cache()
+    return out
+
+
+def real_loop_leg(args, trainer, dev, dt, world, rank, T):
+    """The step as a training loop runs it (svd_xtend_amd.loop.TrainLoop = the loop body of train_svd.py:931-1058): every iteration a NEW
+    pixel clip arrives from pinned host memory, goes through the frozen conditioners (VAE encode of T + 1 frames, CLIP ViT-H embed of the first
+    frame, EDM noising / dropout on the device) -- queued between the backward sweep and the optimizer of the running step, i.e. beside the
+    gradient all-reduce on several ranks (north_star's schedule) -- its batch is copied into the captured tensors, the step is replayed and
+    the loss is read on the host.  The UNet-only headline above replays ONE resident batch; this is the end-to-end figure next to it."""
+    from svd_xtend_amd.clip import CLIPVisionModelWithProjection
+    from svd_xtend_amd.loop import TrainLoop
+    from svd_xtend_amd.vae import AutoencoderKLTemporalDecoder
+    with torch.device(dev):
+        if args.tiny:
+            vae = AutoencoderKLTemporalDecoder(block_out_channels=(64, 128, 128, 128), layers_per_block=1)
+            enc = CLIPVisionModelWithProjection(hidden_size=320, intermediate_size=640, projection_dim=trainer.model.config.cross_attention_dim,
+                                                num_hidden_layers=2, num_attention_heads=4, image_size=56, patch_size=14)
+        else:
+            vae, enc = AutoencoderKLTemporalDecoder(), CLIPVisionModelWithProjection()
+    init_weights_(vae, seed=4321)
+    init_weights_(enc, seed=4322)
+    for m in (vae, enc):
+        m.requires_grad_(False)
+        m.prepare(dt)
+    g = torch.Generator().manual_seed(777 + rank)
+    host_clips = [(torch.rand(1, T, 3, args.height, args.width, generator=g) * 2 - 1).pin_memory() for _ in range(4)]
+    ga = args.grad_accum
+    pick = lambda i: [host_clips[(i * ga + j) % len(host_clips)] for j in range(ga)]           # noqa: E731
+    loop = TrainLoop(trainer, vae, enc, conditioning_dropout_prob=0.1, seed=99 + rank, use_graph=not args.no_graph)
+    loop.start(pick(0))
+    it = 1
+    for _ in range(3):
+        loop.step(pick(it))
+        it += 1
+    K = max(5, min(args.steps, 30))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = []
+    for _ in range(K):
+        losses.append(loop.step(pick(it)))
+        it += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        el = float(te)
+    # the conditioners on their own (same eager launches, nothing beside them)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(5):
+        loop.prepare_batch(host_clips[i % len(host_clips)])
+    e1.record()
+    torch.cuda.synchronize()
+    out = {"ms_per_step": el / K * 1e3, "value": world * ga * K / el, "unit": "samples/s", "steps": K,
+           "conditioners_ms_alone": e0.elapsed_time(e1) / 5,
+           "what": "TrainLoop.step: new pixel clip from pinned host memory -> VAE encode (T + 1 frames) + CLIP image embed + EDM noising on the "
+                   "device, queued between this step's backward sweep and its optimizer (beside the gradient all-reduce when N > 1) -> batch copied "
+                   "into the captured tensors -> hipGraph replay -> loss read on the host (one host sync per step)",
+           "loss_first": losses[0], "loss_last": losses[-1], "losses_finite": all(l == l and abs(l) != float("inf") for l in losses),
+           "host_syncs_per_step": 1, "exec": "hipgraph" if loop.graphed is not None else "eager"}
+    del loop, vae, enc
+    torch.cuda.empty_cache()
     return out
 
 
@@ -274,6 +349,9 @@ def main():
     ap.add_argument("--with-vae", action="store_true",
                     help="also time the step with the VAE encode of the next micro-batch (train_svd.py:948, 957-960) on a second "
                          "stream; reported as a second field, the headline metric stays UNet-only")
+    ap.add_argument("--no-real-loop", action="store_true",
+                    help="skip the `real_loop` leg (the step inside svd_xtend_amd.loop.TrainLoop: a new pixel clip through VAE + CLIP + EDM prep every "
+                         "iteration, loss read on the host)")
     ap.add_argument("--launch-log", default=None,
                     help="developer aid: write the ordered list of libsvdx calls of ONE eager step (entry name + scalar arguments) to this "
                          "JSON file; tools/step_trace.py joins it with a rocprofv3 kernel trace of the graph-replayed steps")
@@ -468,6 +546,17 @@ def main():
                                  if args.overlap == "vae" else "encode on a second stream beside the whole step"),
                     "allreduce_ms_exposed": (sum(a.elapsed_time(b) for a, b in exposed) / len(exposed)) if exposed else None}
         del vae, gv, pix
+
+    # ---- the step as a training loop runs it ------------------------------------------------------------------------------------
+    real = None
+    if not args.no_real_loop:
+        try:
+            real = real_loop_leg(args, trainer, dev, dt, world, rank, T)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            real = {"error": repr(e)[:300]}
+        torch.cuda.synchronize()
 
     # ---- what RCCL saw: ranks (an all-reduce of ones) and the cost of the gradient exchange on its own -------------------------
     ranks_seen, allreduce_ms = 1, None
@@ -769,7 +858,7 @@ def main():
                        "gemm_variant": args.gemm_variant, "loss": loss, "loss_scale": state[1], "opt_steps": state[0],
                        "step_tflops_per_gpu": (STEP_TFLOP_C2 * args.grad_accum / (ms * 1e-3) if full else None),
                        "step_frac_of_mfma_peak": (STEP_TFLOP_C2 * args.grad_accum / (ms * 1e-3) / MFMA_PEAK_TFLOPS if full else None)},
-            "roofline": roof, "cpu_baseline": cpu, "with_vae": vae_info,
+            "roofline": roof, "cpu_baseline": cpu, "with_vae": vae_info, "real_loop": real,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

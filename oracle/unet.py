@@ -79,8 +79,54 @@ class TimestepEmbedding(nn.Module):
 #             TemporalBasicTransformerBlock}); reached through get_down_block/get_up_block/mid,
 #             src/unet_spatio_temporal_condition.py:170-192, 219-234
 # --------------------------------------------------------------------------------------------------
+class _ChunkedAttention(torch.autograd.Function):
+    """softmax(Q K^T * scale) V over query chunks, the probabilities recomputed in backward instead of saved.
+
+    The SAME function as the explicit three-line form in `Attention.forward` (every row's softmax runs over ALL keys at once: no
+    online rescaling, no approximation) -- only the order in which rows are visited and what autograd keeps differ.  It exists so
+    that the oracle can check reference config 4's largest level (25 frames x 9216 latent pixels: 125 score maps of 340 MB each,
+    ~42 GB if saved) on an ordinary host; tests/test_oracle.py holds it to the explicit form at small sizes, forward and gradients."""
+
+    CHUNK = 1024
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        out = torch.empty_like(q)
+        for b in range(q.shape[0]):
+            kt = k[b].transpose(-1, -2)
+            for s0 in range(0, q.shape[2], _ChunkedAttention.CHUNK):
+                sl = slice(s0, s0 + _ChunkedAttention.CHUNK)
+                probs = (torch.matmul(q[b, :, sl], kt) * scale).softmax(dim=-1)
+                out[b, :, sl] = torch.matmul(probs, v[b])
+        ctx.save_for_backward(q, k, v)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v = ctx.saved_tensors
+        scale = ctx.scale
+        dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        for b in range(q.shape[0]):
+            kt, vt = k[b].transpose(-1, -2), v[b].transpose(-1, -2)
+            for s0 in range(0, q.shape[2], _ChunkedAttention.CHUNK):
+                sl = slice(s0, s0 + _ChunkedAttention.CHUNK)
+                probs = (torch.matmul(q[b, :, sl], kt) * scale).softmax(dim=-1)
+                do = dout[b, :, sl]
+                dv[b] += torch.matmul(probs.transpose(-1, -2), do)
+                dp = torch.matmul(do, vt)
+                ds = probs * (dp - (dp * probs).sum(dim=-1, keepdim=True)) * scale      # softmax backward, row by row
+                dq[b, :, sl] = torch.matmul(ds, k[b])
+                dk[b] += torch.matmul(ds.transpose(-1, -2), q[b, :, sl])
+        return dq, dk, dv, None
+
+
 class Attention(nn.Module):
     """q/k/v without bias, `to_out.0` with bias, scale = dim_head**-0.5, dropout 0."""
+
+    # score maps above this many bytes (fp32, all batch x heads) go through _ChunkedAttention: same arithmetic per row, nothing
+    # quadratic kept for backward.  The benched shape's largest map (14 x 5 x 2560^2 x 4 B = 1.8 GB) stays on the explicit form.
+    SCORE_BYTES_LIMIT = 4 << 30
 
     def __init__(self, query_dim: int, heads: int, dim_head: int, cross_attention_dim: Optional[int] = None):
         super().__init__()
@@ -100,9 +146,12 @@ class Attention(nn.Module):
         k = self.to_k(ctx).view(b, -1, self.heads, self.dim_head).transpose(1, 2)
         v = self.to_v(ctx).view(b, -1, self.heads, self.dim_head).transpose(1, 2)
         # explicit softmax(QK^T * scale) V  == F.scaled_dot_product_attention (AttnProcessor2_0)
-        scores = torch.matmul(q, k.transpose(-1, -2)) * (self.dim_head ** -0.5)
-        probs = scores.softmax(dim=-1)
-        out = torch.matmul(probs, v)
+        if 4 * b * self.heads * s * k.shape[2] > self.SCORE_BYTES_LIMIT:
+            out = _ChunkedAttention.apply(q, k, v, self.dim_head ** -0.5)
+        else:
+            scores = torch.matmul(q, k.transpose(-1, -2)) * (self.dim_head ** -0.5)
+            probs = scores.softmax(dim=-1)
+            out = torch.matmul(probs, v)
         out = out.transpose(1, 2).reshape(b, s, self.heads * self.dim_head)
         out = self.to_out[0](out)
         return self.to_out[1](out)

@@ -337,7 +337,7 @@ __device__ __forceinline__ typename TT<T>::v8 tn_frag(const char* tile, int colb
 //   * split_k a multiple of 8 (the 64x40-level gradients: 16-32 slices of 35840 rows): XCD x runs slices x, x + 8, ... -- ALL output
 //     tiles of a slice side by side, walking the slice's rows in step, so each row of dY and X comes over the fabric once (round 3 put
 //     the slices of one TILE on an XCD: they share nothing, and every operand row was fetched by up to 8 XCDs -- 344 MB where 115 MB are
-//     algorithmic on the 320 x 1280 gradient, profiles/r4c_pmc_traffic_by_shape.txt);
+//     algorithmic on the 320 x 1280 gradient, profiles/r4_pmc_traffic_by_shape.txt);
 //   * split_k in {1, 2, 4}: each slice owns 8 / split_k XCDs, arranged xm x xn over its tile grid so that the cheaper operand is the one
 //     re-fetched (host: tn_arrange -- the rule of launch_gemm_v4).
 // Grid: 8 * zsets * sub_m * sub_n workgroups in x; out-of-range ids exit.

@@ -102,10 +102,11 @@ class Runtime:
         # attn1.to_out weight-gradient GEMM already computes on the matrix pipe: no svdx_colsum pass.  SVDX_DVEC_FROM_DW=0: A/B knob
         self.dvec_from_dw = os.environ.get("SVDX_DVEC_FROM_DW", "1") != "0"
         self._q_nn, self._q_outer, self._q_ln, self._q_M, self._q_outer_dst = [], [], [], None, set()
-        self._q_fin, self._q_fin_dst = [], set()
+        self._q_fin, self._q_fin_dst, self._q_fin_bytes = [], set(), 0
         # the reducing launches of the row-sliced weight-gradient GEMMs wait for one table-driven launch at the end of the sweep (or of
         # the transformer block, with gradient buckets); SVDX_DEFER_GRAD_FINALIZE=0: developer knob for A/B runs
         self.defer_grad_finalize = os.environ.get("SVDX_DEFER_GRAD_FINALIZE", "1") != "0"
+        self.fin_queue_budget = 768 << 20      # bytes of float slabs the queue may keep alive before it flushes (c2: ~3 flushes per sweep)
         # GroupNorm statistics of a tensor come from the store loop of the GEMM that writes it (svdx_gemm_gn) instead of a pass of their
         # own over it; SVDX_FUSE_GN_STATS=0: developer knob for A/B runs
         self.fuse_gn_stats = os.environ.get("SVDX_FUSE_GN_STATS", "1") != "0"
@@ -160,8 +161,13 @@ class Runtime:
         """job of kernels.grad_finalize_batch (the reducing launch of a row-sliced weight-gradient GEMM).  A destination may be queued
         once per table (the jobs of a launch run concurrently): a second job on it first flushes what is queued."""
         dst = job[3].data_ptr()
-        if dst in self._q_fin_dst or (job[6] is not None and job[6].data_ptr() in self._q_fin_dst):
+        nbytes = job[0].numel() * job[0].element_size()
+        # the queued float slabs stay alive until the flush (16-32 slices x the gradient's size at the 64x40 level, and the temporal
+        # blocks of that level run first in the backward sweep, while every saved activation is still live): bound what the queue holds
+        if dst in self._q_fin_dst or (job[6] is not None and job[6].data_ptr() in self._q_fin_dst) or \
+                self._q_fin_bytes + nbytes > self.fin_queue_budget:
             self.flush_deferred()
+        self._q_fin_bytes += nbytes
         self._q_fin_dst.add(dst)
         if job[6] is not None:
             self._q_fin_dst.add(job[6].data_ptr())
@@ -184,7 +190,7 @@ class Runtime:
 
     def drop_deferred(self) -> None:
         self._q_nn, self._q_outer, self._q_ln, self._q_M, self._q_outer_dst = [], [], [], None, set()
-        self._q_fin, self._q_fin_dst = [], set()
+        self._q_fin, self._q_fin_dst, self._q_fin_bytes = [], set(), 0
 
     @property
     def deferred_pending(self) -> bool:
@@ -467,7 +473,10 @@ def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowve
     k = rt.k
     splittable = rt.split_k and N % 4 == 0 and ldc % 4 == 0
     key = ("nt", M, N, Kd, lda, ldc, 0 if gather is None else (gather.mode, gather.stride, gather.ups, gather.cin),
-           bias is not None, rowvec is not None, res is not None) + (() if dual is None else (("dual", dual[2]),))
+           bias is not None, rowvec is not None, res is not None, gn is not None) + (() if dual is None else (("dual", dual[2]),))
+    # svdx_gemm_gn serves operands below 2 GiB only (buffer descriptors; csrc/gemm.hip returns -2 beyond that): larger operands keep the
+    # separate statistics pass instead of turning a working forward into an error
+    gn_fits = gn is not None and max(A.numel() * A.element_size(), B.numel() * B.element_size()) < (1 << 31)
     assert alpha == 1.0 or dual is None
 
     done = [False]
@@ -476,7 +485,7 @@ def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowve
         split, variant = cfg
         fused = dual if (split == 1 and rt.fuse_dual) else None
         if split == 1:
-            take = gn if (gn is not None and dual is None and rt.fuse_gn_stats and ldc % 8 == 0 and gn_tile_ok(_tile_launched(variant, M, N), N, gn[1], gn[2])) else None
+            take = gn if (gn_fits and dual is None and rt.fuse_gn_stats and ldc % 8 == 0 and gn_tile_ok(_tile_launched(variant, M, N), N, gn[1], gn[2])) else None
             done[0] = take is not None
             k.gemm(A, B, out, M, N, Kd, lda, ldb, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg, rv_mod=rv_mod,
                    res=res, ldres=ldres, gather=gather, variant=variant, dual=fused, alpha=alpha, gn=take)
@@ -484,7 +493,8 @@ def gemm_act(rt: "Runtime", A, B, out, M, N, Kd, lda, ldb, ldc, bias=None, rowve
             acc = rt.f32(split, M, N)
             k.gemm(A, B, acc, M, N, Kd, lda, ldb, N, gather=gather, out_mode=K.OUT_F32_SLAB, split_k=split, variant=variant, alpha=alpha)
             # the reducing launch writes the tensor: the statistics ride there (a block's 1024 consecutive elements: <= 2 samples)
-            take = gn if (gn is not None and rt.fuse_gn_stats and N * gn[1] >= 1024 and N // gn[2] <= 64) else None
+            # (dual is None: an unfused adapter term below would change `out` after its statistics were taken)
+            take = gn if (gn is not None and dual is None and rt.fuse_gn_stats and N * gn[1] >= 1024 and N // gn[2] <= 64) else None
             done[0] = take is not None
             k.gemm_finalize(acc, split, M * N, out, M, N, ldc, bias=bias, rowvec=rowvec, rv_ld=rv_ld, rv_rpg=rv_rpg,
                             rv_mod=rv_mod, res=res, ldres=ldres, gn=take)
@@ -631,7 +641,7 @@ class LinearOp:
 
 
 # Round 4 timed eight-wave 128 x 256 / 128 x 384 / 256 x 128 weight-gradient tiles (two and three stages) inside the step: the four-wave
-# 128 x 128 tile with two workgroups per CU won every problem by 5-40 % (profiles/r4_tn_tile_sweep.txt); they were removed again.
+# 128 x 128 tile with two workgroups per CU won every problem by 5-40 % (profiles/r4_dropped_experiments.txt, item 2); they were removed again.
 STAGED_TN_TILES = {}
 
 

@@ -456,6 +456,7 @@ class GraphedStep:
                 self.g_opt.capture_end()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+
     def __call__(self, side_work=None) -> None:
         """side_work: callable queued between the backward sweep and the optimizer, beside the gradient collective
         (`Trainer.finish_grads`) -- e.g. the replay of the next micro-batch's VAE-encode graph."""

@@ -507,30 +507,29 @@ class TemporalBasicTransformerBlock(nn.Module):
                      scratch=rt.f32(K.colsum_slabs(M, rv["rv_rpg"], rv["rv_mod"]) * g.B * C))
             self.attn2.cross_vec_bwd(rt, dvec, cv, tctx, g.B)
         dvec = _zeroed_vec(rt, C) if (dvec_from_dw or cs_lora) else None
-        region = rt.region("temporal_self_attention.bwd", M=M, C=C, T=g.T)     # ... to the norm1 backward; the skinny cross-attention
-        region.__enter__()                                                      # gradient launches in between belong to attn2
-        d_o = _proj_bwd_dx(rt, self.attn1.o, self.attn1.o_lora, dh1, C, o, xs_o, M, colsum_to=dvec if cs_lora else None)
-        if cs_lora:
-            self.attn2.cross_vec_bwd(rt, dvec.view(1, C), cv, tctx, 1)
-        if dvec_from_dw:
-            self.attn1.o.bwd_dw(rt, dh1, o, M, colsum_to=dvec)
-            if rt.batch_small:
-                rt.defer_outer((dvec, None, self.attn1.o.b_grad, C, 1, 1.0), 1)
-            else:
-                k.outer_acc(dvec.view(1, C), ops_ones(rt), self.attn1.o.b_grad.view(C, 1), 1, C, 1, 1.0)
-            self.attn2.cross_vec_bwd(rt, dvec.view(1, C), cv, tctx, 1)
-        elif self.attn1.o.trainable:
-            self.attn1.o.bwd_dw(rt, dh1, o, M)
-        dqkv = rt.empty(M, 3 * C)
-        k.tattn_bwd(qkv, qkv[:, C:], qkv[:, 2 * C:], d_o, dqkv, dqkv[:, C:], dqkv[:, 2 * C:], g.B, g.T, g.HW,
-                    self.heads, 3 * C, C, 3 * C, HEAD_DIM ** -0.5)
-        del d_o, qkv, o
-        dn1 = _proj_bwd_dx(rt, self.attn1.qkv, self.attn1.qkv_lora, dqkv, 3 * C, n1, xs_qkv, M)
-        if self.attn1.qkv.trainable:
-            self.attn1.qkv.bwd_dw(rt, dqkv, n1, M)
-        del dqkv, n1
-        dh = self.ln1.bwd(rt, dn1, h, st1, M, add=dh1)
-        region.__exit__(None, None, None)
+        # ... to the norm1 backward; the skinny cross-attention gradient launches in between belong to attn2
+        with rt.region("temporal_self_attention.bwd", M=M, C=C, T=g.T):
+            d_o = _proj_bwd_dx(rt, self.attn1.o, self.attn1.o_lora, dh1, C, o, xs_o, M, colsum_to=dvec if cs_lora else None)
+            if cs_lora:
+                self.attn2.cross_vec_bwd(rt, dvec.view(1, C), cv, tctx, 1)
+            if dvec_from_dw:
+                self.attn1.o.bwd_dw(rt, dh1, o, M, colsum_to=dvec)
+                if rt.batch_small:
+                    rt.defer_outer((dvec, None, self.attn1.o.b_grad, C, 1, 1.0), 1)
+                else:
+                    k.outer_acc(dvec.view(1, C), ops_ones(rt), self.attn1.o.b_grad.view(C, 1), 1, C, 1, 1.0)
+                self.attn2.cross_vec_bwd(rt, dvec.view(1, C), cv, tctx, 1)
+            elif self.attn1.o.trainable:
+                self.attn1.o.bwd_dw(rt, dh1, o, M)
+            dqkv = rt.empty(M, 3 * C)
+            k.tattn_bwd(qkv, qkv[:, C:], qkv[:, 2 * C:], d_o, dqkv, dqkv[:, C:], dqkv[:, 2 * C:], g.B, g.T, g.HW,
+                        self.heads, 3 * C, C, 3 * C, HEAD_DIM ** -0.5)
+            del d_o, qkv, o
+            dn1 = _proj_bwd_dx(rt, self.attn1.qkv, self.attn1.qkv_lora, dqkv, 3 * C, n1, xs_qkv, M)
+            if self.attn1.qkv.trainable:
+                self.attn1.qkv.bwd_dw(rt, dqkv, n1, M)
+            del dqkv, n1
+            dh = self.ln1.bwd(rt, dn1, h, st1, M, add=dh1)
         del dn1, dh1, h
         dn0 = self.ff_in.bwd(rt, dh, n0, pre0, g0, M)
         if not need_dx and not self.ln0.trainable:

@@ -148,7 +148,10 @@ def test_c5_lora_level_blocks_match_oracle(level):
 @gpu
 @pytest.mark.parametrize("level,lora_r", [("L2", 0), ("L3", 0), ("L3", 64),
                                           pytest.param("L1", 0, marks=pytest.mark.skipif(os.environ.get("SVDX_BIG_PARITY") != "1",
-                                                                                        reason="the 2304-pixel level of config 4: minutes of CPU oracle; SVDX_BIG_PARITY=1"))])
+                                                                                        reason="the 2304-pixel level of config 4: minutes of CPU oracle; SVDX_BIG_PARITY=1")),
+                                          pytest.param("L0", 0, marks=pytest.mark.skipif(os.environ.get("SVDX_BIG_PARITY") != "1",
+                                                                                        reason="the 9216-pixel top level of config 4 (230,400 rows): the oracle's chunked "
+                                                                                               "attention path, tens of GB and minutes of CPU; SVDX_BIG_PARITY=1"))])
 def test_c4_level_blocks_match_oracle(level, lora_r):
     """Reference config 4 (/root/reference/train_svd.py:318 --num_frames 25, 1024 x 576): the T = 25 path -- temporal attention with the
     frame axis padded 25 -> 32 and masked, no fused temporal self-attention (T > 16), Conv3d over 25 frames, 3-D GroupNorm over 25 x HW
@@ -176,6 +179,43 @@ def test_full_topology_c1_matches_oracle():
     for key, r in res.items():
         e2e_checks.assert_parity(key, r)
         assert r["n_grads"] >= 300, r
+
+
+@gpu
+def test_full_topology_c2_matches_oracle():
+    """The benched configuration itself (BASELINE.json configs[1]: 14 frames 512x320, fp16, batch 1) end to end against the CPU oracle:
+    loss <= 1e-3 relative (north_star's metric), gradient cosine of all 416 trainable tensors, prediction, parameters after AdamW.
+    One oracle step at this shape is ~25 TFLOP of fp32 work and ~60 GB of saved activations: skipped on hosts below the gate of
+    bench.py's cpu_baseline.c2 leg (>= 32 cores, >= 110 GB free), SVDX_SKIP_C2_PARITY=1 to opt out."""
+    import e2e_checks
+    ok, why = e2e_checks.host_can_run_c2_oracle()
+    if not ok or os.environ.get("SVDX_SKIP_C2_PARITY") == "1":
+        pytest.skip(f"one CPU-oracle step at 14x512x320 needs >= 32 cores and >= 110 GB free RAM (have {why})")
+    res = e2e_checks.run_full_c2(verbose=True)
+    assert len(res) == 1
+    for key, r in res.items():
+        e2e_checks.assert_parity(key, r)
+        assert r["n_grads"] >= 300, r
+
+
+@gpu
+@pytest.mark.parametrize("case", ["tiny", "L0"])
+def test_three_step_trajectory_matches_oracle(case):
+    """Three consecutive optimizer steps against the oracle in fp16 (e2e_checks.trajectory_vs_oracle): the loss of every step and the
+    accumulated update of every trainable tensor.  A wrong gradient cannot hide behind a correct first-step loss.
+    AdamW's first updates are ~lr * sign(g): where 16-bit storage leaves a gradient element at rounding level its sign may differ, so
+    the update cosine sits below the gradient cosine -- the bar is far above what a zeroed / mis-routed gradient gives (~0)."""
+    import torch
+
+    import e2e_checks
+    from oracle.unet import TINY_CONFIG
+    cfg, geom = (TINY_CONFIG, (1, 3, 16, 16)) if case == "tiny" else (e2e_checks.level_config(320, 5), (1, 14, 40, 64))
+    r = e2e_checks.trajectory_vs_oracle(cfg, geom, dtype=torch.float16, steps=3, lr=1e-4)
+    print(case, r)
+    assert r["opt_steps"] == 3.0, r                       # no step was skipped by the loss-scale state machine
+    assert max(r["loss_rel"]) <= 1e-3, r
+    assert r["update_cos_min"] >= 0.9, r
+    assert 0.9 <= r["update_norm_ratio_min"] and r["update_norm_ratio_max"] <= 1.1, r
 
 
 @gpu

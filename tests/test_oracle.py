@@ -100,3 +100,30 @@ def test_oracle_reproduces_committed_golden_step():
         assert names == sorted(ref["grads"]), tag
         norms = torch.tensor([float(ref["grads"][n].double().norm()) for n in names], dtype=torch.float64)
         assert torch.allclose(norms, gold[f"{tag}.grad_norms"], rtol=1e-3, atol=1e-9), tag
+
+
+def test_chunked_attention_equals_the_explicit_form(monkeypatch):
+    """`oracle.unet._ChunkedAttention` (the memory-frugal path the oracle takes for config 4's 9216-pixel level) against the explicit
+    softmax(QK^T s)V of `Attention.forward`: the same module, the same input, once under the byte limit and once over it -- output and
+    every gradient (input, q/k/v/out weights), with a sequence that is not a multiple of the chunk and cross-attention-shaped keys."""
+    from oracle import unet as ou
+    torch.manual_seed(3)
+    monkeypatch.setattr(ou._ChunkedAttention, "CHUNK", 48)
+    for s, kv, cross in ((130, 130, None), (40, 7, 24)):
+        att = ou.Attention(64, heads=2, dim_head=32, cross_attention_dim=cross).double()
+        x = torch.randn(3, s, 64, dtype=torch.float64, requires_grad=True)
+        ctx = None if cross is None else torch.randn(3, kv, cross, dtype=torch.float64)
+        w = torch.randn(3, s, 64, dtype=torch.float64)
+        outs = []
+        for limit in (1 << 40, 0):
+            monkeypatch.setattr(ou.Attention, "SCORE_BYTES_LIMIT", limit)
+            att.zero_grad()
+            x.grad = None
+            y = att(x, ctx)
+            (y * w).sum().backward()
+            outs.append((y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in att.parameters()]))
+        (y0, gx0, gp0), (y1, gx1, gp1) = outs
+        assert torch.allclose(y0, y1, rtol=1e-12, atol=1e-13)
+        assert torch.allclose(gx0, gx1, rtol=1e-10, atol=1e-12)
+        for a, b in zip(gp0, gp1):
+            assert torch.allclose(a, b, rtol=1e-10, atol=1e-12)
