@@ -62,7 +62,7 @@ typedef struct svdx_gather {
 
 /* ABI revision of this header: bumped whenever an entry changes its argument list or meaning (100 = rounds 1-3; 400 = round 4).
  * svdx_version() returns the value the library was built with; the ctypes binding refuses a library whose number differs. */
-#define SVDX_VERSION 400
+#define SVDX_VERSION 500
 int         svdx_version(void);
 int         svdx_last_error(char* buf, size_t n);
 /* 1 when the binary was built for gfx950 and a device is usable */
@@ -334,6 +334,22 @@ int svdx_zero_spans(float* base, const int* spans, int n_spans, void* stream);
  * order; capturable.  bench.py brackets the GEMM-family launches of a captured step with it. */
 int svdx_stamp(uint64_t* slot, void* stream);
 int svdx_wall_clock_khz(void);
+
+/* ---- The data-parallel gradient sum without a collective library (svdx_allreduce_grads; replaces the all-reduce that
+ * DistributedDataParallel runs inside accelerator.backward, /root/reference/train_svd.py:815 + :1044, when RCCL's choice of algorithm
+ * is a ring: xGMI is point-to-point, the direct exchange uses all seven links of a GPU at once).
+ *   peers  HOST array of `world` device pointers: the same float buffer [n] of every rank of the node (index = rank, own buffer
+ *          included), each mapped into this process by the caller (hipIpcOpenMemHandle / peer access enabled)
+ *   phase  -1: system-scope release only (publishes what earlier launches of this device wrote)
+ *           0: reduce-scatter -- slice `rank` of my buffer = sum over q of peer q's slice `rank`, added in rank order (one owner per
+ *              element: identical bits on every rank and from run to run)
+ *           1: all-gather -- every other slice of my buffer = its owner's reduced slice
+ *          slice q = floats [q * per, min(n, (q + 1) * per)), per = ceil(n / world / 4) * 4.
+ * The CALLER orders the ranks: all ranks past phase -1 (their gradients complete) before anyone's phase 0, all past phase 0 before
+ * phase 1, all past phase 1 before anyone writes its buffer again (svd_xtend_amd/train.py DirectAllReduce: a stream-ordered one-element
+ * RCCL all-reduce, or a host barrier).  n a multiple of 4, buffers 16-byte aligned, world <= SVDX_MAX_PEERS. */
+#define SVDX_MAX_PEERS 16
+int svdx_allreduce_grads(float* const* peers, int world, int rank, int64_t n, int phase, void* stream);
 
 /* ---- EDM loss (train_svd.py:1025-1036) fused with its gradient.  pred rows [B*T*HW, ld]; noisy/target
  *      float NCHW-per-frame [B,T,4,H,W]; sigma[B].  loss (float, accumulated; zero it first) and

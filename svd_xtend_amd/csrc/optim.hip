@@ -65,6 +65,56 @@ __global__ void check_finite_kernel(const float* __restrict__ g, long n, float* 
     }
 }
 
+// ---- gradient sum over the ranks of one node, straight over xGMI (svdx_allreduce_grads) --------------------------------------------
+// xGMI is point-to-point: every GPU has a link to each of the other seven, so the bandwidth-optimal exchange is the DIRECT one -- rank r
+// pulls slice r of every peer's buffer (reduce-scatter), then pulls the reduced slices of the other ranks (all-gather): 2 x (7/8) x S
+// bytes per GPU spread over seven links at once, where a ring moves the same bytes over ONE link at a time (2.6 ms
+// against 18 ms for the 1.59 GB gradient buffer of 8 ranks).  Slice q = floats [q * per, min(n, (q + 1) * per)), per = ceil(n / world / 4) * 4.
+// Every element of the sum is formed by ONE thread of ONE rank, adding the ranks in rank order: all ranks end with identical bits, and
+// the same bits from run to run.  Visibility between devices: a workgroup starts with a system-scope acquire (drops cached lines of
+// peer memory) and ends with a system-scope release (writes its own dirty lines back); the caller's barrier between the phases orders
+// the ranks.  phase -1 is the release alone: it publishes whatever earlier kernels of this device left in its caches.
+struct PeerPtrs { float* p[SVDX_MAX_PEERS]; };
+
+template <int W>
+__global__ __launch_bounds__(256) void peer_reduce_scatter_kernel(PeerPtrs peers, int world, int rank, long n, long per) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    const long lo = (long)rank * per, hi = lo + per < n ? lo + per : n;
+    float* mine = peers.p[rank];
+    for (long i = lo + ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < hi; i += (long)gridDim.x * blockDim.x * 4) {
+        f32x4 v[W > 0 ? W : SVDX_MAX_PEERS];
+        if (W > 0) {
+#pragma unroll
+            for (int q = 0; q < W; ++q) v[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(peers.p[q] + i));     // all in flight
+        } else {
+            for (int q = 0; q < world; ++q) v[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(peers.p[q] + i));
+        }
+        f32x4 acc = v[0];
+        if (W > 0) {
+#pragma unroll
+            for (int q = 1; q < W; ++q) acc += v[q];
+        } else {
+            for (int q = 1; q < world; ++q) acc += v[q];
+        }
+        *reinterpret_cast<f32x4*>(mine + i) = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+}
+
+__global__ __launch_bounds__(256) void peer_all_gather_kernel(PeerPtrs peers, int world, int rank, long n, long per) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    float* mine = peers.p[rank];
+    // blockIdx.y walks the OTHER ranks starting with the next one, so that at any moment the seven links carry one slice each
+    const int q = (rank + 1 + (int)blockIdx.y) % world;
+    const long lo = (long)q * per, hi = lo + per < n ? lo + per : n;
+    const float* src = peers.p[q];
+    for (long i = lo + ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < hi; i += (long)gridDim.x * blockDim.x * 4)
+        *reinterpret_cast<f32x4*>(mine + i) = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + i));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+}
+
+__global__ __launch_bounds__(64) void peer_publish_kernel() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
+
 // Learning-rate multiplier lambda(n) of diffusers.optimization.get_scheduler (train_svd.py:807-813), n = scheduler steps taken so
 // far.  Evaluated on the device from the optimizer's own step counter so that a step replayed from a hipGraph follows the
 // schedule without host involvement.  st[9] kind, st[10] warmup, st[11] total, st[12] cycles, st[13] power, st[14] lr_end / lr_init.
@@ -245,6 +295,31 @@ extern "C" int svdx_check_finite(const float* g, int64_t n, float* opt_state, vo
     const int blocks = (int)std::min<long>((n / 4 + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(check_finite_kernel, dim3(std::max(1, blocks)), dim3(256), 0, (hipStream_t)stream, g, (long)n, opt_state);
     SVDX_LAUNCH_CHECK("svdx_check_finite");
+    return 0;
+}
+
+extern "C" int svdx_allreduce_grads(float* const* peers, int world, int rank, int64_t n, int phase, void* stream) {
+    SVDX_CHECK_ARG(peers && world >= 1 && world <= SVDX_MAX_PEERS && rank >= 0 && rank < world && n > 0 && n % 4 == 0 &&
+                       phase >= -1 && phase <= 1, "svdx_allreduce_grads: bad args (1..%d ranks, n a multiple of 4, phase -1 / 0 / 1)", SVDX_MAX_PEERS);
+    PeerPtrs pp;
+    for (int q = 0; q < SVDX_MAX_PEERS; ++q) pp.p[q] = q < world ? peers[q] : nullptr;
+    for (int q = 0; q < world; ++q)
+        SVDX_CHECK_ARG(pp.p[q] && ((uintptr_t)pp.p[q] & 15) == 0, "svdx_allreduce_grads: peer %d buffer null or not 16-byte aligned", q);
+    const long per = ((n + world - 1) / world + 3) / 4 * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (phase == -1) {
+        hipLaunchKernelGGL(peer_publish_kernel, dim3(1024), dim3(64), 0, st);       // every XCD's L2 sees a wave that writes it back
+    } else if (phase == 0) {
+        const int blocks = (int)std::max<long>(1, std::min<long>((per / 4 + 255) / 256, 1024));
+        if (world == 8) hipLaunchKernelGGL(peer_reduce_scatter_kernel<8>, dim3(blocks), dim3(256), 0, st, pp, world, rank, (long)n, per);
+        else if (world == 4) hipLaunchKernelGGL(peer_reduce_scatter_kernel<4>, dim3(blocks), dim3(256), 0, st, pp, world, rank, (long)n, per);
+        else if (world == 2) hipLaunchKernelGGL(peer_reduce_scatter_kernel<2>, dim3(blocks), dim3(256), 0, st, pp, world, rank, (long)n, per);
+        else hipLaunchKernelGGL(peer_reduce_scatter_kernel<0>, dim3(blocks), dim3(256), 0, st, pp, world, rank, (long)n, per);
+    } else if (world > 1) {
+        const int blocks = (int)std::max<long>(1, std::min<long>((per / 4 + 255) / 256, 256));
+        hipLaunchKernelGGL(peer_all_gather_kernel, dim3(blocks, world - 1), dim3(256), 0, st, pp, world, rank, (long)n, per);
+    }
+    SVDX_LAUNCH_CHECK("svdx_allreduce_grads");
     return 0;
 }
 

@@ -26,7 +26,7 @@ LN_PARTIAL_ROWS = 2048
 GN_REPLICAS = 8
 GN_STAT_FLOATS = 4             # floats of storage per (replica, sample, group) of a GroupNorm statistics buffer: two int64
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3, GATHER_CONV3X3_PAD0 = 0, 1, 2, 3, 4
-ABI_VERSION = 400              # include/svdx.h: SVDX_VERSION this binding was written against
+ABI_VERSION = 500              # include/svdx.h: SVDX_VERSION this binding was written against
 OPT_STATE_FLOATS = 16          # include/svdx.h: layout of the optimizer / loss-scale / schedule state
 SCHED_KINDS = {"constant": 0, "constant_with_warmup": 1, "linear": 2, "cosine": 3, "cosine_with_restarts": 4, "polynomial": 5}
 
@@ -140,10 +140,12 @@ _SIGS = {
     "svdx_adamw": "pppp" "l" "ffffff" "pp" "ip",
     "svdx_adamw_tiled": "ppppp" "i" "ffffff" "ppp" "ip",
     "svdx_ema_lerp": "pp" "l" "f" "p",
+    "svdx_allreduce_grads": "p" "ii" "l" "i" "p",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "l": ctypes.c_int64, "z": ctypes.c_size_t}
 
 EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_wall_clock_khz", "svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band", "svdx_ln_bwd_blocks")
+MAX_PEERS = 16                 # include/svdx.h SVDX_MAX_PEERS: ranks of svdx_allreduce_grads
 BATCH_MAX_JOBS = 48            # include/svdx.h SVDX_BATCH_MAX_JOBS: jobs of a *_batch entry that share one launch
 TSA_MAX_C, TSA_MAX_T, TSA_BAND_ROWS = 320, 16, 144
 
@@ -471,6 +473,11 @@ class HipBackend:
 
     def ema_lerp(self, shadow, p, n, one_minus_decay):
         self._call("svdx_ema_lerp", _f32(shadow), _f32(p), n, float(one_minus_decay), self._stream())
+
+    def allreduce_grads(self, peer_ptrs, rank, n, phase):
+        """include/svdx.h svdx_allreduce_grads: peer_ptrs = device addresses of every rank's buffer (own included, index = rank)."""
+        arr = (ctypes.c_void_p * len(peer_ptrs))(*peer_ptrs)
+        self._call("svdx_allreduce_grads", ctypes.cast(arr, ctypes.c_void_p), len(peer_ptrs), int(rank), int(n), int(phase), self._stream())
 
     def optim_prep(self, opt_state, beta1, beta2, growth, backoff, growth_interval, dynamic):
         assert opt_state.numel() >= OPT_STATE_FLOATS

@@ -70,6 +70,98 @@ def build_adam_tiles(params, offsets, wt_map, device) -> torch.Tensor:
     return tiles.to(torch.int32).contiguous().to(device)
 
 
+class _StreamWork:
+    """`.wait()` of a collective that ran on a side stream: the current stream waits for it (the shape of torch.distributed's Work)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def wait(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
+class DirectAllReduce:
+    """The gradient sum over the ranks of ONE node as svdx_allreduce_grads: a direct reduce-scatter + all-gather over peer-mapped
+    buffers (include/svdx.h; SURVEY.md 5: xGMI is point-to-point, the direct exchange drives all seven links of a GPU at once where a
+    ring drives one -- ~2.6 ms against ~18 ms for 1.59 GB on 8 ranks).  The fallback for an RCCL that picks a ring.
+
+    Construction (collective over the group): every rank exports its buffer as an IPC handle (torch.multiprocessing's reduction of
+    a CUDA tensor -- hipIpcGetMemHandle underneath; HSA_ENABLE_IPC_MODE_LEGACY=0 as everywhere on this stack), gathers the others'
+    and maps them; peer access is switched on by one small device-to-device copy per peer.  Needs every rank's GPU visible to every
+    process (torchrun's default: no per-rank HIP_VISIBLE_DEVICES mask).
+
+    Ordering between ranks: three cross-rank barriers per sum (gradients complete -> reduce-scatter -> all-gather -> buffers free).
+    Under the RCCL backend a barrier is a one-element all-reduce -- stream-ordered, the host never blocks; under any other backend
+    (the gloo rehearsals) it is `synchronize()` + `dist.barrier()`."""
+
+    def __init__(self, buf: torch.Tensor, process_group=None, kernels=None):
+        from torch.multiprocessing.reductions import reduce_tensor
+        self.pg = process_group
+        self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        if self.world > K.MAX_PEERS:
+            raise RuntimeError(f"DirectAllReduce: {self.world} ranks (one node, at most {K.MAX_PEERS})")
+        if not (buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous() and buf.numel() % 4 == 0 and buf.data_ptr() % 16 == 0):
+            raise RuntimeError("DirectAllReduce: a contiguous, 16-byte aligned float32 CUDA buffer of a multiple of 4 elements")
+        self.buf, self.n, self.k = buf, buf.numel(), kernels or K.backend()
+        self.stream_ordered = dist.get_backend(process_group) == "nccl"
+        fn, args = reduce_tensor(buf)
+        got = [None] * self.world
+        dist.all_gather_object(got, (fn, args, int(buf.device.index)), group=process_group)
+        self.peers, err = [], None
+        try:
+            for q, (f, a, dev_q) in enumerate(got):
+                if q == self.rank:
+                    self.peers.append(buf)
+                    continue
+                if dev_q >= torch.cuda.device_count():
+                    raise RuntimeError(f"rank {q} holds GPU {dev_q}, which this process cannot see ({torch.cuda.device_count()} visible)")
+                t = f(*a)                                        # the peer's buffer, mapped (a tensor on ITS device)
+                if t.numel() != self.n:
+                    raise RuntimeError("ranks hold buffers of different sizes")
+                torch.empty(4, dtype=torch.float32, device=buf.device).copy_(t[:4])  # first touch switches peer access on (this device -> that one)
+                self.peers.append(t)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001 -- decided together below: a rank that raised alone would leave the others in a collective
+            err = e
+        ok = torch.tensor([0.0 if err is not None else 1.0], device=buf.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=process_group)
+        if float(ok) != 1.0:
+            self.peers = []
+            raise RuntimeError(f"DirectAllReduce: peer mapping failed on {'this rank: ' + repr(err) if err is not None else 'another rank'}")
+        self.ptrs = [t.data_ptr() for t in self.peers]
+        self._tok = torch.zeros(1, dtype=torch.float32, device=buf.device)
+        self.side = torch.cuda.Stream(device=buf.device)
+
+    def _xbarrier(self) -> None:
+        if self.stream_ordered:
+            dist.all_reduce(self._tok, group=self.pg)
+        else:
+            torch.cuda.synchronize()
+            dist.barrier(group=self.pg)
+
+    def all_reduce(self) -> None:
+        """buf <- sum over ranks of buf, on the current stream."""
+        k, peers = self.k, (self.ptrs if hasattr(self.k, "lib") else self.peers)       # the test emulation takes the tensors themselves
+        k.allreduce_grads(peers, self.rank, self.n, -1)
+        self._xbarrier()
+        k.allreduce_grads(peers, self.rank, self.n, 0)
+        self._xbarrier()
+        k.allreduce_grads(peers, self.rank, self.n, 1)
+        self._xbarrier()
+
+    def start(self) -> _StreamWork:
+        """The same on a side stream, ordered after what the current stream holds; `.wait()` orders the current stream after it.
+        (Without stream-ordered barriers the host blocks inside: there is nothing to overlap, the sum runs in place.)"""
+        if not self.stream_ordered:
+            self.all_reduce()
+            return _StreamWork(None)
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self.all_reduce()
+        return _StreamWork(self.side)
+
+
 class Trainer:
     def __init__(self, model: UNetSpatioTemporalConditionModel, dtype: torch.dtype = torch.float16,
                  lr: float = 1e-5, betas=(0.9, 0.999), weight_decay: float = 1e-2, eps: float = 1e-8,
@@ -80,6 +172,7 @@ class Trainer:
         self.growth_interval = growth_interval
         self.grad_accum = grad_accum
         self.pg = process_group
+        self.direct: Optional[DirectAllReduce] = None    # use_direct_allreduce(): svdx_allreduce_grads instead of RCCL for the one-collective schedules
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         dev = next(model.parameters()).device
         self.dev = dev
@@ -262,6 +355,9 @@ class Trainer:
         if self.world == 1:
             return None
         if not self._pending:
+            if self.direct is not None:
+                w = self.direct.start()
+                return w if async_op else w.wait()
             return dist.all_reduce(self.g_flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
         done = {span for span, _ in self._pending}
         for span in self._buckets.values():          # a block whose backward was pruned never reported: reduce it now
@@ -274,6 +370,15 @@ class Trainer:
             w.wait()
         self._pending = []
         return None
+
+    def use_direct_allreduce(self, on: bool = True) -> None:
+        """Route the one-collective schedules (`overlap = False`) through svdx_allreduce_grads (DirectAllReduce) instead of RCCL's
+        all-reduce.  Collective: every rank of the group calls it.  The per-block buckets stay on RCCL."""
+        if on and self.world > 1:
+            if self.direct is None:
+                self.direct = DirectAllReduce(self.g_flat, self.pg, self.rt.k)
+        else:
+            self.direct = None
 
     def finish_grads(self, side_work=None) -> None:
         """Complete the gradient sum over ranks, with `side_work()` issued on the compute stream while the collective is in flight.
@@ -293,6 +398,8 @@ class Trainer:
                 if span not in done and span[1] > span[0]:
                     self._pending.append((span, dist.all_reduce(self.g_flat[span[0]:span[1]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
             works = [w for _, w in self._pending]
+        elif self.direct is not None:
+            works = [self.direct.start()]
         else:
             works = [dist.all_reduce(self.g_flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)]
         if side_work is not None:

@@ -135,11 +135,11 @@ def assert_parity(key, r, bf16=None):
     bf16 = ("bfloat16" in key) if bf16 is None else bf16          # NB: "float16" is a substring of "bfloat16"
     assert r["loss_rel"] <= (8e-3 if bf16 else 1e-3), f"{key}: loss rel err {r['loss_rel']:.3e}"
     assert r["grad_cos_min"] >= (0.95 if bf16 else 0.99), f"{key}: {r}"
-    # prediction (the tensor the reference's loss is built from): measured 1.1e-3 (c2) / 1.3e-3 (c1') at fp16 on the full model and up to
-    # 1.96e-3 on the tiny LoRA topology (profiles/r2_gpu_parity_real_widths.json), 16-bit storage through ~100 chained layers; bf16 up to
-    # 1.57e-2.  The bars sit a quarter above the worst measured case (round 3: 5e-3 / 4e-2)
-    assert r["pred_rel_l2"] is None or r["pred_rel_l2"] <= (2e-2 if bf16 else 2.5e-3), f"{key}: {r}"
-    assert r["pred_after_rel_l2"] is None or r["pred_after_rel_l2"] <= (2e-2 if bf16 else 2.5e-3), f"{key}: {r}"
+    # prediction (the tensor the reference's loss is built from): 16-bit storage through ~100 chained layers.  Measured at fp16 on the full
+    # model: 1.1e-3 (c2, bench.py's seed) / 1.3e-3 (c1') / 2.28e-3 (c2, this suite's seed: round 5's test_full_topology_c2_matches_oracle);
+    # 1.96e-3 on the tiny LoRA topology; bf16 up to 1.57e-2.  The bars sit a quarter above the worst measured case (round 4: 2.5e-3)
+    assert r["pred_rel_l2"] is None or r["pred_rel_l2"] <= (2e-2 if bf16 else 3e-3), f"{key}: {r}"
+    assert r["pred_after_rel_l2"] is None or r["pred_after_rel_l2"] <= (2e-2 if bf16 else 3e-3), f"{key}: {r}"
     if r.get("lr"):
         assert r["param_max_diff"] <= 2.5 * r["lr"], f"{key}: {r}"
         assert r["param_mean_diff"] <= (0.2 if bf16 else 0.05) * r["lr"], f"{key}: {r}"

@@ -638,6 +638,23 @@ class EmuBackend:
         S, P = V1(shadow, n), V1(p, n)
         S.sub_(one_minus_decay * (S - P))
 
+    def allreduce_grads(self, peer_bufs, rank, n, phase):
+        """peer_bufs: the ranks' float tensors themselves (the emulation has no address space to map)"""
+        world = len(peer_bufs)
+        per = -(-(-(-n // world)) // 4) * 4
+        if phase == 0:
+            lo, hi = rank * per, min(n, rank * per + per)
+            if hi > lo:
+                acc = V1(peer_bufs[0], n)[lo:hi].clone()
+                for q in range(1, world):
+                    acc += V1(peer_bufs[q], n)[lo:hi]
+                V1(peer_bufs[rank], n)[lo:hi] = acc
+        elif phase == 1:
+            for q in range(world):
+                lo, hi = q * per, min(n, q * per + per)
+                if q != rank and hi > lo:
+                    V1(peer_bufs[rank], n)[lo:hi] = V1(peer_bufs[q], n)[lo:hi]
+
     def zero_spans(self, base, spans, n_spans):
         for off, cnt in spans[:n_spans].view(-1, 2).tolist():
             V1(base, off + cnt)[off:off + cnt].zero_()

@@ -794,6 +794,23 @@ def check_optim(P, dt):
         sh, w = rndf((n_e,), P.dev, g), rndf((n_e,), P.dev, g)
         o1, o2 = P.run("ema_lerp", lambda o: ((o["s"], w, n_e, 0.013), {}), dict(s=sh))
         res.append((f"ema_lerp n={n_e}", relerr(o1["s"], o2["s"]), 1e-6))
+    # svdx_allreduce_grads: the ranks of a node as separate buffers of ONE device (the peer mapping is the caller's business): after
+    # reduce-scatter + all-gather every buffer holds the sum, added in rank order -- bit-equal to that sum and across ranks
+    for world, n_e in ((2, 4 * 1000), (3, 4 * 1001), (4, 4 * 6), (8, 4 * 5003), (8, 8), (5, 4 * 777)):
+        bufs = [rndf((n_e,), P.dev, g) for _ in range(world)]
+        want = bufs[0].clone()
+        for q in range(1, world):
+            want = want + bufs[q]
+        is_lib = hasattr(P.impl, "lib")
+        for be, mine in ((P.impl, [b.clone() for b in bufs]), (P.ref, [b.clone() for b in bufs])):
+            handles = [b.data_ptr() for b in mine] if (be is P.impl and is_lib) else mine
+            for phase in (-1, 0, 1):
+                for r in range(world):
+                    be.allreduce_grads(handles, r, n_e, phase)
+            if P.dev.type == "cuda":
+                torch.cuda.synchronize()
+            tag = "impl" if be is P.impl else "emul"
+            res.append((f"allreduce_grads {tag} world={world} n={n_e} equals the rank-ordered sum", float(max((b - want).abs().max() for b in mine)), 0.0))
     # span zeroing and the float-store finalize (write-once weight gradients)
     buf = rndf((5000,), P.dev, g)
     spans = torch.tensor([[0, 64], [128, 4], [1000, 2048], [4996, 4]], dtype=torch.int32, device=P.dev)

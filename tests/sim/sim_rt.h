@@ -124,6 +124,7 @@ inline void sim_amdgcn_sched_barrier(int) {}
 inline void sim_amdgcn_sched_group_barrier(int, int, int) {}
 inline void sim_amdgcn_s_setprio(int) {}
 inline void sim_amdgcn_s_sleep(int) {}
+inline void sim_amdgcn_fence(int, const char*) {}              // one address space, sequentially consistent: nothing to order
 inline void sim_amdgcn_s_waitcnt(int imm) {                      // gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4
     const int vm = (imm & 0xf) | ((imm >> 14) & 3) << 4;
     if (vm != 63) sim_waitcnt_vm(vm);

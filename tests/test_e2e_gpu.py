@@ -214,8 +214,8 @@ def test_three_step_trajectory_matches_oracle(case):
     print(case, r)
     assert r["opt_steps"] == 3.0, r                       # no step was skipped by the loss-scale state machine
     assert max(r["loss_rel"]) <= 1e-3, r
-    assert r["update_cos_min"] >= 0.9, r
-    assert 0.9 <= r["update_norm_ratio_min"] and r["update_norm_ratio_max"] <= 1.1, r
+    assert r["update_cos_min"] >= 0.98, r                  # measured 0.9960 (tiny) / 0.9959 (L0); a zeroed or mis-routed gradient gives ~0
+    assert 0.97 <= r["update_norm_ratio_min"] and r["update_norm_ratio_max"] <= 1.03, r
 
 
 @gpu
