@@ -122,7 +122,14 @@ int svdx_gemm_dual(const void* A, const void* B, void* C, int M, int N, int K, i
  * the rows in order -- a fixed summation order, so the bias gradient is run-to-run identical.  With split_k > 1 a_colsum needs the
  * slab mode.  stages selects the kernel: 0 / 2 = four waves, 128 x 128 output tiles, two LDS stages (two workgroups per CU, drained
  * every K-step); 3 / 4 = the same tile with 2 / 3 row tiles in flight across the barrier (one workgroup per CU); 18 = eight waves,
- * 256 x 256 output tiles, one workgroup per CU (outputs of >= 1024 x 512 that 180-256 such tiles x row slices cover). */
+ * 256 x 256 output tiles, one workgroup per CU (outputs of >= 1024 x 512 that 180-256 such tiles x row slices cover).
+ * stages | SVDX_TN_PREFETCH (with 0 / 2 / 18): every wave also touches its share of the operand tiles three K-steps ahead (one 4-byte
+ * LDS-DMA per wave and step, left in flight by the counted wait): both operands of a weight gradient stream from HBM and the LDS ring
+ * holds one tile ahead, so without it every K-step waits a fabric round trip (profiles/r5_stall_counters.txt).  Same results, bit for bit. */
+#define SVDX_TN_PREFETCH 32
+/* stages | SVDX_TN_FLAT: developer knob -- the flat global_load_lds staging of rounds 1-4 (what operands of 2 GiB and more still get)
+ * instead of buffer descriptors, for A/B runs: behind it the compiler serialises loads and MFMAs (csrc/gemm.hip gemm_tn_kernel). */
+#define SVDX_TN_FLAT 64
 int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
                  float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, int dtype, void* stream);
 

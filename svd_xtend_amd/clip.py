@@ -204,6 +204,9 @@ class CLIPVisionModelWithProjection(nn.Module):
 _TAPS = {}
 
 
+_AFFINE = {}
+
+
 def _gaussian_taps(factor: float, dev) -> torch.Tensor:
     """train_svd.py:141-161 + :218-232: sigma = max((factor - 1) / 2, 0.001); window = max(int(4 sigma), 3) made odd."""
     key = (round(float(factor), 9), str(dev))
@@ -228,10 +231,14 @@ def clip_pixel_values(frames: torch.Tensor, size: Sequence[int] = (224, 224), k=
     t1, t2 = torch.empty_like(x), torch.empty_like(x)
     k.blur_axis(x, t1, b * c, h, w, _gaussian_taps(w / size[1], dev), 0)
     k.blur_axis(t1, t2, b * c, h, w, _gaussian_taps(h / size[0], dev), 1)
-    mean = torch.tensor(CLIP_MEAN[:c], dtype=torch.float32, device=dev)
-    std = torch.tensor(CLIP_STD[:c], dtype=torch.float32, device=dev)
+    key = (c, str(dev))
+    if key not in _AFFINE:                      # built once per device: a host->device copy per call would also forbid hipGraph capture
+        mean = torch.tensor(CLIP_MEAN[:c], dtype=torch.float32, device=dev)
+        std = torch.tensor(CLIP_STD[:c], dtype=torch.float32, device=dev)
+        _AFFINE[key] = ((0.5 / std).contiguous(), ((0.5 - mean) / std).contiguous())
+    scale, shift = _AFFINE[key]
     out = torch.empty(b, c, size[0], size[1], dtype=torch.float32, device=dev)
-    k.bicubic_affine(t2, out, b, c, h, w, size[0], size[1], (0.5 / std).contiguous(), ((0.5 - mean) / std).contiguous())
+    k.bicubic_affine(t2, out, b, c, h, w, size[0], size[1], scale, shift)
     return out
 
 

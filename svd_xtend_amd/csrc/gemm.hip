@@ -316,6 +316,34 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
 // one owner, so no atomics either.  8-byte units of a row are XOR-swizzled with a 3-bit row id so the 32 lanes of
 // a half-wave hit 32 distinct bank pairs.
 // ================================================================================================================
+// ---- LDS-DMA that the compiler does not see (the TN kernels, round 5) ----------------------------------------------------------------------
+// hipcc (ROCm 7.2) orders every ds_read_b64_tr_b16 INTRINSIC behind all pending LDS-DMA with an `s_waitcnt vmcnt(0)` -- for the plain
+// ds_read_b128 of gemm_v4_kernel it proves the stage being read distinct from the stage being filled, for the intrinsic it has no alias
+// information -- so in every TN kernel of rounds 1-4 the next tile's loads and this tile's MFMAs ran strictly one after the other
+// (profiles/r5_tn_isa_waits.txt: the wait sits between the staging pieces and the first fragment read of every K-step; standalone counters:
+// waves parked 57-63 % of their cycles, MFMA busy 0.18 in the step).  Issued from an `asm` statement the DMA is invisible to that pass; the
+// kernels count their vmcnt themselves (they always did: counted waits + s_barrier).  No VGPR destination, so nothing for the register
+// allocator to mis-track (cdna_hip_programming.md 5.7); M0 -- the LDS base of the instruction -- is saved and restored inside the statement.
+typedef int desc4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ desc4 hidden_desc(const void* p, unsigned bytes) {      // raw buffer descriptor: base, stride 0, num_records, gfx950 flags
+    const unsigned long a = (unsigned long)p;
+    return desc4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+template <int SIZE>
+__device__ __forceinline__ void hidden_dma(desc4 d, char* lds, unsigned voff) {     // lane l: SIZE bytes from d.base + voff -> lds + l * SIZE (0 beyond num_records)
+    static_assert(SIZE == 16 || SIZE == 4, "dwordx4 or dword");
+    /*SIM-BEGIN*/
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds);
+    unsigned keep;
+    if (SIZE == 16)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(la), "v"(voff), "s"(d) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(la), "v"(voff), "s"(d) : "memory");
+    /*SIM-END sim_hidden_dma<SIZE>(d, lds, voff); */
+}
+
 __device__ __forceinline__ int tn_rid(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
 template <typename T>
@@ -363,7 +391,20 @@ __device__ __forceinline__ TnWho tn_who(const GemmParams& p) {
     return w;
 }
 
-template <typename T, int NSTG>
+// L2 prefetch (PF; round 5).  Counters of the kernel standalone (profiles/r5_stall_counters.txt): its waves sit PARKED at the staging wait
+// for 57-63 % of their cycles -- a K-step takes ~1.5 us where its MFMAs are 0.25 us per workgroup.  Both operands stream from HBM (the
+// reduction index is the long one: 560-35840 rows), the tiles of a row slice walk the rows in lockstep on one XCD, and the LDS ring holds
+// ONE tile ahead: every K-step waits a whole fabric round trip, and "bytes a CU ingests" is simply LDS-ring bytes in flight / that
+// latency.  The ring cannot grow (two workgroups per CU fill the LDS), the L2 can: every wave touches the 64 lines of its share of the
+// tile PF_DIST K-steps ahead with ONE 4-byte LDS-DMA into a dump slot (no VGPR destination: nothing for the compiler to mis-track), the
+// youngest entry of the in-order vmcnt queue, which the counted wait leaves in flight.  The staging DMA then hits the L2.
+constexpr int PF_DIST = 3;
+constexpr int PF_DUMP = 256;                              // bytes of LDS behind the stages that prefetches land in (never read)
+
+// BUF (round 5): the staging as buffer_load ... lds through two raw descriptors (operands below 2 GiB), issued by hidden_dma above: per-thread
+// byte offsets computed once, the row bound from num_records instead of a zero page (a column beyond the operand gets an offset beyond it), and
+// -- the point -- no compiler-inserted vmcnt(0) between the staging pieces and the fragment reads: loads and MFMAs overlap at last.
+template <typename T, int NSTG, bool PF = false, bool BUF = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
@@ -389,10 +430,34 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
     const T* zero = reinterpret_cast<const T*>(p.zero_page);
     const T* A = reinterpret_cast<const T*>(p.A);
     const T* B = reinterpret_cast<const T*>(p.B);
+    static_assert(!PF || BUF, "the L2 prefetch rides on the buffer descriptors");
+    // BUF: byte offsets of this thread's four pieces inside K-tile 0 (the K-tile adds kt * BK rows); a column beyond the operand gets an
+    // offset beyond num_records, so the piece reads zeros like a row beyond R does (the descriptor checks voffset, not soffset)
+    const desc4 rsA = hidden_desc(p.A, BUF ? (unsigned)p.a_bytes : 0u), rsB = hidden_desc(p.B, BUF ? (unsigned)p.b_bytes : 0u);
+    constexpr unsigned OOB = 0x7ffffff0u;
+    unsigned voa[4], vob[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 16 + ld_row;
+        const int lc = pc ^ (tn_rid(row) << 1);
+        const int ca = m0 + lc * 8, cb = n0 + lc * 8;
+        voa[i] = ca < p.M ? (unsigned)(row * p.lda + ca) * 2u : OOB;
+        vob[i] = cb < p.N ? (unsigned)(row * p.ldb + cb) * 2u : OOB;
+    }
     auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
         char* As = smem + stage * STAGE_BYTES;
         char* Bs = As + BM * BK * 2;
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        if (BUF) {
+            const unsigned ka = (unsigned)kt * (unsigned)(BK * 2) * (unsigned)p.lda, kb = (unsigned)kt * (unsigned)(BK * 2) * (unsigned)p.ldb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int base = (i * 256 + wave_u * 64) * 16;
+                hidden_dma<16>(rsA, As + base, voa[i] + ka);
+                hidden_dma<16>(rsB, Bs + base, vob[i] + kb);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = i * 16 + ld_row;
@@ -406,6 +471,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
                                              (__attribute__((address_space(3))) void*)(As + base), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb,
                                              (__attribute__((address_space(3))) void*)(Bs + base), 16, 0, 0);
+        }
+    };
+    // PF: wave w touches operand (w >> 1)'s rows (w & 1) * 32 + lane / 2, line lane & 1 (a tile row is 256 bytes = two lines) of K-tile kt
+    // (clamped to the slice's last tile: one piece per step whatever the position, so the wait's count is exact)
+    auto prefetch = [&](int kt) __attribute__((always_inline)) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned r = (unsigned)(min(kt, kt_end - 1) * BK + (wv & 1) * 32 + (lane >> 1));      // beyond R: out of the descriptor's range, no access
+        const int col = (lane & 1) * 64;
+        char* dump = smem + NSTG * STAGE_BYTES;
+        if (wv >> 1) {
+            const unsigned off = n0 + col < p.N ? (r * (unsigned)p.ldb + (unsigned)(n0 + col)) * 2u : OOB;
+            hidden_dma<4>(rsB, dump, off);
+        } else {
+            const unsigned off = m0 + col < p.M ? (r * (unsigned)p.lda + (unsigned)(m0 + col)) * 2u : OOB;
+            hidden_dma<4>(rsA, dump, off);
         }
     };
     f32x4 acc[4][4];
@@ -451,14 +531,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
     // the same stage ring as gemm_v4_kernel (see its K-loop banner): NSTG - 1 tiles staged ahead, counted vmcnt + raw s_barrier when
     // NSTG > 2.  Every wave issues 8 pieces (4 of A, 4 of B) per tile.
     static_assert(NSTG >= 2 && NSTG <= 4, "2 to 4 LDS stages");
+    static_assert(!PF || NSTG == 2, "the L2 prefetch is written for the two-stage ring");
     constexpr int LA = NSTG - 1;
     auto wait_tiles = [&](int t) __attribute__((always_inline)) {
-        if (NSTG == 2 || t <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");          // everything but the youngest piece: this step's prefetch
+        else if (NSTG == 2 || t <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (t == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     };
     auto stage_barrier = [&]() __attribute__((always_inline)) {
-        if (NSTG == 2) { __syncthreads(); return; }
+        if (NSTG == 2 && !PF) { __syncthreads(); return; }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -468,12 +550,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
 #pragma unroll
     for (int t = 0; t < LA; ++t)
         if (t < n_tiles) issue(kt_begin + t, t);
-    wait_tiles(min(LA, n_tiles) - 1);
+    if (PF) {
+        // the tiles the first steps will stage; younger than tile 0's pieces, so the wait below leaves them in flight
+#pragma unroll
+        for (int t = 1; t <= PF_DIST; ++t) prefetch(kt_begin + t);
+        if (PF_DIST == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        wait_tiles(min(LA, n_tiles) - 1);
+    }
     stage_barrier();
     {
         int cur = 0, nxt = LA, kt = 0;
         for (; kt + LA < n_tiles; ++kt) {
             issue(kt_begin + kt + LA, nxt);
+            if (PF) prefetch(kt_begin + kt + LA + PF_DIST);
             __builtin_amdgcn_sched_barrier(0);
             compute(cur);
             wait_tiles(LA - 1);
@@ -490,6 +581,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
             cur = cur + 1 == NSTG ? 0 : cur + 1;
         }
     }
+    if (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the last prefetch: its dump slot lies outside what the epilogue parks
     __syncthreads();
     if (do_cs && (lane & 15) == 0) {        // every column of the 16x16 result holds the sums: lanes 0/16/32/48 own rows 4*(lane>>4)..+3
 #pragma unroll
@@ -517,7 +609,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
 // transposed (acc = mfma(B_frag, A_frag)) so that a lane owns 4 consecutive output columns: results leave as 16-byte stores
 // straight from the registers.  Stage ring as in gemm_v4_kernel.
 // ----------------------------------------------------------------------------------------------------------------
-template <typename T, int PA, int PB, int NSTG>
+template <typename T, int PA, int PB, int NSTG, bool PF = false, bool BUF = false>
 __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
@@ -549,9 +641,43 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
     const T* A = reinterpret_cast<const T*>(p.A);
     const T* B = reinterpret_cast<const T*>(p.B);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    static_assert(!PF || BUF, "the L2 prefetch rides on the buffer descriptors");
+    // BUF: see gemm_tn_kernel -- buffer_load ... lds through descriptors; per-thread byte offsets of its pieces inside K-tile 0
+    const desc4 rsA = hidden_desc(p.A, BUF ? (unsigned)p.a_bytes : 0u), rsB = hidden_desc(p.B, BUF ? (unsigned)p.b_bytes : 0u);
+    constexpr unsigned OOB = 0x7ffffff0u;
+    unsigned voa[2][PA], vob[2][PB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = i * 32 + ld_row;
+        const int lc = pc ^ (tn_rid(row) << 1);
+#pragma unroll
+        for (int pa = 0; pa < PA; ++pa) {
+            const int ca = m0 + pa * 128 + lc * 8;
+            voa[i][pa] = ca < p.M ? (unsigned)(row * p.lda + ca) * 2u : OOB;
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const int cb = n0 + pb * 128 + lc * 8;
+            vob[i][pb] = cb < p.N ? (unsigned)(row * p.ldb + cb) * 2u : OOB;
+        }
+    }
     auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
         char* As = smem + stage * STAGE;
         char* Bs = As + PA * PANEL;
+        if (BUF) {
+            const unsigned ka = (unsigned)kt * (unsigned)(BK * 2) * (unsigned)p.lda, kb = (unsigned)kt * (unsigned)(BK * 2) * (unsigned)p.ldb;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int base = (i * NT + wave_u * 64) * 16;
+#pragma unroll
+                for (int pa = 0; pa < PA; ++pa)
+                    hidden_dma<16>(rsA, As + pa * PANEL + base, voa[i][pa] + ka);
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb)
+                    hidden_dma<16>(rsB, Bs + pb * PANEL + base, vob[i][pb] + kb);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = i * 32 + ld_row;
@@ -614,13 +740,29 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
         }
     };
     static_assert(NSTG >= 2 && NSTG <= 3, "2 or 3 LDS stages");
+    static_assert(!PF || (NSTG == 2 && PA == 2 && PB == 2), "the L2 prefetch is written for the two-stage 256 x 256 tile");
     constexpr int LA = NSTG - 1;
+    // PF (see gemm_tn_kernel): an operand tile row is 512 bytes = four lines; wave w touches operand (w >> 2)'s rows (w & 3) * 16 + lane / 4,
+    // line lane & 3 of K-tile kt
+    auto prefetch = [&](int kt) __attribute__((always_inline)) {
+        const unsigned r = (unsigned)(min(kt, kt_end - 1) * BK + (wave_u & 3) * 16 + (lane >> 2));
+        const int col = (lane & 3) * 64;
+        char* dump = smem + NSTG * STAGE;
+        if (wave_u >> 2) {
+            const unsigned off = n0 + col < p.N ? (r * (unsigned)p.ldb + (unsigned)(n0 + col)) * 2u : OOB;
+            hidden_dma<4>(rsB, dump, off);
+        } else {
+            const unsigned off = m0 + col < p.M ? (r * (unsigned)p.lda + (unsigned)(m0 + col)) * 2u : OOB;
+            hidden_dma<4>(rsA, dump, off);
+        }
+    };
     auto wait_tiles = [&](int t) __attribute__((always_inline)) {
-        if (NSTG == 2 || t <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");          // everything but the youngest piece: this step's prefetch
+        else if (NSTG == 2 || t <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
     };
     auto stage_barrier = [&]() __attribute__((always_inline)) {
-        if (NSTG == 2) { __syncthreads(); return; }
+        if (NSTG == 2 && !PF) { __syncthreads(); return; }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -630,12 +772,20 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
 #pragma unroll
     for (int t = 0; t < LA; ++t)
         if (t < n_tiles) issue(kt_begin + t, t);
-    wait_tiles(min(LA, n_tiles) - 1);
+    if (PF) {
+#pragma unroll
+        for (int t = 1; t <= PF_DIST; ++t) prefetch(kt_begin + t);
+        if (PF_DIST == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        wait_tiles(min(LA, n_tiles) - 1);
+    }
     stage_barrier();
     {
         int cur = 0, nxt = LA, kt = 0;
         for (; kt + LA < n_tiles; ++kt) {
             issue(kt_begin + kt + LA, nxt);
+            if (PF) prefetch(kt_begin + kt + LA + PF_DIST);
             __builtin_amdgcn_sched_barrier(0);
             compute(cur);
             wait_tiles(LA - 1);
@@ -652,6 +802,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
             cur = cur + 1 == NSTG ? 0 : cur + 1;
         }
     }
+    if (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (do_cs && fr == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1608,33 +1759,33 @@ static long tn_arrange(GemmParams& p) {
     return 8L * p.sub_m * p.sub_n;
 }
 
-template <typename T, int NSTG>
+template <typename T, int NSTG, bool PF = false, bool BUF = false>
 int launch_gemm_tn(GemmParams p, hipStream_t st) {
+    constexpr int LDS = NSTG * STAGE_BYTES + (PF ? PF_DUMP : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  NSTG * STAGE_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T, NSTG, PF, BUF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     dim3 grid((unsigned)tn_arrange(p));
-    hipLaunchKernelGGL((gemm_tn_kernel<T, NSTG>), grid, dim3(NTHREADS), NSTG * STAGE_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_tn_kernel<T, NSTG, PF, BUF>), grid, dim3(NTHREADS), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm_tn");
     return 0;
 }
 
-template <typename T, int PA, int PB, int NSTG>
+template <typename T, int PA, int PB, int NSTG, bool PF = false, bool BUF = false>
 int launch_gemm_tn8(GemmParams p, hipStream_t st) {
-    constexpr int LDS = NSTG * (PA + PB) * 64 * 256;
+    constexpr int LDS = NSTG * (PA + PB) * 64 * 256 + (PF ? PF_DUMP : 0);
     static_assert(LDS <= 160 * 1024, "stages must fit the 160 KiB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn8_kernel<T, PA, PB, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn8_kernel<T, PA, PB, NSTG, PF, BUF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     p.tiles_m = cdiv(p.M, 128 * PA);
     p.tiles_n = cdiv(p.N, 128 * PB);
     dim3 grid((unsigned)tn_arrange(p));
-    hipLaunchKernelGGL((gemm_tn8_kernel<T, PA, PB, NSTG>), grid, dim3(512), LDS, st, p);
+    hipLaunchKernelGGL((gemm_tn8_kernel<T, PA, PB, NSTG, PF, BUF>), grid, dim3(512), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm_tn");
     return 0;
 }
@@ -1644,8 +1795,14 @@ int launch_gemm_tn8(GemmParams p, hipStream_t st) {
 extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
                             float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, int dtype, void* stream) {
     SVDX_CHECK_ARG(A && B && C && zero_page && R > 0 && N > 0 && K > 0, "svdx_gemm_tn: bad args");
+    // operands below 2 GiB are staged through buffer descriptors (always, unless SVDX_TN_FLAT asks for rounds 1-4's flat staging for an A/B)
+    const long a_span = ((long)(R - 1) * lda + N) * 2, b_span = ((long)(R - 1) * ldb + K) * 2;
+    const bool buf = a_span < (1L << 31) && b_span < (1L << 31) && !(stages & SVDX_TN_FLAT);
+    const bool pf = (stages & SVDX_TN_PREFETCH) != 0 && buf;
+    stages &= ~(SVDX_TN_PREFETCH | SVDX_TN_FLAT);
     SVDX_CHECK_ARG(stages == 0 || (stages >= 2 && stages <= 4) || stages == 18,
                    "svdx_gemm_tn: stages=%d (0 = default, 2..4 stages of the 128x128 tile, 18 = the 256x256 eight-wave tile)", stages);
+    SVDX_CHECK_ARG(!(pf && (stages == 3 || stages == 4)), "svdx_gemm_tn: SVDX_TN_PREFETCH goes with the two-stage tiles (stages 0 / 2 / 18)");
     // the unsplit / ADD modes read-modify-write a_colsum from every z slice: one slice only (SVDX_OUT_F32_SLAB keeps a row per slice)
     SVDX_CHECK_ARG(!a_colsum || split_k == 1 || out_mode == SVDX_OUT_F32_SLAB, "svdx_gemm_tn: a_colsum with split_k > 1 needs slab output");
     SVDX_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
@@ -1660,16 +1817,18 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
     p.A = A; p.B = B; p.C = C; p.M = N; p.N = K; p.K = R; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = nullptr; p.rowvec = nullptr; p.rv_ld = 0; p.rv_rpg = 0; p.rv_mod = 0; p.res = nullptr; p.ldres = 0;
     p.g = svdx_gather{}; p.zero_page = zero_page; p.out_mode = out_mode; p.alpha = 1.f; p.split_k = split_k;
-    p.epi = 0; p.aux_in = nullptr; p.aux_out = nullptr; p.aux_dim = 0; p.a_bytes = 0; p.b_bytes = 0; p.a_colsum = a_colsum;
+    p.epi = 0; p.aux_in = nullptr; p.aux_out = nullptr; p.aux_dim = 0; p.a_colsum = a_colsum;
+    p.a_bytes = buf ? (int)a_span : 0; p.b_bytes = buf ? (int)b_span : 0;
     p.gn_stats = nullptr; p.gn_rows = p.gn_cg = 0; p.gn_m0 = p.gn_m1 = 0.f;
     p.tiles_m = cdiv(N, BM); p.tiles_n = cdiv(K, BN);
     p.vec_ok = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) && (K % 8 == 0);
     p.slab_stride = (long)N * ldc;
     DISPATCH_DTYPE(dtype, {
-        if (stages == 18) return launch_gemm_tn8<T, 2, 2, 2>(p, (hipStream_t)stream);
-        if (stages == 3) return launch_gemm_tn<T, 3>(p, (hipStream_t)stream);
-        if (stages == 4) return launch_gemm_tn<T, 4>(p, (hipStream_t)stream);
-        return launch_gemm_tn<T, 2>(p, (hipStream_t)stream);
+        hipStream_t st = (hipStream_t)stream;
+        if (stages == 18) return pf ? launch_gemm_tn8<T, 2, 2, 2, true, true>(p, st) : buf ? launch_gemm_tn8<T, 2, 2, 2, false, true>(p, st) : launch_gemm_tn8<T, 2, 2, 2>(p, st);
+        if (stages == 3) return buf ? launch_gemm_tn<T, 3, false, true>(p, st) : launch_gemm_tn<T, 3>(p, st);
+        if (stages == 4) return buf ? launch_gemm_tn<T, 4, false, true>(p, st) : launch_gemm_tn<T, 4>(p, st);
+        return pf ? launch_gemm_tn<T, 2, true, true>(p, st) : buf ? launch_gemm_tn<T, 2, false, true>(p, st) : launch_gemm_tn<T, 2>(p, st);
     });
 }
 

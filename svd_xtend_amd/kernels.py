@@ -145,6 +145,8 @@ _SIGS = {
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "l": ctypes.c_int64, "z": ctypes.c_size_t}
 
 EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_wall_clock_khz", "svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band", "svdx_ln_bwd_blocks")
+TN_FLAT = 64                   # include/svdx.h SVDX_TN_FLAT (developer knob: rounds 1-4's staging)
+TN_PREFETCH = 32               # include/svdx.h SVDX_TN_PREFETCH: flag of svdx_gemm_tn's `stages`
 MAX_PEERS = 16                 # include/svdx.h SVDX_MAX_PEERS: ranks of svdx_allreduce_grads
 BATCH_MAX_JOBS = 48            # include/svdx.h SVDX_BATCH_MAX_JOBS: jobs of a *_batch entry that share one launch
 TSA_MAX_C, TSA_MAX_T, TSA_BAND_ROWS = 320, 16, 144

@@ -19,26 +19,19 @@ Everything random (noise, sigmas, dropout mask) is drawn on the device from one 
 validation sampler); `bench.py` times it as `real_loop` beside the UNet-only headline."""
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional
 
 import torch
 
 from .clip import encode_image
 from .train import GraphedStep, Trainer, conditioning_dropout, edm_prepare
-from .vae import tensor_to_vae_latent
 
 BATCH_KEYS = ("unet_in", "timesteps", "ehs", "added_time_ids", "noisy_latents", "target", "sigmas")
 
 
-def rand_log_normal(shape, loc: float, scale: float, generator: torch.Generator, device) -> torch.Tensor:
-    """train_svd.py:63-66 on the device: exp(Normal(loc, scale).icdf(u)), u ~ U(1e-7, 1 - 1e-7)."""
-    u = torch.rand(shape, generator=generator, device=device, dtype=torch.float32) * (1 - 2e-7) + 1e-7
-    return (loc + scale * (2.0 ** 0.5) * torch.erfinv(2.0 * u - 1.0)).exp()
-
-
 class TrainLoop:
     def __init__(self, trainer: Trainer, vae, image_encoder, conditioning_dropout_prob: Optional[float] = None, seed: int = 0,
-                 use_graph: bool = True, ema=None, fps: int = 7, motion_bucket_id: int = 127):
+                 use_graph: bool = True, ema=None, fps: int = 7, motion_bucket_id: int = 127, graph_conditioners: bool = True):
         self.tr, self.vae, self.enc = trainer, vae, image_encoder
         self.p_drop = conditioning_dropout_prob
         self.use_graph = use_graph and trainer.dev.type == "cuda"
@@ -46,60 +39,113 @@ class TrainLoop:
         self.fps, self.bucket = fps, motion_bucket_id
         self.dev = trainer.dev
         self.gen = torch.Generator(device=self.dev).manual_seed(seed)
-        self.batches: Optional[List[Dict[str, torch.Tensor]]] = None      # the tensors the captured step reads
-        self.staged: Optional[List[Dict[str, torch.Tensor]]] = None       # the next step's batch, produced while this one runs
+        self.batches: Optional[List[Dict[str, torch.Tensor]]] = None      # the tensors the (captured) step reads
         self.graphed: Optional[GraphedStep] = None
+        self.graph_conditioners = graph_conditioners and self.use_graph
+        self.cond_graph = None
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.global_step = 0
 
     # ---- conditioners + EDM data prep of one micro-batch, all on the device (train_svd.py:942-1017) ----------------------------
+    def _draw_shapes(self, bsz: int, T: int, H: int, W: int) -> Dict[str, tuple]:
+        down = 2 ** (len(self.vae.config.block_out_channels) - 1)
+        zc, h, w = self.vae.config.latent_channels, H // down, W // down
+        return dict(u_cond=(bsz,), n_cpix=(bsz, 1, 3, H, W), eps=(bsz, T + 1, zc, h, w), noise=(bsz, T, zc, h, w), u_sig=(bsz,), p_drop=(bsz,))
+
+    def _draw(self, bsz: int, T: int, H: int, W: int, into: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """Every random number of one micro-batch, in a fixed order from the loop's generator (eager launches: the arithmetic that consumes
+        them may then be replayed from a hipGraph without the generator being part of the capture)."""
+        shapes = self._draw_shapes(bsz, T, H, W)
+        out = into if into is not None else {k: torch.empty(v, dtype=torch.float32, device=self.dev) for k, v in shapes.items()}
+        for k in ("u_cond", "u_sig", "p_drop"):
+            torch.rand(shapes[k], generator=self.gen, out=out[k])
+        for k in ("n_cpix", "eps", "noise"):
+            torch.randn(shapes[k], generator=self.gen, out=out[k])
+        return out
+
     @torch.no_grad()
-    def prepare_batch(self, pixel_values: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """pixel_values [B, T, 3, H, W] in [-1, 1] (host or device) -> the step's inputs on the device."""
-        dev, g = self.dev, self.gen
-        pix = pixel_values.to(dev, non_blocking=True).to(torch.float32)
+    def _compute(self, pix: torch.Tensor, d: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """pix [B, T, 3, H, W] float in [-1, 1] on the device + the draws -> the step's inputs.  No host<->device traffic, no generator: capturable."""
         bsz, T = pix.shape[:2]
-        cond_sigmas = rand_log_normal([bsz], -3.0, 0.5, g, dev)                                   # :954
+        log_normal = lambda u, loc, scale: (loc + scale * (2.0 ** 0.5) * torch.erfinv(2.0 * (u * (1 - 2e-7) + 1e-7) - 1.0)).exp()   # noqa: E731  (:63-66)
+        cond_sigmas = log_normal(d["u_cond"], -3.0, 0.5)                                          # :954
         noise_aug_strength = cond_sigmas[0]                                                       # :955 (the reference's batch-1 TODO)
-        cpix = pix[:, 0:1]
-        cpix = torch.randn(cpix.shape, generator=g, device=dev) * cond_sigmas[:, None, None, None, None] + cpix      # :957-958
+        cpix = d["n_cpix"] * cond_sigmas[:, None, None, None, None] + pix[:, 0:1]                 # :957-958
         # one encoder pass over the clip's T frames and the noise-augmented first frame (:948 and :959 are two calls there)
-        z = tensor_to_vae_latent(torch.cat([pix, cpix], dim=1), self.vae, generator=g)
+        frames = torch.cat([pix, cpix], dim=1)
+        dist_ = self.vae.encode(frames.reshape(bsz * (T + 1), *frames.shape[2:])).latent_dist    # tensor_to_vae_latent, :283-291
+        z = (dist_.mean + dist_.std * d["eps"].reshape(dist_.mean.shape)).reshape(bsz, T + 1, *dist_.mean.shape[1:]) * self.vae.config.scaling_factor
         latents = z[:, :T]
         conditional_latents = z[:, T] / self.vae.config.scaling_factor                            # :959-960
-        noise = torch.randn(latents.shape, generator=g, device=dev, dtype=latents.dtype)          # :951
-        sigmas = rand_log_normal([bsz], 0.7, 1.6, g, dev)                                         # :964
+        sigmas = log_normal(d["u_sig"], 0.7, 1.6)                                                 # :964
         ehs = encode_image(pix[:, 0], self.enc).to(torch.float32)                                 # :975-976
         ids = torch.stack([torch.full_like(noise_aug_strength, float(self.fps)), torch.full_like(noise_aug_strength, float(self.bucket)),
                            noise_aug_strength]).unsqueeze(0).repeat(bsz, 1)                       # :981-988 (fps passed as 7 there)
         if self.p_drop is not None:                                                               # :992-1011
-            random_p = torch.rand(bsz, generator=g, device=dev)
-            ehs, conditional_latents = conditioning_dropout(random_p, ehs, conditional_latents, self.p_drop)
+            ehs, conditional_latents = conditioning_dropout(d["p_drop"], ehs, conditional_latents, self.p_drop)
         else:
             ehs = ehs.unsqueeze(1)
-        unet_in, timesteps, noisy = edm_prepare(latents, noise, conditional_latents, sigmas)      # :966-972, :1014-1017
+        unet_in, timesteps, noisy = edm_prepare(latents, d["noise"], conditional_latents, sigmas)  # :966-972, :1014-1017
         return dict(unet_in=unet_in.contiguous(), timesteps=timesteps, ehs=ehs.contiguous(), added_time_ids=ids.contiguous(),
                     noisy_latents=noisy.contiguous(), target=latents.contiguous(), sigmas=sigmas)
 
-    def _prepare_all(self, clips: Sequence[torch.Tensor]) -> List[Dict[str, torch.Tensor]]:
-        if len(clips) != self.tr.grad_accum:
-            raise ValueError(f"expected {self.tr.grad_accum} clip(s) per optimizer step, got {len(clips)}")
-        return [self.prepare_batch(c) for c in clips]
+    @torch.no_grad()
+    def prepare_batch(self, pixel_values: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """pixel_values [B, T, 3, H, W] in [-1, 1] (host or device) -> the step's inputs on the device (eager launches)."""
+        pix = pixel_values.to(self.dev, non_blocking=True).to(torch.float32)
+        return self._compute(pix, self._draw(pix.shape[0], pix.shape[1], pix.shape[3], pix.shape[4]))
 
+    def _capture_conditioners(self, like: torch.Tensor) -> None:
+        """The conditioners of one micro-batch as ONE hipGraph over static inputs (pixels, draws) and outputs: ~600 eager launches of
+        5-10 us of host time each become one replay (the eager form is host-bound once the UNet step itself comes from a graph)."""
+        self._pix = torch.empty(like.shape, dtype=torch.float32, device=self.dev)
+        # static draw buffers: filled per clip by _draw(into=...); zeros for the warm-up and the capture (the generator is not touched here,
+        # so the captured and the eager loop consume the same random sequence)
+        self._draws = {k: torch.zeros(v, dtype=torch.float32, device=self.dev)
+                       for k, v in self._draw_shapes(like.shape[0], like.shape[1], like.shape[3], like.shape[4]).items()}
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._pix.copy_(like.to(self.dev, non_blocking=True))
+            self._compute(self._pix, self._draws)              # warm-up on the capture stream
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                self._cond_out = self._compute(self._pix, self._draws)
+        torch.cuda.current_stream().wait_stream(s)
+        self.cond_graph = g
+
+    def _produce(self, j: int, clip: torch.Tensor) -> None:
+        """Micro-batch j of the NEXT step: conditioners on `clip`, result written into the tensors the captured step reads (in stream
+        order this runs after the last backward sweep that read them)."""
+        if self.cond_graph is not None:
+            self._pix.copy_(clip.to(self.dev, non_blocking=True))
+            self._draw(clip.shape[0], clip.shape[1], clip.shape[3], clip.shape[4], into=self._draws)
+            self.cond_graph.replay()
+            src = self._cond_out
+        else:
+            src = self.prepare_batch(clip)
+        for k in BATCH_KEYS:
+            self.batches[j][k].copy_(src[k])
+
+    # ---- the pipeline ----------------------------------------------------------------------------------------------------------
     @staticmethod
     def _as_list(clips) -> List[torch.Tensor]:
         return [clips] if isinstance(clips, torch.Tensor) else list(clips)
 
-    # ---- the pipeline ----------------------------------------------------------------------------------------------------------
     def start(self, clips) -> None:
-        """First clip(s) of the run: conditioners, then capture of the step on the tensors they produced."""
-        self.batches = self._prepare_all(self._as_list(clips))
-        self.staged = None
+        """First clip(s) of the run: conditioners (eager), then capture of the step on the tensors they produced and of the conditioners."""
+        clips = self._as_list(clips)
+        if len(clips) != self.tr.grad_accum:
+            raise ValueError(f"expected {self.tr.grad_accum} clip(s) per optimizer step, got {len(clips)}")
+        self.batches = [self.prepare_batch(c) for c in clips]
         if self.use_graph:
             # GraphedStep's warm-up pass is one real optimizer step on this batch; the loop counts it as step 1 (see step())
             self.graphed = GraphedStep(self.tr, self.batches)
             self._after_step()
             self._warm = True
+            if self.graph_conditioners:
+                self._capture_conditioners(clips[0])
         else:
             self._warm = False
 
@@ -115,9 +161,13 @@ class TrainLoop:
         if self.batches is None:
             raise RuntimeError("TrainLoop.start(first_clips) first")
         nxt = self._as_list(next_clips) if next_clips is not None else None
+        if nxt is not None and len(nxt) != self.tr.grad_accum:
+            raise ValueError(f"expected {self.tr.grad_accum} clip(s) per optimizer step, got {len(nxt)}")
 
         def side():
-            self.staged = self._prepare_all(nxt) if nxt is not None else None
+            if nxt is not None:
+                for j, c in enumerate(nxt):
+                    self._produce(j, c)
 
         if self._warm:                                   # the capture's warm-up pass already was this step
             self._warm = False
@@ -128,9 +178,4 @@ class TrainLoop:
             else:
                 self.tr.step(self.batches if self.tr.grad_accum > 1 else self.batches[0], side_work=side)
             self._after_step()
-        if self.staged is not None:                      # hand the next batch to the captured tensors (in stream order: after the step)
-            for dst, src in zip(self.batches, self.staged):
-                for k in BATCH_KEYS:
-                    dst[k].copy_(src[k])
-            self.staged = None
         return float(self._loss)                         # the iteration's one host synchronisation (train_svd.py:1039-1041)

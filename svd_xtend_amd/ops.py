@@ -106,6 +106,11 @@ class Runtime:
         # the reducing launches of the row-sliced weight-gradient GEMMs wait for one table-driven launch at the end of the sweep (or of
         # the transformer block, with gradient buckets); SVDX_DEFER_GRAD_FINALIZE=0: developer knob for A/B runs
         self.defer_grad_finalize = os.environ.get("SVDX_DEFER_GRAD_FINALIZE", "1") != "0"
+        # weight-gradient GEMMs may touch their operand tiles three K-steps ahead (svdx_gemm_tn: stages | SVDX_TN_PREFETCH).  Built against the
+        # one-tile-ahead staging of a two-stage ring; measured in the step it COSTS 0.69 ms (profiles/r5_ab_tn.txt: it doubles the L2 request
+        # count of a kernel whose tiles already share their lines), so it is off; SVDX_TN_PREFETCH=1: A/B knob
+        self.tn_prefetch = os.environ.get("SVDX_TN_PREFETCH", "0") == "1"
+        self.tn_flat = os.environ.get("SVDX_TN_FLAT", "0") == "1"        # A/B knob: rounds 1-4's flat staging (compiler-serialised loads / MFMAs)
         self.fin_queue_budget = 768 << 20      # bytes of float slabs the queue may keep alive before it flushes (c2: ~3 flushes per sweep)
         # GroupNorm statistics of a tensor come from the store loop of the GEMM that writes it (svdx_gemm_gn) instead of a pass of their
         # own over it; SVDX_FUSE_GN_STATS=0: developer knob for A/B runs
@@ -642,7 +647,9 @@ class LinearOp:
 
 # Round 4 timed eight-wave 128 x 256 / 128 x 384 / 256 x 128 weight-gradient tiles (two and three stages) inside the step: the four-wave
 # 128 x 128 tile with two workgroups per CU won every problem by 5-40 % (profiles/r4_dropped_experiments.txt, item 2); they were removed again.
-STAGED_TN_TILES = {}
+# Round 5: with the staging hidden from the compiler's wait pass (csrc/gemm.hip hidden_dma) loads and MFMAs overlap for the first time, so the
+# deeper rings of the 128 x 128 tile (stages 3 / 4: one workgroup per CU, 2 / 3 tiles in flight) are offered to the in-situ tuner again.
+STAGED_TN_TILES = {3: (128, 128), 4: (128, 128)}
 
 
 @functools.lru_cache(maxsize=None)
@@ -687,6 +694,10 @@ def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tenso
 
     def run(cfg):
         sk, stages = cfg if isinstance(cfg, tuple) else (cfg, 0)
+        if rt.tn_prefetch and stages in (0, 2, 18):
+            stages |= K.TN_PREFETCH                # L2 prefetch three K-steps ahead (csrc/gemm.hip gemm_tn_kernel<..., PF>)
+        if rt.tn_flat:
+            stages = (stages & ~K.TN_PREFETCH) | K.TN_FLAT
         # the bias gradient (column sums of dy) rides on the same launch
         if sk == 1:
             k.gemm_tn(dy, x, dst, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32 if store else K.OUT_F32_ADD, a_colsum=a_colsum, stages=stages)

@@ -31,6 +31,7 @@ SUBS = [
     (re.compile(r'asm volatile\("s_waitcnt lgkmcnt\((\d+)\)"\s*:::\s*"memory"\)'), r"sim_waitcnt_lgkm(\1)"),
     (re.compile(r'asm volatile\("buffer_store_dwordx4 %0, %1, %2, %3 offen\\n\\ts_nop 1"\s*::\s*"v"\((\w+)\),\s*"v"\((\w+)\),\s*"s"\((\w+)\),\s*"s"\((\w+)\)\s*:\s*"memory"\)'),
      r"sim_buffer_store(&\1, 16, \3, \2, \4)"),
+    (re.compile(r"/\*SIM-BEGIN\*/.*?/\*SIM-END (.*?)\*/", re.S), r"\1"),          # a region the simulator models as one call (hidden_dma)
     (re.compile(r"extern __shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];"), r"\1* \2 = reinterpret_cast<\1*>(sim_dyn_lds());"),
     (re.compile(r"__builtin_amdgcn_"), "sim_amdgcn_"),
     (re.compile(r'#include "\.\./\.\./include/svdx\.h"'), f'#include "{os.path.join(ROOT, "include", "svdx.h")}"'),

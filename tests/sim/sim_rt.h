@@ -191,6 +191,12 @@ const char* sim_buffer_addr(const SimRsrc& rs, int voffset, int soffset, int imm
 template <typename P> inline void sim_amdgcn_raw_ptr_buffer_load_lds(SimRsrc rs, P lds, int size, int voffset, int soffset, int imm, int) {
     sim_dma((char*)lds + sim_lane->lane * size + imm, sim_buffer_addr(rs, voffset, soffset, imm, size), size);
 }
+// csrc/gemm.hip hidden_dma: buffer_load_dword[x4] ... lds issued from an asm statement, with a hand-built raw descriptor {base lo, base hi16, num_records, flags}
+typedef int sim_desc4 __attribute__((ext_vector_type(4)));
+template <int SIZE> inline void sim_hidden_dma(sim_desc4 d, char* lds, unsigned voff) {
+    char* base = (char*)(((uint64_t)(uint32_t)d[0]) | ((uint64_t)((uint32_t)d[1] & 0xffffu) << 32));
+    sim_amdgcn_raw_ptr_buffer_load_lds(SimRsrc{base, (uint32_t)d[2]}, lds, SIZE, (int)voff, 0, 0, 0);
+}
 template <typename G, typename P> inline void sim_amdgcn_global_load_lds(G gptr, P lds, int size, int imm, int) {
     sim_dma((char*)lds + sim_lane->lane * size + imm, (const char*)gptr + imm, size);
 }
