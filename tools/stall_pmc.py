@@ -29,13 +29,16 @@ def cases(K):
     def rnd(*shape, scale=1.0):
         return (torch.randn(*shape, device=dev) * scale).to(dt)
 
-    def nt(name, M, N, Kd, variant, gather=None, a_rows=None, lda=None, epi=0):
+    def nt(name, M, N, Kd, variant, gather=None, a_rows=None, lda=None, epi=0, res=False):
         As = [rnd(a_rows or M, lda or Kd) for _ in range(4)]
         B = rnd(N, Kd, scale=Kd ** -0.5)
         Cs = [torch.zeros(M, N, device=dev, dtype=dt) for _ in range(4)]
         aux = [torch.zeros(M, N // 2, device=dev, dtype=dt) for _ in range(4)] if epi == 1 else None
+        Rs = [rnd(M, N) for _ in range(4)] if res else None
         def run(be, i):
             kw = dict(gather=gather, variant=variant)
+            if res:
+                kw.update(res=Rs[(i + 1) % 4], ldres=N)
             if epi == 1:
                 kw.update(epilogue=K.EPI_GEGLU_FWD, aux_out=aux[i % 4], aux_dim=N // 2)
             be.gemm(As[i % 4], B, Cs[i % 4], M, N, Kd, lda or Kd, Kd, N, **kw)
@@ -64,6 +67,9 @@ def cases(K):
     geglu_bwd("nt geglu bwd L0 35840x1280x320 v26", 35840, 1280, 320, 26)
     nt("nt linear L0 35840x320x1280 v6", 35840, 320, 1280, 6)
     nt("nt linear L2 2240x1280x1280 v24", 2240, 1280, 1280, 24)
+    nt("nt linear+res L0 35840x320x1280 v6", 35840, 320, 1280, 6, res=True)
+    nt("nt linear+res L1 8960x640x2560 v22", 8960, 640, 2560, 22, res=True)
+    nt("nt linear+res L2 2240x1280x5120 v24", 2240, 1280, 5120, 24, res=True)
     nt("nt linear L1 8960x640x5120 v22", 8960, 640, 5120, 22)
     tn("tn L0 2560x320 over 35840 sk8 128x128", 35840, 2560, 320, 8, 0)
     tn("tn L0 320x1280 over 35840 sk16 128x128", 35840, 320, 1280, 16, 0)
@@ -87,6 +93,25 @@ def run():
         marks.append((name, fl))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(marks, open(os.path.join(ROOT, "gpurun_out", "stall_cases.json"), "w"))
+
+
+def timeit():
+    """python tools/stall_pmc.py time: us per launch of every case (HIP events around 40 launches, buffers rotating), no profiler"""
+    import torch
+    from svd_xtend_amd import kernels as K
+    be = K.backend()
+    for name, (fn, fl) in cases(K).items():
+        for i in range(6):
+            fn(be, i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(40):
+            fn(be, i)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 40 * 1e3
+        print(f"{name:48s} {us:8.1f} us  {fl / us / 1e6:7.0f} TFLOP/s", flush=True)
 
 
 def report(dirs):
@@ -143,5 +168,7 @@ def report(dirs):
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run()
+    elif sys.argv[1] == "time":
+        timeit()
     else:
         report(sys.argv[2:])
