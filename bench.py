@@ -59,8 +59,13 @@ class ClockSampler:
             cand = f"/sys/bus/pci/devices/{addr}/pp_dpm_sclk"
             self.node = cand if os.path.exists(cand) else None
             self.pci = addr
+            # the DRM card / render node of THIS device (an outside sampler that reads /sys/class/drm/card0 may be looking at another
+            # tenant's GPU: the record names the card it should read)
+            drm = glob.glob(f"/sys/bus/pci/devices/{addr}/drm/card*") + glob.glob(f"/sys/bus/pci/devices/{addr}/drm/renderD*")
+            self.drm = sorted(os.path.basename(d) for d in drm) or None
         except Exception:  # noqa: BLE001
             self.pci = None
+        self.drm = getattr(self, "drm", None)
         self.pnode = None
         if self.node:
             hw = glob.glob(os.path.join(os.path.dirname(self.node), "hwmon", "hwmon*", "power1_average")) + \
@@ -114,7 +119,7 @@ class ClockSampler:
             return None
         v = sorted(self.samples)
         out = {"sclk_mhz_median": v[len(v) // 2], "sclk_mhz_min": v[0], "sclk_mhz_max": v[-1], "samples": len(v), "source": self.source,
-               "pci": self.pci, "max_sclk_mhz": 2400}
+               "pci": self.pci, "drm_nodes": self.drm, "max_sclk_mhz": 2400}
         if self.power:
             w = sorted(self.power)
             out["power_w_median"] = w[len(w) // 2]

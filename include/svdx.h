@@ -62,7 +62,7 @@ typedef struct svdx_gather {
 
 /* ABI revision of this header: bumped whenever an entry changes its argument list or meaning (100 = rounds 1-3; 400 = round 4).
  * svdx_version() returns the value the library was built with; the ctypes binding refuses a library whose number differs. */
-#define SVDX_VERSION 500
+#define SVDX_VERSION 501
 int         svdx_version(void);
 int         svdx_last_error(char* buf, size_t n);
 /* 1 when the binary was built for gfx950 and a device is usable */
@@ -123,15 +123,17 @@ int svdx_gemm_dual(const void* A, const void* B, void* C, int M, int N, int K, i
  * slab mode.  stages selects the kernel: 0 / 2 = four waves, 128 x 128 output tiles, two LDS stages (two workgroups per CU, drained
  * every K-step); 3 / 4 = the same tile with 2 / 3 row tiles in flight across the barrier (one workgroup per CU); 18 = eight waves,
  * 256 x 256 output tiles, one workgroup per CU (outputs of >= 1024 x 512 that 180-256 such tiles x row slices cover).
- * stages | SVDX_TN_PREFETCH (with 0 / 2 / 18): every wave also touches its share of the operand tiles three K-steps ahead (one 4-byte
- * LDS-DMA per wave and step, left in flight by the counted wait): both operands of a weight gradient stream from HBM and the LDS ring
- * holds one tile ahead, so without it every K-step waits a fabric round trip (profiles/r5_stall_counters.txt).  Same results, bit for bit. */
+ * stages | SVDX_TN_PREFETCH (with 0 / 2 / 18; developer knob): every wave also touches its share of the operand tiles three K-steps
+ * ahead (one 4-byte LDS-DMA per wave and step, left in flight by the counted wait).  Same results bit for bit; measured 0.69 ms/step
+ * SLOWER in the step (profiles/r5_ab_tn.txt), so the host does not set it. */
 #define SVDX_TN_PREFETCH 32
 /* stages | SVDX_TN_FLAT: developer knob -- the flat global_load_lds staging of rounds 1-4 (what operands of 2 GiB and more still get)
  * instead of buffer descriptors, for A/B runs: behind it the compiler serialises loads and MFMAs (csrc/gemm.hip gemm_tn_kernel). */
 #define SVDX_TN_FLAT 64
+/* found_inf (may be NULL; SVDX_OUT_F32 / SVDX_OUT_F32_ADD only): *found_inf = 1.0f when a value this launch leaves in C is not finite --
+ * GradScaler's inf check (accelerate fp16; train_svd.py:1047) done where the gradient is written; pass &opt_state[3]. */
 int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
-                 float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, int dtype, void* stream);
+                 float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, float* found_inf, int dtype, void* stream);
 
 /* Epilogue of a split-K GEMM run with SVDX_OUT_F32_SLAB: v = sum_z acc[z*slab_stride + m*N + n] + bias + rowvec + res (same operand
  * meaning as svdx_gemm); c_is_f32_accumulate: 0 -> C[m*ldc+n] = (dtype)v, 1 -> ((float*)C)[m*ldc+n] += v, 2 -> ((float*)C)[m*ldc+n] = v
@@ -194,6 +196,7 @@ typedef struct svdx_gradfin_job {
     int nsplit, colsum_n;
     int store;                  /* 1: dst = sum (a gradient written once per step), 0: dst += sum */
     int reserved;
+    float* found_inf;           /* NULL, or &opt_state[3]: set to 1.0f when a value left in dst is not finite (see svdx_gemm_tn) */
 } svdx_gradfin_job;
 int svdx_grad_finalize_batch(const svdx_gradfin_job* jobs, int n_jobs, void* stream);
 /* out[i, :] = [cos(t_i f_j), sin(t_i f_j)], f_j = exp(-ln(1e4) j / (dim/2))  (diffusers Timesteps,
@@ -381,7 +384,16 @@ int svdx_edm_loss(const void* pred, int ld, const float* noisy, const float* tar
 #define SVDX_SCHED_COSINE 3
 #define SVDX_SCHED_COSINE_WITH_RESTARTS 4
 #define SVDX_SCHED_POLYNOMIAL 5
+/* diffusers' piecewise_constant (step rules "m0:s0,m1:s1,...,m_last"; train_svd.py:807-812 passes --lr_scheduler straight through):
+ * opt_state[10] = n rules (<= SVDX_SCHED_MAX_RULES) and, BEHIND the 16 floats, opt_state[16 + 2i] = boundary s_i, opt_state[17 + 2i] =
+ * multiplier m_i for i < n, opt_state[16 + 2n] = m_last: lambda(step) = m_i of the first s_i > step, m_last beyond the last boundary.
+ * Only this kind reads beyond SVDX_OPT_STATE_FLOATS (the buffer is then SVDX_OPT_STATE_FLOATS + 2 * SVDX_SCHED_MAX_RULES + 1 floats). */
+#define SVDX_SCHED_PIECEWISE_CONSTANT 6
+#define SVDX_SCHED_MAX_RULES 8
 int svdx_check_finite(const float* g, int64_t n, float* opt_state, void* stream);
+/* The same over `n_spans` (offset, count) pairs of g (ints; multiples of 4): with svdx_gemm_tn / svdx_grad_finalize_batch raising found_inf
+ * for the gradients they store, only the accumulated slots of the flat buffer (the span table of svdx_zero_spans) are left to test. */
+int svdx_check_finite_spans(const float* g, const int* spans, int n_spans, float* opt_state, void* stream);
 int svdx_optim_prep(float* opt_state, float beta1, float beta2, float growth, float backoff, int growth_interval,
                     int dynamic, void* stream);
 int svdx_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -35,6 +35,21 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+# Memory-frugal mode for the largest parity cases (reference config 4's 9216-pixel level: the fp32 activations of every block at once
+# exceed an ordinary host): with RECOMPUTE = True every resnet / transformer module runs under torch.utils.checkpoint -- its forward is
+# evaluated again during backward instead of its activations being kept.  The same operations on the same values: outputs and gradients
+# are unchanged (tests/test_oracle.py holds the two modes to each other); only tests/golden/make_big_refs.py switches it on.
+RECOMPUTE = False
+
+
+class _Recomputable(nn.Module):
+    def __call__(self, *args, **kwargs):
+        if RECOMPUTE and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+            return checkpoint(super().__call__, *args, use_reentrant=False, **kwargs)
+        return super().__call__(*args, **kwargs)
+
+
 # --------------------------------------------------------------------------------------------------
 # embeddings  (diffusers.models.embeddings; used at src/unet_spatio_temporal_condition.py:138-144)
 # --------------------------------------------------------------------------------------------------
@@ -310,7 +325,7 @@ class TemporalResnetBlock(nn.Module):
         return input_tensor + h
 
 
-class SpatioTemporalResBlock(nn.Module):
+class SpatioTemporalResBlock(_Recomputable):
     def __init__(self, in_channels: int, out_channels: int, temb_channels: int, eps: float):
         super().__init__()
         self.spatial_res_block = ResnetBlock2D(in_channels, out_channels, temb_channels, eps)
@@ -350,7 +365,7 @@ class Upsample2D(nn.Module):
 # --------------------------------------------------------------------------------------------------
 # transformer_temporal.TransformerSpatioTemporalModel
 # --------------------------------------------------------------------------------------------------
-class TransformerSpatioTemporalModel(nn.Module):
+class TransformerSpatioTemporalModel(_Recomputable):
     def __init__(self, num_attention_heads: int, attention_head_dim: int, in_channels: int,
                  num_layers: int, cross_attention_dim: int):
         super().__init__()

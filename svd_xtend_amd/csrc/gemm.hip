@@ -36,6 +36,7 @@ struct GemmParams {
     int z_xcd;                 // variant 4, split_k in {2, 4, 8}: K slice z owns 8 / split_k XCDs, arranged (8/split_k/xcd_n) x xcd_n over the tiles (1-D grid)
     int epi; const void* aux_in; void* aux_out; int aux_dim;   // fused GEGLU epilogues (variant 4)
     float* a_colsum;                                           // TN form: += column sums of A (the bias gradient), or null
+    float* found_inf;                                          // TN form, float store / += modes: *found_inf = 1 when a value written is not finite (or null)
     // variant 4, second operand pair: acc += A2 [M, K2] B2^T [N, K2] after the main reduction (the LoRA term of a projection)
     const void* A2; const void* B2; int K2, lda2, ldb2, a2_bytes, b2_bytes;
     int a2_seg;   // > 0: output columns [j * a2_seg, (j + 1) * a2_seg) read A2 columns [j * K2, (j + 1) * K2) (fused q/k/v adapters)
@@ -99,11 +100,20 @@ __device__ __forceinline__ RowInfo decode_row(const svdx_gather& g, int m) {
     return ri;
 }
 
+// GradScaler's inf check folded into the kernels that WRITE the gradients (round 5): a weight gradient that is stored once per step is
+// tested where it is stored, and svdx_check_finite_spans covers the few slots that are accumulated -- the 1.59 GB pass of
+// svdx_check_finite over the flat buffer leaves the single-rank step.  Any number of threads may raise the flag (same value, no ordering).
+__device__ __forceinline__ bool not_finite(float v) { return (__builtin_bit_cast(unsigned, v) & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ void raise_found_inf(float* found, bool bad) {
+    if (found && __any(bad) && (threadIdx.x & 63) == 0) *found = 1.f;
+}
+
 template <typename T>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], char* smem, int m0, int n0, int z, int tid,
                                               int lane, int wm, int wn) {
     // ---- epilogue: stage 64 rows at a time through LDS as f32, then vectorised fused store ----
     float* Cs = reinterpret_cast<float*>(smem);
+    bool bad_any = false;
     const bool lead = (z == 0) && p.out_mode != SVDX_OUT_F32_SLAB;
     T* Ct = reinterpret_cast<T*>(p.C);
     float* Cf = reinterpret_cast<float*>(p.C) + (p.out_mode == SVDX_OUT_F32_SLAB ? (size_t)z * p.slab_stride : 0);
@@ -173,6 +183,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
                     for (int j = 0; j < 8; ++j) if (j < nvalid) Cf[co + j] = v[j];
                 }
+                if (p.found_inf && p.out_mode == SVDX_OUT_F32) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bad_any |= j < nvalid && not_finite(v[j]);
+                }
             } else if (p.out_mode == SVDX_OUT_F32_ADD) {      // this block owns the element: plain read-modify-write
                 if (full) {
                     f32x4 c0 = *reinterpret_cast<const f32x4*>(Cf + co), c1 = *reinterpret_cast<const f32x4*>(Cf + co + 4);
@@ -180,9 +194,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                     c1 += f32x4{v[4], v[5], v[6], v[7]};
                     *reinterpret_cast<f32x4*>(Cf + co) = c0;
                     *reinterpret_cast<f32x4*>(Cf + co + 4) = c1;
+                    if (p.found_inf) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bad_any |= not_finite(c0[j]) || not_finite(c1[j]);
+                    }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) if (j < nvalid) Cf[co + j] += v[j];
+                    for (int j = 0; j < 8; ++j) if (j < nvalid) { const float t = Cf[co + j] + v[j]; Cf[co + j] = t; bad_any |= p.found_inf && not_finite(t); }
                 }
             } else {
 #pragma unroll
@@ -191,6 +209,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
         __syncthreads();
     }
+    raise_found_inf(p.found_inf, bad_any);
 }
 
 template <typename T>
@@ -815,6 +834,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
             }
     }
     float* Cf = reinterpret_cast<float*>(p.C) + (p.out_mode == SVDX_OUT_F32_SLAB ? (size_t)z * p.slab_stride : 0);
+    bool bad_any = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = m0 + wm * 64 + i * 16 + fr;
@@ -826,10 +846,15 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
             float* o = Cf + (size_t)n * p.ldc + k;
             const f32x4 v = acc[i][j] * p.alpha;
             if (p.vec_ok && k + 4 <= p.N) {
-                if (p.out_mode == SVDX_OUT_F32) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o));      // a weight gradient: read next by the optimizer
-                else if (p.out_mode == SVDX_OUT_F32_SLAB) *reinterpret_cast<f32x4*>(o) = v;
-                else if (p.out_mode == SVDX_OUT_F32_ADD) *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(o) + v;
-                else {
+                if (p.out_mode == SVDX_OUT_F32) {
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o));      // a weight gradient: read next by the optimizer
+                    if (p.found_inf) bad_any |= not_finite(v[0]) || not_finite(v[1]) || not_finite(v[2]) || not_finite(v[3]);
+                } else if (p.out_mode == SVDX_OUT_F32_SLAB) *reinterpret_cast<f32x4*>(o) = v;
+                else if (p.out_mode == SVDX_OUT_F32_ADD) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(o) + v;
+                    *reinterpret_cast<f32x4*>(o) = t;
+                    if (p.found_inf) bad_any |= not_finite(t[0]) || not_finite(t[1]) || not_finite(t[2]) || not_finite(t[3]);
+                } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) atomicAdd(o + e, v[e]);
                 }
@@ -837,13 +862,19 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (k + e >= p.N) continue;
-                    if (p.out_mode == SVDX_OUT_F32 || p.out_mode == SVDX_OUT_F32_SLAB) o[e] = v[e];
-                    else if (p.out_mode == SVDX_OUT_F32_ADD) o[e] += v[e];
-                    else atomicAdd(o + e, v[e]);
+                    if (p.out_mode == SVDX_OUT_F32 || p.out_mode == SVDX_OUT_F32_SLAB) {
+                        o[e] = v[e];
+                        bad_any |= p.found_inf && p.out_mode == SVDX_OUT_F32 && not_finite(v[e]);
+                    } else if (p.out_mode == SVDX_OUT_F32_ADD) {
+                        const float t = o[e] + v[e];
+                        o[e] = t;
+                        bad_any |= p.found_inf && not_finite(t);
+                    } else atomicAdd(o + e, v[e]);
                 }
             }
         }
     }
+    raise_found_inf(p.found_inf, bad_any);
 }
 
 
@@ -1598,14 +1629,17 @@ __global__ __launch_bounds__(256) void grad_finalize_batch_kernel(const GradFinP
         }
     }
     const long total4 = q.count / 4;
+    bool bad_any = false;
     for (long i4 = (long)blk * 256 + threadIdx.x; i4 < total4; i4 += (long)nblk * 256) {
         const long i = i4 * 4;
         f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q.acc + i));
         for (int z = 1; z < q.nsplit; ++z) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q.acc + (size_t)z * q.slab_stride + i));
         f32x4* o = reinterpret_cast<f32x4*>(q.dst + i);
         if (q.store) __builtin_nontemporal_store(v, o);
-        else *o = *o + v;
+        else { v = *o + v; *o = v; }
+        bad_any |= not_finite(v[0]) || not_finite(v[1]) || not_finite(v[2]) || not_finite(v[3]);
     }
+    raise_found_inf(q.found_inf, bad_any);
 }
 
 // X == nullptr: a column of ones (the bias gradient, K = 1)
@@ -1793,8 +1827,10 @@ int launch_gemm_tn8(GemmParams p, hipStream_t st) {
 }  // namespace
 
 extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N, int K, int lda, int ldb, int ldc,
-                            float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, int dtype, void* stream) {
+                            float* a_colsum, const void* zero_page, int out_mode, int split_k, int stages, float* found_inf, int dtype,
+                            void* stream) {
     SVDX_CHECK_ARG(A && B && C && zero_page && R > 0 && N > 0 && K > 0, "svdx_gemm_tn: bad args");
+    SVDX_CHECK_ARG(!found_inf || out_mode == SVDX_OUT_F32 || out_mode == SVDX_OUT_F32_ADD, "svdx_gemm_tn: found_inf goes with the store / += modes");
     // operands below 2 GiB are staged through buffer descriptors (always, unless SVDX_TN_FLAT asks for rounds 1-4's flat staging for an A/B)
     const long a_span = ((long)(R - 1) * lda + N) * 2, b_span = ((long)(R - 1) * ldb + K) * 2;
     const bool buf = a_span < (1L << 31) && b_span < (1L << 31) && !(stages & SVDX_TN_FLAT);
@@ -1817,7 +1853,7 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
     p.A = A; p.B = B; p.C = C; p.M = N; p.N = K; p.K = R; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = nullptr; p.rowvec = nullptr; p.rv_ld = 0; p.rv_rpg = 0; p.rv_mod = 0; p.res = nullptr; p.ldres = 0;
     p.g = svdx_gather{}; p.zero_page = zero_page; p.out_mode = out_mode; p.alpha = 1.f; p.split_k = split_k;
-    p.epi = 0; p.aux_in = nullptr; p.aux_out = nullptr; p.aux_dim = 0; p.a_colsum = a_colsum;
+    p.epi = 0; p.aux_in = nullptr; p.aux_out = nullptr; p.aux_dim = 0; p.a_colsum = a_colsum; p.found_inf = found_inf;
     p.a_bytes = buf ? (int)a_span : 0; p.b_bytes = buf ? (int)b_span : 0;
     p.gn_stats = nullptr; p.gn_rows = p.gn_cg = 0; p.gn_m0 = p.gn_m1 = 0.f;
     p.tiles_m = cdiv(N, BM); p.tiles_n = cdiv(K, BN);
@@ -1877,7 +1913,7 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
     p.bias = bias; p.rowvec = rowvec; p.rv_ld = rv_ld; p.rv_rpg = rv_rows_per_group; p.rv_mod = rv_mod;
     p.res = res; p.ldres = ldres; p.zero_page = zero_page;
     p.out_mode = out_mode; p.alpha = alpha; p.split_k = split_k; p.slab_stride = (long)M * ldc;
-    p.epi = epilogue; p.aux_in = aux_in; p.aux_out = aux_out; p.aux_dim = aux_dim; p.a_colsum = nullptr;
+    p.epi = epilogue; p.aux_in = aux_in; p.aux_out = aux_out; p.aux_dim = aux_dim; p.a_colsum = nullptr; p.found_inf = nullptr;
     p.A2 = A2; p.B2 = B2; p.K2 = K2 > 0 ? K2 : 0; p.lda2 = lda2; p.ldb2 = ldb2; p.a2_bytes = p.b2_bytes = 0; p.a2_seg = K2 > 0 ? a2_seg : 0;
     p.gn_stats = reinterpret_cast<unsigned long long*>(gn_stats); p.gn_rows = gn_rows; p.gn_cg = gn_cg; p.gn_m0 = p.gn_m1 = 0.f;
     if (gn_stats) {

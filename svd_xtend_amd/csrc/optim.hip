@@ -65,6 +65,19 @@ __global__ void check_finite_kernel(const float* __restrict__ g, long n, float* 
     }
 }
 
+// the same test over a table of (offset, count) spans: the slots of the flat gradient buffer that are ACCUMULATED (biases, LayerNorm, skinny
+// cross-attention weights, alignment gaps) -- the gradients that one GEMM stores per step are tested by the kernel that stores them
+__global__ __launch_bounds__(256) void check_finite_spans_kernel(const float* __restrict__ g, const int* __restrict__ spans, float* opt_state) {
+    const int off = spans[2 * blockIdx.x], cnt = spans[2 * blockIdx.x + 1];
+    bool bad = false;
+    for (int i = threadIdx.x * 4; i < cnt; i += 256 * 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + off + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bad |= !isfinite(v[e]);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) opt_state[3] = 1.f;
+}
+
 // ---- gradient sum over the ranks of one node, straight over xGMI (svdx_allreduce_grads) --------------------------------------------
 // xGMI is point-to-point: every GPU has a link to each of the other seven, so the bandwidth-optimal exchange is the DIRECT one -- rank r
 // pulls slice r of every peer's buffer (reduce-scatter), then pulls the reduced slices of the other ranks (all-gather): 2 x (7/8) x S
@@ -122,6 +135,12 @@ __device__ float lr_lambda(const float* st, float n) {
     const int kind = (int)st[9];
     const float warm = st[10], total = st[11], cycles = st[12], power = st[13], end_ratio = st[14];
     if (kind == SVDX_SCHED_CONSTANT) return 1.f;
+    if (kind == SVDX_SCHED_PIECEWISE_CONSTANT) {                       // get_piecewise_constant_schedule: the first boundary beyond n decides
+        const int nr = min((int)st[10], SVDX_SCHED_MAX_RULES);
+        for (int i = 0; i < nr; ++i)
+            if (n < st[SVDX_OPT_STATE_FLOATS + 2 * i]) return st[SVDX_OPT_STATE_FLOATS + 2 * i + 1];
+        return st[SVDX_OPT_STATE_FLOATS + 2 * nr];
+    }
     if (kind == SVDX_SCHED_POLYNOMIAL) {
         if (n < warm) return n / fmaxf(1.f, warm);
         if (n > total) return end_ratio;
@@ -320,6 +339,14 @@ extern "C" int svdx_allreduce_grads(float* const* peers, int world, int rank, in
         hipLaunchKernelGGL(peer_all_gather_kernel, dim3(blocks, world - 1), dim3(256), 0, st, pp, world, rank, (long)n, per);
     }
     SVDX_LAUNCH_CHECK("svdx_allreduce_grads");
+    return 0;
+}
+
+extern "C" int svdx_check_finite_spans(const float* g, const int* spans, int n_spans, float* opt_state, void* stream) {
+    if (n_spans <= 0) return 0;
+    SVDX_CHECK_ARG(g && spans && opt_state && ((uintptr_t)g & 15) == 0, "svdx_check_finite_spans: bad args");
+    hipLaunchKernelGGL(check_finite_spans_kernel, dim3(n_spans), dim3(256), 0, (hipStream_t)stream, g, spans, opt_state);
+    SVDX_LAUNCH_CHECK("svdx_check_finite_spans");
     return 0;
 }
 

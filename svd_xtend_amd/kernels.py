@@ -26,9 +26,11 @@ LN_PARTIAL_ROWS = 2048
 GN_REPLICAS = 8
 GN_STAT_FLOATS = 4             # floats of storage per (replica, sample, group) of a GroupNorm statistics buffer: two int64
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3, GATHER_CONV3X3_PAD0 = 0, 1, 2, 3, 4
-ABI_VERSION = 500              # include/svdx.h: SVDX_VERSION this binding was written against
+ABI_VERSION = 501              # include/svdx.h: SVDX_VERSION this binding was written against
 OPT_STATE_FLOATS = 16          # include/svdx.h: layout of the optimizer / loss-scale / schedule state
-SCHED_KINDS = {"constant": 0, "constant_with_warmup": 1, "linear": 2, "cosine": 3, "cosine_with_restarts": 4, "polynomial": 5}
+SCHED_KINDS = {"constant": 0, "constant_with_warmup": 1, "linear": 2, "cosine": 3, "cosine_with_restarts": 4, "polynomial": 5, "piecewise_constant": 6}
+SCHED_MAX_RULES = 8            # include/svdx.h SVDX_SCHED_MAX_RULES: step rules of piecewise_constant, stored behind the 16 state floats
+OPT_STATE_ALLOC = 40           # floats the Trainer allocates: the 16 of the contract + 2 * 8 rule floats + the last multiplier, rounded up
 
 
 class SvdxError(RuntimeError):
@@ -48,7 +50,7 @@ class _OuterJobC(ctypes.Structure):          # include/svdx.h: svdx_outer_job
 class _GradFinJobC(ctypes.Structure):        # include/svdx.h: svdx_gradfin_job
     _fields_ = [("acc", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("colsum_slabs", ctypes.c_void_p), ("colsum_out", ctypes.c_void_p),
                 ("slab_stride", ctypes.c_int64), ("count", ctypes.c_int64), ("nsplit", ctypes.c_int), ("colsum_n", ctypes.c_int),
-                ("store", ctypes.c_int), ("reserved", ctypes.c_int)]
+                ("store", ctypes.c_int), ("reserved", ctypes.c_int), ("found_inf", ctypes.c_void_p)]
 
 
 class _LnRedJobC(ctypes.Structure):          # include/svdx.h: svdx_lnred_job
@@ -87,7 +89,7 @@ _SIGS = {
     "svdx_gemm": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifii" "ippi" "ip",
     "svdx_gemm_dual": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifi" "pp" "iiii" "ip",
     "svdx_gemm_gn": "ppp" "iiiiii" "p" "piii" "pi" "pp" "fi" "pii" "ip",
-    "svdx_gemm_tn": "ppp" "iiiiii" "pp" "iii" "ip",
+    "svdx_gemm_tn": "ppp" "iiiiii" "pp" "iii" "p" "ip",
     "svdx_gemm_finalize": "pil" "pi" "iii" "pp" "iii" "pi" "ppi" "ip",
     "svdx_gemm_finalize_gn": "pil" "p" "iii" "pp" "iii" "pi" "pii" "ip",
     "svdx_small_linear": "pppp" "iiii" "iii" "ip",
@@ -136,6 +138,7 @@ _SIGS = {
     "svdx_zero_spans": "pp" "ip",
     "svdx_edm_loss": "pi" "ppppp" "iiii" "pp" "ip",
     "svdx_check_finite": "plpp",
+    "svdx_check_finite_spans": "pp" "i" "pp",
     "svdx_optim_prep": "p" "ffff" "ii" "p",
     "svdx_adamw": "pppp" "l" "ffffff" "pp" "ip",
     "svdx_adamw_tiled": "ppppp" "i" "ffffff" "ppp" "ip",
@@ -284,9 +287,10 @@ class HipBackend:
                    _p(self._zero_page), out_mode, float(alpha), split_k, variant, epilogue, _p(aux_in), _p(aux_out), aux_dim,
                    _dt(A), self._stream())
 
-    def gemm_tn(self, A, B, C, R, N, K, lda, ldb, ldc, out_mode=OUT_F32_ADD, split_k=1, a_colsum=None, stages=0):
+    def gemm_tn(self, A, B, C, R, N, K, lda, ldb, ldc, out_mode=OUT_F32_ADD, split_k=1, a_colsum=None, stages=0, found_inf=None):
+        """found_inf: one-float view (opt_state[3:4]) set to 1 when a value left in C is not finite (store / += modes)."""
         self._call("svdx_gemm_tn", _p(A), _p(B), _f32(C), R, N, K, lda, ldb, ldc, _f32(a_colsum), _p(self._zero_page), out_mode, split_k, stages,
-                   _dt(A), self._stream())
+                   _f32(found_inf), _dt(A), self._stream())
 
     def gemm_finalize(self, acc, nsplit, slab_stride, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
                       res=None, ldres=0, accumulate_f32=False, dtype=None, colsum_slabs=None, colsum_out=None, gn=None):
@@ -321,10 +325,10 @@ class HipBackend:
         self._call("svdx_outer_acc_batch", ctypes.cast(arr, ctypes.c_void_p), len(jobs), M, self._stream())
 
     def grad_finalize_batch(self, jobs):
-        """jobs: sequence of (slabs, nsplit, slab_stride, dst, count, colsum_slabs or None, colsum_out or None, store) -- each what the
-        float forms of `gemm_finalize` take; ONE launch per BATCH_MAX_JOBS jobs, distinct destinations."""
-        arr = (_GradFinJobC * len(jobs))(*[_GradFinJobC(_f32(a), _f32(d), _f32(cs), _f32(co), st, cnt, ns, co.numel() if co is not None else 0, int(bool(sto)), 0)
-                                           for a, ns, st, d, cnt, cs, co, sto in jobs])
+        """jobs: sequence of (slabs, nsplit, slab_stride, dst, count, colsum_slabs or None, colsum_out or None, store[, found_inf]) -- each
+        what the float forms of `gemm_finalize` take (+ the one-float non-finite flag); ONE launch per BATCH_MAX_JOBS jobs, distinct destinations."""
+        arr = (_GradFinJobC * len(jobs))(*[_GradFinJobC(_f32(j[0]), _f32(j[3]), _f32(j[5]), _f32(j[6]), j[2], j[4], j[1], j[6].numel() if j[6] is not None else 0,
+                                                        int(bool(j[7])), 0, _f32(j[8]) if len(j) > 8 else None) for j in jobs])
         self._call("svdx_grad_finalize_batch", ctypes.cast(arr, ctypes.c_void_p), len(jobs), self._stream())
 
     def timestep_embed(self, t, out, n, dim):
@@ -480,6 +484,9 @@ class HipBackend:
         """include/svdx.h svdx_allreduce_grads: peer_ptrs = device addresses of every rank's buffer (own included, index = rank)."""
         arr = (ctypes.c_void_p * len(peer_ptrs))(*peer_ptrs)
         self._call("svdx_allreduce_grads", ctypes.cast(arr, ctypes.c_void_p), len(peer_ptrs), int(rank), int(n), int(phase), self._stream())
+
+    def check_finite_spans(self, g, spans, n_spans, opt_state):
+        self._call("svdx_check_finite_spans", _f32(g), spans.data_ptr(), n_spans, _f32(opt_state), self._stream())
 
     def optim_prep(self, opt_state, beta1, beta2, growth, backoff, growth_interval, dynamic):
         assert opt_state.numel() >= OPT_STATE_FLOATS

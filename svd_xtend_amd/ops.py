@@ -111,6 +111,11 @@ class Runtime:
         # count of a kernel whose tiles already share their lines), so it is off; SVDX_TN_PREFETCH=1: A/B knob
         self.tn_prefetch = os.environ.get("SVDX_TN_PREFETCH", "0") == "1"
         self.tn_flat = os.environ.get("SVDX_TN_FLAT", "0") == "1"        # A/B knob: rounds 1-4's flat staging (compiler-serialised loads / MFMAs)
+        # svdx_gemm_tn / svdx_grad_finalize_batch raise this one-float flag (the trainer's opt_state[3]) for the write-once gradients they
+        # store, so the optimizer only has to test the accumulated slots (Trainer.optimizer_step); None: nobody folds, the full pass runs
+        self.found_inf = None
+        self.fold_finite = os.environ.get("SVDX_FOLD_FINITE", "1") != "0"      # A/B knob: 0 = the 1.59 GB svdx_check_finite pass of rounds 1-4
+        self.unchecked_grads = False
         self.fin_queue_budget = 768 << 20      # bytes of float slabs the queue may keep alive before it flushes (c2: ~3 flushes per sweep)
         # GroupNorm statistics of a tensor come from the store loop of the GEMM that writes it (svdx_gemm_gn) instead of a pass of their
         # own over it; SVDX_FUSE_GN_STATS=0: developer knob for A/B runs
@@ -699,8 +704,11 @@ def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tenso
         if rt.tn_flat:
             stages = (stages & ~K.TN_PREFETCH) | K.TN_FLAT
         # the bias gradient (column sums of dy) rides on the same launch
+        # GradScaler's inf check where the gradient is written (Runtime.found_inf: the trainer's opt_state[3]; None = no folding)
+        found = rt.found_inf if (write_once and rt.fold_finite) else None
         if sk == 1:
-            k.gemm_tn(dy, x, dst, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32 if store else K.OUT_F32_ADD, a_colsum=a_colsum, stages=stages)
+            k.gemm_tn(dy, x, dst, M, N, Kd, lda, ldb, Kd, out_mode=K.OUT_F32 if store else K.OUT_F32_ADD, a_colsum=a_colsum, stages=stages,
+                      found_inf=found)
         else:
             slabs = rt.f32(sk, N, Kd)
             cs = rt.f32(sk, N) if a_colsum is not None else None       # per-slice column sums, added in slice order by the finalize
@@ -708,10 +716,12 @@ def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tenso
             if rt.batch_small and rt.defer_grad_finalize and (N * Kd) % 4 == 0 and not _tuning(rt):
                 # nothing reads a weight gradient before the optimizer (or the block's gradient bucket): the reducing launch waits for
                 # the sweep's one table-driven launch (Runtime.flush_deferred); the slabs stay alive in the queue until then
-                rt.defer_grad_finalize_job((slabs, sk, N * Kd, dst, N * Kd, cs, a_colsum, store))
+                rt.defer_grad_finalize_job((slabs, sk, N * Kd, dst, N * Kd, cs, a_colsum, store, found))
             else:
                 k.gemm_finalize(slabs, sk, N * Kd, dst, N, Kd, Kd, accumulate_f32=2 if store else 1, dtype=rt.dt, colsum_slabs=cs,
                                 colsum_out=a_colsum)
+                if found is not None:
+                    rt.unchecked_grads = True          # the single-launch reduction carries no flag: this step takes the full pass instead
 
     TN_TILES = {2: (128, 128), 18: (256, 256)}     # svdx_gemm_tn `stages`: output tile (rows of dst, columns)
     ALL_TN_TILES = {**TN_TILES, **STAGED_TN_TILES}

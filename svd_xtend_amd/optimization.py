@@ -54,8 +54,21 @@ class LRSchedule:
             raise ValueError(f"scheduler state has base lr {sd['base_lrs'][0]}, the trainer {self.trainer.lr}")
 
 
+def parse_step_rules(step_rules: str):
+    """diffusers.optimization.get_piecewise_constant_schedule's rule string "m0:s0,m1:s1,...,m_last" -> (boundaries sorted ascending,
+    their multipliers, m_last).  Same parsing: `value:steps` pairs, the last entry a bare multiplier."""
+    rule_list = step_rules.split(",")
+    rules = {}
+    for rule_str in rule_list[:-1]:
+        value_str, steps_str = rule_str.split(":")
+        rules[int(steps_str)] = float(value_str)
+    last = float(rule_list[-1])
+    bounds = sorted(rules)
+    return [float(b) for b in bounds], [rules[b] for b in bounds], last
+
+
 def lr_lambda(step: int, name: str, num_warmup_steps: int = 0, num_training_steps: int = 0, num_cycles: float = 0.0,
-              power: float = 1.0, lr_end: float = 1e-7, base_lr: float = 1.0, steps_per_step: int = 1) -> float:
+              power: float = 1.0, lr_end: float = 1e-7, base_lr: float = 1.0, steps_per_step: int = 1, step_rules: Optional[str] = None) -> float:
     """Host evaluation of the multiplier the device applies (same arithmetic as csrc/optim.hip lr_lambda, in double); used for
     reporting only -- the step itself never reads it."""
     kind = K.SCHED_KINDS[name]
@@ -63,6 +76,12 @@ def lr_lambda(step: int, name: str, num_warmup_steps: int = 0, num_training_step
     n = float(step)
     if kind == 0:
         return 1.0
+    if kind == 6:
+        bounds, mults, last = parse_step_rules(step_rules)
+        for b, m in zip(bounds, mults):
+            if n < b:
+                return m
+        return last
     if kind == 5:
         if n < warm:
             return n / max(1.0, warm)
@@ -90,8 +109,8 @@ def get_scheduler(name, optimizer=None, step_rules: Optional[str] = None, num_wa
 
     The reference multiplies warmup / total steps by `accelerator.num_processes` because accelerate steps the scheduler that
     many times per optimizer step; pass the same products here -- `steps_per_step` defaults to the trainer's world size, which
-    reproduces that stepping.  Same argument errors as diffusers; `piecewise_constant` (free-form step rules) has no device form
-    and is refused."""
+    reproduces that stepping.  Same argument errors as diffusers; `piecewise_constant` (diffusers' step rules "m0:s0,...,m_last")
+    is evaluated on the device from up to 8 rules stored behind the 16 state floats."""
     name = getattr(name, "value", name)                 # diffusers accepts its SchedulerType enum as well
     trainer = optimizer
     if trainer is None or not hasattr(trainer, "set_schedule"):
@@ -99,7 +118,13 @@ def get_scheduler(name, optimizer=None, step_rules: Optional[str] = None, num_wa
     if last_epoch != -1:
         raise NotImplementedError("get_scheduler: resume by loading the optimizer state (the schedule follows its step counter)")
     if name == "piecewise_constant":
-        raise NotImplementedError("get_scheduler: piecewise_constant is not supported (no device form for free-form step rules)")
+        if not step_rules:
+            raise ValueError("piecewise_constant requires `step_rules`, e.g. \"1:10,0.1:20,0.01:30,0.005\"")
+        bounds, _, _ = parse_step_rules(step_rules)
+        if len(bounds) > K.SCHED_MAX_RULES:
+            raise ValueError(f"piecewise_constant: at most {K.SCHED_MAX_RULES} step rules have a device form (got {len(bounds)})")
+        return LRSchedule(trainer, name=name, step_rules=step_rules,
+                          steps_per_step=trainer.world if steps_per_step is None else steps_per_step)
     if name not in K.SCHED_KINDS:
         raise ValueError(f"{name} is not a valid SchedulerType")
     if name in _NEEDS_WARMUP and num_warmup_steps is None:

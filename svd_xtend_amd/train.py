@@ -189,7 +189,7 @@ class Trainer:
         self.loss_slot = self.g_flat[off:off + 1]
         # opt_state: 0 step, 1 loss_scale, 2 growth_tracker, 3 found_inf, 4 inv_scale, 5 bc1, 6 bc2, 7 skip
         self.dynamic = dtype == torch.float16
-        st = [0.0] * K.OPT_STATE_FLOATS
+        st = [0.0] * K.OPT_STATE_ALLOC
         st[1], st[4], st[5], st[6], st[8] = (init_scale if self.dynamic else 1.0), 1.0, 1.0, 1.0, 1.0   # slots 9..15: schedule
         self.opt_state = torch.tensor(st, dtype=torch.float32, device=dev)
         self.micro = 0
@@ -243,6 +243,11 @@ class Trainer:
         if os.environ.get("SVDX_WRITE_ONCE", "1") == "0":      # developer knob for A/B runs: plain memset + accumulate
             self.rt.write_once.clear()
         self.zero_spans = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous() if self.rt.write_once else None
+        # GradScaler's inf check folded into the gradient-writing kernels (single rank; Runtime.fold_finite / SVDX_FOLD_FINITE=0: A/B knob).
+        # finite_spans: the accumulated slots below n_flat (zero_spans without the loss slot at the tail, which is not a gradient)
+        fin = [(c, min(n, self.n_flat - c)) for c, n in chunks if c < self.n_flat]
+        self.finite_spans = torch.tensor(fin, dtype=torch.int32, device=dev).contiguous() if (self.rt.write_once and fin) else None
+        self.rt.found_inf = self.opt_state[3:4] if (self.world == 1 and self.zero_spans is not None) else None
         # gradient buckets for overlapping the all-reduce with the backward sweep: one contiguous slice of g_flat per transformer
         # block (its trainables are adjacent in named_parameters order), reduced as soon as backward_rows leaves the block
         # default schedule of the gradient sum over ranks: ONE collective after the backward sweep (north_star's form).  True = one
@@ -342,6 +347,9 @@ class Trainer:
         for _, w in self._pending:        # collectives of a step that was abandoned before allreduce_grads(): finish them first
             w.wait()
         self._pending = []
+        if self.rt.fold_finite and self.rt.found_inf is not None:
+            self.rt.k.zero(self.rt.found_inf)       # raised by the gradient-writing kernels of THIS step only (a sweep abandoned before its
+                                                    # optimizer step must not make the next one skip)
         if self.zero_spans is None:
             self.rt.k.zero(self.g_flat)
         else:
@@ -419,7 +427,14 @@ class Trainer:
     def optimizer_step(self):
         k = self.rt.k
         n = self.n_flat
-        k.check_finite(self.g_flat, n, self.opt_state)
+        if self.rt.fold_finite and self.rt.found_inf is not None and not self.rt.unchecked_grads:
+            # the write-once gradients were tested by the kernels that stored them (ops.gemm_tn_acc -> opt_state[3]); what is left are
+            # the accumulated slots.  On several ranks the SUM over ranks has to be tested: the full pass, after the all-reduce.
+            if self.finite_spans is not None:
+                k.check_finite_spans(self.g_flat, self.finite_spans, self.finite_spans.shape[0], self.opt_state)
+        else:
+            k.check_finite(self.g_flat, n, self.opt_state)
+        self.rt.unchecked_grads = False
         k.optim_prep(self.opt_state, self.betas[0], self.betas[1], 2.0, 0.5, self.growth_interval, int(self.dynamic))
         grad_mul = 1.0 / (self.world * self.grad_accum)
         if self.adam_tiles is not None:
@@ -447,16 +462,29 @@ class Trainer:
 
     # ---- learning-rate schedule, evaluated on the device from the optimizer's step counter --------------------
     def set_schedule(self, name: str, num_warmup_steps: int = 0, num_training_steps: int = 0, num_cycles: float = 0.0,
-                     power: float = 1.0, lr_end: float = 1e-7, steps_per_step: int = 1) -> None:
+                     power: float = 1.0, lr_end: float = 1e-7, steps_per_step: int = 1, step_rules: Optional[str] = None) -> None:
         """Install lambda(step) of diffusers' get_scheduler (train_svd.py:807-813) into opt_state[9..15] (include/svdx.h).
         `steps_per_step`: scheduler steps per optimizer step (accelerate steps the wrapped scheduler num_processes times)."""
         if name not in K.SCHED_KINDS:
             raise ValueError(f"unknown lr schedule {name!r} (have {sorted(K.SCHED_KINDS)})")
         vals = [float(K.SCHED_KINDS[name]), float(num_warmup_steps), float(num_training_steps), float(num_cycles), float(power),
                 float(lr_end) / float(self.lr), float(steps_per_step)]
+        extra = [0.0] * (K.OPT_STATE_ALLOC - K.OPT_STATE_FLOATS)
+        if name == "piecewise_constant":
+            from .optimization import parse_step_rules
+            bounds, mults, last = parse_step_rules(step_rules or "")
+            if len(bounds) > K.SCHED_MAX_RULES:
+                raise ValueError(f"piecewise_constant: at most {K.SCHED_MAX_RULES} step rules")
+            vals[1] = float(len(bounds))
+            for i, (b, m) in enumerate(zip(bounds, mults)):
+                extra[2 * i], extra[2 * i + 1] = b, m
+            extra[2 * len(bounds)] = last
         self.opt_state[9:16] = torch.tensor(vals, dtype=torch.float32).to(self.dev)
+        self.opt_state[K.OPT_STATE_FLOATS:] = torch.tensor(extra, dtype=torch.float32).to(self.dev)
         self.schedule = dict(name=name, num_warmup_steps=num_warmup_steps, num_training_steps=num_training_steps,
                              num_cycles=num_cycles, power=power, lr_end=lr_end, steps_per_step=steps_per_step)
+        if name == "piecewise_constant":
+            self.schedule["step_rules"] = step_rules
 
     def weights_changed(self) -> None:
         """The float masters of the trainables were written by something other than `optimizer_step` (EMA copy_to / restore,

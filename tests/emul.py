@@ -180,7 +180,7 @@ class EmuBackend:
                 xf = c.float().reshape(M // rows, rows, N // cg, cg)
                 gn_encode_add(stats, M // rows, N // cg, rows * cg, 0, xf.sum((1, 3)), (xf * xf).sum((1, 3)))
 
-    def gemm_tn(self, A, B, C, R, N, Kd, lda, ldb, ldc, out_mode=K.OUT_F32_ADD, split_k=1, a_colsum=None, stages=0):
+    def gemm_tn(self, A, B, C, R, N, Kd, lda, ldb, ldc, out_mode=K.OUT_F32_ADD, split_k=1, a_colsum=None, stages=0, found_inf=None):
         a, b = V(A, R, N, lda).float(), V(B, R, Kd, ldb).float()
         if a_colsum is not None and out_mode != K.OUT_F32_SLAB:
             V1(a_colsum, N).add_(a.sum(0))
@@ -200,6 +200,8 @@ class EmuBackend:
             c.copy_(v)
         else:
             c += v
+        if found_inf is not None and not torch.isfinite(c).all():
+            found_inf[0] = 1.0
 
     def gemm_finalize(self, acc, nsplit, slab_stride, C, M, N, ldc, bias=None, rowvec=None, rv_ld=0, rv_rpg=0, rv_mod=0,
                       res=None, ldres=0, accumulate_f32=False, dtype=None, colsum_slabs=None, colsum_out=None, gn=None):
@@ -229,7 +231,9 @@ class EmuBackend:
                 gn_encode_add(stats, M // rows, N // cg, rows * cg, 0, xf.sum((1, 3)), (xf * xf).sum((1, 3)))
 
     def grad_finalize_batch(self, jobs):
-        for acc, nsplit, stride, dst, count, cs, co, store in jobs:
+        for job in jobs:
+            acc, nsplit, stride, dst, count, cs, co, store = job[:8]
+            found = job[8] if len(job) > 8 else None
             v = torch.zeros(count, device=acc.device)
             for z in range(nsplit):
                 v = v + torch.as_strided(acc, (count,), (1,), acc.storage_offset() + z * stride)
@@ -238,6 +242,8 @@ class EmuBackend:
                 d.copy_(v)
             else:
                 d.add_(v)
+            if found is not None and not torch.isfinite(d).all():
+                found[0] = 1.0
             if cs is not None:
                 n = co.numel()
                 V1(co, n).add_(V(cs, nsplit, n, n).sum(0))
@@ -592,6 +598,11 @@ class EmuBackend:
         if not torch.isfinite(V1(g, n)).all():
             opt_state[3] = 1.0
 
+    def check_finite_spans(self, g, spans, n_spans, opt_state):
+        for off, cnt in spans[:n_spans].view(-1, 2).tolist():
+            if not torch.isfinite(V1(g, off + cnt)[off:off + cnt]).all():
+                opt_state[3] = 1.0
+
     def optim_prep(self, st, beta1, beta2, growth, backoff, interval, dynamic):
         found = bool(st[3] > 0)
         inv = 1.0 / float(st[1])
@@ -615,6 +626,12 @@ class EmuBackend:
         kind = int(kind)
         if kind == 0:
             return 1.0
+        if kind == 6:
+            nr = min(int(st[10]), K.SCHED_MAX_RULES)
+            for i in range(nr):
+                if n < float(st[16 + 2 * i]):
+                    return float(st[17 + 2 * i])
+            return float(st[16 + 2 * nr])
         if kind == 5:
             if n < warm:
                 return n / max(1.0, warm)

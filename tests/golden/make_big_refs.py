@@ -21,6 +21,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 def main():
     os.environ["SVDX_SAVE_BIG_REF"] = "1"
     import e2e_checks
+    from oracle import unet as ou
+    ou.RECOMPUTE = True           # resnet / transformer modules under torch.utils.checkpoint: same values, a fraction of the memory
     want = sys.argv[1:] or ["L0"]
     for name, (C, heads, h, w) in e2e_checks.C4_LEVELS.items():
         if name.split()[0] not in want:

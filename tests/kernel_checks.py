@@ -199,7 +199,43 @@ def check_gemm_tn(P, dt, stages=0):
     o1, o2 = P.run("gemm_tn", lambda o: ((big[:, 128:], X, o["C"], 300, 128, 64, 384, 64, 64), dict(out_mode=K.OUT_F32, stages=stages)),
                    dict(C=torch.zeros(128, 64, device=P.dev)))
     res.append(("gemm_tn strided A", relerr(o1["C"], o2["C"]), tol_for(dt)))
+    # found_inf (GradScaler's inf check where the gradient is written): raised iff a value left in C is not finite, in the store and the
+    # += form, by an inf that sits in ONE element of one operand row; left alone by finite operands
+    for (R, N, Kd) in [(200, 320, 64), (130, 256, 384)]:
+        A, B = rnd((R, N), dt, P.dev, g), rnd((R, Kd), dt, P.dev, g, R ** -0.5)
+        Abad = A.clone()
+        Abad[R // 2, N // 3] = float("inf")
+        for mode in (K.OUT_F32, K.OUT_F32_ADD):
+            for bad, Aop in ((0.0, A), (1.0, Abad)):
+                flag = torch.zeros(4, device=P.dev)
+                P.impl.gemm_tn(Aop, B, torch.ones(N, Kd, device=P.dev), R, N, Kd, N, Kd, Kd, out_mode=mode, stages=stages, found_inf=flag[3:4])
+                if P.dev.type == "cuda":
+                    torch.cuda.synchronize()
+                res.append((f"gemm_tn s{stages} {R}x{N}x{Kd} mode={mode} found_inf with {'an inf' if bad else 'finite'} operand",
+                            abs(float(flag[3]) - bad) + float(flag[:3].abs().sum()), 0.0))
     if stages == 0:
+        # the same flag from the table-driven reduction, and svdx_check_finite_spans over a span table
+        slabs = rndf((3, 64, 128), P.dev, g)
+        slabs_bad = slabs.clone()
+        slabs_bad[1, 5, 77] = float("nan")
+        for bad, sl in ((0.0, slabs), (1.0, slabs_bad)):
+            for store in (True, False):
+                flag = torch.zeros(4, device=P.dev)
+                P.impl.grad_finalize_batch([(sl, 3, 64 * 128, torch.ones(64, 128, device=P.dev), 64 * 128, None, None, store, flag[3:4])])
+                if P.dev.type == "cuda":
+                    torch.cuda.synchronize()
+                res.append((f"grad_finalize_batch found_inf store={store} bad={bad}", abs(float(flag[3]) - bad) + float(flag[:3].abs().sum()), 0.0))
+        buf = rndf((9000,), P.dev, g)
+        spans = torch.tensor([[0, 64], [128, 4], [1000, 2048], [8996, 4]], dtype=torch.int32, device=P.dev)
+        for idx, want in ((70, 0.0), (130, 1.0), (3047, 1.0), (3048, 0.0), (8999, 1.0), (8990, 0.0)):
+            bb = buf.clone()
+            bb[idx] = float("-inf")
+            for be, tag in ((P.impl, "impl"), (P.ref, "emul")):
+                st = torch.zeros(16, device=P.dev)
+                be.check_finite_spans(bb, spans, 4, st)
+                if P.dev.type == "cuda":
+                    torch.cuda.synchronize()
+                res.append((f"check_finite_spans [{tag}] inf at {idx}", abs(float(st[3]) - want) + float(st[:3].abs().sum()), 0.0))
         # table-driven float finalize (svdx_grad_finalize_batch): store and accumulate forms, with and without bias-gradient slabs,
         # bit-compared with one svdx_gemm_finalize launch each on the implementation under test
         g2 = torch.Generator().manual_seed(77)
@@ -767,12 +803,13 @@ def check_optim(P, dt):
     # (found_inf, schedule slots 9..15: kind, warmup, total, cycles, power, lr_end ratio, scheduler steps per step)
     cases = [(False, [0, 0, 0, 0, 0, 0, 0]), (True, [0, 0, 0, 0, 0, 0, 0]), (False, [1, 10, 0, 0, 0, 0, 1]), (False, [2, 2, 40, 0, 0, 0, 2]),
              (False, [3, 1, 20, 0.5, 0, 0, 1]), (False, [4, 1, 20, 3, 0, 0, 2]), (False, [5, 2, 30, 0, 2.0, 1e-2, 1]),
-             (False, [5, 1, 2, 0, 1.0, 1e-2, 1])]
+             (False, [5, 1, 2, 0, 1.0, 1e-2, 1]),
+             (False, [6, 2, 0, 0, 0, 0, 1]), (False, [6, 2, 0, 0, 0, 0, 4])]     # piecewise_constant: 2 rules behind the state (boundaries 2 and 11)
     for found, sched in cases:
         gg = gr.clone()
         if found:
             gg[1234] = float("inf")
-        st0 = torch.tensor([3, 1024.0, 5, 0, 1, 1, 1, 0, 1.0] + sched, dtype=torch.float32, device=P.dev)
+        st0 = torch.tensor([3, 1024.0, 5, 0, 1, 1, 1, 0, 1.0] + sched + [2.0, 0.7, 11.0, 0.3, 0.05] + [0.0] * 19, dtype=torch.float32, device=P.dev)
         outs = dict(st=st0, p=p.clone(), m=m.clone(), v=v.clone(), pa=torch.zeros(n, dtype=dt, device=P.dev))
 
         def seq(be, o):

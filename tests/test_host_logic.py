@@ -501,3 +501,34 @@ def test_trajectory_check_sees_a_zeroed_gradient(emu_backend, monkeypatch):
     r = e2e_checks.trajectory_vs_oracle(TINY_CONFIG, (1, 3, 16, 16), dtype=torch.float32, steps=3, lr=1e-3, dev=CPU)
     assert max(r["loss_rel"][:1]) < 2e-5, r            # the first loss is blind to it ...
     assert r["update_cos_min"] < 0.9, r                # ... the updates are not
+
+
+def test_folded_inf_check_equals_the_full_pass(emu_backend):
+    """GradScaler's inf check where the gradients are written (Runtime.fold_finite: svdx_gemm_tn / svdx_grad_finalize_batch raise
+    opt_state[3], svdx_check_finite_spans covers the accumulated slots) against the 1.59 GB pass of svdx_check_finite: a loss scale that
+    overflows fp16 in the backward sweep must skip the step and halve the scale in both forms, a sane one must step in both, and the two
+    trajectories must be the same bits."""
+    batch = make_synthetic_batch(1, 3, 16, 16, 7, cross_dim=64)
+    unet_in, ts, ehs, ids, noisy, _ = edm_inputs(batch)
+    b = dict(unet_in=unet_in, timesteps=ts, ehs=ehs, added_time_ids=ids, noisy_latents=noisy, target=batch["latents"], sigmas=batch["sigmas"])
+    out = {}
+    for fold in (True, False):
+        _, m = build_pair(4)
+        tr = Trainer(m, dtype=torch.float16, lr=1e-3, init_scale=2.0 ** 30)
+        tr.rt.fold_finite = fold
+        assert tr.rt.found_inf is not None and tr.finite_spans is not None
+        k, names = tr.rt.k, []
+        for nm in ("check_finite", "check_finite_spans"):
+            setattr(k, nm, (lambda f, nm: lambda *a, **kw: (names.append("svdx_" + nm), f(*a, **kw))[1])(getattr(k, nm), nm))
+        states = []
+        for _ in range(8):                      # 2^30 overflows; the scale halves until the sweep is finite, then the steps are taken
+            tr.step(b)
+            states.append((float(tr.opt_state[0]), float(tr.opt_state[1])))
+        for nm in ("check_finite", "check_finite_spans"):
+            k.__dict__.pop(nm, None)
+        assert ("svdx_check_finite_spans" in names) == fold and ("svdx_check_finite" in names) == (not fold)
+        out[fold] = (states, tr.p_flat.clone())
+    assert out[True][0] == out[False][0], (out[True][0], out[False][0])
+    assert out[True][0][0][0] == 0.0 and out[True][0][0][1] == 2.0 ** 29          # the first step was skipped, the scale halved
+    assert out[True][0][-1][0] >= 1.0                                            # ... and steps were taken once the sweep was finite
+    assert torch.equal(out[True][1], out[False][1])

@@ -127,3 +127,19 @@ def test_chunked_attention_equals_the_explicit_form(monkeypatch):
         assert torch.allclose(gx0, gx1, rtol=1e-10, atol=1e-12)
         for a, b in zip(gp0, gp1):
             assert torch.allclose(a, b, rtol=1e-10, atol=1e-12)
+
+
+def test_recompute_mode_changes_nothing(monkeypatch):
+    """oracle.unet.RECOMPUTE (torch.utils.checkpoint around every resnet / transformer module, used for the cached references of config 4's
+    upper levels) against the default mode: loss, prediction and every gradient of one seeded step, bit for bit."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import e2e_checks
+    from oracle import unet as ou
+    a = e2e_checks.oracle_step(TINY_CONFIG, 1, 3, 16, 16, seed=3, lr=1e-4, cross_dim=TINY_CONFIG["cross_attention_dim"], with_pred_after=False)
+    monkeypatch.setattr(ou, "RECOMPUTE", True)
+    b = e2e_checks.oracle_step(TINY_CONFIG, 1, 3, 16, 16, seed=3, lr=1e-4, cross_dim=TINY_CONFIG["cross_attention_dim"], with_pred_after=False)
+    assert a["loss"] == b["loss"] and torch.equal(a["pred"], b["pred"])
+    assert sorted(a["grads"]) == sorted(b["grads"]) and all(torch.equal(a["grads"][n], b["grads"][n]) for n in a["grads"])

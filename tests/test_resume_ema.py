@@ -104,12 +104,39 @@ def test_get_scheduler_argument_errors(emu_backend):
         get_scheduler("cosine", optimizer=tr, num_warmup_steps=1)
     with pytest.raises(ValueError):
         get_scheduler("no_such_schedule", optimizer=tr)
-    with pytest.raises(NotImplementedError):
-        get_scheduler("piecewise_constant", optimizer=tr, step_rules="1:10,0.1")
+    with pytest.raises(ValueError, match="requires `step_rules`"):
+        get_scheduler("piecewise_constant", optimizer=tr)
+    with pytest.raises(ValueError, match="at most 8"):
+        get_scheduler("piecewise_constant", optimizer=tr, step_rules=",".join(f"1:{i}" for i in range(1, 11)) + ",0.5")
     with pytest.raises(TypeError):
         get_scheduler("constant", optimizer=torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1))
     s = get_scheduler("constant", optimizer=tr)                 # the reference's default (--lr_scheduler constant)
     assert s.get_last_lr() == [1e-3] and float(tr.opt_state[9]) == 0.0
+
+
+def test_piecewise_constant_schedule_on_device(emu_backend):
+    """diffusers' get_piecewise_constant_schedule (train_svd.py:807-812 passes --lr_scheduler through): the rule string of its docstring,
+    evaluated by svdx_optim_prep from the rules stored behind the 16 state floats, against the rule restated here -- with num_processes
+    scheduler steps per optimizer step and a skipped step that must not advance it."""
+    tr = Trainer(build(0), dtype=torch.float16, lr=1e-3, init_scale=256.0)
+    sched = get_scheduler("piecewise_constant", optimizer=tr, step_rules="1:10,0.1:20,0.01:30,0.005", steps_per_step=3)
+
+    def rule(n):
+        return 1.0 if n < 10 else 0.1 if n < 20 else 0.01 if n < 30 else 0.005
+    k, n = tr.rt.k, 0
+    for i in range(14):
+        skip = i == 5
+        assert abs(sched.get_last_lr()[0] - 1e-3 * rule(n)) <= 1e-12, i
+        tr.g_flat.zero_()
+        if skip:
+            tr.g_flat[3] = float("inf")
+        k.check_finite(tr.g_flat, tr.n_flat, tr.opt_state)
+        k.optim_prep(tr.opt_state, 0.9, 0.999, 2.0, 0.5, 2000, 1)
+        if not skip:
+            assert abs(float(tr.opt_state[8]) - rule(n)) <= 1e-7, (i, n)
+            n += 3
+        sched.step()
+    assert sched.last_epoch == 13 * 3
 
 
 def test_scheduled_step_moves_weights_by_scheduled_lr(emu_backend):

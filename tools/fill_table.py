@@ -22,8 +22,24 @@ class _RT:
 
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "gemm_table.json")
+    if not os.path.exists(path):
+        # no fresh table on this machine: the tracked per-call join of the latest profiled step (tools/step_trace.py) holds the same columns
+        import glob
+        import re
+        traces = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_trace.txt")))
+        if not traces:
+            raise SystemExit(f"{path} not found and no profiles/r*_step_trace.txt: run `python bench.py --gemm-table --steps 20 --no-cpu-baseline` on the GPU box")
+        path = traces[-1]
+        print(f"# reading {os.path.relpath(path, ROOT)} (no gpurun_out/gemm_table.json here)")
+        table = []
+        for line in open(path):
+            m = re.match(r"(nt|tn)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\(.*?\)|0)\s+(\d+)\s+\d+\s+\d \d \d \d\s+\d+\s+(\d+)\s+([\d.]+)\s+[\d.]+\s+([\d.]+)", line)
+            if m:
+                table.append([m[1], int(m[2]), int(m[3]), int(m[4]), m[5], int(m[6]), int(m[7]), float(m[8]) / 1e3, float(m[9])])
+    else:
+        table = json.load(open(path))
     rows = []
-    for kind, M, N, Kd, _gather, _spl, n, ms, tf in json.load(open(path)):
+    for kind, M, N, Kd, _gather, _spl, n, ms, tf in table:
         if kind != "nt":
             continue
         s, v = ops.choose_cfg(_RT(), M, N, Kd, N, 0)
