@@ -271,8 +271,8 @@ def main(argv=None):
                 print(f"Saved state to {save_path}", flush=True)
             if global_step % args.validation_steps == 0 or global_step == 1:     # :1092-1096
                 validate(global_step)
-        if world > 1:
-            dist.barrier()
+    if world > 1:
+        dist.barrier()                                    # accelerator.wait_for_everyone(), :1167
     if is_main:                                           # :1171-1187: the final pipeline folder
         if args.use_ema:
             ema_unet.copy_to(unet.parameters())

@@ -116,6 +116,8 @@ class DirectAllReduce:
                     continue
                 if dev_q >= torch.cuda.device_count():
                     raise RuntimeError(f"rank {q} holds GPU {dev_q}, which this process cannot see ({torch.cuda.device_count()} visible)")
+                if dev_q != buf.device.index and not torch.cuda.can_device_access_peer(buf.device.index, dev_q):
+                    raise RuntimeError(f"GPU {buf.device.index} has no peer access to GPU {dev_q}")
                 t = f(*a)                                        # the peer's buffer, mapped (a tensor on ITS device)
                 if t.numel() != self.n:
                     raise RuntimeError("ranks hold buffers of different sizes")
