@@ -163,7 +163,10 @@ __global__ void bicubic_affine_kernel(const float* __restrict__ in, float* __res
 // qkv rows [n*S, ld]: head h of q at column h*dp, of k at (heads + h)*dp, of v at (2 heads + h)*dp; d <= dp real channels (the rest of
 // a head's dp columns is padding).  Block = (32 queries, head, image): K and V of the head live in LDS; a wave takes 8 queries, its
 // lanes split the keys for the scores and the channels for the output.  10 GFLOP over the whole tower: VALU work, latency-shaped.
-constexpr int AS_QT = 32, AS_MAXS = 384, AS_MAXD = 128;
+// Round 5: 16 queries per block instead of 32 (the CLIP tower's one image x 16 heads x 257 tokens is 272 blocks = one round of the chip
+// instead of 144 blocks on 256 CUs, each wave walking 4 queries instead of 8) and the P.V loop four keys at a time on independent
+// accumulators: the launch was 244 us of dependent LDS round trips, 32 of them per clip = a quarter of the frozen conditioners' time.
+constexpr int AS_QT = 16, AS_MAXS = 384, AS_MAXD = 128;
 template <typename T>
 __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int S, int heads, int d, int dp,
                                                              long ld, long ld_o, float sl2) {
@@ -235,12 +238,27 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const T* __restrict
         __builtin_amdgcn_wave_barrier();
         // output channels lane and lane + 64
         float o0 = 0.f, o1 = 0.f;
-        const bool two = lane + 64 < dr;
-        for (int k = 0; k < S; ++k) {
-            const float pk = P[k];
-            const T* vr = reinterpret_cast<const T*>(Vs + k * pitch);
-            if (lane < dr) o0 += pk * to_f<T>(vr[lane]);
-            if (two) o1 += pk * to_f<T>(vr[lane + 64]);
+        const bool one = lane < dr, two = lane + 64 < dr;
+        {
+            float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+            int k = 0;
+            for (; k + 4 <= S; k += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float pk = P[k + u];
+                    const T* vr = reinterpret_cast<const T*>(Vs + (k + u) * pitch);
+                    if (one) a0[u] += pk * to_f<T>(vr[lane]);
+                    if (two) a1[u] += pk * to_f<T>(vr[lane + 64]);
+                }
+            }
+            for (; k < S; ++k) {
+                const float pk = P[k];
+                const T* vr = reinterpret_cast<const T*>(Vs + k * pitch);
+                if (one) a0[0] += pk * to_f<T>(vr[lane]);
+                if (two) a1[0] += pk * to_f<T>(vr[lane + 64]);
+            }
+            o0 = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+            o1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
         }
         T* op = out + ((size_t)n * S + q) * ld_o + h * dp;
         for (int c = lane; c < dp; c += 64) op[c] = from_f<T>(c < d ? (c < 64 ? o0 : o1) : 0.f);     // padding channels of the head: zeros

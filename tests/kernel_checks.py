@@ -637,7 +637,7 @@ def check_tsa(P, dt):
 
 
 def check_encoders(P, dt):
-    """svdx_patch_rows / svdx_softmax_rows / svdx_act_rows (csrc/encoders.hip) and the pad-0 stride-2 gather of the VAE downsample."""
+    """svdx_patch_rows / svdx_softmax_rows / svdx_act_rows / svdx_attn_small_fwd (csrc/encoders.hip) and the pad-0 stride-2 gather of the VAE downsample."""
     g = torch.Generator().manual_seed(18)
     res = []
     for (n, C, H, W, kh, st, pad, ldk) in [(2, 3, 16, 24, 3, 1, 1, 64), (1, 3, 28, 42, 14, 14, 0, 640), (3, 3, 9, 7, 3, 1, 1, 32)]:
@@ -655,6 +655,12 @@ def check_encoders(P, dt):
     for act in (0, 1):
         o1, o2 = P.run("act_rows", lambda o: ((x, o["y"], x.numel(), act), {}), dict(y=torch.zeros_like(x)))
         res.append((f"act_rows act={act}", relerr(o1["y"], o2["y"]), tol_for(dt)))
+    # the CLIP tower's attention (257 tokens, heads of 80 channels) and ragged shapes either side of its 16-query blocks / 4-key P.V groups
+    for (n, S, heads, d) in [(1, 257, 2, 80), (2, 37, 3, 64), (1, 5, 1, 128), (1, 66, 2, 16)]:
+        qkv = rnd((n * S, 3 * heads * d), dt, P.dev, g, 1.5)
+        o1, o2 = P.run("attn_small_fwd", lambda o: ((qkv, o["y"], n, S, heads, d, d, 3 * heads * d, heads * d, d ** -0.5), {}),
+                       dict(y=torch.ones(n * S, heads * d, dtype=dt, device=P.dev)))
+        res.append((f"attn_small_fwd n={n} S={S} heads={heads} d={d}", relerr(o1["y"], o2["y"]), tol_for(dt)))
     # Downsample2D(padding=0): stride 2 over F.pad(x, (0, 1, 0, 1))
     for (n, h, w, cin, cout) in [(2, 8, 12, 64, 64), (1, 6, 6, 128, 192)]:
         ho, wo = h // 2, w // 2
