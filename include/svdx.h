@@ -334,7 +334,7 @@ int svdx_bicubic_affine(const float* in, float* out, int n_img, int C, int H, in
 /* Self-attention over a short sequence with any head dimension (CLIP ViT-H/14: 257 tokens, 16 heads of 80; transformers
  * CLIPAttention reached from train_svd.py:875).  qkv rows [n_img*S, ld]; head h: q at column h*dp, k at (heads + h)*dp, v at
  * (2*heads + h)*dp, d real channels out of the dp the packed projection gives every head; out rows [n_img*S, ld_o], head h at h*dp
- * (channels d..dp written as zeros).  S <= 384, dp <= 128. */
+ * (channels d..dp written as zeros).  Any S; dp <= 128, dp % 8 == 0; matrix-pipe kernel (key tiles of 64 through LDS). */
 int svdx_attn_small_fwd(const void* qkv, void* out, int n_img, int S, int heads, int d, int dp, int64_t ld, int64_t ld_o, float scale,
                         int dtype, void* stream);
 /* base[off .. off+cnt) = 0 for each (off, cnt) pair of `spans` (int pairs; off and cnt multiples of 4): ONE launch for the scattered

@@ -159,110 +159,128 @@ __global__ void bicubic_affine_kernel(const float* __restrict__ in, float* __res
     }
 }
 
-// ---- self-attention of a short sequence with an arbitrary head dimension (CLIP ViT-H: 257 tokens, 16 heads of 80) ----------------
+// ---- self-attention of a short sequence whose head dimension is not 64 (CLIP ViT-H: 257 tokens, 16 heads of 80) ------------------
 // qkv rows [n*S, ld]: head h of q at column h*dp, of k at (heads + h)*dp, of v at (2 heads + h)*dp; d <= dp real channels (the rest of
-// a head's dp columns is padding).  Block = (32 queries, head, image): K and V of the head live in LDS; a wave takes 8 queries, its
-// lanes split the keys for the scores and the channels for the output.  10 GFLOP over the whole tower: VALU work, latency-shaped.
-// Round 5: 16 queries per block instead of 32 (the CLIP tower's one image x 16 heads x 257 tokens is 272 blocks = one round of the chip
-// instead of 144 blocks on 256 CUs, each wave walking 4 queries instead of 8) and the P.V loop four keys at a time on independent
-// accumulators: the launch was 244 us of dependent LDS round trips, 32 of them per clip = a quarter of the frozen conditioners' time.
-constexpr int AS_QT = 16, AS_MAXS = 384, AS_MAXD = 128;
+// a head's dp columns is padding and is written as zeros).  Block = (64 queries, head, image), one wave per 16 queries; key tiles of 64
+// rows go through LDS (rows padded by 16 B: conflict-free for both read shapes), channels beyond d staged as zeros up to the next
+// multiple of 32.  The arithmetic is csrc/attention.hip's: S^T = K Q^T on the matrix pipe, online softmax per query column, P^T packed
+// straight from the accumulators as the B operand of O^T += V^T P^T, V^T fragments by the transposing LDS read.
+// Round 5: replaces the VALU form (one query per wave at a time, 244 us per launch, a quarter of the frozen conditioners' time).
+constexpr int AS_MAXD = 128, AS_KT = 64, AS_MAXPITCH = (AS_MAXD / 8) * 16 + 16;
+template <typename T>
+__device__ __forceinline__ typename TT<T>::v8 as_frag_tr(const char* lds, int pitch, int db, int pb0, int pb1, int fr, int fg) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const int u = db * 4 + (fr & 3);                 // 8-byte unit of the row: channels u*4 .. u*4+3
+    const int r0 = pb0 * 16 + fg * 4 + (fr >> 2), r1 = pb1 * 16 + fg * 4 + (fr >> 2);
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(lds + r0 * pitch + u * 8));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(lds + r1 * pitch + u * 8));
+    const v8s r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(typename TT<T>::v8, r);
+}
 template <typename T>
 __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int S, int heads, int d, int dp,
                                                              long ld, long ld_o, float sl2) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int dr = (d + 7) / 8 * 8;                 // staged channels per row (multiple of 8)
-    const int pitch = (dr + 8) * 2;                 // bytes; +16 B keeps 16-byte row reads of consecutive keys on distinct banks
+    typedef typename TT<T>::v8 v8;
+    __shared__ __attribute__((aligned(16))) char smem[2 * AS_KT * AS_MAXPITCH];
+    const int nk = (d + 31) / 32, nd = (d + 15) / 16;      // 32-channel steps of the scores, 16-channel blocks of the output
+    const int dc = nk * 4, c8 = (d + 7) / 8;               // staged / real 16-byte chunks per row
+    const int pitch = dc * 16 + 16;
     char* Ks = smem;
-    char* Vs = smem + (size_t)S * pitch;
-    float* Pw = reinterpret_cast<float*>(smem + 2 * (size_t)S * pitch);      // [4 waves][AS_MAXS]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.y, n = blockIdx.z, q0 = blockIdx.x * AS_QT;
+    char* Vs = smem + AS_KT * pitch;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y, n = blockIdx.z, q0 = blockIdx.x * 64 + wave * 16;
     const T* base = qkv + (size_t)n * S * ld;
-    const int c8 = dr / 8;
-    for (int i = tid; i < S * c8; i += 256) {
-        const int r = i / c8, c = i - r * c8;
-        *reinterpret_cast<uint4*>(Ks + r * pitch + c * 16) = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + (heads + h) * dp + c * 8);
-        *reinterpret_cast<uint4*>(Vs + r * pitch + c * 16) = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + (2 * heads + h) * dp + c * 8);
+    const uint4 zero4 = {0u, 0u, 0u, 0u};
+
+    v8 qf[AS_MAXD / 32];
+#pragma unroll
+    for (int ks = 0; ks < AS_MAXD / 32; ++ks) {
+        const int c = ks * 4 + fg;
+        const uint4 v = (ks < nk && c < c8) ? *reinterpret_cast<const uint4*>(base + (size_t)min(q0 + fr, S - 1) * ld + h * dp + c * 8) : zero4;
+        qf[ks] = __builtin_bit_cast(v8, v);
     }
-    __syncthreads();
-    float* P = Pw + wave * AS_MAXS;
-    for (int qi = 0; qi < AS_QT / 4; ++qi) {
-        const int q = q0 + wave * (AS_QT / 4) + qi;
-        if (q >= S) break;                                           // wave-uniform
-        float qv[AS_MAXD];
+    f32x4 oacc[AS_MAXD / 16];
 #pragma unroll
-        for (int c = 0; c < AS_MAXD / 8; ++c) {
-            if (c < c8) {
-                float t8[8];
-                load8<T>(base + (size_t)q * ld + h * dp + c * 8, t8);        // same address in every lane: one broadcast transaction
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qv[c * 8 + e] = t8[e];
-            }
+    for (int i = 0; i < AS_MAXD / 16; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrow = -1e30f, lrow = 0.f;
+
+    const int ntiles = (S + AS_KT - 1) / AS_KT;
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        for (int i = tid; i < AS_KT * dc; i += 256) {
+            const int r = i / dc, c = i - r * dc;
+            const T* row = base + (size_t)min(t * AS_KT + r, S - 1) * ld + h * dp + c * 8;
+            const bool real = c < c8;
+            *reinterpret_cast<uint4*>(Ks + r * pitch + c * 16) = real ? *reinterpret_cast<const uint4*>(row + (size_t)heads * dp) : zero4;
+            *reinterpret_cast<uint4*>(Vs + r * pitch + c * 16) = real ? *reinterpret_cast<const uint4*>(row + (size_t)2 * heads * dp) : zero4;
         }
-        float sc[AS_MAXS / 64];
+        __syncthreads();
+        f32x4 s[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < AS_MAXD / 32; ++ks)
+            if (ks < nk) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const v8 kf = *reinterpret_cast<const v8*>(Ks + (kb * 16 + fr) * pitch + (ks * 4 + fg) * 16);
+                    s[kb] = TT<T>::mfma(kf, qf[ks], s[kb]);            // S^T[key kb*16 + fg*4 + r][query fr]
+                }
+            }
         float mx = -1e30f;
 #pragma unroll
-        for (int j = 0; j < AS_MAXS / 64; ++j) {
-            const int ki = lane + 64 * j;
-            float a = -1e30f;
-            if (ki < S) {
-                a = 0.f;
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int c = 0; c < AS_MAXD / 8; ++c) {
-                    if (c < c8) {
-                        float k8[8];
-                        load8<T>(reinterpret_cast<const T*>(Ks + ki * pitch + c * 16), k8);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) a += qv[c * 8 + e] * k8[e];
-                    }
-                }
-                a *= sl2;
+            for (int r = 0; r < 4; ++r) {
+                if (t * AS_KT + kb * 16 + fg * 4 + r >= S) s[kb][r] = -1e30f;
+                mx = fmaxf(mx, s[kb][r]);
             }
-            sc[j] = a;
-            mx = fmaxf(mx, a);
-        }
-        mx = wave_max(mx);
-        float sum = 0.f;
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(mrow, fmaxf(mx * sl2, -1e30f));
+        const float alpha = __builtin_amdgcn_exp2f(mrow - mn);
+        mrow = mn;
+        lrow *= alpha;
 #pragma unroll
-        for (int j = 0; j < AS_MAXS / 64; ++j) {
-            const float pv = (lane + 64 * j) < S ? __builtin_amdgcn_exp2f(sc[j] - mx) : 0.f;
-            sc[j] = pv;
-            sum += pv;
-        }
-        const float inv = 1.f / wave_sum(sum);
+        for (int db = 0; db < AS_MAXD / 16; ++db) oacc[db] *= alpha;
 #pragma unroll
-        for (int j = 0; j < AS_MAXS / 64; ++j)
-            if (lane + 64 * j < S) P[lane + 64 * j] = sc[j] * inv;
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        // output channels lane and lane + 64
-        float o0 = 0.f, o1 = 0.f;
-        const bool one = lane < dr, two = lane + 64 < dr;
-        {
-            float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
-            int k = 0;
-            for (; k + 4 <= S; k += 4) {
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float pk = P[k + u];
-                    const T* vr = reinterpret_cast<const T*>(Vs + (k + u) * pitch);
-                    if (one) a0[u] += pk * to_f<T>(vr[lane]);
-                    if (two) a1[u] += pk * to_f<T>(vr[lane + 64]);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const float pr = __builtin_amdgcn_exp2f(s[kb][r] * sl2 - mn);
+                s[kb][r] = pr;
+                lrow += pr;
             }
-            for (; k < S; ++k) {
-                const float pk = P[k];
-                const T* vr = reinterpret_cast<const T*>(Vs + k * pitch);
-                if (one) a0[0] += pk * to_f<T>(vr[lane]);
-                if (two) a1[0] += pk * to_f<T>(vr[lane + 64]);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            v8 pf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pf[e] = from_f<T>(s[2 * k2][e]);
+                pf[4 + e] = from_f<T>(s[2 * k2 + 1][e]);
             }
-            o0 = (a0[0] + a0[1]) + (a0[2] + a0[3]);
-            o1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+#pragma unroll
+            for (int db = 0; db < AS_MAXD / 16; ++db)
+                if (db < nd) oacc[db] = TT<T>::mfma(as_frag_tr<T>(Vs, pitch, db, 2 * k2, 2 * k2 + 1, fr, fg), pf, oacc[db]);   // O^T[channel][query fr]
         }
+    }
+    lrow += __shfl_xor(lrow, 16, 64);
+    lrow += __shfl_xor(lrow, 32, 64);
+    const int q = q0 + fr;
+    if (q < S) {
+        const float inv = 1.f / lrow;
         T* op = out + ((size_t)n * S + q) * ld_o + h * dp;
-        for (int c = lane; c < dp; c += 64) op[c] = from_f<T>(c < d ? (c < 64 ? o0 : o1) : 0.f);     // padding channels of the head: zeros
-        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int db = 0; db < AS_MAXD / 16; ++db) {
+            const int c0 = db * 16 + fg * 4;
+            if (c0 < dp) {                                               // dp % 8 == 0: the four channels are all inside the head's columns
+                Vec4<T> o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o.v[r] = from_f<T>(c0 + r < d ? oacc[db][r] * inv : 0.f);     // padding channels: zeros
+                *reinterpret_cast<Vec4<T>*>(op + c0) = o;
+            }
+        }
     }
 }
 
@@ -323,20 +341,14 @@ extern "C" int svdx_bicubic_affine(const float* in, float* out, int n_img, int C
 
 extern "C" int svdx_attn_small_fwd(const void* qkv, void* out, int n_img, int S, int heads, int d, int dp, int64_t ld, int64_t ld_o, float scale,
                                    int dtype, void* stream) {
-    SVDX_CHECK_ARG(qkv && out && n_img > 0 && S > 0 && S <= AS_MAXS && heads > 0 && d > 0 && d <= dp && dp <= AS_MAXD && dp % 8 == 0,
-                   "svdx_attn_small_fwd: needs S <= %d, d <= dp <= %d, dp %% 8 == 0 (got S=%d d=%d dp=%d)", AS_MAXS, AS_MAXD, S, d, dp);
-    SVDX_CHECK_ARG(ld % 8 == 0 && ld >= 3L * heads * dp && ld_o >= (long)heads * dp && (((uintptr_t)qkv) & 15) == 0, "svdx_attn_small_fwd: alignment");
-    const int dr = (d + 7) / 8 * 8;
-    const size_t lds = 2 * (size_t)S * (dr + 8) * 2 + 4 * AS_MAXS * sizeof(float);
-    SVDX_CHECK_ARG(lds <= 160 * 1024, "svdx_attn_small_fwd: K/V of one head do not fit LDS");
-    dim3 grid((S + AS_QT - 1) / AS_QT, heads, n_img);
+    SVDX_CHECK_ARG(qkv && out && n_img > 0 && S > 0 && heads > 0 && d > 0 && d <= dp && dp <= AS_MAXD && dp % 8 == 0,
+                   "svdx_attn_small_fwd: needs d <= dp <= %d, dp %% 8 == 0 (got S=%d d=%d dp=%d)", AS_MAXD, S, d, dp);
+    SVDX_CHECK_ARG(ld % 8 == 0 && ld >= 3L * heads * dp && ld_o % 4 == 0 && ld_o >= (long)heads * dp && (((uintptr_t)qkv) & 15) == 0 &&
+                   (((uintptr_t)out) & 7) == 0, "svdx_attn_small_fwd: alignment");
+    SVDX_CHECK_ARG(heads <= 65535 && n_img <= 65535, "svdx_attn_small_fwd: grid");
+    dim3 grid((S + 63) / 64, heads, n_img);
     DISPATCH_DTYPE(dtype, {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((attn_small_fwd_kernel<T>), grid, dim3(256), lds, (hipStream_t)stream, (const T*)qkv, (T*)out, S, heads, d, dp,
+        hipLaunchKernelGGL((attn_small_fwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)qkv, (T*)out, S, heads, d, dp,
                            (long)ld, (long)ld_o, scale * 1.4426950408889634f);
     });
     SVDX_LAUNCH_CHECK("svdx_attn_small_fwd");

@@ -463,8 +463,23 @@ def fuzz_gradfin(P, dt, rng, g):
     return f"gradfin {len(jobs)} jobs", (e if same else float("inf")), 1e-5
 
 
+def fuzz_attn_small(P, dt, rng, g):
+    """svdx_attn_small_fwd: any head dimension up to 128 (real channels d inside dp packed columns), any S, wide rows either side."""
+    n, heads, S = rng.randint(1, 2), rng.randint(1, 3), pick_dim(rng, 1, 300)
+    dp = 8 * rng.randint(1, 16)
+    d = dp if rng.random() < 0.6 else rng.randint(max(1, dp - 7), dp)
+    ld, ld_o = 3 * heads * dp + 8 * rng.randint(0, 2), heads * dp + 4 * rng.randint(0, 2)
+    qkv = kc.rnd((n * S, ld), dt, P.dev, g, rng.choice((0.5, 1.5, 3.0)))
+    if d < dp:                                   # the padding columns of every head hold zeros (what the packed projection produces)
+        cols = torch.arange(3 * heads * dp) % dp >= d
+        qkv[:, :3 * heads * dp][:, cols] = 0
+    o1, o2 = P.run("attn_small_fwd", lambda o: ((qkv, o["y"], n, S, heads, d, dp, ld, ld_o, d ** -0.5), {}),
+                   dict(y=torch.ones(n * S, ld_o, dtype=dt, device=P.dev)))
+    return f"attn_small n={n} heads={heads} S={S} d={d} dp={dp} ld={ld} ld_o={ld_o}", kc.relerr(o1["y"], o2["y"]), kc.tol_for(dt)
+
+
 FAMILIES = {"gemm": fuzz_gemm, "gemm_gn": fuzz_gemm_gn, "gradfin": fuzz_gradfin, "gather": fuzz_gather, "tn": fuzz_tn, "geglu": fuzz_geglu, "norm": fuzz_norm, "lnbwd": fuzz_lnbwd,
-            "attn": fuzz_attn, "tattn": fuzz_tattn, "tsa": fuzz_tsa, "small": fuzz_small, "batch": fuzz_batch, "rows": fuzz_rows, "optim": fuzz_optim}
+            "attn": fuzz_attn, "attn_small": fuzz_attn_small, "tattn": fuzz_tattn, "tsa": fuzz_tsa, "small": fuzz_small, "batch": fuzz_batch, "rows": fuzz_rows, "optim": fuzz_optim}
 
 
 def run(P, dt, families, n, seed, verbose=True):
