@@ -389,10 +389,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # developer knobs (single-GPU rehearsal of the multi-rank path: all ranks on one device over gloo; RCCL refuses that)
     backend = os.environ.get("SVDX_DIST_BACKEND", "nccl")
-    if os.environ.get("SVDX_BENCH_DEVICE") is not None:
-        local_rank = int(os.environ["SVDX_BENCH_DEVICE"])
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if os.environ.get("SVDX_BENCH_DEVICE") == "cpu":
+        # host-logic rehearsal without a GPU (tests/bench_cpu_harness.py: the kernel emulation of the test suite is installed as the backend
+        # first; without that, kernels.backend() raises as everywhere -- this is not a CPU mode of the product)
+        dev = torch.device("cpu")
+    else:
+        if os.environ.get("SVDX_BENCH_DEVICE") is not None:
+            local_rank = int(os.environ["SVDX_BENCH_DEVICE"])
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
