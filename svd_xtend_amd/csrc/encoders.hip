@@ -5,8 +5,9 @@
 //   * patch_rows     -- im2col of a FEW-channel image (cin = 3) into GEMM rows: the VAE's conv_in (3x3, pad 1) and CLIP's patch
 //                       embedding (14x14, stride 14).  K = cin*kh*kw is zero-padded to the GEMM's K granule; 27 -> 64 costs 2.4x the
 //                       MFMA work of the real 27 instead of the 21x of padding the CHANNELS to 64.
-//   * softmax_rows   -- row softmax (fp32 inside) between the two plain GEMMs of an attention whose head dimension is not 64:
-//                       the VAE mid-block's single head of 512 over 2560 tokens, CLIP ViT-H's heads of 80 over 257 tokens.
+//   * softmax_rows   -- row softmax (fp32 inside) between the two plain GEMMs of an attention whose head dimension is not 64 and
+//                       too wide for one fused kernel: the VAE mid-block's single head of 512 over 2560 tokens.
+//   * attn_small_fwd -- fused attention on the matrix pipe for heads of up to 128 channels: CLIP ViT-H's heads of 80 over 257 tokens.
 //   * gelu_rows      -- bias-free exact-erf GELU (the GEMM epilogue already added the bias), CLIP's MLP activation.
 #include "common.h"
 
