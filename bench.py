@@ -171,11 +171,12 @@ def cpu_baseline(dev=None, dtype=torch.float16, c2=True):
     import statistics
 
     from oracle.step import edm_inputs, make_optimizer, make_synthetic_batch, train_step
-    from oracle.unet import SVD_CONFIG, UNetSpatioTemporalConditionOracle, scaled_init_
+    from oracle.unet import SVD_CONFIG, UNetSpatioTemporalConditionOracle, no_default_init, scaled_init_
     torch.manual_seed(0)
     cores = torch.get_num_threads()
     t0 = time.time()
-    orc = UNetSpatioTemporalConditionOracle(**SVD_CONFIG)
+    with no_default_init():                         # scaled_init_ fills every parameter: skip 1.52 B kaiming draws on one core
+        orc = UNetSpatioTemporalConditionOracle(**SVD_CONFIG)
     scaled_init_(orc, 0)                            # O(1) activations through all 4 levels: the prediction matters in the loss
     opt = make_optimizer(orc, lr=0.0)               # lr 0: the timed steps do the full AdamW arithmetic but leave the weights where
     batch = make_synthetic_batch(1, 8, 24, 32, 1)   # the HIP model copied them, so every step is the same step

@@ -26,6 +26,7 @@ Module / parameter names are exactly diffusers' so `state_dict()` keys match a r
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from types import SimpleNamespace
 from typing import Optional, Sequence
@@ -694,6 +695,22 @@ class UNetSpatioTemporalConditionOracle(nn.Module):
         if not return_dict:
             return (sample,)
         return SimpleNamespace(sample=sample)
+
+
+@contextlib.contextmanager
+def no_default_init():
+    """Model construction without PyTorch's default weight init.  `nn.Linear` / `nn.Conv*d` draw kaiming_uniform_ weights in their
+    constructors -- one core, ~30 s for the 1.52 B-parameter topology -- which every caller here overwrites at once (`scaled_init_`,
+    `load_state_dict(strict=True)`).  Inside this context the weights stay `torch.empty`; the caller MUST fill every parameter."""
+    classes = (nn.Linear, nn.modules.conv._ConvNd)
+    saved = [cls.reset_parameters for cls in classes]
+    for cls in classes:
+        cls.reset_parameters = lambda self: None
+    try:
+        yield
+    finally:
+        for cls, fn in zip(classes, saved):
+            cls.reset_parameters = fn
 
 
 def scaled_init_(model: nn.Module, seed: int = 0, gain: float = 1.0) -> None:

@@ -878,255 +878,22 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
 }
 
 
-// ================================================================================================================
-// variant 4 (production): 128 x (32*NB) x 64 tile, NB = 4 or 5, lean K-loop.
-//  * All channel counts of the SVD UNet are multiples of 320, so BN = 160 tiles N exactly (BN = 128 wastes 17 % of the MFMA
-//    work at N = 320) and raises the MFMA : ds_read ratio (40 : 18 per wave per K-tile).
-//  * Accumulators are kept TRANSPOSED (acc = mfma(B_frag, A_frag)): a lane owns 4 consecutive output columns of one row.
-//    Activation outputs are rounded, parked in LDS and written with full-line coalesced 16-byte stores (bias / row vector /
-//    residual / GEGLU forward+backward fused there); float outputs (slabs, += for weight-grad style uses) go straight from
-//    registers with 16-byte stores.
-//  * Staging: buffer_load_dwordx4 ... lds with per-lane 32-bit byte offsets computed once per filter tap, the K position as a
-//    single scalar soffset, and zero padding from the buffer bounds check (offset >= num_records reads 0) -- no zero page,
-//    no select, no 64-bit pointer arithmetic in the loop.  PMC counters that motivated this (profiles/r1_gemm_pmc.txt): the
-//    pointer-arithmetic loop issued 2.4 VALU + 2.9 SALU instructions per MFMA (issue bound, MFMA busy ~33 %); this loop issues
-//    0.3 VALU + 0.95 SALU.
-//  * Tried and dropped (DESIGN.md section 6): a 5-stage / 4-stage LDS ring with counted vmcnt + raw s_barrier (no gain in
-//    situ, slower in isolation: the loop is not latency bound), direct 8-byte epilogue stores (worse DRAM efficiency).
-// ================================================================================================================
-template <typename T, int NB, int MB, bool DUAL, int WGM, int NSTG>
-__global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and LDS-DMA builtin only exist in the device pass
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef typename TT<T>::v8 v8;
-    constexpr int NT = 128 * WGM;                     // threads: WGM x 2 waves (WGM = 2: four waves, WGM = 4: eight = two per SIMD)
-    constexpr int BM4 = 16 * MB * WGM;                // tile rows: 128 / 160 (four waves) or 256 / 320 (eight waves)
-    constexpr int WM4 = 16 * MB;                      // rows per wave
-    constexpr int BN3 = 32 * NB;                      // 2 waves along N, NB/2... each wave owns NB*16 columns
-    constexpr int WN3 = 16 * NB;                      // columns per wave
-    constexpr int KT = BK;                             // K extent of one stage
-    constexpr int STAGE3 = (BM4 + BN3) * KT * 2;
-    constexpr int CPRW = KT / 8;                       // 16-byte chunks per staged row (8 | 4)
-    constexpr int RPP = NT / CPRW;                     // rows covered by one load pass (32 | 64)
-    constexpr int NLA = BM4 / RPP;                      // A loads per thread per stage (4 | 2)
-    constexpr int NLB = (BN3 + RPP - 1) / RPP;         // B loads per thread per stage (NB | 3 or 2)
-    constexpr int ROWB = KT * 2;                       // bytes per staged row (128 | 64)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    // Workgroup ids go round-robin to the 8 XCDs (id & 7), each with a private 4 MiB L2.  Every XCD re-fetches whatever operand
-    // rows its tiles touch, so the host picks an (8/xcd_n) x xcd_n arrangement of XCDs over the tile grid that minimises
-    // A_bytes * xcd_n + B_bytes * (8 / xcd_n): row bands when A dominates (the 64x40 level: A = 23 MB x taps, B < 2 MB), column
-    // bands when the weights dominate (10x16 / 5x8 levels: B = 30-60 MB, A = 1-6 MB; measured 8x weight re-fetch before).
-    // Split-K (round 4): the K slices of one tile share nothing, so a slice count of 2 / 4 / 8 gives every slice its OWN 8 / split_k XCDs
-    // (z_xcd): an XCD then streams half / a quarter / an eighth of K for its tiles instead of all of it -- 2240 x 1280 x 10240 in two slices
-    // fetched 197 MB where 72 MB are algorithmic with every XCD holding both slices of a 3 x 5 tile block; 144 MB with 2 x 2 XCDs per slice.
-    const int bid = blockIdx.x;
-    int pid_m, pid_n, z = blockIdx.y;
-    if (p.z_xcd) {
-        const int xcd = bid & 7, l = bid >> 3, xps = 8 / p.split_k;
-        z = xcd / xps;
-        const int xi = xcd - z * xps;
-        const int xi_m = xi / p.xcd_n, xi_n = xi - xi_m * p.xcd_n;
-        const int lm = l / p.sub_n;
-        pid_m = xi_m * p.sub_m + lm;
-        pid_n = xi_n * p.sub_n + (l - lm * p.sub_n);
-        if (lm >= p.sub_m || pid_m >= p.tiles_m || pid_n >= p.tiles_n) return;
-    } else if (p.xcd_n > 0) {
-        const int xcd = bid & 7, l = bid >> 3;
-        const int xi_m = xcd / p.xcd_n, xi_n = xcd - xi_m * p.xcd_n;
-        const int lm = l / p.sub_n;
-        pid_m = xi_m * p.sub_m + lm;
-        pid_n = xi_n * p.sub_n + (l - lm * p.sub_n);
-        if (lm >= p.sub_m || pid_m >= p.tiles_m || pid_n >= p.tiles_n) return;
-    } else {
-        const int nwg = p.tiles_m * p.tiles_n;
-        const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-        const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-        pid_m = swz / p.tiles_n;
-        pid_n = swz - pid_m * p.tiles_n;
-    }
-    const int m0 = pid_m * BM4, n0 = pid_n * BN3;
-    const int kt_total = p.K / KT;
-    const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
-    const int kt_begin = z * kt_per;
-    const int kt_end = min(kt_total, kt_begin + kt_per);
-    if (kt_begin >= kt_end) return;
+// GEGLU-forward tiles pair 16 value columns with their 16 gate columns: local n-block 2q is rows F*0 + c, block 2q+1 is rows
+// F + c of the [2F, K] projection, so a lane ends up holding a value and its gate (no weight re-packing needed).
+template <int BN3>
+__device__ __forceinline__ int v4_brow(const GemmParams& p, int pid_n, int n0, int nl) {
+    return p.epi == SVDX_EPI_GEGLU_FWD ? (((nl >> 4) & 1) ? p.aux_dim : 0) + pid_n * (BN3 / 2) + (nl >> 5) * 16 + (nl & 15)
+                                       : min(n0 + nl, p.N - 1);
+}
 
-    // ---- lean staging: buffer_load ... lds with per-lane byte offsets (fixed per filter tap) + one scalar K offset ----
-    const int ld_row = tid / CPRW, pc = tid % CPRW;
-    const int lc = pc ^ (ld_row & 7);
-    RowInfo a_ri[NLA];
-    int a_m[NLA], voa[NLA], vob[NLB];
-#pragma unroll
-    for (int i = 0; i < NLA; ++i) {
-        a_m[i] = min(m0 + i * RPP + ld_row, p.M - 1);
-        a_ri[i] = decode_row(p.g, a_m[i]);
-    }
-    // GEGLU-forward tiles pair 16 value columns with their 16 gate columns: local n-block 2q is rows F*0 + c, block 2q+1 is rows
-    // F + c of the [2F, K] projection, so a lane ends up holding a value and its gate (no weight re-packing needed).
+// ---- the store side shared by gemm_v4_kernel and gemm_v5_kernel.  acc[i][j] is the TRANSPOSED 16x16 block (n-block i, m-block j) of a wave that owns
+// rows wm * WM4 + j * 16 .. and columns wn * WN3 + i * 16 .. of a BM4 x BN3 tile computed by NT threads: lane (fr, fg) holds row fr, columns fg * 4 .. + 3.
+template <typename T, int NB, int MB, int NT, int BM4, int BN3, int WM4, int WN3>
+__device__ __forceinline__ void v4_epilogue(const GemmParams& p, char* smem, f32x4 (&acc)[NB][MB], int z, int m0, int n0, int pid_m, int pid_n,
+                                            int wm, int wn, int tid) {
+    const int lane = tid & 63, fr = lane & 15, fg = lane >> 4;
     const int Fdim = p.aux_dim;
-    auto brow = [&](int nl) __attribute__((always_inline)) {
-        return p.epi == SVDX_EPI_GEGLU_FWD ? (((nl >> 4) & 1) ? Fdim : 0) + pid_n * (BN3 / 2) + (nl >> 5) * 16 + (nl & 15)
-                                           : min(n0 + nl, p.N - 1);
-    };
-#pragma unroll
-    for (int i = 0; i < NLB; ++i) {
-        const int nl = i * RPP + ld_row;               // tile-local B row; rows >= BN3 (ring, NB = 5) are dummy loads that keep vmcnt uniform
-        vob[i] = nl < BN3 ? (brow(nl) * p.ldb + lc * 8) * 2 : (int)0x80000000;
-    }
-    const bool plain = p.g.mode == SVDX_GATHER_PLAIN;
-    const int cin = plain ? p.K : p.g.cin;
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // DUAL: after the K-tiles of (A, B) the same pipeline runs the K2 / KT tiles of the plain pair (A2, B2) into the same
-    // accumulators -- y = x W^T + (s x A^T) B^T in one launch instead of a second GEMM that re-reads and re-writes y
-    bool seg2 = false;
-    int tap = plain ? 0 : (kt_begin * KT) / cin;
-    int ci0 = kt_begin * KT - tap * cin;                // channel offset inside the tap (plain: k offset)
-    auto set_tap = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NLA; ++i) {
-            bool valid;
-            const T* ptr = a_row_ptr<T>(p, a_ri[i], a_m[i], 0, tap, 0, valid);
-            // invalid (zero-padding) rows: an offset beyond num_records makes the buffer load return zeros
-            voa[i] = valid ? (int)((ptr - reinterpret_cast<const T*>(p.A)) + lc * 8) * 2 : (int)0x80000000;
-        }
-    };
-    set_tap();
-    // One staging piece = one buffer_load ... lds per wave (1 KiB).  Issuing an LDS-DMA piece costs the wave ~60-180 issue cycles
-    // (MI355X_MICROARCH.md), so the pieces of the NEXT stage are spread between the MFMA rows of the current one instead of being
-    // issued as a burst in front of them (which left the wave's MFMA pipe idle for ~1000 cycles per K-step).
-    constexpr int NPIECE = NLA + NLB;
-    // Eight waves cover 64 tile rows per pass, so a 160-row B tile ends in the middle of its third pass: the waves whose 8 rows lie
-    // beyond the tile have nothing to fetch there and skip that piece (their vmcnt arithmetic below counts one piece less per tile).
-    constexpr bool B_PARTIAL = NLB * RPP > BN3;
-    const bool skip_last = B_PARTIAL && (NLB - 1) * RPP + wave_u * (64 / CPRW) >= BN3;
-    auto issue_piece = [&](int stage, int pi) __attribute__((always_inline)) {
-        char* As = smem + stage * STAGE3;
-        char* Bs = As + BM4 * KT * 2;
-        if (pi < NLA) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(As + (pi * NT + wave_u * 64) * 16), 16,
-                                                     voa[pi], ci0 * 2, 0, 0);
-        } else {
-            const int i = pi - NLA;
-            if (B_PARTIAL && i == NLB - 1 && skip_last) return;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(Bs + (i * NT + wave_u * 64) * 16), 16, vob[i],
-                                                     (tap * cin + ci0) * 2, 0, 0);
-        }
-    };
-    const int n_main = kt_end - kt_begin;                          // K-tiles of the main pair handled by this block
-    const int n_tiles = n_main + (DUAL ? p.K2 / KT : 0);
-    int issued = 0;
-    // called after a tile was issued: make the addressing state describe the next one
-    auto advance_k = [&]() __attribute__((always_inline)) {
-        ++issued;
-        if (DUAL && issued == n_main) {                            // next tile is the first one of (A2, B2): plain addressing
-            seg2 = true;
-            ci0 = 0;
-            tap = 0;                                                   // B offset (tap * cin + ci0) becomes ci0
-            rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A2), 0, p.a2_bytes, 0x00020000);
-            rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B2), 0, p.b2_bytes, 0x00020000);
-            const int a2_col = p.a2_seg > 0 ? (n0 / p.a2_seg) * p.K2 : 0;
-#pragma unroll
-            for (int i = 0; i < NLA; ++i) voa[i] = (min(m0 + i * RPP + ld_row, p.M - 1) * p.lda2 + a2_col + lc * 8) * 2;
-#pragma unroll
-            for (int i = 0; i < NLB; ++i) {
-                const int nl = i * RPP + ld_row;
-                vob[i] = nl < BN3 ? (brow(nl) * p.ldb2 + lc * 8) * 2 : (int)0x80000000;
-            }
-            return;
-        }
-        ci0 += KT;
-        if (!plain && !(DUAL && seg2) && ci0 == cin) { ci0 = 0; ++tap; set_tap(); }
-    };
-    f32x4 acc[NB][MB];                                   // [n-block][m-block], transposed: rows = n, cols = m
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, fg = lane >> 4;
-    // compute stage `stage`; when ISSUE, stage a later K-tile into `nstage` piece by piece between the MFMA rows
-#define SVDX_V4_COMPUTE(stage, nstage, ISSUE)                                                                                \
-    {                                                                                                                        \
-        const char* As_ = smem + (stage) * STAGE3;                                                                           \
-        const char* Bs_ = As_ + BM4 * KT * 2;                                                                                \
-        _Pragma("unroll") for (int kk = 0; kk < KT / 32; ++kk) {                                                             \
-            const int chunk = ((kk * 4 + fg) ^ (fr & 7)) * 16;                                                               \
-            v8 af[MB], bf[NB];                                                                                               \
-            _Pragma("unroll") for (int i = 0; i < MB; ++i)                                                                   \
-                af[i] = *reinterpret_cast<const v8*>(As_ + (wm * WM4 + i * 16 + fr) * ROWB + chunk);                         \
-            _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                   \
-                bf[i] = *reinterpret_cast<const v8*>(Bs_ + (wn * WN3 + i * 16 + fr) * ROWB + chunk);                         \
-            _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                                 \
-                __builtin_amdgcn_s_setprio(1);  /* the MFMA row outranks the other waves' loads and LDS reads */            \
-                _Pragma("unroll") for (int j = 0; j < MB; ++j) acc[i][j] = TT<T>::mfma(bf[i], af[j], acc[i][j]);             \
-                __builtin_amdgcn_s_setprio(0);                                                                               \
-                if (ISSUE && kk * NB + i < NPIECE) {                                                                         \
-                    __builtin_amdgcn_sched_barrier(0);                                                                       \
-                    issue_piece((nstage), kk * NB + i);                                                                      \
-                    __builtin_amdgcn_sched_barrier(0);                                                                       \
-                }                                                                                                            \
-            }                                                                                                                \
-        }                                                                                                                    \
-    }
-    static_assert(NPIECE <= (KT / 32) * NB, "not enough MFMA rows to hide the staging pieces");
-    static_assert(NSTG >= 2 && NSTG <= 4, "2 to 4 LDS stages");
-    // The stages form a ring: while tile kt is computed, tiles kt+1 .. kt+NSTG-2 are in flight and the pieces of tile kt+NSTG-1 are
-    // issued into the stage tile kt-1 just left.  One barrier per K-step.  With more than two stages the wait in front of it is a
-    // COUNTED vmcnt -- it retires this wave's pieces of tile kt+1 and leaves the younger tiles in flight across the barrier, which
-    // must then be the raw s_barrier (__syncthreads() fences with vmcnt(0) while an LDS-DMA is pending); every wave issues the same
-    // number of pieces per tile, so the count is exact.  The two-stage form (wait for everything, __syncthreads) is the round-1 loop:
-    // right when two workgroups share a CU and hide each other's drain; the ring is for grids of <= 1 workgroup per CU (the 10x16 /
-    // 5x8 levels, where a drained K-step is one exposed L2 / HBM round trip) and for the eight-wave tiles.
-    auto wait_tiles = [&](int t) __attribute__((always_inline)) {          // leave at most the t youngest tiles in flight (wave-uniform)
-        if (NSTG == 2 || t <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-        if (B_PARTIAL && skip_last) {
-            if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE - 1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NPIECE - 1)) : "memory");
-        } else {
-            if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPIECE) : "memory");
-        }
-    };
-    auto stage_barrier = [&]() __attribute__((always_inline)) {
-        if (NSTG == 2) { __syncthreads(); return; }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    {
-        constexpr int LA = NSTG - 1;                                       // tiles staged ahead of the one being computed
-#pragma unroll
-        for (int t = 0; t < LA; ++t)
-            if (t < n_tiles) {
-#pragma unroll
-                for (int pi = 0; pi < NPIECE; ++pi) issue_piece(t, pi);
-                advance_k();
-            }
-        wait_tiles(min(LA, n_tiles) - 1);
-        stage_barrier();
-        int cur = 0, nxt = LA, kt = 0;
-        for (; kt + LA < n_tiles; ++kt) {
-            SVDX_V4_COMPUTE(cur, nxt, true);
-            advance_k();
-            wait_tiles(LA - 1);
-            stage_barrier();
-            cur = cur + 1 == NSTG ? 0 : cur + 1;
-            nxt = nxt + 1 == NSTG ? 0 : nxt + 1;
-        }
-        for (; kt < n_tiles; ++kt) {
-            SVDX_V4_COMPUTE(cur, nxt, false);
-            if (kt + 1 < n_tiles) {
-                wait_tiles(n_tiles - 2 - kt);
-                stage_barrier();
-            }
-            cur = cur + 1 == NSTG ? 0 : cur + 1;
-        }
-    }
-#undef SVDX_V4_COMPUTE
-
+    auto brow = [&](int nl) __attribute__((always_inline)) { return v4_brow<BN3>(p, pid_n, n0, nl); };
     // ---- epilogue A (activation output): coalesced.  Each lane adds bias / row vector to its 4-column groups, rounds to the
     //      activation dtype and parks them in LDS (the stage buffers are free now); then every thread moves 16-byte row
     //      pieces: residual add + store with full-line coalescing (20 lanes cover one 320-byte output row of the tile).
@@ -1380,6 +1147,258 @@ __global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
             }
         }
     }
+}
+
+// ================================================================================================================
+// variant 4 (production): 128 x (32*NB) x 64 tile, NB = 4 or 5, lean K-loop.
+//  * All channel counts of the SVD UNet are multiples of 320, so BN = 160 tiles N exactly (BN = 128 wastes 17 % of the MFMA
+//    work at N = 320) and raises the MFMA : ds_read ratio (40 : 18 per wave per K-tile).
+//  * Accumulators are kept TRANSPOSED (acc = mfma(B_frag, A_frag)): a lane owns 4 consecutive output columns of one row.
+//    Activation outputs are rounded, parked in LDS and written with full-line coalesced 16-byte stores (bias / row vector /
+//    residual / GEGLU forward+backward fused there); float outputs (slabs, += for weight-grad style uses) go straight from
+//    registers with 16-byte stores.
+//  * Staging: buffer_load_dwordx4 ... lds with per-lane 32-bit byte offsets computed once per filter tap, the K position as a
+//    single scalar soffset, and zero padding from the buffer bounds check (offset >= num_records reads 0) -- no zero page,
+//    no select, no 64-bit pointer arithmetic in the loop.  PMC counters that motivated this (profiles/r1_gemm_pmc.txt): the
+//    pointer-arithmetic loop issued 2.4 VALU + 2.9 SALU instructions per MFMA (issue bound, MFMA busy ~33 %); this loop issues
+//    0.3 VALU + 0.95 SALU.
+//  * Tried and dropped (DESIGN.md section 6): a 5-stage / 4-stage LDS ring with counted vmcnt + raw s_barrier (no gain in
+//    situ, slower in isolation: the loop is not latency bound), direct 8-byte epilogue stores (worse DRAM efficiency).
+// ================================================================================================================
+template <typename T, int NB, int MB, bool DUAL, int WGM, int NSTG>
+__global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and LDS-DMA builtin only exist in the device pass
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename TT<T>::v8 v8;
+    constexpr int NT = 128 * WGM;                     // threads: WGM x 2 waves (WGM = 2: four waves, WGM = 4: eight = two per SIMD)
+    constexpr int BM4 = 16 * MB * WGM;                // tile rows: 128 / 160 (four waves) or 256 / 320 (eight waves)
+    constexpr int WM4 = 16 * MB;                      // rows per wave
+    constexpr int BN3 = 32 * NB;                      // 2 waves along N, NB/2... each wave owns NB*16 columns
+    constexpr int WN3 = 16 * NB;                      // columns per wave
+    constexpr int KT = BK;                             // K extent of one stage
+    constexpr int STAGE3 = (BM4 + BN3) * KT * 2;
+    constexpr int CPRW = KT / 8;                       // 16-byte chunks per staged row (8 | 4)
+    constexpr int RPP = NT / CPRW;                     // rows covered by one load pass (32 | 64)
+    constexpr int NLA = BM4 / RPP;                      // A loads per thread per stage (4 | 2)
+    constexpr int NLB = (BN3 + RPP - 1) / RPP;         // B loads per thread per stage (NB | 3 or 2)
+    constexpr int ROWB = KT * 2;                       // bytes per staged row (128 | 64)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // Workgroup ids go round-robin to the 8 XCDs (id & 7), each with a private 4 MiB L2.  Every XCD re-fetches whatever operand
+    // rows its tiles touch, so the host picks an (8/xcd_n) x xcd_n arrangement of XCDs over the tile grid that minimises
+    // A_bytes * xcd_n + B_bytes * (8 / xcd_n): row bands when A dominates (the 64x40 level: A = 23 MB x taps, B < 2 MB), column
+    // bands when the weights dominate (10x16 / 5x8 levels: B = 30-60 MB, A = 1-6 MB; measured 8x weight re-fetch before).
+    // Split-K (round 4): the K slices of one tile share nothing, so a slice count of 2 / 4 / 8 gives every slice its OWN 8 / split_k XCDs
+    // (z_xcd): an XCD then streams half / a quarter / an eighth of K for its tiles instead of all of it -- 2240 x 1280 x 10240 in two slices
+    // fetched 197 MB where 72 MB are algorithmic with every XCD holding both slices of a 3 x 5 tile block; 144 MB with 2 x 2 XCDs per slice.
+    const int bid = blockIdx.x;
+    int pid_m, pid_n, z = blockIdx.y;
+    if (p.z_xcd) {
+        const int xcd = bid & 7, l = bid >> 3, xps = 8 / p.split_k;
+        z = xcd / xps;
+        const int xi = xcd - z * xps;
+        const int xi_m = xi / p.xcd_n, xi_n = xi - xi_m * p.xcd_n;
+        const int lm = l / p.sub_n;
+        pid_m = xi_m * p.sub_m + lm;
+        pid_n = xi_n * p.sub_n + (l - lm * p.sub_n);
+        if (lm >= p.sub_m || pid_m >= p.tiles_m || pid_n >= p.tiles_n) return;
+    } else if (p.xcd_n > 0) {
+        const int xcd = bid & 7, l = bid >> 3;
+        const int xi_m = xcd / p.xcd_n, xi_n = xcd - xi_m * p.xcd_n;
+        const int lm = l / p.sub_n;
+        pid_m = xi_m * p.sub_m + lm;
+        pid_n = xi_n * p.sub_n + (l - lm * p.sub_n);
+        if (lm >= p.sub_m || pid_m >= p.tiles_m || pid_n >= p.tiles_n) return;
+    } else {
+        const int nwg = p.tiles_m * p.tiles_n;
+        const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+        const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+        pid_m = swz / p.tiles_n;
+        pid_n = swz - pid_m * p.tiles_n;
+    }
+    const int m0 = pid_m * BM4, n0 = pid_n * BN3;
+    const int kt_total = p.K / KT;
+    const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
+    const int kt_begin = z * kt_per;
+    const int kt_end = min(kt_total, kt_begin + kt_per);
+    if (kt_begin >= kt_end) return;
+
+    // ---- lean staging: buffer_load ... lds with per-lane byte offsets (fixed per filter tap) + one scalar K offset ----
+    const int ld_row = tid / CPRW, pc = tid % CPRW;
+    const int lc = pc ^ (ld_row & 7);
+    RowInfo a_ri[NLA];
+    int a_m[NLA], voa[NLA], vob[NLB];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        a_m[i] = min(m0 + i * RPP + ld_row, p.M - 1);
+        a_ri[i] = decode_row(p.g, a_m[i]);
+    }
+    // GEGLU-forward tiles pair 16 value columns with their 16 gate columns: local n-block 2q is rows F*0 + c, block 2q+1 is rows
+    // F + c of the [2F, K] projection, so a lane ends up holding a value and its gate (no weight re-packing needed).
+    const int Fdim = p.aux_dim;
+    auto brow = [&](int nl) __attribute__((always_inline)) {
+        return p.epi == SVDX_EPI_GEGLU_FWD ? (((nl >> 4) & 1) ? Fdim : 0) + pid_n * (BN3 / 2) + (nl >> 5) * 16 + (nl & 15)
+                                           : min(n0 + nl, p.N - 1);
+    };
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        const int nl = i * RPP + ld_row;               // tile-local B row; rows >= BN3 (ring, NB = 5) are dummy loads that keep vmcnt uniform
+        vob[i] = nl < BN3 ? (brow(nl) * p.ldb + lc * 8) * 2 : (int)0x80000000;
+    }
+    const bool plain = p.g.mode == SVDX_GATHER_PLAIN;
+    const int cin = plain ? p.K : p.g.cin;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // DUAL: after the K-tiles of (A, B) the same pipeline runs the K2 / KT tiles of the plain pair (A2, B2) into the same
+    // accumulators -- y = x W^T + (s x A^T) B^T in one launch instead of a second GEMM that re-reads and re-writes y
+    bool seg2 = false;
+    int tap = plain ? 0 : (kt_begin * KT) / cin;
+    int ci0 = kt_begin * KT - tap * cin;                // channel offset inside the tap (plain: k offset)
+    auto set_tap = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            bool valid;
+            const T* ptr = a_row_ptr<T>(p, a_ri[i], a_m[i], 0, tap, 0, valid);
+            // invalid (zero-padding) rows: an offset beyond num_records makes the buffer load return zeros
+            voa[i] = valid ? (int)((ptr - reinterpret_cast<const T*>(p.A)) + lc * 8) * 2 : (int)0x80000000;
+        }
+    };
+    set_tap();
+    // One staging piece = one buffer_load ... lds per wave (1 KiB).  Issuing an LDS-DMA piece costs the wave ~60-180 issue cycles
+    // (MI355X_MICROARCH.md), so the pieces of the NEXT stage are spread between the MFMA rows of the current one instead of being
+    // issued as a burst in front of them (which left the wave's MFMA pipe idle for ~1000 cycles per K-step).
+    constexpr int NPIECE = NLA + NLB;
+    // Eight waves cover 64 tile rows per pass, so a 160-row B tile ends in the middle of its third pass: the waves whose 8 rows lie
+    // beyond the tile have nothing to fetch there and skip that piece (their vmcnt arithmetic below counts one piece less per tile).
+    constexpr bool B_PARTIAL = NLB * RPP > BN3;
+    const bool skip_last = B_PARTIAL && (NLB - 1) * RPP + wave_u * (64 / CPRW) >= BN3;
+    auto issue_piece = [&](int stage, int pi) __attribute__((always_inline)) {
+        char* As = smem + stage * STAGE3;
+        char* Bs = As + BM4 * KT * 2;
+        if (pi < NLA) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(As + (pi * NT + wave_u * 64) * 16), 16,
+                                                     voa[pi], ci0 * 2, 0, 0);
+        } else {
+            const int i = pi - NLA;
+            if (B_PARTIAL && i == NLB - 1 && skip_last) return;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(Bs + (i * NT + wave_u * 64) * 16), 16, vob[i],
+                                                     (tap * cin + ci0) * 2, 0, 0);
+        }
+    };
+    const int n_main = kt_end - kt_begin;                          // K-tiles of the main pair handled by this block
+    const int n_tiles = n_main + (DUAL ? p.K2 / KT : 0);
+    int issued = 0;
+    // called after a tile was issued: make the addressing state describe the next one
+    auto advance_k = [&]() __attribute__((always_inline)) {
+        ++issued;
+        if (DUAL && issued == n_main) {                            // next tile is the first one of (A2, B2): plain addressing
+            seg2 = true;
+            ci0 = 0;
+            tap = 0;                                                   // B offset (tap * cin + ci0) becomes ci0
+            rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A2), 0, p.a2_bytes, 0x00020000);
+            rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B2), 0, p.b2_bytes, 0x00020000);
+            const int a2_col = p.a2_seg > 0 ? (n0 / p.a2_seg) * p.K2 : 0;
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) voa[i] = (min(m0 + i * RPP + ld_row, p.M - 1) * p.lda2 + a2_col + lc * 8) * 2;
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) {
+                const int nl = i * RPP + ld_row;
+                vob[i] = nl < BN3 ? (brow(nl) * p.ldb2 + lc * 8) * 2 : (int)0x80000000;
+            }
+            return;
+        }
+        ci0 += KT;
+        if (!plain && !(DUAL && seg2) && ci0 == cin) { ci0 = 0; ++tap; set_tap(); }
+    };
+    f32x4 acc[NB][MB];                                   // [n-block][m-block], transposed: rows = n, cols = m
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    // compute stage `stage`; when ISSUE, stage a later K-tile into `nstage` piece by piece between the MFMA rows
+#define SVDX_V4_COMPUTE(stage, nstage, ISSUE)                                                                                \
+    {                                                                                                                        \
+        const char* As_ = smem + (stage) * STAGE3;                                                                           \
+        const char* Bs_ = As_ + BM4 * KT * 2;                                                                                \
+        _Pragma("unroll") for (int kk = 0; kk < KT / 32; ++kk) {                                                             \
+            const int chunk = ((kk * 4 + fg) ^ (fr & 7)) * 16;                                                               \
+            v8 af[MB], bf[NB];                                                                                               \
+            _Pragma("unroll") for (int i = 0; i < MB; ++i)                                                                   \
+                af[i] = *reinterpret_cast<const v8*>(As_ + (wm * WM4 + i * 16 + fr) * ROWB + chunk);                         \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                   \
+                bf[i] = *reinterpret_cast<const v8*>(Bs_ + (wn * WN3 + i * 16 + fr) * ROWB + chunk);                         \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                                 \
+                __builtin_amdgcn_s_setprio(1);  /* the MFMA row outranks the other waves' loads and LDS reads */            \
+                _Pragma("unroll") for (int j = 0; j < MB; ++j) acc[i][j] = TT<T>::mfma(bf[i], af[j], acc[i][j]);             \
+                __builtin_amdgcn_s_setprio(0);                                                                               \
+                if (ISSUE && kk * NB + i < NPIECE) {                                                                         \
+                    __builtin_amdgcn_sched_barrier(0);                                                                       \
+                    issue_piece((nstage), kk * NB + i);                                                                      \
+                    __builtin_amdgcn_sched_barrier(0);                                                                       \
+                }                                                                                                            \
+            }                                                                                                                \
+        }                                                                                                                    \
+    }
+    static_assert(NPIECE <= (KT / 32) * NB, "not enough MFMA rows to hide the staging pieces");
+    static_assert(NSTG >= 2 && NSTG <= 4, "2 to 4 LDS stages");
+    // The stages form a ring: while tile kt is computed, tiles kt+1 .. kt+NSTG-2 are in flight and the pieces of tile kt+NSTG-1 are
+    // issued into the stage tile kt-1 just left.  One barrier per K-step.  With more than two stages the wait in front of it is a
+    // COUNTED vmcnt -- it retires this wave's pieces of tile kt+1 and leaves the younger tiles in flight across the barrier, which
+    // must then be the raw s_barrier (__syncthreads() fences with vmcnt(0) while an LDS-DMA is pending); every wave issues the same
+    // number of pieces per tile, so the count is exact.  The two-stage form (wait for everything, __syncthreads) is the round-1 loop:
+    // right when two workgroups share a CU and hide each other's drain; the ring is for grids of <= 1 workgroup per CU (the 10x16 /
+    // 5x8 levels, where a drained K-step is one exposed L2 / HBM round trip) and for the eight-wave tiles.
+    auto wait_tiles = [&](int t) __attribute__((always_inline)) {          // leave at most the t youngest tiles in flight (wave-uniform)
+        if (NSTG == 2 || t <= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+        if (B_PARTIAL && skip_last) {
+            if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE - 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NPIECE - 1)) : "memory");
+        } else {
+            if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPIECE) : "memory");
+        }
+    };
+    auto stage_barrier = [&]() __attribute__((always_inline)) {
+        if (NSTG == 2) { __syncthreads(); return; }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+        constexpr int LA = NSTG - 1;                                       // tiles staged ahead of the one being computed
+#pragma unroll
+        for (int t = 0; t < LA; ++t)
+            if (t < n_tiles) {
+#pragma unroll
+                for (int pi = 0; pi < NPIECE; ++pi) issue_piece(t, pi);
+                advance_k();
+            }
+        wait_tiles(min(LA, n_tiles) - 1);
+        stage_barrier();
+        int cur = 0, nxt = LA, kt = 0;
+        for (; kt + LA < n_tiles; ++kt) {
+            SVDX_V4_COMPUTE(cur, nxt, true);
+            advance_k();
+            wait_tiles(LA - 1);
+            stage_barrier();
+            cur = cur + 1 == NSTG ? 0 : cur + 1;
+            nxt = nxt + 1 == NSTG ? 0 : nxt + 1;
+        }
+        for (; kt < n_tiles; ++kt) {
+            SVDX_V4_COMPUTE(cur, nxt, false);
+            if (kt + 1 < n_tiles) {
+                wait_tiles(n_tiles - 2 - kt);
+                stage_barrier();
+            }
+            cur = cur + 1 == NSTG ? 0 : cur + 1;
+        }
+    }
+#undef SVDX_V4_COMPUTE
+
+    v4_epilogue<T, NB, MB, NT, BM4, BN3, WM4, WN3>(p, smem, acc, z, m0, n0, pid_m, pid_n, wm, wn, tid);
 #endif
 }
 

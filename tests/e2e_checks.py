@@ -7,9 +7,21 @@ import time
 import torch
 
 from oracle.step import edm_inputs, edm_loss, make_optimizer, make_synthetic_batch
-from oracle.unet import TINY_CONFIG, UNetSpatioTemporalConditionOracle, scaled_init_
+from oracle.unet import TINY_CONFIG, UNetSpatioTemporalConditionOracle as _Oracle, no_default_init, scaled_init_
 from svd_xtend_amd.train import Trainer
-from svd_xtend_amd.unet import UNetSpatioTemporalConditionModel
+from svd_xtend_amd.unet import UNetSpatioTemporalConditionModel as _Product
+
+
+def UNetSpatioTemporalConditionOracle(**cfg):
+    """Every caller below fills all parameters right after (scaled_init_): skip the constructors' own kaiming draws (16-33 s per model at the real widths)."""
+    with no_default_init():
+        return _Oracle(**cfg)
+
+
+def UNetSpatioTemporalConditionModel(**cfg):
+    """The product model, constructed for a `load_state_dict(strict=True)` that follows at once."""
+    with no_default_init():
+        return _Product(**cfg)
 
 
 def cosine(a, b):
@@ -17,7 +29,12 @@ def cosine(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-def oracle_step(cfg, B, T, h, w, seed, lr, cross_dim, lora_r=0, orc=None, with_pred_after=True):
+def oracle_step(cfg, B, T, h, w, seed, lr, cross_dim, lora_r=0, orc=None, with_pred_after=True, more_steps=0):
+    """One optimizer step of the CPU oracle on seeded weights and a seeded batch: everything `compare` holds the product to.
+    more_steps > 0: the oracle keeps stepping on the same batch (the trajectory test's reference) -- `traj` then carries every step's loss
+    and the accumulated update of each trainable tensor, and the forward of step 2 IS the prediction of the updated weights (`pred_after`
+    costs no pass of its own)."""
+    t0 = time.time()
     if orc is None:
         orc = UNetSpatioTemporalConditionOracle(**cfg)
         scaled_init_(orc, seed)
@@ -35,19 +52,38 @@ def oracle_step(cfg, B, T, h, w, seed, lr, cross_dim, lora_r=0, orc=None, with_p
     opt = make_optimizer(orc, lr=lr) if not lora_r else torch.optim.AdamW([p for p in orc.parameters() if p.requires_grad], lr=lr,
                                                                           betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
     sd0 = copy.deepcopy(orc.state_dict())
+    t1 = time.time()
     unet_in, ts, ehs, ids, noisy, sig = edm_inputs(batch)
     pred = orc(unet_in, ts, ehs, added_time_ids=ids).sample
     loss = edm_loss(pred, noisy, batch["latents"], sig)
+    t2 = time.time()
     loss.backward()
+    t3 = time.time()
     grads = {n: p.grad.clone() for n, p in orc.named_parameters() if p.grad is not None}
     opt.step()
-    pred_after = None
-    if with_pred_after:
+    params_after = {n: p.detach().clone() for n, p in orc.named_parameters() if p.requires_grad}
+    pred_after, traj = None, None
+    if more_steps:
+        p0 = {n: sd0[n] for n in params_after}
+        losses = [float(loss.detach())]
+        for k in range(more_steps):
+            opt.zero_grad()
+            pk = orc(unet_in, ts, ehs, added_time_ids=ids).sample
+            if k == 0:
+                pred_after = pk.detach()
+            lk = edm_loss(pk, noisy, batch["latents"], sig)
+            lk.backward()
+            opt.step()
+            losses.append(float(lk.detach()))
+        traj = dict(losses=losses, update={n: p.detach() - p0[n] for n, p in orc.named_parameters() if p.requires_grad})
+    elif with_pred_after:
         with torch.no_grad():                    # the prediction of the UPDATED weights (checks the optimizer step end to end)
             pred_after = orc(unet_in, ts, ehs, added_time_ids=ids).sample
+    t4 = time.time()
+    print(f"[oracle_step] {T}x{h}x{w} build {t1 - t0:.1f}s forward {t2 - t1:.1f}s backward {t3 - t2:.1f}s rest {t4 - t3:.1f}s "
+          f"({torch.get_num_threads()} threads)", flush=True)
     return dict(sd0=sd0, batch=batch, inputs=(unet_in, ts, ehs, ids, noisy), loss=float(loss.detach()), pred=pred.detach(),
-                pred_after=pred_after, lr=lr,
-                grads=grads, params_after={n: p.detach().clone() for n, p in orc.named_parameters() if p.requires_grad})
+                pred_after=pred_after, lr=lr, grads=grads, params_after=params_after, traj=traj)
 
 
 BIG_REF_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "_big")
@@ -77,6 +113,19 @@ def oracle_step_cached(tag, cfg, B, T, h, w, seed, lr, cross_dim):
         keep["sd0_fingerprint"] = float(sum(v.double().abs().sum() for v in ref["sd0"].values()))
         torch.save(keep, path)
     return ref
+
+
+_SESSION_REFS = {}
+
+
+def oracle_steps_shared(cfg, B, T, h, w, seed, lr, cross_dim, steps=3):
+    """`steps` oracle steps on one batch, computed once per pytest session: the 64x40-level block test reads step 1 (loss, gradients,
+    updated weights, and step 2's forward as the prediction after the update), the trajectory test reads all of them -- one ~25 s CPU
+    run of the 35840-row level instead of four."""
+    key = (repr(sorted(cfg.items())), B, T, h, w, seed, lr, cross_dim, steps)
+    if key not in _SESSION_REFS:
+        _SESSION_REFS[key] = oracle_step(cfg, B, T, h, w, seed=seed, lr=lr, cross_dim=cross_dim, more_steps=steps - 1)
+    return _SESSION_REFS[key]
 
 
 def product_step(ref, cfg, dtype, dev, lr, lora_r=0):
@@ -199,7 +248,14 @@ def graphed_vs_eager(dev=None, dtype=torch.float16, steps=3):
                 param_abs_max=float(e["p"].abs().max()), opt_steps=(e["state"][0], g["state"][0]), segments=g["segments"])
 
 
-def replays_with_traffic_between(dev=None, dtype=torch.float16, replays=4, disturb=True, cfg=None, geom=(1, 3, 16, 16), lora_r=0):
+def seeded_weights(cfg, seed):
+    """State dict of the oracle topology under scaled_init_(seed) (the product's keys are the same)."""
+    orc = UNetSpatioTemporalConditionOracle(**cfg)
+    scaled_init_(orc, seed)
+    return orc.state_dict()
+
+
+def replays_with_traffic_between(dev=None, dtype=torch.float16, replays=4, disturb=True, cfg=None, geom=(1, 3, 16, 16), lora_r=0, sd=None):
     """`replays` replays of the captured step with -- when `disturb` -- the things a real training loop does between two replays: a new
     batch copied into the captured input tensors (here: the same values, so the trajectory must not move), the loss read on the host,
     ATen launches, a matmul.  Returns the flat parameters, the loss slot and the optimizer state.  lora_r: config 5's trainable set
@@ -208,14 +264,13 @@ def replays_with_traffic_between(dev=None, dtype=torch.float16, replays=4, distu
     dev = dev or torch.device("cuda")
     cfg = cfg or TINY_CONFIG
     B, T, h, w = geom
-    orc = UNetSpatioTemporalConditionOracle(**cfg)
-    scaled_init_(orc, 5)
+    sd = sd if sd is not None else seeded_weights(cfg, 5)       # sd: the caller's seeded_weights(cfg, 5), drawn once for both of its runs
     b = make_synthetic_batch(B, T, h, w, 77, cross_dim=cfg["cross_attention_dim"])
     unet_in, ts, ehs, ids, noisy, _ = edm_inputs(b)
     host = dict(unet_in=unet_in, timesteps=ts, ehs=ehs, added_time_ids=ids, noisy_latents=noisy, target=b["latents"], sigmas=b["sigmas"])
     batch = {k: v.to(dev) for k, v in host.items()}
     m = UNetSpatioTemporalConditionModel(**cfg)
-    m.load_state_dict(orc.state_dict(), strict=True)
+    m.load_state_dict(sd, strict=True)
     if lora_r:
         from svd_xtend_amd.lora import LoraConfig
         torch.manual_seed(11)
@@ -345,7 +400,7 @@ def resume_vs_straight(tmpdir, dev=None, dtype=torch.float16, steps=4, cut=2):
         m.to(dev)
         tr = Trainer(m, dtype=dtype, lr=1e-3)
         sched = get_scheduler("cosine", optimizer=tr, num_warmup_steps=1, num_training_steps=steps + 2)
-        ema = EMAModel(m.parameters(), decay=0.8, model_cls=UNetSpatioTemporalConditionModel, model_config=m.config,
+        ema = EMAModel(m.parameters(), decay=0.8, model_cls=_Product, model_config=m.config,
                        on_weights_changed=tr.weights_changed)
         return tr, sched, ema
 
@@ -455,6 +510,8 @@ def run_levels(levels=None, dtypes=(torch.float16,), T=14, lora_r=0, verbose=Fal
         t0 = time.time()
         if lora_r:
             ref = oracle_step(cfg, 1, T, h, w, seed=seed, lr=1e-4, cross_dim=cfg["cross_attention_dim"], lora_r=lora_r)
+        elif table is None and T == 14 and h * w == 2560:      # shared with test_three_step_trajectory_matches_oracle[L0]
+            ref = oracle_steps_shared(cfg, 1, T, h, w, seed, 1e-4, cfg["cross_attention_dim"])
         else:
             ref = oracle_step_cached(f"{name} T={T} seed={seed}", cfg, 1, T, h, w, seed, 1e-4, cfg["cross_attention_dim"])
         t_or = time.time() - t0
@@ -531,28 +588,19 @@ def run_full_c2(dtypes=(torch.float16,), verbose=False, dev=None):
     return res
 
 
-def trajectory_vs_oracle(cfg, geom, dtype=torch.float16, steps=3, lr=1e-4, seed=21, dev=None):
+def trajectory_vs_oracle(cfg, geom, dtype=torch.float16, steps=3, lr=1e-4, seed=11, dev=None):
     """`steps` consecutive optimizer steps on one batch, oracle (autograd + torch.optim.AdamW, fp32) against the product (Trainer.step).
     A first-step loss / prediction cannot see a wrong GRADIENT (four commits of round 4 carried one); the second step's
     loss is computed on weights that the first step's gradients moved, and the per-tensor UPDATE p_final - p_0 is compared directly:
-    its cosine against the oracle's update drops to ~0 for a tensor whose gradient was zeroed, mis-scaled per element or mis-routed."""
+    its cosine against the oracle's update drops to ~0 for a tensor whose gradient was zeroed, mis-scaled per element or mis-routed.
+    (Seed 11 = run_levels' seed: at the 64x40 level the oracle's three steps are the ones test_c2_level_blocks_match_oracle[L0] read step 1 of.)"""
     dev = dev or torch.device("cuda")
     B, T, h, w = geom
-    orc = UNetSpatioTemporalConditionOracle(**cfg)
-    scaled_init_(orc, seed)
-    sd0 = copy.deepcopy(orc.state_dict())
-    batch = make_synthetic_batch(B, T, h, w, seed + 1, cross_dim=cfg["cross_attention_dim"])
-    unet_in, ts, ehs, ids, noisy, sig = edm_inputs(batch)
-    opt = make_optimizer(orc, lr=lr)
-    p0 = {n: p.detach().clone() for n, p in orc.named_parameters() if p.requires_grad}
-    ref_losses = []
-    for _ in range(steps):
-        opt.zero_grad()
-        loss = edm_loss(orc(unet_in, ts, ehs, added_time_ids=ids).sample, noisy, batch["latents"], sig)
-        loss.backward()
-        opt.step()
-        ref_losses.append(float(loss.detach()))
-    ref_upd = {n: p.detach() - p0[n] for n, p in orc.named_parameters() if p.requires_grad}
+    ref = oracle_steps_shared(cfg, B, T, h, w, seed, lr, cfg["cross_attention_dim"], steps=steps)
+    sd0, batch = ref["sd0"], ref["batch"]
+    unet_in, ts, ehs, ids, noisy = ref["inputs"]
+    ref_losses, ref_upd = ref["traj"]["losses"], ref["traj"]["update"]
+    p0 = {n: sd0[n] for n in ref_upd}
 
     m = UNetSpatioTemporalConditionModel(**cfg)
     m.load_state_dict(sd0, strict=True)

@@ -45,13 +45,15 @@ def test_graph_replays_survive_copies_and_eager_launches():
     import torch
 
     import e2e_checks
-    from oracle.unet import SVD_CONFIG
+    from oracle.unet import SVD_CONFIG, TINY_CONFIG
     # the full topology at the benched shape is where the hazard showed (tools/dbg_corrupt.py); the two small cases are quick guards
     # ... and the adapters' trainable set (rank 8: the padded-rank re-layout inside the captured step; rank 64: config 5's)
     for cfg, geom, r in ((None, (1, 3, 16, 16), 0), (None, (1, 3, 16, 16), 8), (None, (1, 3, 16, 16), 64),
                          (e2e_checks.level_config(320, 5), (1, 14, 40, 64), 0), (SVD_CONFIG, (1, 14, 40, 64), 0)):
-        quiet = e2e_checks.replays_with_traffic_between(disturb=False, cfg=cfg, geom=geom, lora_r=r)
-        noisy = e2e_checks.replays_with_traffic_between(disturb=True, cfg=cfg, geom=geom, lora_r=r)
+        sd = e2e_checks.seeded_weights(cfg or TINY_CONFIG, 5)     # one draw of the 1.52 B seeded weights for both runs
+        quiet = e2e_checks.replays_with_traffic_between(disturb=False, cfg=cfg, geom=geom, lora_r=r, sd=sd)
+        noisy = e2e_checks.replays_with_traffic_between(disturb=True, cfg=cfg, geom=geom, lora_r=r, sd=sd)
+        del sd
         assert quiet["state"][0] == noisy["state"][0] >= 5.0, (r, quiet["state"], noisy["state"])       # every replay took its optimizer step
         assert quiet["loss"] == noisy["loss"], (quiet["loss"], noisy["loss"], noisy["losses"])
         assert torch.equal(quiet["p"], noisy["p"]), float((quiet["p"] - noisy["p"]).abs().max())
