@@ -307,8 +307,42 @@ def real_loop_leg(args, trainer, dev, dt, world, rank, T):
         loop.prepare_batch(host_clips[i % len(host_clips)])
     e1.record()
     torch.cuda.synchronize()
+    # ... and split: the VAE encode of T + 1 frames and the CLIP embed each on their own, with the matmul FLOPs their launches carry (2 M N K of
+    # every svdx_gemm* call of one pass, read from the binding's launch log) against the dense MFMA peak
+    def timed(fn, n=5):
+        fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+
+    def gemm_flops(fn):
+        k = trainer.rt.k
+        k.launch_log = log = []
+        try:
+            fn()
+        finally:
+            k.launch_log = None
+        return sum(2.0 * a[3] * a[4] * a[5] for name, a, _ in log if name.startswith("svdx_gemm") and name not in ("svdx_gemm_finalize", "svdx_gemm_finalize_gn")), len(log)
+
+    from svd_xtend_amd.clip import encode_image
+    pix = host_clips[0].to(dev).to(torch.float32)
+    frames = torch.cat([pix, pix[:, 0:1]], dim=1).reshape(T + 1, *pix.shape[2:])
+    with torch.no_grad():
+        vae_fn, clip_fn = (lambda: vae.encode(frames).latent_dist), (lambda: encode_image(pix[:, 0], enc))
+        vae_ms, clip_ms = timed(vae_fn), timed(clip_fn)
+        (vae_fl, vae_n), (clip_fl, clip_n) = gemm_flops(vae_fn), gemm_flops(clip_fn)
+    cond = {"vae_encode": {"ms": vae_ms, "launches": vae_n, "gemm_tflop": vae_fl / 1e12, "frac_of_mfma_peak": vae_fl / 1e12 / (vae_ms * 1e-3) / MFMA_PEAK_TFLOPS,
+                           "what": f"AutoencoderKLTemporalDecoder.encode of {T + 1} frames {args.width}x{args.height}"},
+            "clip_embed": {"ms": clip_ms, "launches": clip_n, "gemm_tflop": clip_fl / 1e12, "frac_of_mfma_peak": clip_fl / 1e12 / (clip_ms * 1e-3) / MFMA_PEAK_TFLOPS,
+                           "what": "resize to 224 + CLIP ViT-H/14 tower + projection of the first frame"}}
+    del pix, frames
     out = {"ms_per_step": el / K * 1e3, "value": world * ga * K / el, "unit": "samples/s", "steps": K,
-           "conditioners_ms_alone": e0.elapsed_time(e1) / 5,
+           "conditioners_ms_alone": e0.elapsed_time(e1) / 5, "conditioners": cond,
            "what": "TrainLoop.step: new pixel clip from pinned host memory -> VAE encode (T + 1 frames) + CLIP image embed + EDM noising on the "
                    "device, queued between this step's backward sweep and its optimizer (beside the gradient all-reduce when N > 1) -> batch copied "
                    "into the captured tensors -> hipGraph replay -> loss read on the host (one host sync per step)",
@@ -475,26 +509,12 @@ def main():
     direct_check = None
     if world > 1 and args.overlap in ("auto", "all"):
         cands = ["single", "buckets"]
-        try:
-            trainer.use_direct_allreduce(True)             # collective: IPC handles of every rank's gradient buffer
-            ok = 1.0
-            keep = trainer.g_flat.clone()
-            for rnd in range(2):                           # fresh data twice: a stale read of a peer's previous contents would show
-                gsrc = torch.randn(trainer.n_total, device=dev, generator=torch.Generator(device=dev).manual_seed(31 * rnd + rank))
-                trainer.g_flat.copy_(gsrc)
-                trainer.direct.all_reduce()
-                got = trainer.g_flat.clone()
-                dist.all_reduce(gsrc)
-                ok = min(ok, float(torch.allclose(got, gsrc, rtol=1e-4, atol=1e-5)))
-            trainer.g_flat.copy_(keep)
-            del keep, gsrc, got
-            flag = torch.tensor([ok], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            direct_check = {"agrees_with_rccl": bool(flag.item() == 1.0)}
-            if direct_check["agrees_with_rccl"]:
-                cands.append("direct")
-        except Exception as e:  # noqa: BLE001 -- no peer mapping on this node: RCCL only
-            direct_check = {"error": repr(e)[:200]}
+        # collective: IPC handles of every rank's gradient buffer, then Trainer's own agreement probe (two rounds of fresh random data
+        # against the library's sum, MIN-voted over the ranks: a rank-local failure turns into "everyone stays on RCCL", never a hang)
+        if trainer.use_direct_allreduce(True):
+            cands.append("direct")
+        direct_check = dict(getattr(trainer, "direct_check", None) or {})
+        direct_check["agrees_with_rccl"] = bool(direct_check.get("agrees_with_library", False))
         trainer.use_direct_allreduce(False)
         n_probe = 24 if args.overlap == "all" else 8
         for name in cands:
@@ -975,7 +995,8 @@ def main():
                                           "one RCCL all-reduce after backward, under the next clip's VAE encode" if args.overlap == "vae" else
                                           "svdx_allreduce_grads (direct reduce-scatter + all-gather over peer-mapped buffers) after backward" if args.overlap == "direct" else
                                           "per-transformer-block RCCL all-reduces overlapped with the backward sweep"),
-                       "schedules": schedules or None, "direct_allreduce_check": direct_check, "allreduce_ms_exposed": exposed_ms,
+                       "schedules": schedules or None, "direct_allreduce_check": direct_check, "direct_allreduce_in_use": trainer.direct is not None,
+                       "allreduce_ms_exposed": exposed_ms,
                        "ranks_seen": ranks_seen, "allreduce_ms": allreduce_ms, "allreduce_direct_ms": direct_ms, "rccl": rccl,
                        "allreduce_bytes": trainer.n_total * 4,
                        "exec": exec_mode, "gemm_tuning_sweeps": tune_sweeps, "gpu_clock": sampler.summary() if sampler is not None else None,

@@ -187,7 +187,8 @@ def main(argv=None):
 
     dataset = (FrameFolders(args.base_folder, args.num_samples, args.width, args.height, args.num_frames) if args.base_folder
                else SyntheticClips(args.num_samples, args.width, args.height, args.num_frames, (args.seed or 0) + rank))
-    sampler = torch.utils.data.RandomSampler(dataset, generator=torch.Generator().manual_seed((args.seed or 0) + rank))
+    sampler_gen = torch.Generator().manual_seed((args.seed or 0) + rank)
+    sampler = torch.utils.data.RandomSampler(dataset, generator=sampler_gen)
     loader = torch.utils.data.DataLoader(dataset, sampler=sampler, batch_size=args.per_gpu_batch_size,
                                          num_workers=args.num_workers if args.base_folder else 0, pin_memory=True)   # :780-786
     num_update_steps_per_epoch = math.ceil(len(loader) / args.gradient_accumulation_steps)                           # :789-793
@@ -206,8 +207,11 @@ def main(argv=None):
             trainer.load_state(os.path.join(args.output_dir, path), ema=ema_unet, scheduler=lr_scheduler)
             global_step = checkpoint.global_step_of(path)
 
+    # A resumed run must not replay the clip order and the sigma / noise / dropout draws of steps 1..N (the reference skips the consumed
+    # batches and restores the generators that drive its noise, train_svd.py:900-931): both streams are re-seeded from (seed, rank, global_step)
+    sampler_gen.manual_seed((args.seed or 0) + rank + 1000003 * global_step)
     loop = TrainLoop(trainer, vae, image_encoder, conditioning_dropout_prob=args.conditioning_dropout_prob,
-                     seed=(args.seed or 0) * 7919 + rank, use_graph=not args.no_graph, ema=ema_unet)
+                     seed=(args.seed or 0) * 7919 + rank + 104729 * global_step, use_graph=not args.no_graph, ema=ema_unet)
 
     def clips():
         while True:
@@ -252,8 +256,9 @@ def main(argv=None):
               f"  Gradient Accumulation steps = {args.gradient_accumulation_steps}\n  Total optimization steps = {args.max_train_steps}\n"
               f"  Trainable parameters = {n_tr:,}", flush=True)
     feed = clips()
-    cur = next(feed)
-    loop.start(cur)                                       # conditioners of the first clip + capture of the step
+    train_loss = float("nan")
+    if global_step < args.max_train_steps:                # (the capture's warm-up pass is a real optimizer step: none is due when the run is already complete)
+        loop.start(next(feed))                            # conditioners of the first clip + capture of the step
     t0, seen = time.perf_counter(), 0
     while global_step < args.max_train_steps:
         nxt = next(feed) if global_step + 1 < args.max_train_steps else None

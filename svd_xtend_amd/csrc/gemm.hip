@@ -878,6 +878,43 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
 }
 
 
+// Which (row tile, column tile, K slice) a workgroup of the gemm_v4 / gemm_v5 kernels computes (false: none -- the grid is rounded up).
+// Workgroup ids go round-robin to the 8 XCDs (id & 7), each with a private 4 MiB L2.  Every XCD re-fetches whatever operand
+// rows its tiles touch, so the host picks an (8/xcd_n) x xcd_n arrangement of XCDs over the tile grid that minimises
+// A_bytes * xcd_n + B_bytes * (8 / xcd_n): row bands when A dominates (the 64x40 level: A = 23 MB x taps, B < 2 MB), column
+// bands when the weights dominate (10x16 / 5x8 levels: B = 30-60 MB, A = 1-6 MB; measured 8x weight re-fetch before).
+// Split-K (round 4): the K slices of one tile share nothing, so a slice count of 2 / 4 / 8 gives every slice its OWN 8 / split_k XCDs
+// (z_xcd): an XCD then streams half / a quarter / an eighth of K for its tiles instead of all of it -- 2240 x 1280 x 10240 in two slices
+// fetched 197 MB where 72 MB are algorithmic with every XCD holding both slices of a 3 x 5 tile block; 144 MB with 2 x 2 XCDs per slice.
+__device__ __forceinline__ bool v4_tile_of_block(const GemmParams& p, int& pid_m, int& pid_n, int& z) {
+    const int bid = blockIdx.x;
+    z = blockIdx.y;
+    if (p.z_xcd) {
+        const int xcd = bid & 7, l = bid >> 3, xps = 8 / p.split_k;
+        z = xcd / xps;
+        const int xi = xcd - z * xps;
+        const int xi_m = xi / p.xcd_n, xi_n = xi - xi_m * p.xcd_n;
+        const int lm = l / p.sub_n;
+        pid_m = xi_m * p.sub_m + lm;
+        pid_n = xi_n * p.sub_n + (l - lm * p.sub_n);
+        if (lm >= p.sub_m || pid_m >= p.tiles_m || pid_n >= p.tiles_n) return false;
+    } else if (p.xcd_n > 0) {
+        const int xcd = bid & 7, l = bid >> 3;
+        const int xi_m = xcd / p.xcd_n, xi_n = xcd - xi_m * p.xcd_n;
+        const int lm = l / p.sub_n;
+        pid_m = xi_m * p.sub_m + lm;
+        pid_n = xi_n * p.sub_n + (l - lm * p.sub_n);
+        if (lm >= p.sub_m || pid_m >= p.tiles_m || pid_n >= p.tiles_n) return false;
+    } else {
+        const int nwg = p.tiles_m * p.tiles_n;
+        const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+        const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+        pid_m = swz / p.tiles_n;
+        pid_n = swz - pid_m * p.tiles_n;
+    }
+    return true;
+}
+
 // GEGLU-forward tiles pair 16 value columns with their 16 gate columns: local n-block 2q is rows F*0 + c, block 2q+1 is rows
 // F + c of the [2F, K] projection, so a lane ends up holding a value and its gate (no weight re-packing needed).
 template <int BN3>
@@ -1166,7 +1203,7 @@ __device__ __forceinline__ void v4_epilogue(const GemmParams& p, char* smem, f32
 //    situ, slower in isolation: the loop is not latency bound), direct 8-byte epilogue stores (worse DRAM efficiency).
 // ================================================================================================================
 template <typename T, int NB, int MB, bool DUAL, int WGM, int NSTG>
-__global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
+__global__ __launch_bounds__(128 * WGM, 2) void gemm_v4_kernel(GemmParams p) {     // (two waves per SIMD: the four-wave tiles share a CU in pairs -- 256 registers, whatever the allocator would like)
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and LDS-DMA builtin only exist in the device pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
@@ -1184,38 +1221,8 @@ __global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
     constexpr int ROWB = KT * 2;                       // bytes per staged row (128 | 64)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // Workgroup ids go round-robin to the 8 XCDs (id & 7), each with a private 4 MiB L2.  Every XCD re-fetches whatever operand
-    // rows its tiles touch, so the host picks an (8/xcd_n) x xcd_n arrangement of XCDs over the tile grid that minimises
-    // A_bytes * xcd_n + B_bytes * (8 / xcd_n): row bands when A dominates (the 64x40 level: A = 23 MB x taps, B < 2 MB), column
-    // bands when the weights dominate (10x16 / 5x8 levels: B = 30-60 MB, A = 1-6 MB; measured 8x weight re-fetch before).
-    // Split-K (round 4): the K slices of one tile share nothing, so a slice count of 2 / 4 / 8 gives every slice its OWN 8 / split_k XCDs
-    // (z_xcd): an XCD then streams half / a quarter / an eighth of K for its tiles instead of all of it -- 2240 x 1280 x 10240 in two slices
-    // fetched 197 MB where 72 MB are algorithmic with every XCD holding both slices of a 3 x 5 tile block; 144 MB with 2 x 2 XCDs per slice.
-    const int bid = blockIdx.x;
-    int pid_m, pid_n, z = blockIdx.y;
-    if (p.z_xcd) {
-        const int xcd = bid & 7, l = bid >> 3, xps = 8 / p.split_k;
-        z = xcd / xps;
-        const int xi = xcd - z * xps;
-        const int xi_m = xi / p.xcd_n, xi_n = xi - xi_m * p.xcd_n;
-        const int lm = l / p.sub_n;
-        pid_m = xi_m * p.sub_m + lm;
-        pid_n = xi_n * p.sub_n + (l - lm * p.sub_n);
-        if (lm >= p.sub_m || pid_m >= p.tiles_m || pid_n >= p.tiles_n) return;
-    } else if (p.xcd_n > 0) {
-        const int xcd = bid & 7, l = bid >> 3;
-        const int xi_m = xcd / p.xcd_n, xi_n = xcd - xi_m * p.xcd_n;
-        const int lm = l / p.sub_n;
-        pid_m = xi_m * p.sub_m + lm;
-        pid_n = xi_n * p.sub_n + (l - lm * p.sub_n);
-        if (lm >= p.sub_m || pid_m >= p.tiles_m || pid_n >= p.tiles_n) return;
-    } else {
-        const int nwg = p.tiles_m * p.tiles_n;
-        const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-        const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-        pid_m = swz / p.tiles_n;
-        pid_n = swz - pid_m * p.tiles_n;
-    }
+    int pid_m, pid_n, z;
+    if (!v4_tile_of_block(p, pid_m, pid_n, z)) return;
     const int m0 = pid_m * BM4, n0 = pid_n * BN3;
     const int kt_total = p.K / KT;
     const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
@@ -1399,6 +1406,247 @@ __global__ __launch_bounds__(128 * WGM) void gemm_v4_kernel(GemmParams p) {
 #undef SVDX_V4_COMPUTE
 
     v4_epilogue<T, NB, MB, NT, BM4, BN3, WM4, WN3>(p, smem, acc, z, m0, n0, pid_m, pid_n, wm, wn, tid);
+#endif
+}
+
+// ================================================================================================================
+// variant 5 family (round 6): two-role eight-wave tiles, (32 MF) x (64 NF) x 64, ONE workgroup per CU.
+//
+// Why: gemm_v4_kernel runs all waves of a workgroup through the same sequence -- fragment reads, then MFMA rows -- so the two waves that
+// share a SIMD's matrix pipe read LDS together and multiply together; counters (profiles/r5_stall_counters.txt) show its waves parked at
+// waits / barriers 35-55 % of their cycles.  Here the eight waves are 2 (M) x 4 (N); waves 0-3 (one per SIMD) and waves 4-7 (their SIMD
+// partners) run the SAME program ONE BARRIER APART: while one group is in the MFMA segment of a phase its partners are in the load
+// segment of theirs (ds_read_b128 of the next fragment group + their share of the staging DMA), and they swap at every barrier -- the
+// matrix pipe of each SIMD always has exactly one wave feeding it (cdna_hip_programming.md, "256^2 8-phase template").
+//
+// One K-tile (64) = four phases, one quadrant of the wave's (16 MF) x (16 NF) output each:
+//     phase     fragments read                 MFMA quadrant      staging issued (LDS-DMA pieces of 64 rows x 128 B by all 512 threads)
+//     0         A sub 0, B sub 0               (m0, n0)           A rows that hold sub 1, K-tile t+1   (last read: phase 2 of t-1)
+//     1         B sub 1                        (m0, n1)           --                                    [wait A]
+//     2         A sub 1                        (m1, n1)           A rows of sub 0 only + B rows that hold sub 0, K-tile t+2   (last read: phase 0 of t)
+//     3         -- (B sub 0 stays in registers) (m1, n0)          B rows of sub 1 only, K-tile t+2     (last read: phase 1 of t)   [wait B]
+// LDS holds TWO K-tiles; inside a tile the rows are grouped by sub-tile ([sub 0: wave row 0, wave row 1][sub 1: ...]), so that a region is
+// free for K-tile t+2 as soon as its last phase of K-tile t is over.  A region is re-staged two phases after its last read (the partner
+// group is one barrier behind: its reads of that phase retire one barrier interval later).  Two counted waits per K-tile, each leaving ONE
+// WHOLE K-TILE of pieces in flight across the barriers: [wait B] in phase 3 retires what phases 0 and 1 of K-tile t+1 read (issued in
+// phases 2 and 3 of t-1), [wait A] in phase 1 retires the sub-1 rows of A that phase 2 reads (issued in phase 0 of t-1) -- every piece
+// flies for four to five phases, and the first read of a region comes a barrier after its wait (both groups), as the LDS-DMA ordering
+// rule demands.  (The first cut of this kernel re-read B sub 0 in phase 3, which held its region until then: the weights' last pieces had
+// two phases to land.  Isolated, L2-warm runs did not care; inside the step, where every weight tile comes from HBM, the tile lost 5-13 %
+// to the two-per-CU four-wave tiles -- profiles/r6d_tune_dump.txt.)  Beyond the last K-tile the pieces are issued with an out-of-range
+// offset (no memory access, zeros into a free region): every wave's vmcnt arithmetic stays the same to the end.
+// Epilogues: v4_epilogue (same accumulator layout: a wave owns rows wr * 16 MF .. and columns wc * 16 NF ..).
+// ================================================================================================================
+template <typename T, int MF, int NF>
+__global__ __launch_bounds__(512) void gemm_v5_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename TT<T>::v8 v8;
+    constexpr int NT = 512;
+    constexpr int BM5 = 32 * MF, BN5 = 64 * NF, WM5 = 16 * MF, WN5 = 16 * NF;
+    constexpr int MF0 = (MF + 1) / 2, MF1 = MF - MF0, NF0 = (NF + 1) / 2, NF1 = NF - NF0;
+    constexpr int A0R = 2 * MF0 * 16, B0R = 4 * NF0 * 16;          // LDS rows of sub-tile 0 of A / B (all wave rows / wave columns)
+    constexpr int KT = BK, ROWB = KT * 2;
+    constexpr int BUFB = (BM5 + BN5) * ROWB;                         // one K-tile: A rows, then B rows
+    constexpr int PA = (BM5 + 63) / 64, PB = BN5 / 64;               // staging passes (64 LDS rows each) per operand and K-tile
+    static_assert(BM5 % 32 == 0 && BN5 % 64 == 0 && 2 * BUFB <= 160 * 1024, "tile does not fit");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wr = wave_u >> 2, wc = wave_u & 3;
+    int pid_m, pid_n, z;
+    if (!v4_tile_of_block(p, pid_m, pid_n, z)) return;
+    const int m0 = pid_m * BM5, n0 = pid_n * BN5;
+    const int kt_total = p.K / KT;
+    const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
+    const int kt_begin = z * kt_per;
+    const int kt_end = min(kt_total, kt_begin + kt_per);
+    if (kt_begin >= kt_end) return;
+    const int n_tiles = kt_end - kt_begin;
+
+    // ---- staging addresses: pass i moves LDS rows 64 i + tid / 8, 16-byte chunk tid % 8 (XOR-swizzled by the row, as in gemm_v4_kernel)
+    const int ld_row = tid >> 3, pc = tid & 7;
+    const int lc = pc ^ (ld_row & 7);
+    RowInfo a_ri[PA];
+    int a_m[PA], voa[PA], vob[PB];
+    constexpr int OOB = (int)0x80000000;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int r = 64 * i + ld_row;                                // LDS row -> row of the tile
+        const int s = r >= A0R, q = s ? r - A0R : r, per = (s ? MF1 : MF0) * 16;
+        const int tr = (q / per) * WM5 + (s ? MF0 * 16 : 0) + q % per;
+        a_m[i] = min(m0 + tr, p.M - 1);
+        a_ri[i] = decode_row(p.g, a_m[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int r = 64 * i + ld_row;
+        const int s = r >= B0R, q = s ? r - B0R : r, per = (s ? NF1 : NF0) * 16;
+        const int nl = (q / per) * WN5 + (s ? NF0 * 16 : 0) + q % per;
+        vob[i] = (v4_brow<BN5>(p, pid_n, n0, nl) * p.ldb + lc * 8) * 2;
+    }
+    const bool plain = p.g.mode == SVDX_GATHER_PLAIN;
+    const int cin = plain ? p.K : p.g.cin;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+    // the A cursor (K-tile a_t: filter tap + channel offset inside it) and the B cursor (K-tile b_t) advance independently: an operand's
+    // pieces are issued in K-tile order, but A's and B's pieces of one K-tile are two phases apart
+    int a_t = 0, b_t = 0;
+    int tap = plain ? 0 : (kt_begin * KT) / cin;
+    int ci0 = kt_begin * KT - tap * cin;
+    int kb = kt_begin * KT * 2;                                      // byte offset of B's K-tile
+    auto set_tap = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            bool valid;
+            const T* ptr = a_row_ptr<T>(p, a_ri[i], a_m[i], 0, tap, 0, valid);
+            voa[i] = valid ? (int)((ptr - reinterpret_cast<const T*>(p.A)) + lc * 8) * 2 : OOB;
+        }
+    };
+    set_tap();
+    auto advance_a = [&]() __attribute__((always_inline)) {
+        ++a_t;
+        ci0 += KT;
+        if (a_t >= n_tiles) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) voa[i] = OOB;
+        } else if (!plain && ci0 == cin) { ci0 = 0; ++tap; set_tap(); }
+    };
+    auto advance_b = [&]() __attribute__((always_inline)) {
+        ++b_t;
+        kb += KT * 2;
+        if (b_t >= n_tiles) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) vob[i] = OOB;
+        }
+    };
+    // pieces of one slot.  SLOT 0: A passes that touch sub 1; 2: A passes inside sub 0 and B passes that touch sub 0; 3: B passes inside sub 1.
+    // An A pass whose rows lie beyond the tile for this wave (160-row tiles: pass 2, waves 4-7) is skipped: that wave's counts are one lower.
+#define SVDX_V5_ISSUE(SLOT, buf)                                                                                                            \
+    {                                                                                                                                       \
+        char* base_ = smem + (buf) * BUFB + wave_u * 1024;                                                                                  \
+        if ((SLOT) == 0 || (SLOT) == 2) {                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < PA; ++i) {          /* ascending: a pass that straddles sub 0 / sub 1 leads slot 0 */       \
+                const bool in0 = 64 * i + 64 <= A0R;                                                                                        \
+                if (((SLOT) == 2) != in0) continue;                                                                                         \
+                if (64 * i + 64 > BM5 && 64 * i + wave_u * 8 >= BM5) continue;                                                              \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base_ + i * 8192), 16, voa[i],      \
+                                                         ci0 * 2, 0, 0);                                                                    \
+            }                                                                                                                               \
+        }                                                                                                                                   \
+        if ((SLOT) == 2 || (SLOT) == 3) {                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < PB; ++i) {                                                                                \
+                const bool in1 = 64 * i >= B0R;                                                                                             \
+                if (((SLOT) == 3) != in1) continue;                                                                                         \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(base_ + BM5 * ROWB + i * 8192), 16, \
+                                                         vob[i], kb, 0, 0);                                                                 \
+            }                                                                                                                               \
+        }                                                                                                                                   \
+    }
+    // [wait A] leaves one K-tile's worth of this wave's pieces in flight.  [wait B] must also retire the A pass that straddles the two
+    // sub-tiles (160-row tiles: rows 64-127 of 96 + 64) -- it holds sub-0 rows that phase 0 reads, but could only be issued with the sub-1
+    // group in phase 0; it is the OLDEST piece of that group (ascending pass order), so [wait B] simply leaves one piece fewer in flight.
+    static_assert(B0R % 64 == 0, "a B pass must not straddle the sub-tiles (it would be restaged one phase after its sub-1 rows were read)");
+    constexpr int N_STRADDLE = (A0R % 64) ? 1 : 0;
+    constexpr bool A_PARTIAL = 64 * PA > BM5;
+    const bool skips_one = A_PARTIAL && 64 * (PA - 1) + wave_u * 8 >= BM5;
+#define SVDX_V5_WAIT(LESS)                                                                                                                  \
+    {                                                                                                                                       \
+        if (A_PARTIAL && skips_one) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB - 1 - (LESS)) : "memory");                             \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB - (LESS)) : "memory");                                                        \
+    }
+
+    f32x4 acc[NF][MF];                                                // [n-block][m-block], transposed like gemm_v4_kernel's
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    const int frag0 = fr * ROWB + ((fg ^ (fr & 7)) * 16), frag1 = fr * ROWB + (((4 + fg) ^ (fr & 7)) * 16);     // k-halves 0 / 1 of a fragment row
+    const int a_lds0 = wr * (MF0 * 16) * ROWB, a_lds1 = (A0R + wr * (MF1 * 16)) * ROWB;
+    const int b_lds0 = (BM5 + wc * (NF0 * 16)) * ROWB, b_lds1 = (BM5 + B0R + wc * (NF1 * 16)) * ROWB;
+    v8 a0f[MF0][2], a1f[MF1 > 0 ? MF1 : 1][2], b0f[NF0][2], b1f[NF1 > 0 ? NF1 : 1][2];
+#define SVDX_V5_READ(dst, n, ldsoff, buf)                                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                                                                                    \
+        dst[i_][0] = *reinterpret_cast<const v8*>(smem + (buf) * BUFB + (ldsoff) + i_ * 16 * ROWB + frag0);                                 \
+        dst[i_][1] = *reinterpret_cast<const v8*>(smem + (buf) * BUFB + (ldsoff) + i_ * 16 * ROWB + frag1);                                 \
+    }
+#define SVDX_V5_MMA(bf_, nb_, ioff, af_, mb_, joff)                                                                                         \
+    {                                                                                                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                                                                      \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                                                                 \
+            _Pragma("unroll") for (int i_ = 0; i_ < (nb_); ++i_)                                                                           \
+                _Pragma("unroll") for (int j_ = 0; j_ < (mb_); ++j_)                                                                       \
+                    acc[(ioff) + i_][(joff) + j_] = TT<T>::mfma(bf_[i_][kk_], af_[j_][kk_], acc[(ioff) + i_][(joff) + j_]);                 \
+        __builtin_amdgcn_s_setprio(0);                                                                                                      \
+    }
+#define SVDX_V5_BARRIER()                                                                                                                   \
+    {                                                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                                                       \
+        asm volatile("" ::: "memory");                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                                  \
+    }
+    // one K-tile out of buffer `buf`; its slot-0 pieces go to the other buffer (K-tile t+1), slots 2 / 3 into this one (K-tile t+2)
+#define SVDX_V5_TILE(buf)                                                                                                                   \
+    {                                                                                                                                       \
+        SVDX_V5_READ(b0f, NF0, b_lds0, buf);                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                                  \
+        SVDX_V5_READ(a0f, MF0, a_lds0, buf);                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                                  \
+        SVDX_V5_ISSUE(0, (buf) ^ 1);                                                                                                        \
+        advance_a();                                                                                                                        \
+        SVDX_V5_BARRIER();                                                                                                                  \
+        SVDX_V5_MMA(b0f, NF0, 0, a0f, MF0, 0);                                                                                              \
+        SVDX_V5_BARRIER();                                                                                                                  \
+        if (NF1 > 0) {                                                                                                                      \
+            SVDX_V5_READ(b1f, NF1, b_lds1, buf);                                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                                              \
+        }                                                                                                                                   \
+        SVDX_V5_WAIT(0);                                                                                                                    \
+        SVDX_V5_BARRIER();                                                                                                                  \
+        if (NF1 > 0) SVDX_V5_MMA(b1f, NF1, NF0, a0f, MF0, 0);                                                                               \
+        SVDX_V5_BARRIER();                                                                                                                  \
+        if (MF1 > 0) {                                                                                                                      \
+            SVDX_V5_READ(a1f, MF1, a_lds1, buf);                                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                                              \
+        }                                                                                                                                   \
+        SVDX_V5_ISSUE(2, buf);                                                                                                              \
+        SVDX_V5_BARRIER();                                                                                                                  \
+        if (MF1 > 0 && NF1 > 0) SVDX_V5_MMA(b1f, NF1, NF0, a1f, MF1, MF0);                                                                  \
+        SVDX_V5_BARRIER();                                                                                                                  \
+        SVDX_V5_ISSUE(3, buf);                                                                                                              \
+        advance_b();                                                                                                                        \
+        SVDX_V5_WAIT(N_STRADDLE);                                                                                                                   \
+        SVDX_V5_BARRIER();                                                                                                                  \
+        if (MF1 > 0) SVDX_V5_MMA(b0f, NF0, 0, a1f, MF1, MF0);                                                                               \
+        SVDX_V5_BARRIER();                                                                                                                  \
+    }
+    // ---- prologue: what the steady state would have issued before K-tile 0 (phases 2, 3 of "tile -2"; 0, 2, 3 of "tile -1") ----
+    SVDX_V5_ISSUE(2, 0);
+    SVDX_V5_ISSUE(3, 0);
+    advance_b();
+    SVDX_V5_ISSUE(0, 0);
+    advance_a();
+    SVDX_V5_ISSUE(2, 1);
+    SVDX_V5_ISSUE(3, 1);
+    advance_b();
+    SVDX_V5_WAIT(N_STRADDLE);
+    SVDX_V5_BARRIER();
+    if (wr == 1) SVDX_V5_BARRIER();                                  // waves 4-7 run one barrier behind their SIMD partners from here on
+    for (int t = 0; t < n_tiles; t += 2) {
+        SVDX_V5_TILE(0);
+        if (t + 1 < n_tiles) SVDX_V5_TILE(1);
+    }
+    if (wr == 0) SVDX_V5_BARRIER();                                  // ... and meet them again
+#undef SVDX_V5_TILE
+#undef SVDX_V5_WAIT
+#undef SVDX_V5_BARRIER
+#undef SVDX_V5_MMA
+#undef SVDX_V5_READ
+#undef SVDX_V5_ISSUE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the out-of-range tail pieces: the epilogue parks its tile in these buffers
+    __syncthreads();
+    v4_epilogue<T, NF, MF, NT, BM5, BN5, WM5, WN5>(p, smem, acc, z, m0, n0, pid_m, pid_n, wr, wc, tid);
 #endif
 }
 
@@ -1712,21 +1960,9 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
     return 0;
 }
 
-template <typename T, int NB, int MB, int WGM = 2, int NSTG = 2>
-int launch_gemm_v4(GemmParams p, hipStream_t st) {
-    constexpr int BMT = 16 * MB * WGM, BNT = 32 * NB;
-    constexpr int LDS_STG = NSTG * (BMT + BNT) * BK * 2, LDS_EPI = ((BMT * (BNT + 8) * 2 + 15) & ~15) + GN_LDS;      // K-loop stages | the rounded output tile parked for the coalesced stores (+ the GroupNorm statistics table behind it)
-    constexpr int LDS = LDS_STG > LDS_EPI ? LDS_STG : LDS_EPI;
-    static_assert(LDS <= 160 * 1024, "stages (and the epilogue tile parked in them) must fit the 160 KiB LDS");
-    constexpr bool HAS_DUAL = WGM == 2 && NSTG == 2;            // the LoRA second-operand loop is only instantiated for the round-1 tiles
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, MB, false, WGM, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (HAS_DUAL)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, MB, HAS_DUAL, WGM, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
-    if (p.K2 > 0 && !HAS_DUAL) { svdx_set_error("svdx_gemm_dual: this tile variant has no second-operand loop"); return -2; }
+// Tile counts, vector-store eligibility and the XCD arrangement of a BMT x BNT tile grid (see v4_tile_of_block): the arrangement with the
+// least operand re-fetch among those that keep >= 90 % of the best tile balance; -> the launch grid.  Shared by the v4 and v5 launchers.
+static int arrange_nt_grid(GemmParams& p, int BMT, int BNT, dim3& grid) {
     if (p.gn_stats) {
         // the statistics are taken in the coalesced store loop, which handles whole column tiles of 16-byte-aligned rows only
         const bool ok = p.N % BNT == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && (!p.res || (p.ldres % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
@@ -1734,9 +1970,8 @@ int launch_gemm_v4(GemmParams p, hipStream_t st) {
         if (!ok) { svdx_set_error("svdx_gemm_gn: N=%d / ldc=%d / rows=%d / cg=%d do not fit the %dx%d tile's statistics path", p.N, p.ldc, p.gn_rows, p.gn_cg, BMT, BNT); return -2; }
     }
     p.tiles_m = cdiv(p.M, BMT);
-    p.tiles_n = p.epi == SVDX_EPI_GEGLU_FWD ? cdiv(p.aux_dim, 16 * NB) : cdiv(p.N, BNT);
+    p.tiles_n = p.epi == SVDX_EPI_GEGLU_FWD ? cdiv(p.aux_dim, BNT / 2) : cdiv(p.N, BNT);
     p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 15) == 0));
-    // XCD arrangement (see the kernel): least operand re-fetch among the arrangements that keep >= 90 % of the best tile balance
     static const int force_xn = getenv("SVDX_XCD_N") ? atoi(getenv("SVDX_XCD_N")) : -1;     // developer knob: 0 = old split, 1/2/4/8
     const double a_bytes = 2.0 * p.M * (p.g.mode == SVDX_GATHER_PLAIN ? p.K : 2 * p.g.cin);   // conv: unique rows + halo
     const double b_bytes = 2.0 * (p.epi == SVDX_EPI_GEGLU_FWD ? 2 * p.aux_dim : p.N) * p.K;
@@ -1759,7 +1994,7 @@ int launch_gemm_v4(GemmParams p, hipStream_t st) {
         p.sub_n = cdiv(p.tiles_n, best_xn);
         gx = 8 * p.sub_m * p.sub_n;
     }
-    // K slices on XCDs of their own (see the kernel): among the arrangements of the 8 / split_k XCDs of a slice, the least re-fetch that keeps
+    // K slices on XCDs of their own (see v4_tile_of_block): among the arrangements of the 8 / split_k XCDs of a slice, the least re-fetch that keeps
     // >= 90 % of the best balance; taken when it fetches less than the slice-agnostic arrangement and leaves no more workgroup slots empty
     const char* zx_env = getenv("SVDX_ZXCD");                                               // developer knob, read per launch (tools/ab_inproc.py
     const int zxcd_on = zx_env ? atoi(zx_env) : 1;                                           // toggles it between captures): 0 = every XCD holds all slices
@@ -1780,9 +2015,49 @@ int launch_gemm_v4(GemmParams p, hipStream_t st) {
             gx = 8 * zsm * zsn; gy = 1;
         }
     }
-    dim3 grid(gx, gy);
+    grid = dim3(gx, gy);
+    return 0;
+}
+
+template <typename T, int NB, int MB, int WGM = 2, int NSTG = 2>
+int launch_gemm_v4(GemmParams p, hipStream_t st) {
+    constexpr int BMT = 16 * MB * WGM, BNT = 32 * NB;
+    constexpr int LDS_STG = NSTG * (BMT + BNT) * BK * 2, LDS_EPI = ((BMT * (BNT + 8) * 2 + 15) & ~15) + GN_LDS;      // K-loop stages | the rounded output tile parked for the coalesced stores (+ the GroupNorm statistics table behind it)
+    constexpr int LDS = LDS_STG > LDS_EPI ? LDS_STG : LDS_EPI;
+    static_assert(LDS <= 160 * 1024, "stages (and the epilogue tile parked in them) must fit the 160 KiB LDS");
+    constexpr bool HAS_DUAL = WGM == 2 && NSTG == 2;            // the LoRA second-operand loop is only instantiated for the round-1 tiles
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, MB, false, WGM, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (HAS_DUAL)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<T, NB, MB, HAS_DUAL, WGM, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    if (p.K2 > 0 && !HAS_DUAL) { svdx_set_error("svdx_gemm_dual: this tile variant has no second-operand loop"); return -2; }
+    dim3 grid;
+    if (int rc = arrange_nt_grid(p, BMT, BNT, grid)) return rc;
     if (p.K2 > 0) hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB, HAS_DUAL, WGM, NSTG>), grid, dim3(128 * WGM), LDS, st, p);
     else hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB, false, WGM, NSTG>), grid, dim3(128 * WGM), LDS, st, p);
+    SVDX_LAUNCH_CHECK("svdx_gemm");
+    return 0;
+}
+
+// the two-role eight-wave tiles (gemm_v5_kernel): (32 MF) x (64 NF), two K-tiles of LDS
+template <typename T, int MF, int NF>
+int launch_gemm_v5(GemmParams p, hipStream_t st) {
+    constexpr int BMT = 32 * MF, BNT = 64 * NF;
+    constexpr int LDS_STG = 2 * (BMT + BNT) * BK * 2, LDS_EPI = ((BMT * (BNT + 8) * 2 + 15) & ~15) + GN_LDS;
+    constexpr int LDS = LDS_STG > LDS_EPI ? LDS_STG : LDS_EPI;
+    static_assert(LDS <= 160 * 1024, "K-tiles (and the epilogue tile parked in them) must fit the 160 KiB LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v5_kernel<T, MF, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    if (p.K2 > 0) { svdx_set_error("svdx_gemm_dual: this tile variant has no second-operand loop"); return -2; }
+    dim3 grid;
+    if (int rc = arrange_nt_grid(p, BMT, BNT, grid)) return rc;
+    hipLaunchKernelGGL((gemm_v5_kernel<T, MF, NF>), grid, dim3(512), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm");
     return 0;
 }
@@ -1852,7 +2127,8 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
     SVDX_CHECK_ARG(!found_inf || out_mode == SVDX_OUT_F32 || out_mode == SVDX_OUT_F32_ADD, "svdx_gemm_tn: found_inf goes with the store / += modes");
     // operands below 2 GiB are staged through buffer descriptors (always, unless SVDX_TN_FLAT asks for rounds 1-4's flat staging for an A/B)
     const long a_span = ((long)(R - 1) * lda + N) * 2, b_span = ((long)(R - 1) * ldb + K) * 2;
-    const bool buf = a_span < (1L << 31) && b_span < (1L << 31) && !(stages & SVDX_TN_FLAT);
+    // (the kernels mark columns beyond the operand with the offset 0x7ffffff0, which must itself lie beyond num_records: spans up to that value only)
+    const bool buf = a_span <= 0x7ffffff0L && b_span <= 0x7ffffff0L && !(stages & SVDX_TN_FLAT);
     const bool pf = (stages & SVDX_TN_PREFETCH) != 0 && buf;
     stages &= ~(SVDX_TN_PREFETCH | SVDX_TN_FLAT);
     SVDX_CHECK_ARG(stages == 0 || (stages >= 2 && stages <= 4) || stages == 18,
@@ -2014,6 +2290,11 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
                 // A 160-wide request on an N that 160 does not divide (or with the GEGLU-forward epilogue) takes the 128-wide sibling;
                 // 256-wide tiles need N % 256 == 0 (their GEGLU epilogues have no partial column tile).
                 const int n_cols = epilogue == SVDX_EPI_GEGLU_FWD ? 2 * aux_dim : N;
+                // Two-role tiles (gemm_v5_kernel, round 6), one workgroup per CU:   32: 256x256   34: 160x320.  Their GEGLU epilogues take whole
+                // column tiles; a request that does not divide runs the ring tiles' 160- / 128-wide siblings instead (like 18 -> 17 below).
+                if (variant == 32 && (epilogue == SVDX_EPI_NONE || n_cols % 256 == 0)) return launch_gemm_v5<T, 8, 4>(p, st);
+                if (variant == 34 && (epilogue == SVDX_EPI_NONE || n_cols % 320 == 0)) return launch_gemm_v5<T, 5, 5>(p, st);
+                if (variant == 32 || variant == 34) variant = 16;
                 switch (variant) {
                     case 18: if (n_cols % 256 == 0) return launch_gemm_v4<T, 8, 4, 4, 2>(p, st);   // else: fall through to 256 x 128
                     case 16: case 17: return nb5 ? launch_gemm_v4<T, 5, 4, 4, 3>(p, st) : launch_gemm_v4<T, 4, 4, 4, 3>(p, st);

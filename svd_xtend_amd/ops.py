@@ -266,8 +266,13 @@ def choose_split(rt: "Runtime", M: int, N: int, Kd: int, ldc: int, bn: int = 0) 
 TILE_OF_VARIANT = {7: (128, 160, 2, 4), 6: (160, 160, 2, 4), 8: (128, 128, 2, 4),
                    16: (256, 160, 3, 8), 17: (256, 128, 3, 8), 18: (256, 256, 2, 8), 20: (128, 160, 4, 4), 21: (128, 128, 4, 4),
                    23: (192, 160, 3, 8), 22: (192, 128, 3, 8), 25: (96, 160, 4, 4), 24: (96, 128, 4, 4)}
-# instantiated in csrc/gemm.hip and offered to the in-situ tuner (bench.py --tune), but without a measured rate: the cost model never picks them
-STAGED_TILES = {27: (128, 128, 2, 8), 28: (128, 160, 2, 8)}
+# instantiated in csrc/gemm.hip and offered to the in-situ tuner (bench.py --tune), but not to the cost model:
+#   27 / 28: two-stage eight-wave tiles without a measured rate;
+#   32 / 34: round 6's two-role eight-wave tiles (gemm_v5_kernel: 256 x 256 and 160 x 320).  Isolated they are the fastest kernels of the library
+#   (8192^3: 1397 TF/s against 1297 for tile 18; the 64x40-level convolutions 5-20 % ahead of tile 6), inside the step they only TIE with
+#   the two-per-CU four-wave tiles (in-situ sweep: +-3 % per problem, one problem -10 %; cost-model selection +0.45 ms / step):
+#   profiles/r6e_tune_dump_reworked.txt, DESIGN.md 6.4.  A 160 x 320 two-role workgroup IS two 160 x 160 workgroups side by side.
+STAGED_TILES = {27: (128, 128, 2, 8), 28: (128, 160, 2, 8), 32: (256, 256, 2, 8), 34: (160, 320, 2, 8)}
 # TFLOP/s one CU sustains on a variant's K-loop when the CU is full (8192^3 runs of tools/ring_check.py divided by 256 CUs, trimmed by
 # the in-situ sweeps of bench.py --tune): the two-stage four-wave tiles need two workgroups per CU for it
 _TILE_RATE = {6: 4.05, 7: 3.5, 8: 3.5, 16: 4.4, 17: 4.0, 18: 3.6, 20: 2.75, 21: 2.5, 22: 3.8, 23: 3.8, 24: 2.4, 25: 2.05}
@@ -319,6 +324,8 @@ def _nt_candidates(M: int, N: int, Kd: int, splittable: bool, fused_epilogue: bo
         if bn == 128 and N % 160 == 0 and N % 128 and N > 160:
             continue
         if bn == 256 and N % 256:
+            continue
+        if bn == 320 and N % 320:
             continue
         if waves == 8 and M < 2 * bm:
             continue
@@ -375,6 +382,8 @@ def _choose_geglu_variant(M: int, N: int, Kd: int, fwd: bool, rule) -> int:
     the 256 x 256 tile keeps the forward at the 32x20 level (80.3 against 80.9), ring tiles the 8x5 level (M = 560)."""
     if not fwd and N % 128:
         return 4                                             # the backward epilogue takes whole column tiles: 160-wide ones here (N % 160 == 0)
+    if rule and rule.isdigit():                              # developer knob for A/B runs: one tile variant wherever it is a candidate
+        return int(rule) if int(rule) in geglu_candidates(M, N, Kd, fwd) else _choose_geglu_variant(M, N, Kd, fwd, None)
     if rule == "sweep":        # developer knob for A/B runs: the in-situ sweep's winners among the one-per-CU tiles
         if fwd:
             return 18 if (M >= 4096 and N % 256 == 0) else (17 if M >= 512 else 4)
@@ -534,6 +543,7 @@ def _tile_launched(variant: int, M: int, N: int) -> int:
     if variant == 18 and N % 256:
         return 17
     return variant
+
 
 
 # --------------------------------------------------------------------------------------------------

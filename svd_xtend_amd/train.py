@@ -381,14 +381,54 @@ class Trainer:
         self._pending = []
         return None
 
-    def use_direct_allreduce(self, on: bool = True) -> None:
+    def use_direct_allreduce(self, on: bool = True, verify: bool = True) -> bool:
         """Route the one-collective schedules (`overlap = False`) through svdx_allreduce_grads (DirectAllReduce) instead of RCCL's
-        all-reduce.  Collective: every rank of the group calls it.  The per-block buckets stay on RCCL."""
-        if on and self.world > 1:
-            if self.direct is None:
-                self.direct = DirectAllReduce(self.g_flat, self.pg, self.rt.k)
-        else:
-            self.direct = None
+        all-reduce.  Collective: every rank of the group calls it.  The per-block buckets stay on RCCL.
+        verify: before the path is adopted, two rounds of fresh random data go through it and through the library's all-reduce; every
+        rank votes (MIN over the group) and on any disagreement -- or any rank's exception -- ALL ranks stay on the library
+        (`self.direct_check` says why).  A stale read of a peer-mapped buffer would otherwise corrupt gradients silently.
+        Returns whether the direct path is in use."""
+        self.direct = None
+        if not (on and self.world > 1):
+            return False
+        if getattr(self, "_direct_verified", None) is not None:      # mapped and verified before (every rank took the same decision then)
+            self.direct = self._direct_verified
+            return True
+        ok, why, direct = 1.0, None, None
+        try:
+            direct = DirectAllReduce(self.g_flat, self.pg, self.rt.k)
+        except Exception as e:  # noqa: BLE001 -- its constructor has already agreed with the other ranks (MIN) that the mapping failed
+            self.direct_check = {"agrees_with_library": False, "error": repr(e)[:200]}
+            return False
+        if verify:
+            keep = self.g_flat.clone()
+            for rnd in range(2):                           # fresh data twice: a stale read of a peer's previous contents would show
+                err = None
+                gsrc = torch.randn(self.g_flat.numel(), device=self.g_flat.device,
+                                   generator=torch.Generator(device=self.g_flat.device).manual_seed(31 * rnd + dist.get_rank(self.pg)))
+                try:                                       # a rank-local failure must not leave the others alone in the collectives below
+                    self.g_flat.copy_(gsrc)
+                    direct.all_reduce()
+                    got = self.g_flat.clone()
+                except Exception as e:  # noqa: BLE001
+                    err, got = repr(e)[:200], None
+                dist.all_reduce(gsrc, op=dist.ReduceOp.SUM, group=self.pg)
+                if err is not None:
+                    ok, why = 0.0, err
+                elif not torch.allclose(got, gsrc, rtol=1e-4, atol=1e-5):
+                    ok, why = 0.0, f"round {rnd}: direct sum differs from the library's by {float((got - gsrc).abs().max()):.3e}"
+            self.g_flat.copy_(keep)
+            flag = torch.tensor([ok], device=self.g_flat.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            agreed = bool(flag.item() == 1.0)
+            self.direct_check = {"agrees_with_library": agreed, "rounds": 2}
+            if why is not None:
+                self.direct_check["error"] = why
+            if not agreed:
+                return False
+            self._direct_verified = direct
+        self.direct = direct
+        return True
 
     def finish_grads(self, side_work=None) -> None:
         """Complete the gradient sum over ranks, with `side_work()` issued on the compute stream while the collective is in flight.

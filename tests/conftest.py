@@ -11,6 +11,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle is memory-bound torch fp32 work: on the GPU box's 2 x 64-core host one step of the 64x40-level block takes 30 s on 32
+    # threads, 43 s on 64, 81 s on PyTorch's default of 128 and 419 s on 256 (profiles/r6b_oracle_threads.txt) -- pin it.
+    import torch
+    n = int(os.environ.get("SVDX_ORACLE_THREADS", "32"))
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
 
 
 def pytest_collection_modifyitems(config, items):

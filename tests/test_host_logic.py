@@ -401,11 +401,17 @@ def test_tile_table_matches_the_kernel_dispatch():
         assert tiles, line
         for v in variants:
             seen[v] = tiles
+    # the two-role tiles: `if (variant == V && ...) return launch_gemm_v5<T, MF, NF>(p, st);` -> rows = 32 * MF, columns = 64 * NF, two K-tiles, eight waves
+    for v, mf, nf in re.findall(r"if \(variant == (\d+) &&[^\n]*launch_gemm_v5<T, (\d+), (\d+)>", src):
+        seen[int(v)] = [("v5", int(mf), int(nf))]
     assert not set(STAGED_TILES) & set(TILE_OF_VARIANT)
     for v, (bm, bn, stages, waves) in list(TILE_OF_VARIANT.items()) + list(STAGED_TILES.items()):
         if v < 16:
             continue                                   # 6 / 7 / 8: the two-stage four-wave defaults of launch_gemm_v4<T, NB, MB>
-        geo = {(16 * mb * wgm, 32 * nb, nstg, 2 * wgm) for nb, mb, wgm, nstg in seen[v]}
+        if seen[v][0][0] == "v5":
+            geo = {(32 * mf, 64 * nf, 2, 8) for _, mf, nf in seen[v]}
+        else:
+            geo = {(16 * mb * wgm, 32 * nb, nstg, 2 * wgm) for nb, mb, wgm, nstg in seen[v]}
         assert (bm, bn, stages, waves) in geo, (v, (bm, bn, stages, waves), geo)
     assert {(16 * mb * wgm, 32 * nb, nstg, 2 * wgm) for nb, mb, wgm, nstg in seen[GEGLU_TWO_PER_CU]} == {(192, 128, 2, 8)}
 

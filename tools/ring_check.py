@@ -90,7 +90,10 @@ def do_check():
         groups = []
         for v in kc.RING_VARIANTS:
             groups += [(f"plain v{v}", lambda v=v: kc.check_gemm_plain(P, dt, v)), (f"gather v{v}", lambda v=v: kc.check_gemm_gather(P, dt, v))]
-        groups += [(f"geglu v{v}", lambda v=v: kc.check_gemm_geglu(P, dt, v)) for v in (17, 18, 21)]
+        for v in (32, 34):          # the two-role tiles of round 6
+            groups += [(f"plain v{v}", lambda v=v: kc.check_gemm_plain(P, dt, v)), (f"gather v{v}", lambda v=v: kc.check_gemm_gather(P, dt, v)),
+                       (f"gn v{v}", lambda v=v: kc.check_gemm_gn(P, dt, v))]
+        groups += [(f"geglu v{v}", lambda v=v: kc.check_gemm_geglu(P, dt, v)) for v in (17, 18, 21, 32, 34)]
         groups += [(f"tn s{s}", lambda s=s: kc.check_gemm_tn(P, dt, s)) for s in (0, 3, 4, 18)]
         for name, fn in groups:
             try:
@@ -180,6 +183,23 @@ def do_time():
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "ring_time.json"), "w"))
 
 
+def do_big():
+    """square problems on uniform random [-1, 1) operands (the data fill cdna_hip_programming.md quotes its 8-phase template on)"""
+    dt = torch.bfloat16
+    for n in (4096, 8192):
+        g = torch.Generator(device="cpu").manual_seed(n)
+        A = (torch.rand(n, n, generator=g) * 2 - 1).to(dt).to(dev)
+        B = (torch.rand(n, n, generator=g) * 2 - 1).to(dt).to(dev)
+        out = torch.empty(n, n, dtype=dt, device=dev)
+        res = {}
+        for v in (6, 8, 16, 17, 18, 32, 34):
+            if TILE_OF_VARIANT[v][1] in (160, 320) and n % TILE_OF_VARIANT[v][1]:
+                continue
+            res[v] = timeit(lambda: be.gemm(A, B, out, n, n, n, n, n, n, variant=v), iters=10)
+        fl = 2.0 * n ** 3
+        print(f"square {n}: " + "  ".join(f"v{v} {u:.0f} us ({fl / u / 1e6:.0f} TF)" for v, u in sorted(res.items(), key=lambda kv: kv[1])), flush=True)
+
+
 TN_SHAPES = [(35840, 2560, 320), (35840, 320, 1280), (35840, 960, 320), (35840, 320, 320), (8960, 5120, 640), (8960, 640, 2560), (8960, 1920, 640),
              (8960, 640, 640), (2240, 10240, 1280), (2240, 1280, 5120), (2240, 3840, 1280), (2240, 1280, 1280), (560, 10240, 1280), (560, 1280, 5120)]
 
@@ -227,3 +247,5 @@ if __name__ == "__main__":
         do_time()
     if "tn" in what:
         do_tn_time()
+    if "big" in what:
+        do_big()
