@@ -173,7 +173,14 @@ def cpu_baseline(dev=None, dtype=torch.float16, c2=True):
     from oracle.step import edm_inputs, make_optimizer, make_synthetic_batch, train_step
     from oracle.unet import SVD_CONFIG, UNetSpatioTemporalConditionOracle, no_default_init, scaled_init_
     torch.manual_seed(0)
-    cores = torch.get_num_threads()
+    # Threads: the oracle is memory-bound torch fp32 work and PyTorch's default (one thread per physical core: 128 on the GPU box's 2 x 64-core
+    # host) is far from its best there -- one c1' step takes 4.6 s on 16 threads, 7 s on 32, 12 s on 64 and 20.9 s on 128; one step of the
+    # 64x40-level block 30 s on 32 threads, 43 s on 64, 81 s on 128 (profiles/r6b_oracle_threads.txt, r6c_oracle_threads_c1.txt).  The baseline
+    # is timed at the fastest setting measured, and `cores` states the threads actually used.
+    host_threads = torch.get_num_threads()
+    cores = min(host_threads, 16)
+    cores_c2 = min(host_threads, 32)
+    torch.set_num_threads(cores)
     t0 = time.time()
     with no_default_init():                         # scaled_init_ fills every parameter: skip 1.52 B kaiming draws on one core
         orc = UNetSpatioTemporalConditionOracle(**SVD_CONFIG)
@@ -235,16 +242,19 @@ def cpu_baseline(dev=None, dtype=torch.float16, c2=True):
         avail = psutil.virtual_memory().available / 2 ** 30
     except Exception:  # noqa: BLE001
         avail = 0.0
-    if c2 and cores >= 32 and avail >= 110.0 and dt <= 45.0:
+    if c2 and host_threads >= 32 and avail >= 110.0 and dt <= 45.0:
         b2 = make_synthetic_batch(1, 14, 40, 64, 2)
+        torch.set_num_threads(cores_c2)
         t1 = time.time()
         loss2, pred2 = train_step(orc, b2, opt)
         t2 = time.time() - t1
-        out["c2"] = {"value": 1.0 / t2, "unit": "samples/s", "seconds": t2, "loss": float(loss2),
+        out["c2"] = {"value": 1.0 / t2, "unit": "samples/s", "seconds": t2, "loss": float(loss2), "cores": cores_c2,
                      "sample": "c2: ONE un-warmed step of the benched shape (14 frames 512x320, latent 40x64), same model, fp32; 24.8 TFLOP",
                      "parity_c2": hip_loss(b2, loss2, pred2)}
     else:
-        out["c2"] = {"skipped": f"needs >= 32 cores, >= 110 GB free RAM and a c1' step <= 45 s (have {cores} cores, {avail:.0f} GB, {dt:.1f} s)"}
+        out["c2"] = {"skipped": f"needs >= 32 cores, >= 110 GB free RAM and a c1' step <= 45 s (have {host_threads} cores, {avail:.0f} GB, {dt:.1f} s)"}
+    torch.set_num_threads(host_threads)
+    out["host_threads_default"] = host_threads
     del prod
     if dev is not None:
         torch.cuda.empty_cache()

@@ -62,12 +62,18 @@ class _Resnet(nn.Module):
             if op is not None:
                 op.pack(rt, need_dx=False)
 
-    def fwd(self, rt: Runtime, x, n: int, h: int, w: int):
-        a, _ = self.gn1.fwd(rt, x, n, h * w)
-        y, _, _ = self.c1.fwd(rt, a, n, h, w)
-        a, _ = self.gn2.fwd(rt, y, n, h * w)
+    def fwd(self, rt: Runtime, x, n: int, h: int, w: int, pre=None, want_out=None):
+        """pre: (stats, filled) when the launch that wrote x already took norm1's statistics (GroupNormOp.fwd); want_out: what the norm
+        that reads THIS block's output wants from the launch that writes it (GroupNormOp.want) -- `self.took_out` says whether it got them.
+        As in the UNet's resnets, the statistics passes over the full-resolution tensors ride on the producing GEMM's store loop."""
+        a, _ = self.gn1.fwd(rt, x, n, h * w, pre=pre)
+        w2 = self.gn2.want(rt, n, h * w)
+        y, _, _ = self.c1.fwd(rt, a, n, h, w, gn=w2)
+        a, _ = self.gn2.fwd(rt, y, n, h * w, pre=(w2[0], self.c1.took_gn) if w2 is not None else None)
         sc = x if self.sc is None else self.sc.fwd(rt, x, n, h, w)[0]
-        return self.c2.fwd(rt, a, n, h, w, res=sc)[0]
+        out = self.c2.fwd(rt, a, n, h, w, res=sc, gn=want_out)[0]
+        self.took_out = want_out is not None and self.c2.took_gn
+        return out
 
 
 class _Downsample(nn.Module):
@@ -381,19 +387,33 @@ class AutoencoderKLTemporalDecoder(nn.Module):
         k.patch_rows(x.contiguous(), a, n, cin, H, W, 3, 3, 1, 1, H, W, self.k_in)
         c0 = self.config.block_out_channels[0]
         y = rt.empty(n * H * W, c0)
-        gemm_act(rt, a, self.w_in, y, n * H * W, c0, self.k_in, self.k_in, self.k_in, c0, bias=enc.conv_in.bias.data)
+        # the chain of stages; every producer (conv_in, a resnet's second convolution, a downsampling convolution) is told what the NEXT
+        # stage's first GroupNorm wants, so that the statistics passes over the full-resolution tensors ride on the producing GEMMs
+        blocks = list(enc.down_blocks)
+        mid = enc.mid_block
+        first = blocks[0].resnets[0].gn1.want(rt, n, H * W)
+        took = gemm_act(rt, a, self.w_in, y, n * H * W, c0, self.k_in, self.k_in, self.k_in, c0, bias=enc.conv_in.bias.data, gn=first)
+        pre = (first[0], took) if first is not None else None
         del a
         h, w = H, W
-        for blk in enc.down_blocks:
-            for r in blk.resnets:
-                y = r.fwd(rt, y, n, h, w)
-            if hasattr(blk, "downsamplers"):
-                y, h, w = blk.downsamplers[0].op.fwd(rt, y, n, h, w)
-        mid = enc.mid_block
-        y = mid.resnets[0].fwd(rt, y, n, h, w)
+        for bi, blk in enumerate(blocks):
+            rs = list(blk.resnets)
+            down = blk.downsamplers[0].op if hasattr(blk, "downsamplers") else None
+            after = (blocks[bi + 1].resnets[0] if bi + 1 < len(blocks) else mid.resnets[0]).gn1      # the norm behind this block
+            for i, r in enumerate(rs):
+                nxt = rs[i + 1].gn1.want(rt, n, h * w) if i + 1 < len(rs) else (after.want(rt, n, h * w) if down is None else None)
+                y = r.fwd(rt, y, n, h, w, pre=pre, want_out=nxt)
+                pre = (nxt[0], r.took_out) if nxt is not None else None
+            if down is not None:
+                ho, wo = down.out_hw(h, w)
+                nxt = after.want(rt, n, ho * wo)
+                y, h, w = down.fwd(rt, y, n, h, w, gn=nxt)
+                pre = (nxt[0], down.took_gn) if nxt is not None else None
+        y = mid.resnets[0].fwd(rt, y, n, h, w, pre=pre)
         y = mid.attentions[0].fwd(rt, y, n, h, w)
-        y = mid.resnets[1].fwd(rt, y, n, h, w)
-        a, _ = self.gn_out.fwd(rt, y, n, h * w)
+        want = self.gn_out.want(rt, n, h * w)
+        y = mid.resnets[1].fwd(rt, y, n, h, w, want_out=want)
+        a, _ = self.gn_out.fwd(rt, y, n, h * w, pre=(want[0], mid.resnets[1].took_out) if want is not None else None)
         return self.c_out.fwd(rt, a, n, h, w)[0], h, w
 
     def max_frames(self, H: int, W: int) -> int:
