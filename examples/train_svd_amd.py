@@ -65,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--num_samples", type=int, default=100000, help="length of the dataset (train_svd.py:70)")
     ap.add_argument("--tiny", action="store_true", help="smoke configuration: tiny UNet / VAE / CLIP topologies instead of SVD's")
     ap.add_argument("--no_graph", action="store_true", help="eager launches instead of the captured step")
+    ap.add_argument("--reference_rng", action="store_true",
+                    help="draw cond_sigmas / sigmas the reference's way (host, process-global generator, train_svd.py:954 / :964): with --seed the run "
+                         "walks the reference's sigma sequence")
     return ap.parse_args(argv)
 
 
@@ -211,7 +214,7 @@ def main(argv=None):
     # batches and restores the generators that drive its noise, train_svd.py:900-931): both streams are re-seeded from (seed, rank, global_step)
     sampler_gen.manual_seed((args.seed or 0) + rank + 1000003 * global_step)
     loop = TrainLoop(trainer, vae, image_encoder, conditioning_dropout_prob=args.conditioning_dropout_prob,
-                     seed=(args.seed or 0) * 7919 + rank + 104729 * global_step, use_graph=not args.no_graph, ema=ema_unet)
+                     seed=(args.seed or 0) * 7919 + rank + 104729 * global_step, use_graph=not args.no_graph, ema=ema_unet, reference_rng=args.reference_rng)
 
     def clips():
         while True:

@@ -29,9 +29,23 @@ from .train import GraphedStep, Trainer, conditioning_dropout, edm_prepare
 BATCH_KEYS = ("unet_in", "timesteps", "ehs", "added_time_ids", "noisy_latents", "target", "sigmas")
 
 
+def rand_log_normal_reference(shape, loc: float = 0.0, scale: float = 1.0) -> torch.Tensor:
+    """The reference's sigma draw, arithmetic and generator included (train_svd.py:63-67, called without a device at :954 and :964):
+    uniforms from the PROCESS-GLOBAL CPU generator, the normal's inverse CDF on the host.  `torch.manual_seed(s)` therefore reproduces
+    the reference's sigma sequence (tests/test_train_loop.py pins it to the values the reference's own function produced)."""
+    u = torch.rand(shape, dtype=torch.float32, device="cpu") * (1 - 2e-7) + 1e-7
+    return torch.distributions.Normal(loc, scale).icdf(u).exp()
+
+
 class TrainLoop:
     def __init__(self, trainer: Trainer, vae, image_encoder, conditioning_dropout_prob: Optional[float] = None, seed: int = 0,
-                 use_graph: bool = True, ema=None, fps: int = 7, motion_bucket_id: int = 127, graph_conditioners: bool = True):
+                 use_graph: bool = True, ema=None, fps: int = 7, motion_bucket_id: int = 127, graph_conditioners: bool = True,
+                 reference_rng: bool = False):
+        """reference_rng: draw cond_sigmas (:954) and sigmas (:964) the reference's way -- on the host, from the process-global generator, in
+        that order -- instead of on the device from this loop's generator: a run seeded with `torch.manual_seed` then walks the reference's
+        sigma sequence.  (The Gaussian noise tensors stay device draws: the reference's come from the CUDA generator, which no other device
+        reproduces.)  Costs two 4-byte host-to-device copies per micro-batch."""
+        self.reference_rng = reference_rng
         self.tr, self.vae, self.enc = trainer, vae, image_encoder
         self.p_drop = conditioning_dropout_prob
         self.use_graph = use_graph and trainer.dev.type == "cuda"
@@ -50,7 +64,10 @@ class TrainLoop:
     def _draw_shapes(self, bsz: int, T: int, H: int, W: int) -> Dict[str, tuple]:
         down = 2 ** (len(self.vae.config.block_out_channels) - 1)
         zc, h, w = self.vae.config.latent_channels, H // down, W // down
-        return dict(u_cond=(bsz,), n_cpix=(bsz, 1, 3, H, W), eps=(bsz, T + 1, zc, h, w), noise=(bsz, T, zc, h, w), u_sig=(bsz,), p_drop=(bsz,))
+        shapes = dict(u_cond=(bsz,), n_cpix=(bsz, 1, 3, H, W), eps=(bsz, T + 1, zc, h, w), noise=(bsz, T, zc, h, w), u_sig=(bsz,), p_drop=(bsz,))
+        if self.reference_rng:
+            shapes.update(cond_sigmas=(bsz,), sigmas=(bsz,))
+        return shapes
 
     def _draw(self, bsz: int, T: int, H: int, W: int, into: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         """Every random number of one micro-batch, in a fixed order from the loop's generator (eager launches: the arithmetic that consumes
@@ -61,6 +78,9 @@ class TrainLoop:
             torch.rand(shapes[k], generator=self.gen, out=out[k])
         for k in ("n_cpix", "eps", "noise"):
             torch.randn(shapes[k], generator=self.gen, out=out[k])
+        if self.reference_rng:                                      # the reference's order: cond_sigmas (:954), then sigmas (:964)
+            out["cond_sigmas"].copy_(rand_log_normal_reference(shapes["cond_sigmas"], loc=-3.0, scale=0.5), non_blocking=True)
+            out["sigmas"].copy_(rand_log_normal_reference(shapes["sigmas"], loc=0.7, scale=1.6), non_blocking=True)
         return out
 
     @torch.no_grad()
@@ -68,7 +88,7 @@ class TrainLoop:
         """pix [B, T, 3, H, W] float in [-1, 1] on the device + the draws -> the step's inputs.  No host<->device traffic, no generator: capturable."""
         bsz, T = pix.shape[:2]
         log_normal = lambda u, loc, scale: (loc + scale * (2.0 ** 0.5) * torch.erfinv(2.0 * (u * (1 - 2e-7) + 1e-7) - 1.0)).exp()   # noqa: E731  (:63-66)
-        cond_sigmas = log_normal(d["u_cond"], -3.0, 0.5)                                          # :954
+        cond_sigmas = d["cond_sigmas"] if "cond_sigmas" in d else log_normal(d["u_cond"], -3.0, 0.5)   # :954
         noise_aug_strength = cond_sigmas[0]                                                       # :955 (the reference's batch-1 TODO)
         cpix = d["n_cpix"] * cond_sigmas[:, None, None, None, None] + pix[:, 0:1]                 # :957-958
         # one encoder pass over the clip's T frames and the noise-augmented first frame (:948 and :959 are two calls there)
@@ -77,7 +97,7 @@ class TrainLoop:
         z = (dist_.mean + dist_.std * d["eps"].reshape(dist_.mean.shape)).reshape(bsz, T + 1, *dist_.mean.shape[1:]) * self.vae.config.scaling_factor
         latents = z[:, :T]
         conditional_latents = z[:, T] / self.vae.config.scaling_factor                            # :959-960
-        sigmas = log_normal(d["u_sig"], 0.7, 1.6)                                                 # :964
+        sigmas = d["sigmas"] if "sigmas" in d else log_normal(d["u_sig"], 0.7, 1.6)              # :964
         ehs = encode_image(pix[:, 0], self.enc).to(torch.float32)                                 # :975-976
         ids = torch.stack([torch.full_like(noise_aug_strength, float(self.fps)), torch.full_like(noise_aug_strength, float(self.bucket)),
                            noise_aug_strength]).unsqueeze(0).repeat(bsz, 1)                       # :981-988 (fps passed as 7 there)

@@ -51,6 +51,35 @@ def test_prepare_batch_follows_the_reference_statements(emu_backend):
             assert (float(bb["unet_in"][:, :, 4:].abs().max()) == 0.0) == want_cond0
 
 
+def test_reference_rng_walks_the_reference_sigma_sequence(emu_backend):
+    """TrainLoop(reference_rng=True): cond_sigmas (train_svd.py:954) and sigmas (:964) come from the process-global CPU generator through
+    the reference's own arithmetic.  Pinned two ways: (1) `rand_log_normal_reference` against the sigmas the reference's `rand_log_normal`
+    produced when tests/golden/make_golden_step_math.py executed its statements (first draw after `torch.manual_seed(3000 + seed)`), bit
+    for bit; (2) a seeded loop hands the step exactly the two draws, cond_sigma first."""
+    from safetensors.torch import load_file
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_golden_step_math import CASES
+    from svd_xtend_amd.loop import TrainLoop, rand_log_normal_reference
+    gold = load_file(os.path.join(HERE, "golden", "step_math.safetensors"))
+    for i, (bsz, _T, _h, _w, _D, _prob, seed) in enumerate(CASES):
+        torch.manual_seed(3000 + seed)
+        assert torch.equal(rand_log_normal_reference([bsz], loc=0.7, scale=1.6), gold[f"case{i}.sigmas"].reshape(-1)), i
+    tr, vae, enc = build(torch.device("cpu"), torch.float32)
+    loop = TrainLoop(tr, vae, enc, conditioning_dropout_prob=None, seed=3, use_graph=False, reference_rng=True)
+    torch.manual_seed(77)
+    b = loop.prepare_batch(clips(1)[0])
+    torch.manual_seed(77)
+    cond = rand_log_normal_reference([1], loc=-3.0, scale=0.5)          # :954 draws first
+    sig = rand_log_normal_reference([1], loc=0.7, scale=1.6)            # :964 second
+    assert torch.equal(b["sigmas"], sig) and torch.equal(b["added_time_ids"][:, 2], cond), (b["sigmas"], sig, b["added_time_ids"], cond)
+    assert torch.allclose(b["timesteps"], 0.25 * sig.log())
+    # the default stays a device-side draw from the loop's own generator: the global generator is not consumed
+    loop2 = TrainLoop(tr, vae, enc, conditioning_dropout_prob=None, seed=3, use_graph=False)
+    torch.manual_seed(77)
+    loop2.prepare_batch(clips(1)[0])
+    assert torch.equal(torch.rand(1), torch.rand(1, generator=torch.Generator().manual_seed(77)))
+
+
 def test_pipelined_loop_equals_sequential_steps(emu_backend):
     """Producing clip i + 1's batch between the backward sweep and the optimizer of step i changes nothing: the same losses and
     the same weights as prepare -> step -> prepare -> step, and the EMA follows."""
