@@ -62,7 +62,7 @@ typedef struct svdx_gather {
 
 /* ABI revision of this header: bumped whenever an entry changes its argument list or meaning (100 = rounds 1-3; 400 = round 4).
  * svdx_version() returns the value the library was built with; the ctypes binding refuses a library whose number differs. */
-#define SVDX_VERSION 501
+#define SVDX_VERSION 600
 int         svdx_version(void);
 int         svdx_last_error(char* buf, size_t n);
 /* 1 when the binary was built for gfx950 and a device is usable */
@@ -344,6 +344,21 @@ int svdx_zero_spans(float* base, const int* spans, int n_spans, void* stream);
  * order; capturable.  bench.py brackets the GEMM-family launches of a captured step with it. */
 int svdx_stamp(uint64_t* slot, void* stream);
 int svdx_wall_clock_khz(void);
+
+/* ---- Launch plans: one pass of the path replayed from C (SURVEY.md 8b asks for svdx_unet_forward / svdx_unet_backward / svdx_workspace_bytes_*:
+ * what a non-Python host would bind in place of `unet(...)` at /root/reference/train_svd.py:1021 and `accelerator.backward(loss)` at :1044).
+ * The step is ~1,500 launches issued by the host-side operators, which own every buffer; a plan is that launch list -- kernel, grid,
+ * block, LDS bytes, argument bytes (the device pointers among them) -- recorded on the calling thread while the pass runs or is being
+ * captured, and re-issued by svdx_plan_replay with no Python, torch or hipGraph involved.  Every svdx_* entry called between begin and end
+ * on that thread is recorded in call order (and still launched / captured as usual).  The buffers the recorded pointers refer to must
+ * stay alive and in place for as long as the plan is replayed (the captured step's memory pool does that); replays are stream-ordered,
+ * nothing synchronises.  svdx_plan_bytes = host bytes the plan holds. */
+int     svdx_plan_begin(void);
+int     svdx_plan_end(void** plan);
+int64_t svdx_plan_launches(const void* plan);
+int64_t svdx_plan_bytes(const void* plan);
+int     svdx_plan_replay(const void* plan, void* stream);
+int     svdx_plan_free(void* plan);
 
 /* ---- The data-parallel gradient sum without a collective library (svdx_allreduce_grads; replaces the all-reduce that
  * DistributedDataParallel runs inside accelerator.backward, /root/reference/train_svd.py:815 + :1044, when RCCL's choice of algorithm

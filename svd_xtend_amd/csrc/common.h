@@ -17,6 +17,39 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void svdx_set_error(const char* fmt, ...);
 
+// ---- launch plans (include/svdx.h: svdx_plan_*; common.cpp) --------------------------------------------------------------------------------
+// Every kernel of the library is launched through hipLaunchKernelGGL; here that macro is re-pointed at svdx_launch, which issues the same
+// launch through hipLaunchKernel and -- while the calling thread records a plan -- keeps the kernel's address, geometry and a copy of its
+// by-value arguments.  A recorded plan re-issues the launches from C with no Python, torch or hipGraph involved (svdx_plan_replay).
+bool svdx_plan_recording();
+void svdx_plan_record(const void* fn, dim3 grid, dim3 block, unsigned lds, void* const* args, const size_t* sizes, int nargs);
+#ifndef SVDX_SIM
+#include <tuple>
+#include <utility>
+template <typename... KArgs, typename... Args>
+inline void svdx_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t st, Args&&... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    if constexpr (sizeof...(KArgs) == 0) {
+        (void)hipLaunchKernel(fn, grid, block, nullptr, lds, st);
+        if (svdx_plan_recording()) svdx_plan_record(fn, grid, block, lds, nullptr, nullptr, 0);
+    } else {
+        std::tuple<std::remove_cv_t<KArgs>...> held(std::forward<Args>(args)...);    // converted to the kernel's parameter types, as <<< >>> would
+        std::apply([&](auto&... a) {
+            void* ptrs[] = {(void*)&a...};
+            (void)hipLaunchKernel(fn, grid, block, ptrs, lds, st);
+            if (svdx_plan_recording()) {
+                const size_t sizes[] = {sizeof(a)...};
+                svdx_plan_record(fn, grid, block, lds, ptrs, sizes, (int)sizeof...(a));
+            }
+        }, held);
+    }
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
+    svdx_launch(kern, dim3(grid), dim3(block), (unsigned)(shmem), (hipStream_t)(stream), ##__VA_ARGS__)
+#endif
+
 #define SVDX_CHECK_ARG(cond, ...)                 \
     do {                                          \
         if (!(cond)) {                            \

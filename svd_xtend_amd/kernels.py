@@ -26,7 +26,7 @@ LN_PARTIAL_ROWS = 2048
 GN_REPLICAS = 8
 GN_STAT_FLOATS = 4             # floats of storage per (replica, sample, group) of a GroupNorm statistics buffer: two int64
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_CONV3X3_DGRAD2, GATHER_TEMPORAL3, GATHER_CONV3X3_PAD0 = 0, 1, 2, 3, 4
-ABI_VERSION = 501              # include/svdx.h: SVDX_VERSION this binding was written against
+ABI_VERSION = 600              # include/svdx.h: SVDX_VERSION this binding was written against
 OPT_STATE_FLOATS = 16          # include/svdx.h: layout of the optimizer / loss-scale / schedule state
 SCHED_KINDS = {"constant": 0, "constant_with_warmup": 1, "linear": 2, "cosine": 3, "cosine_with_restarts": 4, "polynomial": 5, "piecewise_constant": 6}
 SCHED_MAX_RULES = 8            # include/svdx.h SVDX_SCHED_MAX_RULES: step rules of piecewise_constant, stored behind the 16 state floats
@@ -144,10 +144,15 @@ _SIGS = {
     "svdx_adamw_tiled": "ppppp" "i" "ffffff" "ppp" "ip",
     "svdx_ema_lerp": "pp" "l" "f" "p",
     "svdx_allreduce_grads": "p" "ii" "l" "i" "p",
+    "svdx_plan_begin": "",
+    "svdx_plan_end": "p",
+    "svdx_plan_replay": "pp",
+    "svdx_plan_free": "p",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "l": ctypes.c_int64, "z": ctypes.c_size_t}
 
-EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_wall_clock_khz", "svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band", "svdx_ln_bwd_blocks")
+EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_wall_clock_khz", "svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band", "svdx_ln_bwd_blocks",
+                                    "svdx_plan_launches", "svdx_plan_bytes")
 TN_FLAT = 64                   # include/svdx.h SVDX_TN_FLAT (developer knob: rounds 1-4's staging)
 TN_PREFETCH = 32               # include/svdx.h SVDX_TN_PREFETCH: flag of svdx_gemm_tn's `stages`
 MAX_PEERS = 16                 # include/svdx.h SVDX_MAX_PEERS: ranks of svdx_allreduce_grads
@@ -195,6 +200,9 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.svdx_tsa_pixels_per_band.restype = ctypes.c_int
     lib.svdx_ln_bwd_blocks.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.svdx_ln_bwd_blocks.restype = ctypes.c_int
+    for name in ("svdx_plan_launches", "svdx_plan_bytes"):
+        getattr(lib, name).argtypes = [ctypes.c_void_p]
+        getattr(lib, name).restype = ctypes.c_int64
     lib.svdx_version.restype = ctypes.c_int
     lib.svdx_wall_clock_khz.restype = ctypes.c_int
     lib.svdx_device_ok.restype = ctypes.c_int
@@ -222,6 +230,36 @@ def _f32(t: Optional[torch.Tensor]):
     if t is not None and t.dtype != torch.float32:
         raise SvdxError(f"expected float32 tensor, got {t.dtype}")
     return _p(t)
+
+
+class LaunchPlan:
+    """Handle of a recorded launch plan (svdx_plan_end).  `replay(stream)` re-issues its launches through svdx_plan_replay: ctypes -> C, no
+    torch graph.  The tensors the recorded launches point into are the caller's to keep alive and in place."""
+
+    def __init__(self, backend: "HipBackend", handle: int):
+        self.be, self.handle = backend, handle
+
+    @property
+    def launches(self) -> int:
+        return int(self.be.lib.svdx_plan_launches(self.handle))
+
+    @property
+    def host_bytes(self) -> int:
+        return int(self.be.lib.svdx_plan_bytes(self.handle))
+
+    def replay(self, stream: Optional[int] = None) -> None:
+        self.be._call("svdx_plan_replay", self.handle, stream if stream is not None else self.be._stream())
+
+    def free(self) -> None:
+        if self.handle:
+            self.be.lib.svdx_plan_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 class HipBackend:
@@ -505,6 +543,15 @@ class HipBackend:
 
     def wall_clock_khz(self) -> int:
         return int(self.lib.svdx_wall_clock_khz())
+
+    # ---- launch plans (include/svdx.h svdx_plan_*): the launches of one pass recorded on this thread, replayed from C ----
+    def plan_begin(self) -> None:
+        self._call("svdx_plan_begin")
+
+    def plan_end(self) -> "LaunchPlan":
+        h = ctypes.c_void_p()
+        self._call("svdx_plan_end", ctypes.byref(h))
+        return LaunchPlan(self, h.value)
 
     def zero_spans(self, base, spans, n_spans):
         assert spans.dtype == torch.int32 and spans.is_contiguous()

@@ -563,9 +563,15 @@ class GraphedStep:
     (async: it runs beside the next segments' kernels).  Gradients are only reduced on the last micro-batch, as with
     `accelerator.accumulate` (train_svd.py:941).  On one rank the collectives vanish and the chain is just the step."""
 
-    def __init__(self, trainer: "Trainer", batch, cut_blocks: Optional[bool] = None):
+    def __init__(self, trainer: "Trainer", batch, cut_blocks: Optional[bool] = None, record_plan: bool = False):
         """cut_blocks: cut the chain at every transformer block (None: only when there is a collective to interleave, i.e. on
-        several ranks with `trainer.overlap`; True lets one rank rehearse the multi-rank chain)."""
+        several ranks with `trainer.overlap`; True lets one rank rehearse the multi-rank chain).
+        record_plan: also keep the captured launches as a C-replayable plan (include/svdx.h svdx_plan_*): `replay_plan()` then runs the
+        step through svdx_plan_replay -- ctypes into C, no torch graph -- on the tensors of this object's memory pool.  One rank only (a
+        plan holds kernel launches, not collectives)."""
+        if record_plan and trainer.world > 1:
+            raise ValueError("a launch plan holds kernel launches only: record it on one rank")
+        self.plan = None
         batches = [batch] if isinstance(batch, dict) else list(batch)
         if cut_blocks is None:
             cut_blocks = trainer.world > 1 and trainer.overlap
@@ -596,6 +602,8 @@ class GraphedStep:
             g = torch.cuda.CUDAGraph()
             g.capture_begin(pool=pool, capture_error_mode="thread_local")
             self.graphs.append(g)
+            if record_plan:
+                tr.rt.k.plan_begin()                     # every libsvdx launch from here to the optimizer's last one, in order
             try:
                 calls = lambda: getattr(tr.rt.k, "n_calls", None)       # launches issued so far (None: a backend that does not count)
                 mark = [calls()]
@@ -631,8 +639,16 @@ class GraphedStep:
                 tr.optimizer_step()
             finally:
                 self.g_opt.capture_end()
+                if record_plan:
+                    self.plan = tr.rt.k.plan_end()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+
+    def replay_plan(self) -> None:
+        """The same optimizer step as `__call__()` on one rank, issued by svdx_plan_replay on the current stream instead of hipGraphLaunch."""
+        if self.plan is None:
+            raise RuntimeError("GraphedStep(..., record_plan=True) first")
+        self.plan.replay()
 
     def __call__(self, side_work=None) -> None:
         """side_work: callable queued between the backward sweep and the optimizer, beside the gradient collective

@@ -176,17 +176,33 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+def _log_measured(key, r) -> None:
+    """One line per oracle comparison into gpurun_out/parity_measured.jsonl (when that directory exists: the GPU box): what the bars of
+    `assert_parity` are set against."""
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if not os.path.isdir(out) or "error" in r:
+        return
+    import json
+    keep = {k: r.get(k) for k in ("loss_rel", "grad_cos_min", "grad_cos_worst", "grad_norm_rel", "pred_rel_l2", "pred_after_rel_l2", "param_max_diff",
+                                  "param_mean_diff", "lr", "n_grads")}
+    with open(os.path.join(out, "parity_measured.jsonl"), "a") as f:
+        f.write(json.dumps({"case": key, **keep}) + "\n")
+
+
 def assert_parity(key, r, bf16=None):
     """The acceptance bar of every oracle comparison (north_star: noise-prediction MSE within 1e-3 relative at fp16; bf16 carries
     8x less mantissa).  One AdamW step moves a weight by at most ~lr, and where the gradient is at rounding level its sign -- and
     with it the whole update -- may differ: the worst weight is bounded by 2.5 lr, the mean weight must agree far below lr."""
     assert "error" not in r, f"{key}: {r}"
     bf16 = ("bfloat16" in key) if bf16 is None else bf16          # NB: "float16" is a substring of "bfloat16"
+    _log_measured(key, r)
     assert r["loss_rel"] <= (8e-3 if bf16 else 1e-3), f"{key}: loss rel err {r['loss_rel']:.3e}"
-    assert r["grad_cos_min"] >= (0.95 if bf16 else 0.99), f"{key}: {r}"
+    # gradient direction of every trainable tensor: measured >= 0.99998 (fp16) / >= 0.9998 (bf16) over the suite (profiles/r6_parity_measured.jsonl);
+    # rounds 1-5 held 0.99 / 0.95 -- two orders looser than the data.  A mis-routed or mis-scaled gradient gives ~0, a dropped launch < 0.9.
+    assert r["grad_cos_min"] >= (0.995 if bf16 else 0.9995), f"{key}: {r}"
     # prediction (the tensor the reference's loss is built from): 16-bit storage through ~100 chained layers.  Measured at fp16 on the full
     # model: 1.1e-3 (c2, bench.py's seed) / 1.3e-3 (c1') / 2.28e-3 (c2, this suite's seed: round 5's test_full_topology_c2_matches_oracle);
-    # 1.96e-3 on the tiny LoRA topology; bf16 up to 1.57e-2.  The bars sit a quarter above the worst measured case (round 4: 2.5e-3)
+    # 1.96e-3 on the tiny LoRA topology; bf16 up to 1.57e-2.  Fixed since round 5 (3e-3 / 2e-2); north_star's own metric is the loss above
     assert r["pred_rel_l2"] is None or r["pred_rel_l2"] <= (2e-2 if bf16 else 3e-3), f"{key}: {r}"
     assert r["pred_after_rel_l2"] is None or r["pred_after_rel_l2"] <= (2e-2 if bf16 else 3e-3), f"{key}: {r}"
     if r.get("lr"):
@@ -246,6 +262,35 @@ def graphed_vs_eager(dev=None, dtype=torch.float16, steps=3):
     return dict(loss_eager=e["loss"], loss_graph=g["loss"], param_max_diff=float((e["p"] - g["p"]).abs().max()),
                 param_mean_diff=float((e["p"] - g["p"]).abs().mean()),
                 param_abs_max=float(e["p"].abs().max()), opt_steps=(e["state"][0], g["state"][0]), segments=g["segments"])
+
+
+def plan_vs_graph(dev=None, dtype=torch.float16, steps=4):
+    """One captured step replayed `steps - 1` times as hipGraphs vs. the launch plan recorded during the same kind of capture replayed through
+    svdx_plan_replay (the capture's warm-up pass is step 1 of both)."""
+    from svd_xtend_amd.train import GraphedStep
+    dev = dev or torch.device("cuda")
+    cfg = TINY_CONFIG
+    sd = seeded_weights(cfg, 5)
+    b = make_synthetic_batch(1, 3, 16, 16, 77, cross_dim=cfg["cross_attention_dim"])
+    unet_in, ts, ehs, ids, noisy, _ = edm_inputs(b)
+    out = []
+    for use_plan in (False, True):
+        batch = {k: v.to(dev) for k, v in dict(unet_in=unet_in, timesteps=ts, ehs=ehs, added_time_ids=ids, noisy_latents=noisy,
+                                               target=b["latents"], sigmas=b["sigmas"]).items()}
+        m = UNetSpatioTemporalConditionModel(**cfg)
+        m.load_state_dict(sd, strict=True)
+        m.to(dev)
+        tr = Trainer(m, dtype=dtype, lr=1e-3)
+        gs = GraphedStep(tr, batch, record_plan=use_plan)
+        for _ in range(steps - 1):
+            gs.replay_plan() if use_plan else gs()
+        torch.cuda.synchronize()
+        out.append(dict(p=tr.p_flat.clone(), m=tr.m_flat.clone(), loss=float(tr.loss_slot.cpu()), state=tr.opt_state.cpu().tolist(),
+                        launches=gs.plan.launches if use_plan else 0, bytes=gs.plan.host_bytes if use_plan else 0))
+    g, p = out
+    return dict(loss_graph=g["loss"], loss_plan=p["loss"], param_max_diff=float((g["p"] - p["p"]).abs().max()),
+                m_max_diff=float((g["m"] - p["m"]).abs().max()), opt_steps=(g["state"][0], p["state"][0]),
+                plan_launches=p["launches"], plan_host_bytes=p["bytes"])
 
 
 def seeded_weights(cfg, seed):

@@ -75,6 +75,21 @@ def test_error_reporting_without_device(lib):
     assert b"svdx_gemm" in buf.value
 
 
+def test_launch_plan_handles_without_device(lib):
+    """svdx_plan_*: recording state is per thread, an empty plan is a valid plan, a second begin is an error (no launch involved)."""
+    import ctypes
+    lib.svdx_plan_end.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    h = ctypes.c_void_p()
+    assert lib.svdx_plan_end(ctypes.byref(h)) != 0               # nothing is being recorded
+    assert lib.svdx_plan_begin() == 0
+    assert lib.svdx_plan_begin() != 0
+    assert lib.svdx_plan_end(ctypes.byref(h)) == 0 and h.value
+    assert lib.svdx_plan_launches(h) == 0 and lib.svdx_plan_bytes(h) == 0
+    assert lib.svdx_plan_replay(h, None) == 0                    # no launches: nothing to issue
+    assert lib.svdx_plan_free(h) == 0
+    assert lib.svdx_plan_replay(None, None) != 0
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only box check")
 def test_product_fails_loudly_without_gpu():
     from svd_xtend_amd import kernels

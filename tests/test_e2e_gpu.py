@@ -60,6 +60,22 @@ def test_graph_replays_survive_copies_and_eager_launches():
 
 
 @gpu
+def test_launch_plan_replayed_from_c_equals_the_graph_replay():
+    """include/svdx.h svdx_plan_*: the launches of a captured optimizer step, recorded while they were captured, re-issued by
+    svdx_plan_replay (ctypes -> C: no torch graph, no Python operator code) walk the same trajectory as hipGraph replays of the same
+    capture -- weights, Adam moments and loss bit for bit; and the plan holds every launch of the step."""
+    import torch
+
+    import e2e_checks
+    r = e2e_checks.plan_vs_graph()
+    print(r)
+    assert r["plan_launches"] >= 300 and r["plan_host_bytes"] > 0, r            # the tiny topology's step is several hundred launches
+    assert r["opt_steps"][0] == r["opt_steps"][1] == 4.0, r
+    assert r["loss_graph"] == r["loss_plan"], r
+    assert r["param_max_diff"] == 0.0 and r["m_max_diff"] == 0.0, r
+
+
+@gpu
 def test_same_seed_twice_gives_identical_bits():
     """SURVEY.md section 5 (deterministic replay): two runs of three optimizer steps from the same weights and batch end in
     identical weights, Adam moments and loss -- eager launches, both dtypes."""
