@@ -379,6 +379,9 @@ def main():
     ap.add_argument("--lora-rank", type=int, default=0,
                     help="reference config 5 (train_svd_lora.py): LoRA adapters of this rank on every attention projection are the "
                          "trainable set (the reference runs it in bf16: pass --dtype bf16); 0 = config 2 (default)")
+    ap.add_argument("--lora-param-dtype", default=None, choices=[None, "reference"],
+                    help="with --lora-rank and --dtype bf16: 'reference' keeps adapters and AdamW state as bf16 numbers, torch.optim.AdamW's op "
+                         "sequence (train_svd_lora.py:666-674); default: fp32 masters")
     ap.add_argument("--tune", action="store_true",
                     help="in-situ GEMM tile/split-K tuning sweeps before timing (faster while the GPU is cool, ~1%% slower "
                          "than the built-in formula once the step is power-limited: off by default)")
@@ -468,7 +471,7 @@ def main():
             p.requires_grad_(False)
         with torch.device(dev):
             model.add_adapter(LoraConfig(r=args.lora_rank, lora_alpha=args.lora_rank, init_lora_weights="gaussian"))
-    trainer = Trainer(model, dtype=dt, lr=1e-5, grad_accum=args.grad_accum)
+    trainer = Trainer(model, dtype=dt, lr=1e-5, grad_accum=args.grad_accum, lora_param_dtype=args.lora_param_dtype)
     trainer.rt.gemm_variant = args.gemm_variant
     schedules = {}
 

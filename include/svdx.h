@@ -411,17 +411,26 @@ int svdx_check_finite(const float* g, int64_t n, float* opt_state, void* stream)
 int svdx_check_finite_spans(const float* g, const int* spans, int n_spans, float* opt_state, void* stream);
 int svdx_optim_prep(float* opt_state, float beta1, float beta2, float growth, float backoff, int growth_interval,
                     int dynamic, void* stream);
-int svdx_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-               float eps, float wd, float grad_mul, const float* opt_state, void* p_act, int dtype, void* stream);
+/* param_mode of the two AdamW entries.  SVDX_PARAMS_F32: parameters and moments are fp32 (the default of this library: the 16-bit copies the
+ * kernels read derive from fp32 masters).  SVDX_PARAMS_BF16_REFERENCE: the reference's LoRA recipe under --mixed_precision bf16
+ * (/root/reference/train_svd_lora.py:666-674: the UNet is cast to bf16 before add_adapter, so adapters, gradients and torch.optim.AdamW's
+ * state are bf16 tensors): torch.optim.AdamW's op sequence on bf16 tensors, each op in float and rounded to bf16, on values kept in the same
+ * float buffers (the caller rounds the initial parameters to bf16 once).  torch forms 1 - lr * wd, 1 - beta1, 1 - beta2 in double and hands its
+ * kernels their float roundings; so does this mode -- which is why lr, the betas, eps, wd and grad_mul are doubles here. */
+#define SVDX_PARAMS_F32 0
+#define SVDX_PARAMS_BF16_REFERENCE 1
+/* (the hyper-parameters travel as the doubles the host holds: see param_mode) */
+int svdx_adamw(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+               double eps, double wd, double grad_mul, const float* opt_state, void* p_act, int param_mode, int dtype, void* stream);
 
 /* Same update over a table of tiles (6 ints each: element offset, row pitch, rows <= 64, cols <= 64 -- multiples of 4 --,
  * transposed-twin offset or -1, transposed-twin row pitch): every tile updates p/m/v, writes the row-major 16-bit twin
  * p_act[off + r*ld + c] and, when its transposed-twin offset is >= 0, pt_act[wt_off + c*ldwt + r] (the [K,N] operand of the
  * data-grad GEMM of a trainable nn.Linear), so no separate transposition pass is needed after the optimizer step.
  * All offsets must be multiples of 4 elements; tiles must not overlap. */
-int svdx_adamw_tiled(float* p, const float* g, float* m, float* v, const int* tiles, int n_tiles, float lr, float beta1,
-                     float beta2, float eps, float wd, float grad_mul, const float* opt_state, void* p_act, void* pt_act,
-                     int dtype, void* stream);
+int svdx_adamw_tiled(float* p, const float* g, float* m, float* v, const int* tiles, int n_tiles, double lr, double beta1,
+                     double beta2, double eps, double wd, double grad_mul, const float* opt_state, void* p_act, void* pt_act,
+                     int param_mode, int dtype, void* stream);
 
 /* ---- EMA of the trainable weights (diffusers EMAModel.step, train_svd.py:1053-1054): shadow -= one_minus_decay * (shadow - p)
  *      over n floats (both buffers 16-byte aligned).  The decay itself follows EMAModel.get_decay on the host. */

@@ -98,6 +98,9 @@ extern "C" int64_t svdx_plan_bytes(const void* plan) {
 extern "C" int svdx_plan_replay(const void* plan, void* stream) {
     if (!plan) { svdx_set_error("svdx_plan_replay: null plan"); return -2; }
     const Plan* p = static_cast<const Plan*>(plan);
+#ifdef SVDX_SIM
+    if (!p->nodes.empty()) { svdx_set_error("svdx_plan_replay: the simulator build records no launches"); return -1; }
+#else
     std::vector<void*> ptrs;
     for (const PlanNode& n : p->nodes) {
         ptrs.resize(n.off.size());
@@ -106,6 +109,7 @@ extern "C" int svdx_plan_replay(const void* plan, void* stream) {
         hipError_t e = hipLaunchKernel(n.fn, n.grid, n.block, ptrs.data(), n.lds, (hipStream_t)stream);
         if (e != hipSuccess) { svdx_set_error("svdx_plan_replay: launch %zu failed: %s", (size_t)(&n - p->nodes.data()), hipGetErrorString(e)); return -1; }
     }
+#endif
     return 0;
 }
 

@@ -195,15 +195,64 @@ __global__ __launch_bounds__(256) void ema_lerp_kernel(float* __restrict__ shado
     }
 }
 
+// One AdamW element.  REF = false: fp32 parameters and moments (this library's default: the 16-bit copies the kernels read are derived from
+// fp32 masters).  REF = true: the reference's LoRA recipe under bf16 (/root/reference/train_svd_lora.py:666-674: the UNet is cast to bf16
+// BEFORE add_adapter, so the adapters, their gradients and torch.optim.AdamW's moments are all bf16 tensors): the op sequence of
+// torch.optim.AdamW on bf16 tensors -- mul_, lerp_, mul_ + addcmul_, sqrt, div, add, addcdiv_ -- each computed in float and rounded to
+// bf16, on values held in the same float buffers (every stored value is bf16-representable).  Pinned to torch.optim.AdamW itself on
+// bf16 CPU tensors through the emulation (tests/test_host_logic.py).
+__device__ __forceinline__ float rb16(float x) { return (float)(bf16)x; }
+struct AdamScalars {           // per-launch scalars of one AdamW step (device side)
+    float gmul, decay, beta1, beta2, omb1, omb2, eps, step_size, bc2_sqrt, inv_bc2_sqrt;
+};
+// lr / wd / betas arrive as the doubles the host holds (torch forms 1 - lr * wd, 1 - beta1, 1 - beta2 in double and hands the kernels their
+// float roundings: 1.f - 0.999f is off by 1.3e-5 relative from (float)(1 - 0.999), enough to move 1 % of a bf16 moment by one step)
+__device__ __forceinline__ AdamScalars adam_scalars(const float* st, double lr, double beta1, double beta2, double eps, double wd, double grad_mul,
+                                                    bool ref) {
+    AdamScalars a;
+    const float lr_f = (float)lr * st[8];                            // schedule multiplier of this step (optim_prep)
+    a.gmul = st[4] * (float)grad_mul;
+    a.step_size = lr_f / st[5];
+    a.inv_bc2_sqrt = rsqrtf(st[6]);
+    a.bc2_sqrt = sqrtf(st[6]);
+    a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps;
+    if (ref) {
+        a.decay = (float)(1.0 - lr * (double)st[8] * wd);
+        a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
+    } else {
+        a.decay = 1.f - lr_f * (float)wd;
+        a.omb1 = 1.f - a.beta1; a.omb2 = 1.f - a.beta2;
+    }
+    return a;
+}
+template <bool REF>
+__device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v, const AdamScalars& a) {
+    if (!REF) {
+        const float gg = g * a.gmul;
+        p *= a.decay;
+        m = a.beta1 * m + a.omb1 * gg;
+        v = a.beta2 * v + a.omb2 * gg * gg;
+        const float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;
+        p -= a.step_size * m / denom;
+    } else {
+        const float gg = rb16(g * a.gmul);
+        p = rb16(p * a.decay);
+        m = rb16(fmaf(a.omb1, gg - m, m));                       // lerp_(grad, 1 - beta1): weight < 0.5, fused as torch's kernel
+        v = rb16(v * a.beta2);
+        v = rb16(v + a.omb2 * gg * gg);                          // addcmul_(grad, grad, value = 1 - beta2)
+        float d = rb16(sqrtf(v));
+        d = rb16(d / a.bc2_sqrt);
+        d = rb16(d + a.eps);
+        p = rb16(p + (-a.step_size) * (m / d));                  // addcdiv_(exp_avg, denom, value = -step_size)
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
-                                                    float wd, float grad_mul, const float* __restrict__ st, T* __restrict__ p_act) {
+                                                    float* __restrict__ v, long n, double lr, double beta1, double beta2, double eps,
+                                                    double wd, double grad_mul, const float* __restrict__ st, T* __restrict__ p_act, int ref) {
     if (st[7] > 0.f) return;     // inf/nan in the gradients: skip the step (GradScaler semantics)
-    lr *= st[8];                 // schedule multiplier of this step (optim_prep)
-    const float gmul = st[4] * grad_mul;
-    const float step_size = lr / st[5];
-    const float inv_bc2_sqrt = rsqrtf(st[6]);
+    const AdamScalars a = adam_scalars(st, lr, beta1, beta2, eps, wd, grad_mul, ref != 0);
     const long n4 = n / 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         f32x4 pv = *reinterpret_cast<const f32x4*>(p + i * 4);
@@ -212,12 +261,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         f32x4 vv = *reinterpret_cast<const f32x4*>(v + i * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float gg = gv[e] * gmul;
-            pv[e] *= (1.f - lr * wd);
-            mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
-            vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
-            const float denom = sqrtf(vv[e]) * inv_bc2_sqrt + eps;
-            pv[e] -= step_size * mv[e] / denom;
+            float pe = pv[e], me = mv[e], ve = vv[e];            // (vector elements do not bind to references)
+            if (ref) adamw_elem<true>(pe, gv[e], me, ve, a);
+            else adamw_elem<false>(pe, gv[e], me, ve, a);
+            pv[e] = pe; mv[e] = me; vv[e] = ve;
         }
         *reinterpret_cast<f32x4*>(p + i * 4) = pv;
         *reinterpret_cast<f32x4*>(m + i * 4) = mv;
@@ -237,17 +284,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 // per-step re-transposition of all trainable weights (a separate read + write of every weight) disappears.
 template <typename T>
 __global__ __launch_bounds__(256) void adamw_tiled_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                          float* __restrict__ v, const int* __restrict__ tiles, float lr, float beta1,
-                                                          float beta2, float eps, float wd, float grad_mul,
-                                                          const float* __restrict__ st, T* __restrict__ p_act, T* __restrict__ pt_act) {
+                                                          float* __restrict__ v, const int* __restrict__ tiles, double lr, double beta1,
+                                                          double beta2, double eps, double wd, double grad_mul,
+                                                          const float* __restrict__ st, T* __restrict__ p_act, T* __restrict__ pt_act, int ref) {
     if (st[7] > 0.f) return;     // inf/nan in the gradients: skip the step (GradScaler semantics)
     __shared__ T tile[64][68];
     const int* tl = tiles + (size_t)blockIdx.x * 6;
     const int off = tl[0], ld = tl[1], rows = tl[2], cols = tl[3], wt_off = tl[4], ldwt = tl[5];
-    lr *= st[8];                 // schedule multiplier of this step (optim_prep)
-    const float gmul = st[4] * grad_mul;
-    const float step_size = lr / st[5];
-    const float inv_bc2_sqrt = rsqrtf(st[6]);
+    const AdamScalars a = adam_scalars(st, lr, beta1, beta2, eps, wd, grad_mul, ref != 0);
     const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -262,12 +306,10 @@ __global__ __launch_bounds__(256) void adamw_tiled_kernel(float* __restrict__ p,
             Vec4<T> o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float gg = gv[e] * gmul;
-                pv[e] *= (1.f - lr * wd);
-                mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
-                vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
-                const float denom = sqrtf(vv[e]) * inv_bc2_sqrt + eps;
-                pv[e] -= step_size * mv[e] / denom;
+                float pe = pv[e], me = mv[e], ve = vv[e];
+                if (ref) adamw_elem<true>(pe, gv[e], me, ve, a);
+                else adamw_elem<false>(pe, gv[e], me, ve, a);
+                pv[e] = pe; mv[e] = me; vv[e] = ve;
                 o.v[e] = from_f<T>(pv[e]);
             }
             __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(p + idx));
@@ -367,22 +409,24 @@ extern "C" int svdx_ema_lerp(float* shadow, const float* p, int64_t n, float one
     return 0;
 }
 
-extern "C" int svdx_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                          float wd, float grad_mul, const float* opt_state, void* p_act, int dtype, void* stream) {
+extern "C" int svdx_adamw(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                          double wd, double grad_mul, const float* opt_state, void* p_act, int param_mode, int dtype, void* stream) {
     SVDX_CHECK_ARG(p && g && m && v && opt_state && n > 0 && n % 4 == 0, "svdx_adamw: bad args (n must be a multiple of 4)");
+    SVDX_CHECK_ARG(param_mode == SVDX_PARAMS_F32 || param_mode == SVDX_PARAMS_BF16_REFERENCE, "svdx_adamw: param_mode %d", param_mode);
     const int blocks = (int)std::min<long>((n / 4 + 255) / 256, 256 * 8);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((adamw_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                                             (long)n, lr, beta1, beta2, eps, wd, grad_mul, opt_state, (T*)p_act));
+                                             (long)n, lr, beta1, beta2, eps, wd, grad_mul, opt_state, (T*)p_act, param_mode));
     SVDX_LAUNCH_CHECK("svdx_adamw");
     return 0;
 }
 
-extern "C" int svdx_adamw_tiled(float* p, const float* g, float* m, float* v, const int* tiles, int n_tiles, float lr, float beta1,
-                                float beta2, float eps, float wd, float grad_mul, const float* opt_state, void* p_act, void* pt_act,
-                                int dtype, void* stream) {
+extern "C" int svdx_adamw_tiled(float* p, const float* g, float* m, float* v, const int* tiles, int n_tiles, double lr, double beta1,
+                                double beta2, double eps, double wd, double grad_mul, const float* opt_state, void* p_act, void* pt_act,
+                                int param_mode, int dtype, void* stream) {
     SVDX_CHECK_ARG(p && g && m && v && tiles && opt_state && n_tiles > 0, "svdx_adamw_tiled: bad args");
+    SVDX_CHECK_ARG(param_mode == SVDX_PARAMS_F32 || param_mode == SVDX_PARAMS_BF16_REFERENCE, "svdx_adamw_tiled: param_mode %d", param_mode);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((adamw_tiled_kernel<T>), dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, p, g, m, v, tiles,
-                                             lr, beta1, beta2, eps, wd, grad_mul, opt_state, (T*)p_act, (T*)pt_act));
+                                             lr, beta1, beta2, eps, wd, grad_mul, opt_state, (T*)p_act, (T*)pt_act, param_mode));
     SVDX_LAUNCH_CHECK("svdx_adamw_tiled");
     return 0;
 }

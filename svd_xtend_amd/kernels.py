@@ -84,7 +84,7 @@ class Gather:
                         self.ups, self.t, self.hw, self.lda)
 
 
-# signature table: p void*, i int, f float, l int64, z size_t
+# signature table: p void*, i int, f float, d double, l int64, z size_t
 _SIGS = {
     "svdx_gemm": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifii" "ippi" "ip",
     "svdx_gemm_dual": "ppp" "iiiiii" "p" "piii" "pi" "pp" "ifi" "pp" "iiii" "ip",
@@ -140,8 +140,8 @@ _SIGS = {
     "svdx_check_finite": "plpp",
     "svdx_check_finite_spans": "pp" "i" "pp",
     "svdx_optim_prep": "p" "ffff" "ii" "p",
-    "svdx_adamw": "pppp" "l" "ffffff" "pp" "ip",
-    "svdx_adamw_tiled": "ppppp" "i" "ffffff" "ppp" "ip",
+    "svdx_adamw": "pppp" "l" "dddddd" "pp" "iip",
+    "svdx_adamw_tiled": "ppppp" "i" "dddddd" "ppp" "iip",
     "svdx_ema_lerp": "pp" "l" "f" "p",
     "svdx_allreduce_grads": "p" "ii" "l" "i" "p",
     "svdx_plan_begin": "",
@@ -149,10 +149,11 @@ _SIGS = {
     "svdx_plan_replay": "pp",
     "svdx_plan_free": "p",
 }
-_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "l": ctypes.c_int64, "z": ctypes.c_size_t}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "d": ctypes.c_double, "l": ctypes.c_int64, "z": ctypes.c_size_t}
 
 EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_wall_clock_khz", "svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band", "svdx_ln_bwd_blocks",
                                     "svdx_plan_launches", "svdx_plan_bytes")
+PARAMS_F32, PARAMS_BF16_REFERENCE = 0, 1      # include/svdx.h: param_mode of svdx_adamw / svdx_adamw_tiled
 TN_FLAT = 64                   # include/svdx.h SVDX_TN_FLAT (developer knob: rounds 1-4's staging)
 TN_PREFETCH = 32               # include/svdx.h SVDX_TN_PREFETCH: flag of svdx_gemm_tn's `stages`
 MAX_PEERS = 16                 # include/svdx.h SVDX_MAX_PEERS: ranks of svdx_allreduce_grads
@@ -531,9 +532,9 @@ class HipBackend:
         self._call("svdx_optim_prep", _f32(opt_state), float(beta1), float(beta2), float(growth),
                    float(backoff), int(growth_interval), int(dynamic), self._stream())
 
-    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, grad_mul, opt_state, p_act):
+    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, grad_mul, opt_state, p_act, param_mode=PARAMS_F32):
         self._call("svdx_adamw", _f32(p), _f32(g), _f32(m), _f32(v), n, float(lr), float(beta1), float(beta2),
-                   float(eps), float(wd), float(grad_mul), _f32(opt_state), _p(p_act),
+                   float(eps), float(wd), float(grad_mul), _f32(opt_state), _p(p_act), int(param_mode),
                    _dt(p_act) if p_act is not None else F16, self._stream())
 
     def stamp(self, slots, i):
@@ -557,10 +558,10 @@ class HipBackend:
         assert spans.dtype == torch.int32 and spans.is_contiguous()
         self._call("svdx_zero_spans", _f32(base), spans.data_ptr(), n_spans, self._stream())
 
-    def adamw_tiled(self, p, g, m, v, tiles, n_tiles, lr, beta1, beta2, eps, wd, grad_mul, opt_state, p_act, pt_act):
+    def adamw_tiled(self, p, g, m, v, tiles, n_tiles, lr, beta1, beta2, eps, wd, grad_mul, opt_state, p_act, pt_act, param_mode=PARAMS_F32):
         assert tiles.dtype == torch.int32 and tiles.is_contiguous() and tiles.numel() >= 6 * n_tiles
         self._call("svdx_adamw_tiled", _f32(p), _f32(g), _f32(m), _f32(v), tiles.data_ptr(), n_tiles, float(lr), float(beta1),
-                   float(beta2), float(eps), float(wd), float(grad_mul), _f32(opt_state), _p(p_act), _p(pt_act),
+                   float(beta2), float(eps), float(wd), float(grad_mul), _f32(opt_state), _p(p_act), _p(pt_act), int(param_mode),
                    _dt(p_act), self._stream())
 
 

@@ -168,7 +168,18 @@ class Trainer:
     def __init__(self, model: UNetSpatioTemporalConditionModel, dtype: torch.dtype = torch.float16,
                  lr: float = 1e-5, betas=(0.9, 0.999), weight_decay: float = 1e-2, eps: float = 1e-8,
                  init_scale: float = 65536.0, growth_interval: int = 2000, process_group=None,
-                 grad_accum: int = 1):
+                 grad_accum: int = 1, lora_param_dtype: Optional[str] = None):
+        """lora_param_dtype: None -- the trainable parameters and AdamW's moments are fp32 whatever the activation dtype (this library's
+        default; for LoRA under bf16 a measured improvement on the reference's recipe, profiles/r5_lora_dtype_deviation.json).
+        "reference" -- the recipe of /root/reference/train_svd_lora.py:666-674 itself: with --mixed_precision bf16 the UNet is cast to bf16
+        BEFORE add_adapter, so adapters, gradients and torch.optim.AdamW's state are bf16 tensors.  The parameters are rounded to bf16 once
+        here and every optimizer step runs torch's op sequence with bf16 rounding (svdx_adamw* param_mode 1, include/svdx.h).  Only
+        meaningful with dtype = bfloat16 (under fp16 the reference upcasts the adapters to fp32: cast_training_params, :672-674)."""
+        if lora_param_dtype not in (None, "reference"):
+            raise ValueError(f"lora_param_dtype={lora_param_dtype!r}: None or 'reference'")
+        if lora_param_dtype == "reference" and dtype != torch.bfloat16:
+            raise ValueError("lora_param_dtype='reference' reproduces the bf16 recipe: pass dtype=torch.bfloat16")
+        self.param_mode = K.PARAMS_BF16_REFERENCE if lora_param_dtype == "reference" else K.PARAMS_F32
         self.model, self.dtype = model, dtype
         self.lr, self.betas, self.wd, self.eps = lr, betas, weight_decay, eps
         self.growth_interval = growth_interval
@@ -205,6 +216,8 @@ class Trainer:
             for t in list(model.parameters()) + list(model.buffers()):
                 if not t.requires_grad:
                     dist.broadcast(t.data, src=src, group=process_group)
+        if self.param_mode == K.PARAMS_BF16_REFERENCE:
+            self.p_flat.copy_(self.p_flat.to(torch.bfloat16).to(torch.float32))      # the adapters are created as bf16 tensors there
         self._build_runtime()
         if self.world > 1:
             # ... and the trainables (peft's gaussian LoRA init uses the process-global generator: ranks do differ there)
@@ -482,10 +495,10 @@ class Trainer:
         if self.adam_tiles is not None:
             k.adamw_tiled(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.adam_tiles, self.adam_tiles.shape[0], self.lr,
                           self.betas[0], self.betas[1], self.eps, self.wd, grad_mul, self.opt_state, self.rt.w16_flat,
-                          self.rt.wt16_flat)
+                          self.rt.wt16_flat, param_mode=self.param_mode)
         else:
             k.adamw(self.p_flat, self.g_flat, self.m_flat, self.v_flat, n, self.lr, self.betas[0], self.betas[1],
-                    self.eps, self.wd, grad_mul, self.opt_state, self.rt.w16_flat)
+                    self.eps, self.wd, grad_mul, self.opt_state, self.rt.w16_flat, param_mode=self.param_mode)
         self.model.refresh_trainable(masters_changed_on_host=False)
         self.micro = 0
 

@@ -676,7 +676,27 @@ class EmuBackend:
         for off, cnt in spans[:n_spans].view(-1, 2).tolist():
             V1(base, off + cnt)[off:off + cnt].zero_()
 
-    def adamw_tiled(self, p, g, m, v, tiles, n_tiles, lr, beta1, beta2, eps, wd, grad_mul, st, p_act, pt_act):
+    @staticmethod
+    def _adamw_update(P, G, Mm, Vv, gm, lr, beta1, beta2, eps, wd, ss, bc2_sqrt, param_mode):
+        """in-place update of (P, Mm, Vv) views.  param_mode 1 (SVDX_PARAMS_BF16_REFERENCE): torch.optim.AdamW's op sequence on bf16 TENSORS
+        (the reference's LoRA recipe, train_svd_lora.py:666-674) -- done here with torch's own bf16 ops, results written back as floats."""
+        if not param_mode:
+            gg = G * gm
+            P.mul_(1 - lr * wd)
+            Mm.mul_(beta1).add_(gg, alpha=1 - beta1)
+            Vv.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+            P.addcdiv_(Mm, Vv.sqrt() / bc2_sqrt + eps, value=-ss)
+            return
+        pb, mb, vb = P.to(torch.bfloat16), Mm.to(torch.bfloat16), Vv.to(torch.bfloat16)
+        gb = (G * gm).to(torch.bfloat16)
+        pb.mul_(1 - lr * wd)
+        mb.lerp_(gb, 1 - beta1)
+        vb.mul_(beta2).addcmul_(gb, gb, value=1 - beta2)
+        denom = (vb.sqrt() / bc2_sqrt).add_(eps)
+        pb.addcdiv_(mb, denom, value=-ss)
+        P.copy_(pb.float()); Mm.copy_(mb.float()); Vv.copy_(vb.float())
+
+    def adamw_tiled(self, p, g, m, v, tiles, n_tiles, lr, beta1, beta2, eps, wd, grad_mul, st, p_act, pt_act, param_mode=0):
         if float(st[7]) > 0:
             return
         lr = lr * float(st[8])
@@ -685,26 +705,17 @@ class EmuBackend:
             def T2(t):
                 return torch.as_strided(t, (rows, cols), (ld, 1), t.storage_offset() + off)
             P, G, Mm, Vv = T2(p), T2(g), T2(m), T2(v)
-            gg = G * gm
-            P.mul_(1 - lr * wd)
-            Mm.mul_(beta1).add_(gg, alpha=1 - beta1)
-            Vv.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
-            P.addcdiv_(Mm, Vv.sqrt() / bc2 + eps, value=-ss)
+            self._adamw_update(P, G, Mm, Vv, gm, lr, beta1, beta2, eps, wd, ss, bc2, param_mode)
             if p_act is not None:
                 T2(p_act).copy_(P.to(p_act.dtype))
             if wt_off >= 0:
                 torch.as_strided(pt_act, (cols, rows), (ldwt, 1), pt_act.storage_offset() + wt_off).copy_(P.t().to(pt_act.dtype))
 
-    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, grad_mul, st, p_act):
+    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, grad_mul, st, p_act, param_mode=0):
         if float(st[7]) > 0:
             return
         lr = lr * float(st[8])
         P, G, Mm, Vv = V1(p, n), V1(g, n), V1(m, n), V1(v, n)
-        gg = G * (float(st[4]) * grad_mul)
-        P.mul_(1 - lr * wd)
-        Mm.mul_(beta1).add_(gg, alpha=1 - beta1)
-        Vv.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
-        denom = Vv.sqrt() / math.sqrt(float(st[6])) + eps
-        P.addcdiv_(Mm, denom, value=-lr / float(st[5]))
+        self._adamw_update(P, G, Mm, Vv, float(st[4]) * grad_mul, lr, beta1, beta2, eps, wd, lr / float(st[5]), math.sqrt(float(st[6])), param_mode)
         if p_act is not None:
             V1(p_act, n).copy_(P.to(p_act.dtype))

@@ -833,6 +833,31 @@ def check_optim(P, dt):
         for nm in ("p", "m", "v"):
             res.append((f"adamw found_inf={found} {nm}", relerr(o1[nm], o2[nm]), 1e-5))
         res.append((f"adamw found_inf={found} p_act", relerr(o1["pa"], o2["pa"]), tol_for(dt)))
+    # param_mode 1 (SVDX_PARAMS_BF16_REFERENCE): torch.optim.AdamW's op sequence on bf16 tensors, three steps in a row on bf16-valued state.
+    # Every stored value is a bf16 number; kernel and emulation may differ by one bf16 step on the rare element where a float scalar of the
+    # device (bias corrections by powf) and torch's double differ in the last place -- count them
+    nb = 4 * 5000
+    pb = rndf((nb,), P.dev, g).to(torch.bfloat16).float()
+    for tiled in (False, True):
+        o = [dict(p=pb.clone(), m=torch.zeros(nb, device=P.dev), v=torch.zeros(nb, device=P.dev), pa=torch.zeros(nb, dtype=torch.bfloat16, device=P.dev),
+                  pt=torch.zeros(nb, dtype=torch.bfloat16, device=P.dev), st=torch.tensor([0, 1.0, 0, 0, 1, 1, 1, 0, 1.0] + [0.0] * 27, device=P.dev)) for _ in range(2)]
+        tiles_b = torch.tensor([[i * 2000, 52, 36, 48, -1, 0] for i in range(10)], dtype=torch.int32, device=P.dev)      # 10 tiles of 36 x 48 (pitch 52)
+        for step in range(3):
+            gb = rndf((nb,), P.dev, g) * 0.1
+            for be, oo in ((P.impl, o[0]), (P.ref, o[1])):
+                be.optim_prep(oo["st"], 0.9, 0.999, 2.0, 0.5, 2000, 0)
+                if tiled:
+                    be.adamw_tiled(oo["p"], gb, oo["m"], oo["v"], tiles_b, 10, 1e-2, 0.9, 0.999, 1e-8, 1e-2, 1.0, oo["st"], oo["pa"], oo["pt"], param_mode=1)
+                else:
+                    be.adamw(oo["p"], gb, oo["m"], oo["v"], nb, 1e-2, 0.9, 0.999, 1e-8, 1e-2, 1.0, oo["st"], oo["pa"], param_mode=1)
+        if P.dev.type == "cuda":
+            torch.cuda.synchronize()
+        tag = "adamw_tiled" if tiled else "adamw"
+        for nm in ("p", "m", "v"):
+            a, b = o[0][nm], o[1][nm]
+            res.append((f"{tag} bf16-reference {nm} stays bf16-valued", float((a - a.to(torch.bfloat16).float()).abs().max()), 0.0))
+            res.append((f"{tag} bf16-reference {nm} elements off the emulation", float((a != b).float().mean()), 2e-3))
+            res.append((f"{tag} bf16-reference {nm}", relerr(a, b), 1e-2))      # (a differing element is off by ONE bf16 step, 0.4-0.8 %)
     for n_e in (4 * 3000, 4 * 3000 + 3):
         sh, w = rndf((n_e,), P.dev, g), rndf((n_e,), P.dev, g)
         o1, o2 = P.run("ema_lerp", lambda o: ((o["s"], w, n_e, 0.013), {}), dict(s=sh))

@@ -40,6 +40,8 @@ def header_prototypes():
                 kinds.append("p")
             elif re.match(r"(const\s+)?float\b", a):
                 kinds.append("f")
+            elif re.match(r"(const\s+)?double\b", a):
+                kinds.append("d")
             elif re.match(r"(const\s+)?(long|int64_t|size_t)\b", a):
                 kinds.append("l")
             else:
