@@ -123,12 +123,9 @@ int svdx_gemm_dual(const void* A, const void* B, void* C, int M, int N, int K, i
  * slab mode.  stages selects the kernel: 0 / 2 = four waves, 128 x 128 output tiles, two LDS stages (two workgroups per CU, drained
  * every K-step); 3 / 4 = the same tile with 2 / 3 row tiles in flight across the barrier (one workgroup per CU); 18 = eight waves,
  * 256 x 256 output tiles, one workgroup per CU (outputs of >= 1024 x 512 that 180-256 such tiles x row slices cover).
- * stages | SVDX_TN_PREFETCH (with 0 / 2 / 18; developer knob): every wave also touches its share of the operand tiles three K-steps
- * ahead (one 4-byte LDS-DMA per wave and step, left in flight by the counted wait).  Same results bit for bit; measured 0.69 ms/step
- * SLOWER in the step (profiles/r5_ab_tn.txt), so the host does not set it. */
-#define SVDX_TN_PREFETCH 32
-/* stages | SVDX_TN_FLAT: developer knob -- the flat global_load_lds staging of rounds 1-4 (what operands of 2 GiB and more still get)
- * instead of buffer descriptors, for A/B runs: behind it the compiler serialises loads and MFMAs (csrc/gemm.hip gemm_tn_kernel). */
+ */
+/* stages | SVDX_TN_FLAT: the flat global_load_lds staging that operands of 2 GiB and more get (no buffer descriptor reaches them), requested
+ * for any operand -- how the tests exercise that path without allocating 2 GiB. */
 #define SVDX_TN_FLAT 64
 /* found_inf (may be NULL; SVDX_OUT_F32 / SVDX_OUT_F32_ADD only): *found_inf = 1.0f when a value this launch leaves in C is not finite --
  * GradScaler's inf check (accelerate fp16; train_svd.py:1047) done where the gradient is written; pass &opt_state[3]. */

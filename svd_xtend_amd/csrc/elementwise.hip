@@ -458,15 +458,9 @@ extern "C" int svdx_wall_clock_khz(void) {
 // kernel nodes around them -- every later replay computed with wrong GroupNorm statistics (loss 0.905 where the undisturbed replay and
 // the eager step give 0.988; sometimes NaN), silently and for good.  A training loop copies a new batch in before every replay, so this
 // hit any real use of GraphedStep; the fixed-batch bench and tests never saw it.  With a kernel in place of the memset the replays are
-// bit-identical whatever runs between them.  SVDX_ZERO_MEMSET=1 restores the memset (developer knob: tools/dbg_corrupt.py).
+// bit-identical whatever runs between them (the memset form left the library in round 6; tests/test_e2e_gpu.py keeps the regression test).
 extern "C" int svdx_zero(void* p, size_t bytes, void* stream) {
     if (bytes == 0) return 0;
-    static const bool use_memset = getenv("SVDX_ZERO_MEMSET") && atoi(getenv("SVDX_ZERO_MEMSET")) == 1;
-    if (use_memset) {
-        hipError_t e = hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);
-        if (e != hipSuccess) { svdx_set_error("svdx_zero: %s", hipGetErrorString(e)); return -1; }
-        return 0;
-    }
     const int blocks = (int)std::min<size_t>((bytes / 16 + 255) / 256 + 1, 2048);
     hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (char*)p, bytes);
     SVDX_LAUNCH_CHECK("svdx_zero");

@@ -410,20 +410,10 @@ __device__ __forceinline__ TnWho tn_who(const GemmParams& p) {
     return w;
 }
 
-// L2 prefetch (PF; round 5).  Counters of the kernel standalone (profiles/r5_stall_counters.txt): its waves sit PARKED at the staging wait
-// for 57-63 % of their cycles -- a K-step takes ~1.5 us where its MFMAs are 0.25 us per workgroup.  Both operands stream from HBM (the
-// reduction index is the long one: 560-35840 rows), the tiles of a row slice walk the rows in lockstep on one XCD, and the LDS ring holds
-// ONE tile ahead: every K-step waits a whole fabric round trip, and "bytes a CU ingests" is simply LDS-ring bytes in flight / that
-// latency.  The ring cannot grow (two workgroups per CU fill the LDS), the L2 can: every wave touches the 64 lines of its share of the
-// tile PF_DIST K-steps ahead with ONE 4-byte LDS-DMA into a dump slot (no VGPR destination: nothing for the compiler to mis-track), the
-// youngest entry of the in-order vmcnt queue, which the counted wait leaves in flight.  The staging DMA then hits the L2.
-constexpr int PF_DIST = 3;
-constexpr int PF_DUMP = 256;                              // bytes of LDS behind the stages that prefetches land in (never read)
-
 // BUF (round 5): the staging as buffer_load ... lds through two raw descriptors (operands below 2 GiB), issued by hidden_dma above: per-thread
 // byte offsets computed once, the row bound from num_records instead of a zero page (a column beyond the operand gets an offset beyond it), and
 // -- the point -- no compiler-inserted vmcnt(0) between the staging pieces and the fragment reads: loads and MFMAs overlap at last.
-template <typename T, int NSTG, bool PF = false, bool BUF = false>
+template <typename T, int NSTG, bool BUF = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
@@ -449,7 +439,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
     const T* zero = reinterpret_cast<const T*>(p.zero_page);
     const T* A = reinterpret_cast<const T*>(p.A);
     const T* B = reinterpret_cast<const T*>(p.B);
-    static_assert(!PF || BUF, "the L2 prefetch rides on the buffer descriptors");
     // BUF: byte offsets of this thread's four pieces inside K-tile 0 (the K-tile adds kt * BK rows); a column beyond the operand gets an
     // offset beyond num_records, so the piece reads zeros like a row beyond R does (the descriptor checks voffset, not soffset)
     const desc4 rsA = hidden_desc(p.A, BUF ? (unsigned)p.a_bytes : 0u), rsB = hidden_desc(p.B, BUF ? (unsigned)p.b_bytes : 0u);
@@ -490,21 +479,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
                                              (__attribute__((address_space(3))) void*)(As + base), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb,
                                              (__attribute__((address_space(3))) void*)(Bs + base), 16, 0, 0);
-        }
-    };
-    // PF: wave w touches operand (w >> 1)'s rows (w & 1) * 32 + lane / 2, line lane & 1 (a tile row is 256 bytes = two lines) of K-tile kt
-    // (clamped to the slice's last tile: one piece per step whatever the position, so the wait's count is exact)
-    auto prefetch = [&](int kt) __attribute__((always_inline)) {
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        const unsigned r = (unsigned)(min(kt, kt_end - 1) * BK + (wv & 1) * 32 + (lane >> 1));      // beyond R: out of the descriptor's range, no access
-        const int col = (lane & 1) * 64;
-        char* dump = smem + NSTG * STAGE_BYTES;
-        if (wv >> 1) {
-            const unsigned off = n0 + col < p.N ? (r * (unsigned)p.ldb + (unsigned)(n0 + col)) * 2u : OOB;
-            hidden_dma<4>(rsB, dump, off);
-        } else {
-            const unsigned off = m0 + col < p.M ? (r * (unsigned)p.lda + (unsigned)(m0 + col)) * 2u : OOB;
-            hidden_dma<4>(rsA, dump, off);
         }
     };
     f32x4 acc[4][4];
@@ -550,16 +524,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
     // the same stage ring as gemm_v4_kernel (see its K-loop banner): NSTG - 1 tiles staged ahead, counted vmcnt + raw s_barrier when
     // NSTG > 2.  Every wave issues 8 pieces (4 of A, 4 of B) per tile.
     static_assert(NSTG >= 2 && NSTG <= 4, "2 to 4 LDS stages");
-    static_assert(!PF || NSTG == 2, "the L2 prefetch is written for the two-stage ring");
     constexpr int LA = NSTG - 1;
     auto wait_tiles = [&](int t) __attribute__((always_inline)) {
-        if (PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");          // everything but the youngest piece: this step's prefetch
-        else if (NSTG == 2 || t <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NSTG == 2 || t <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (t == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     };
     auto stage_barrier = [&]() __attribute__((always_inline)) {
-        if (NSTG == 2 && !PF) { __syncthreads(); return; }
+        if (NSTG == 2) { __syncthreads(); return; }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -569,21 +541,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
 #pragma unroll
     for (int t = 0; t < LA; ++t)
         if (t < n_tiles) issue(kt_begin + t, t);
-    if (PF) {
-        // the tiles the first steps will stage; younger than tile 0's pieces, so the wait below leaves them in flight
-#pragma unroll
-        for (int t = 1; t <= PF_DIST; ++t) prefetch(kt_begin + t);
-        if (PF_DIST == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        wait_tiles(min(LA, n_tiles) - 1);
-    }
+    wait_tiles(min(LA, n_tiles) - 1);
     stage_barrier();
     {
         int cur = 0, nxt = LA, kt = 0;
         for (; kt + LA < n_tiles; ++kt) {
             issue(kt_begin + kt + LA, nxt);
-            if (PF) prefetch(kt_begin + kt + LA + PF_DIST);
             __builtin_amdgcn_sched_barrier(0);
             compute(cur);
             wait_tiles(LA - 1);
@@ -600,7 +563,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
             cur = cur + 1 == NSTG ? 0 : cur + 1;
         }
     }
-    if (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the last prefetch: its dump slot lies outside what the epilogue parks
     __syncthreads();
     if (do_cs && (lane & 15) == 0) {        // every column of the 16x16 result holds the sums: lanes 0/16/32/48 own rows 4*(lane>>4)..+3
 #pragma unroll
@@ -628,7 +590,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(GemmParams p) {
 // transposed (acc = mfma(B_frag, A_frag)) so that a lane owns 4 consecutive output columns: results leave as 16-byte stores
 // straight from the registers.  Stage ring as in gemm_v4_kernel.
 // ----------------------------------------------------------------------------------------------------------------
-template <typename T, int PA, int PB, int NSTG, bool PF = false, bool BUF = false>
+template <typename T, int PA, int PB, int NSTG, bool BUF = false>
 __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename TT<T>::v8 v8;
@@ -660,7 +622,6 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
     const T* A = reinterpret_cast<const T*>(p.A);
     const T* B = reinterpret_cast<const T*>(p.B);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    static_assert(!PF || BUF, "the L2 prefetch rides on the buffer descriptors");
     // BUF: see gemm_tn_kernel -- buffer_load ... lds through descriptors; per-thread byte offsets of its pieces inside K-tile 0
     const desc4 rsA = hidden_desc(p.A, BUF ? (unsigned)p.a_bytes : 0u), rsB = hidden_desc(p.B, BUF ? (unsigned)p.b_bytes : 0u);
     constexpr unsigned OOB = 0x7ffffff0u;
@@ -759,29 +720,13 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
         }
     };
     static_assert(NSTG >= 2 && NSTG <= 3, "2 or 3 LDS stages");
-    static_assert(!PF || (NSTG == 2 && PA == 2 && PB == 2), "the L2 prefetch is written for the two-stage 256 x 256 tile");
     constexpr int LA = NSTG - 1;
-    // PF (see gemm_tn_kernel): an operand tile row is 512 bytes = four lines; wave w touches operand (w >> 2)'s rows (w & 3) * 16 + lane / 4,
-    // line lane & 3 of K-tile kt
-    auto prefetch = [&](int kt) __attribute__((always_inline)) {
-        const unsigned r = (unsigned)(min(kt, kt_end - 1) * BK + (wave_u & 3) * 16 + (lane >> 2));
-        const int col = (lane & 3) * 64;
-        char* dump = smem + NSTG * STAGE;
-        if (wave_u >> 2) {
-            const unsigned off = n0 + col < p.N ? (r * (unsigned)p.ldb + (unsigned)(n0 + col)) * 2u : OOB;
-            hidden_dma<4>(rsB, dump, off);
-        } else {
-            const unsigned off = m0 + col < p.M ? (r * (unsigned)p.lda + (unsigned)(m0 + col)) * 2u : OOB;
-            hidden_dma<4>(rsA, dump, off);
-        }
-    };
     auto wait_tiles = [&](int t) __attribute__((always_inline)) {
-        if (PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");          // everything but the youngest piece: this step's prefetch
-        else if (NSTG == 2 || t <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NSTG == 2 || t <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
     };
     auto stage_barrier = [&]() __attribute__((always_inline)) {
-        if (NSTG == 2 && !PF) { __syncthreads(); return; }
+        if (NSTG == 2) { __syncthreads(); return; }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -791,20 +736,12 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
 #pragma unroll
     for (int t = 0; t < LA; ++t)
         if (t < n_tiles) issue(kt_begin + t, t);
-    if (PF) {
-#pragma unroll
-        for (int t = 1; t <= PF_DIST; ++t) prefetch(kt_begin + t);
-        if (PF_DIST == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        wait_tiles(min(LA, n_tiles) - 1);
-    }
+    wait_tiles(min(LA, n_tiles) - 1);
     stage_barrier();
     {
         int cur = 0, nxt = LA, kt = 0;
         for (; kt + LA < n_tiles; ++kt) {
             issue(kt_begin + kt + LA, nxt);
-            if (PF) prefetch(kt_begin + kt + LA + PF_DIST);
             __builtin_amdgcn_sched_barrier(0);
             compute(cur);
             wait_tiles(LA - 1);
@@ -821,7 +758,6 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmParams p) {
             cur = cur + 1 == NSTG ? 0 : cur + 1;
         }
     }
-    if (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (do_cs && fr == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1972,7 +1908,6 @@ static int arrange_nt_grid(GemmParams& p, int BMT, int BNT, dim3& grid) {
     p.tiles_m = cdiv(p.M, BMT);
     p.tiles_n = p.epi == SVDX_EPI_GEGLU_FWD ? cdiv(p.aux_dim, BNT / 2) : cdiv(p.N, BNT);
     p.vec_ok = (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.res || (p.ldres % 4 == 0 && ((uintptr_t)p.res & 15) == 0));
-    static const int force_xn = getenv("SVDX_XCD_N") ? atoi(getenv("SVDX_XCD_N")) : -1;     // developer knob: 0 = old split, 1/2/4/8
     const double a_bytes = 2.0 * p.M * (p.g.mode == SVDX_GATHER_PLAIN ? p.K : 2 * p.g.cin);   // conv: unique rows + halo
     const double b_bytes = 2.0 * (p.epi == SVDX_EPI_GEGLU_FWD ? 2 * p.aux_dim : p.N) * p.K;
     int best_xn = 0;
@@ -1985,7 +1920,6 @@ static int arrange_nt_grid(GemmParams& p, int BMT, int BNT, dim3& grid) {
             const double cost = a_bytes * xn + b_bytes * xm;
             if (eff >= 0.9 * best_eff && (best_xn == 0 || cost < best_cost)) { best_xn = xn; best_cost = cost; }
         }
-    if (force_xn >= 0) best_xn = force_xn;
     p.xcd_n = best_xn;
     p.z_xcd = 0;
     int gx = p.tiles_m * p.tiles_n, gy = p.split_k;
@@ -1996,9 +1930,7 @@ static int arrange_nt_grid(GemmParams& p, int BMT, int BNT, dim3& grid) {
     }
     // K slices on XCDs of their own (see v4_tile_of_block): among the arrangements of the 8 / split_k XCDs of a slice, the least re-fetch that keeps
     // >= 90 % of the best balance; taken when it fetches less than the slice-agnostic arrangement and leaves no more workgroup slots empty
-    const char* zx_env = getenv("SVDX_ZXCD");                                               // developer knob, read per launch (tools/ab_inproc.py
-    const int zxcd_on = zx_env ? atoi(zx_env) : 1;                                           // toggles it between captures): 0 = every XCD holds all slices
-    if (zxcd_on && force_xn < 0 && best_xn > 0 && (p.split_k == 2 || p.split_k == 4 || p.split_k == 8)) {
+    if (best_xn > 0 && (p.split_k == 2 || p.split_k == 4 || p.split_k == 8)) {
         const int xps = 8 / p.split_k;
         int zb_xn = 0; double zb_cost = 0, zb_eff = 0;
         for (int pass = 0; pass < 2; ++pass)
@@ -2087,33 +2019,33 @@ static long tn_arrange(GemmParams& p) {
     return 8L * p.sub_m * p.sub_n;
 }
 
-template <typename T, int NSTG, bool PF = false, bool BUF = false>
+template <typename T, int NSTG, bool BUF = false>
 int launch_gemm_tn(GemmParams p, hipStream_t st) {
-    constexpr int LDS = NSTG * STAGE_BYTES + (PF ? PF_DUMP : 0);
+    constexpr int LDS = NSTG * STAGE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T, NSTG, PF, BUF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T, NSTG, BUF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     dim3 grid((unsigned)tn_arrange(p));
-    hipLaunchKernelGGL((gemm_tn_kernel<T, NSTG, PF, BUF>), grid, dim3(NTHREADS), LDS, st, p);
+    hipLaunchKernelGGL((gemm_tn_kernel<T, NSTG, BUF>), grid, dim3(NTHREADS), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm_tn");
     return 0;
 }
 
-template <typename T, int PA, int PB, int NSTG, bool PF = false, bool BUF = false>
+template <typename T, int PA, int PB, int NSTG, bool BUF = false>
 int launch_gemm_tn8(GemmParams p, hipStream_t st) {
-    constexpr int LDS = NSTG * (PA + PB) * 64 * 256 + (PF ? PF_DUMP : 0);
+    constexpr int LDS = NSTG * (PA + PB) * 64 * 256;
     static_assert(LDS <= 160 * 1024, "stages must fit the 160 KiB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn8_kernel<T, PA, PB, NSTG, PF, BUF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn8_kernel<T, PA, PB, NSTG, BUF>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     p.tiles_m = cdiv(p.M, 128 * PA);
     p.tiles_n = cdiv(p.N, 128 * PB);
     dim3 grid((unsigned)tn_arrange(p));
-    hipLaunchKernelGGL((gemm_tn8_kernel<T, PA, PB, NSTG, PF, BUF>), grid, dim3(512), LDS, st, p);
+    hipLaunchKernelGGL((gemm_tn8_kernel<T, PA, PB, NSTG, BUF>), grid, dim3(512), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm_tn");
     return 0;
 }
@@ -2125,15 +2057,13 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
                             void* stream) {
     SVDX_CHECK_ARG(A && B && C && zero_page && R > 0 && N > 0 && K > 0, "svdx_gemm_tn: bad args");
     SVDX_CHECK_ARG(!found_inf || out_mode == SVDX_OUT_F32 || out_mode == SVDX_OUT_F32_ADD, "svdx_gemm_tn: found_inf goes with the store / += modes");
-    // operands below 2 GiB are staged through buffer descriptors (always, unless SVDX_TN_FLAT asks for rounds 1-4's flat staging for an A/B)
+    // operands below 2 GiB are staged through buffer descriptors (SVDX_TN_FLAT: a test asks for the large-operand path on a small operand)
     const long a_span = ((long)(R - 1) * lda + N) * 2, b_span = ((long)(R - 1) * ldb + K) * 2;
     // (the kernels mark columns beyond the operand with the offset 0x7ffffff0, which must itself lie beyond num_records: spans up to that value only)
     const bool buf = a_span <= 0x7ffffff0L && b_span <= 0x7ffffff0L && !(stages & SVDX_TN_FLAT);
-    const bool pf = (stages & SVDX_TN_PREFETCH) != 0 && buf;
-    stages &= ~(SVDX_TN_PREFETCH | SVDX_TN_FLAT);
+    stages &= ~SVDX_TN_FLAT;
     SVDX_CHECK_ARG(stages == 0 || (stages >= 2 && stages <= 4) || stages == 18,
                    "svdx_gemm_tn: stages=%d (0 = default, 2..4 stages of the 128x128 tile, 18 = the 256x256 eight-wave tile)", stages);
-    SVDX_CHECK_ARG(!(pf && (stages == 3 || stages == 4)), "svdx_gemm_tn: SVDX_TN_PREFETCH goes with the two-stage tiles (stages 0 / 2 / 18)");
     // the unsplit / ADD modes read-modify-write a_colsum from every z slice: one slice only (SVDX_OUT_F32_SLAB keeps a row per slice)
     SVDX_CHECK_ARG(!a_colsum || split_k == 1 || out_mode == SVDX_OUT_F32_SLAB, "svdx_gemm_tn: a_colsum with split_k > 1 needs slab output");
     SVDX_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
@@ -2156,10 +2086,10 @@ extern "C" int svdx_gemm_tn(const void* A, const void* B, float* C, int R, int N
     p.slab_stride = (long)N * ldc;
     DISPATCH_DTYPE(dtype, {
         hipStream_t st = (hipStream_t)stream;
-        if (stages == 18) return pf ? launch_gemm_tn8<T, 2, 2, 2, true, true>(p, st) : buf ? launch_gemm_tn8<T, 2, 2, 2, false, true>(p, st) : launch_gemm_tn8<T, 2, 2, 2>(p, st);
-        if (stages == 3) return buf ? launch_gemm_tn<T, 3, false, true>(p, st) : launch_gemm_tn<T, 3>(p, st);
-        if (stages == 4) return buf ? launch_gemm_tn<T, 4, false, true>(p, st) : launch_gemm_tn<T, 4>(p, st);
-        return pf ? launch_gemm_tn<T, 2, true, true>(p, st) : buf ? launch_gemm_tn<T, 2, false, true>(p, st) : launch_gemm_tn<T, 2>(p, st);
+        if (stages == 18) return buf ? launch_gemm_tn8<T, 2, 2, 2, true>(p, st) : launch_gemm_tn8<T, 2, 2, 2>(p, st);
+        if (stages == 3) return buf ? launch_gemm_tn<T, 3, true>(p, st) : launch_gemm_tn<T, 3>(p, st);
+        if (stages == 4) return buf ? launch_gemm_tn<T, 4, true>(p, st) : launch_gemm_tn<T, 4>(p, st);
+        return buf ? launch_gemm_tn<T, 2, true>(p, st) : launch_gemm_tn<T, 2>(p, st);
     });
 }
 

@@ -555,21 +555,15 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_batch_kernel(const LnRed
 }
 
 // workgroups (= partial rows left in scratch) of the affine-gradient form of svdx_ln_bwd
-static int ln_env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e && *e ? atoi(e) : dflt;
-}
-
 static int ln_bwd_affine_blocks(int rows, int C) {
     const int cc = C / 8;
     const int lanes = cc <= 48 ? 16 : (cc <= 96 ? 32 : 64);
     const int groups = 256 / lanes;
     // Two workgroups per CU (208 VGPRs) x 256 CUs: ONE resident round that strides over the rows, so that the per-block epilogue (two
     // LDS reductions + the partial row) is paid 512 times and no round runs part-empty -- 35.1 -> 27.7 us at 35840 x 320, 22.3 -> 17.5
-    // at 8960 x 640 against the former rows / (2 groups) blocks (profiles/r4_ln_bwd_sweep.txt).  Developer knobs for that sweep
-    // (tools/norm_bench.py --ln-sweep; kernels.ln_bwd_blocks mirrors them): rows per row group and block, block cap.
-    const int per = max(1, ln_env_int("SVDX_LN_AFFINE_R", 1));
-    const int cap = max(1, min(ln_env_int("SVDX_LN_AFFINE_CAP", 512), SVDX_LN_PARTIAL_ROWS));
+    // at 8960 x 640 against the former rows / (2 groups) blocks (profiles/r4_ln_bwd_sweep.txt; kernels.ln_bwd_blocks mirrors the rule).
+    const int per = 1;
+    const int cap = min(512, SVDX_LN_PARTIAL_ROWS);
     return max(1, min(cdiv(rows, per * groups), cap));
 }
 

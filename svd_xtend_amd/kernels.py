@@ -154,8 +154,7 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "d": ctypes
 EXPORTED_SYMBOLS = tuple(_SIGS) + ("svdx_wall_clock_khz", "svdx_version", "svdx_last_error", "svdx_device_ok", "svdx_tsa_pixels_per_band", "svdx_ln_bwd_blocks",
                                     "svdx_plan_launches", "svdx_plan_bytes")
 PARAMS_F32, PARAMS_BF16_REFERENCE = 0, 1      # include/svdx.h: param_mode of svdx_adamw / svdx_adamw_tiled
-TN_FLAT = 64                   # include/svdx.h SVDX_TN_FLAT (developer knob: rounds 1-4's staging)
-TN_PREFETCH = 32               # include/svdx.h SVDX_TN_PREFETCH: flag of svdx_gemm_tn's `stages`
+TN_FLAT = 64                   # include/svdx.h SVDX_TN_FLAT: the staging of operands >= 2 GiB, on request (tests)
 MAX_PEERS = 16                 # include/svdx.h SVDX_MAX_PEERS: ranks of svdx_allreduce_grads
 BATCH_MAX_JOBS = 48            # include/svdx.h SVDX_BATCH_MAX_JOBS: jobs of a *_batch entry that share one launch
 TSA_MAX_C, TSA_MAX_T, TSA_BAND_ROWS = 320, 16, 144
@@ -175,8 +174,7 @@ def ln_bwd_blocks(rows: int, C: int) -> int:
     """include/svdx.h svdx_ln_bwd_blocks: partial rows the affine-gradient form of svdx_ln_bwd leaves in its scratch."""
     cc = C // 8
     lanes = 16 if cc <= 48 else (32 if cc <= 96 else 64)
-    per = max(1, int(os.environ.get("SVDX_LN_AFFINE_R") or 1))                       # developer knobs, mirrored from csrc/norm.hip
-    cap = max(1, min(int(os.environ.get("SVDX_LN_AFFINE_CAP") or 512), LN_PARTIAL_ROWS))
+    per, cap = 1, min(512, LN_PARTIAL_ROWS)                                          # csrc/norm.hip: rows per workgroup pass, cap on the partial rows
     return max(1, min(-(-rows // (per * (256 // lanes))), cap))
 
 

@@ -75,10 +75,11 @@ class Runtime:
         self.split_k = True
         self.fuse_geglu = True
         # temporal self-attention op (norm1 -> q/k/v -> attention over frames -> out-projection + residual) as one launch when
-        # the level qualifies (csrc/tsa.hip); SVDX_FUSE_TSA=0: developer knob for A/B runs
-        self.fuse_tsa = os.environ.get("SVDX_FUSE_TSA", "1") != "0"
-        self.fuse_dual = os.environ.get("SVDX_LORA_FUSED", "1") != "0"   # developer knob for A/B runs: adapter term as its own launch
-        self.lora_stack_da = os.environ.get("SVDX_LORA_STACK_DA", "1") != "0"   # A/B knob: dA of fused q/k/v adapters as one TN GEMM
+        # the level qualifies (csrc/tsa.hip).  This and the switches below are plain attributes (no environment variable selects a kernel):
+        # tools/ab_inproc.py flips them between two captures of the step in one process -- every one is ON because it measured faster
+        self.fuse_tsa = True
+        self.fuse_dual = True       # False: the LoRA adapter term as its own accumulate launch
+        self.lora_stack_da = True   # False: dA of fused q/k/v adapters as three TN GEMMs
         self.tuner = None           # GemmTuner (Trainer.tune_gemms): measured tile / split-K per GEMM problem
         # transposed 16-bit twins ([K,N], operand of the data-grad GEMM) of the trainable nn.Linear weights live in one arena so
         # that the tiled AdamW kernel can write them (wt_map: id(weight) -> (element offset of W^T[0, n0], row pitch))
@@ -96,30 +97,26 @@ class Runtime:
         self.arena_cur, self.arena_pos = None, 0
         # launches of a few us whose results nothing in the sweep reads (skinny weight gradients of the cross-attention value path,
         # the affine-gradient reductions of LayerNorm) are queued and run as table-driven launches when the sweep -- or, with gradient
-        # buckets, the transformer block -- ends; SVDX_BATCH_SMALL=0: developer knob for A/B runs (one launch each, as before)
-        self.batch_small = os.environ.get("SVDX_BATCH_SMALL", "1") != "0"
+        # buckets, the transformer block -- ends (False: one launch each, as before round 3)
+        self.batch_small = True
         # at one clip per rank the gradient of a temporal block's cross-attention vector IS colsum(d(h1)) = the bias gradient the
-        # attn1.to_out weight-gradient GEMM already computes on the matrix pipe: no svdx_colsum pass.  SVDX_DVEC_FROM_DW=0: A/B knob
-        self.dvec_from_dw = os.environ.get("SVDX_DVEC_FROM_DW", "1") != "0"
+        # attn1.to_out weight-gradient GEMM already computes on the matrix pipe: no svdx_colsum pass
+        self.dvec_from_dw = True
         self._q_nn, self._q_outer, self._q_ln, self._q_M, self._q_outer_dst = [], [], [], None, set()
         self._q_fin, self._q_fin_dst, self._q_fin_bytes = [], set(), 0
         # the reducing launches of the row-sliced weight-gradient GEMMs wait for one table-driven launch at the end of the sweep (or of
-        # the transformer block, with gradient buckets); SVDX_DEFER_GRAD_FINALIZE=0: developer knob for A/B runs
-        self.defer_grad_finalize = os.environ.get("SVDX_DEFER_GRAD_FINALIZE", "1") != "0"
-        # weight-gradient GEMMs may touch their operand tiles three K-steps ahead (svdx_gemm_tn: stages | SVDX_TN_PREFETCH).  Built against the
-        # one-tile-ahead staging of a two-stage ring; measured in the step it COSTS 0.69 ms (profiles/r5_ab_tn.txt: it doubles the L2 request
-        # count of a kernel whose tiles already share their lines), so it is off; SVDX_TN_PREFETCH=1: A/B knob
-        self.tn_prefetch = os.environ.get("SVDX_TN_PREFETCH", "0") == "1"
-        self.tn_flat = os.environ.get("SVDX_TN_FLAT", "0") == "1"        # A/B knob: rounds 1-4's flat staging (compiler-serialised loads / MFMAs)
+        # the transformer block, with gradient buckets)
+        self.defer_grad_finalize = True
+        # (round 5's L2 prefetch of the weight-gradient kernels cost 0.69 ms in the step -- profiles/r5_ab_tn.txt -- and left the library in round 6)
         # svdx_gemm_tn / svdx_grad_finalize_batch raise this one-float flag (the trainer's opt_state[3]) for the write-once gradients they
         # store, so the optimizer only has to test the accumulated slots (Trainer.optimizer_step); None: nobody folds, the full pass runs
         self.found_inf = None
-        self.fold_finite = os.environ.get("SVDX_FOLD_FINITE", "1") != "0"      # A/B knob: 0 = the 1.59 GB svdx_check_finite pass of rounds 1-4
+        self.fold_finite = True     # False: the 1.59 GB svdx_check_finite pass of rounds 1-4
         self.unchecked_grads = False
         self.fin_queue_budget = 768 << 20      # bytes of float slabs the queue may keep alive before it flushes (c2: ~3 flushes per sweep)
         # GroupNorm statistics of a tensor come from the store loop of the GEMM that writes it (svdx_gemm_gn) instead of a pass of their
-        # own over it; SVDX_FUSE_GN_STATS=0: developer knob for A/B runs
-        self.fuse_gn_stats = os.environ.get("SVDX_FUSE_GN_STATS", "1") != "0"
+        # own over it
+        self.fuse_gn_stats = True
         self.p_flat = None          # flat float master buffer of the trainables (ops.flatten_trainables)
         self.w16_flat = None        # same layout in the activation dtype, written by svdx_adamw / one cast per refresh
 
@@ -370,26 +367,20 @@ def geglu_candidates(M: int, N: int, Kd: int, fwd: bool = True):
 
 
 def choose_geglu_variant(M: int, N: int, Kd: int, fwd: bool = True) -> int:
-    return _choose_geglu_variant(M, N, Kd, fwd, os.environ.get("SVDX_GEGLU_TILE"))
+    return _choose_geglu_variant(M, N, Kd, fwd)
 
 
 @functools.lru_cache(maxsize=None)
-def _choose_geglu_variant(M: int, N: int, Kd: int, fwd: bool, rule) -> int:
+def _choose_geglu_variant(M: int, N: int, Kd: int, fwd: bool) -> int:
     """Tile variant of a GEMM with a fused GEGLU epilogue (no split-K there) without a measurement.  Under these epilogues a
     workgroup runs its main loop, the GELU polynomial and its 200-400 KB of stores one after the other, so two workgroups per CU
     matter more than the main loop: the two-stage eight-wave 192 x 128 tile is the default (isolated, us: forward M = 35840
     111.4 -> 100.2, M = 2240 73.8 -> 70.1; backward 126.4 -> 105.3 / 68.6 -> 57.8 / 53.8 -> 44.3 at M = 35840 / 8960 / 2240);
-    the 256 x 256 tile keeps the forward at the 32x20 level (80.3 against 80.9), ring tiles the 8x5 level (M = 560)."""
+    the 256 x 256 tile keeps the forward at the 32x20 level (80.3 against 80.9), ring tiles the 8x5 level (M = 560).  (Rounds 3-6 A/B-ed
+    the alternatives in the step -- the in-situ sweep's one-per-CU winners, the two-role tiles 32 / 34: +0.1 to +1.7 ms, profiles/r5_ab_c2.txt,
+    r6c_ab_two_role_first_cut.txt.)"""
     if not fwd and N % 128:
         return 4                                             # the backward epilogue takes whole column tiles: 160-wide ones here (N % 160 == 0)
-    if rule and rule.isdigit():                              # developer knob for A/B runs: one tile variant wherever it is a candidate
-        return int(rule) if int(rule) in geglu_candidates(M, N, Kd, fwd) else _choose_geglu_variant(M, N, Kd, fwd, None)
-    if rule == "sweep":        # developer knob for A/B runs: the in-situ sweep's winners among the one-per-CU tiles
-        if fwd:
-            return 18 if (M >= 4096 and N % 256 == 0) else (17 if M >= 512 else 4)
-        if M >= 16384 and N % 256 == 0:
-            return 18
-        return 4 if M >= 1024 else 21
     if M < 1024:
         return (17 if M >= 512 else 4) if fwd else 21
     if fwd and 4096 <= M < 16384 and N % 256 == 0:
@@ -709,10 +700,6 @@ def gemm_tn_acc(rt: Runtime, dy: torch.Tensor, x: torch.Tensor, dst: torch.Tenso
 
     def run(cfg):
         sk, stages = cfg if isinstance(cfg, tuple) else (cfg, 0)
-        if rt.tn_prefetch and stages in (0, 2, 18):
-            stages |= K.TN_PREFETCH                # L2 prefetch three K-steps ahead (csrc/gemm.hip gemm_tn_kernel<..., PF>)
-        if rt.tn_flat:
-            stages = (stages & ~K.TN_PREFETCH) | K.TN_FLAT
         # the bias gradient (column sums of dy) rides on the same launch
         # GradScaler's inf check where the gradient is written (Runtime.found_inf: the trainer's opt_state[3]; None = no folding)
         found = rt.found_inf if (write_once and rt.fold_finite) else None

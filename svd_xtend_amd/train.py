@@ -235,7 +235,7 @@ class Trainer:
             for knob in ("tuner", "gemm_variant", "split_k", "fuse_geglu", "fuse_dual", "fuse_tsa"):
                 setattr(self.rt, knob, getattr(old, knob))
         # AdamW walks a tile table so that it can also emit the transposed 16-bit twins the data-grad GEMMs read
-        tiled = bool(self.params) and os.environ.get("SVDX_ADAM_TILED", "1") != "0"      # developer knob for A/B runs
+        tiled = bool(self.params)
         self.adam_tiles = build_adam_tiles(self.params, self.offsets, self.rt.wt_map, dev) if tiled else None
         self.rt.adam_writes_wt = self.adam_tiles is not None
         # zero_grad(): gradients written by exactly one GEMM per step (rt.write_once: the big matrices, 99 % of the buffer) are
@@ -255,10 +255,8 @@ class Trainer:
             lo4, hi4 = lo // 4 * 4, -(-hi // 4) * 4          # write-once matrices are multiples of 4 elements
             for c in range(lo4, hi4, 1 << 16):
                 chunks.append((c, min(1 << 16, hi4 - c)))
-        if os.environ.get("SVDX_WRITE_ONCE", "1") == "0":      # developer knob for A/B runs: plain memset + accumulate
-            self.rt.write_once.clear()
         self.zero_spans = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous() if self.rt.write_once else None
-        # GradScaler's inf check folded into the gradient-writing kernels (single rank; Runtime.fold_finite / SVDX_FOLD_FINITE=0: A/B knob).
+        # GradScaler's inf check folded into the gradient-writing kernels (single rank; Runtime.fold_finite).
         # finite_spans: the accumulated slots below n_flat (zero_spans without the loss slot at the tail, which is not a gradient)
         fin = [(c, min(n, self.n_flat - c)) for c, n in chunks if c < self.n_flat]
         self.finite_spans = torch.tensor(fin, dtype=torch.int32, device=dev).contiguous() if (self.rt.write_once and fin) else None

@@ -929,7 +929,7 @@ def run_all(impl, dev, dtypes=DTYPES, verbose=True):
             checks += [(f"gemm_plain_v{v}", lambda v=v: check_gemm_plain(P, dt, v)), (f"gemm_gather_v{v}", lambda v=v: check_gemm_gather(P, dt, v))]
         checks += [("gemm_tn", lambda: check_gemm_tn(P, dt)), ("gemm_tn_s3", lambda: check_gemm_tn(P, dt, 3)), ("gemm_tn_s4", lambda: check_gemm_tn(P, dt, 4)),
                    ("gemm_tn_v18", lambda: check_gemm_tn(P, dt, 18)),
-                   ("gemm_tn_pf", lambda: check_gemm_tn(P, dt, K.TN_PREFETCH)), ("gemm_tn_v18_pf", lambda: check_gemm_tn(P, dt, 18 | K.TN_PREFETCH)),
+                   ("gemm_tn_flat", lambda: check_gemm_tn(P, dt, K.TN_FLAT)), ("gemm_tn_v18_flat", lambda: check_gemm_tn(P, dt, 18 | K.TN_FLAT)),
                    ("gemm_gn_v4", lambda: check_gemm_gn(P, dt, 4)), ("gemm_gn_v6", lambda: check_gemm_gn(P, dt, 6)), ("gemm_gn_v23", lambda: check_gemm_gn(P, dt, 23)),
                    ("gemm_gn_v18", lambda: check_gemm_gn(P, dt, 18)), ("gemm_gn_v24", lambda: check_gemm_gn(P, dt, 24)), ("gemm_gn_v26", lambda: check_gemm_gn(P, dt, 26)),
                    ("gemm_geglu", lambda: check_gemm_geglu(P, dt))]

@@ -108,7 +108,7 @@ def fuzz_gather(P, dt, rng, g):
 
 
 def fuzz_tn(P, dt, rng, g):
-    stages = rng.choice((0, 3, 4, 18, 0 | K.TN_PREFETCH, 18 | K.TN_PREFETCH, 0 | K.TN_FLAT, 18 | K.TN_FLAT))     # + the L2-prefetch forms and rounds 1-4's flat staging
+    stages = rng.choice((0, 3, 4, 18, 0 | K.TN_FLAT, 18 | K.TN_FLAT))     # + the L2-prefetch forms and rounds 1-4's flat staging
     R, N, Kd = pick_dim(rng, 1, 2400), pick_dim(rng, 8, 600, 8), pick_dim(rng, 8, 600, 8)
     A, B = kc.rnd((R, N), dt, P.dev, g), kc.rnd((R, Kd), dt, P.dev, g, R ** -0.5)
     mode = rng.choice((K.OUT_F32, K.OUT_F32_ADD, K.OUT_F32_SLAB))

@@ -15,7 +15,7 @@ from backend import SimBackend  # noqa: E402
 def groups(P, dt):
     fns = {"gemm_tn": lambda: kc.check_gemm_tn(P, dt), "gemm_tn_s3": lambda: kc.check_gemm_tn(P, dt, 3), "gemm_tn_s4": lambda: kc.check_gemm_tn(P, dt, 4),
            "gemm_tn_v18": lambda: kc.check_gemm_tn(P, dt, 18),
-           "gemm_tn_pf": lambda: kc.check_gemm_tn(P, dt, 32), "gemm_tn_v18_pf": lambda: kc.check_gemm_tn(P, dt, 18 | 32), "gemm_geglu": lambda: kc.check_gemm_geglu(P, dt),
+           "gemm_tn_flat": lambda: kc.check_gemm_tn(P, dt, 64), "gemm_tn_v18_flat": lambda: kc.check_gemm_tn(P, dt, 18 | 64), "gemm_geglu": lambda: kc.check_gemm_geglu(P, dt),
            "small": lambda: kc.check_small(P, dt), "groupnorm": lambda: kc.check_groupnorm(P, dt), "layernorm": lambda: kc.check_layernorm(P, dt),
            "attention": lambda: kc.check_attention(P, dt), "temporal_attention": lambda: kc.check_temporal_attention(P, dt),
            "tsa": lambda: kc.check_tsa(P, dt), "encoders": lambda: kc.check_encoders(P, dt), "elementwise": lambda: kc.check_elementwise(P, dt),

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "sim"))
 FULL = os.environ.get("SVDX_SIM_FULL") == "1"
 
-QUICK = [("gemm_plain_v4", "f16"), ("gemm_gn_v6", "f16"), ("gemm_gn_v23", "bf16"), ("gemm_gather_v16", "f16"), ("gemm_plain_v23", "bf16"), ("gemm_tn", "bf16"), ("gemm_tn_v18", "f16"), ("gemm_tn_pf", "f16"), ("gemm_tn_v18_pf", "bf16"), ("gemm_geglu_v26", "f16"),
+QUICK = [("gemm_plain_v4", "f16"), ("gemm_gn_v6", "f16"), ("gemm_gn_v23", "bf16"), ("gemm_gather_v16", "f16"), ("gemm_plain_v23", "bf16"), ("gemm_tn", "bf16"), ("gemm_tn_v18", "f16"), ("gemm_tn_flat", "f16"), ("gemm_tn_v18_flat", "bf16"), ("gemm_geglu_v26", "f16"),
          ("groupnorm", "f16"), ("layernorm", "bf16"), ("temporal_attention", "f16"), ("temporal_attention", "bf16"), ("tsa", "f16"), ("small", "f16"),
          ("encoders", "f16"), ("elementwise", "bf16"), ("optim", "f16")]
 DT = {"f16": torch.float16, "bf16": torch.bfloat16}
