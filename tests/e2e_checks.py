@@ -343,7 +343,7 @@ def replays_with_traffic_between(dev=None, dtype=torch.float16, replays=4, distu
     return dict(p=tr.p_flat.clone(), loss=float(tr.loss_slot.cpu()), state=tr.opt_state.cpu().tolist(), losses=losses)
 
 
-def run_steps(dev=None, dtype=torch.float16, steps=3, seed=5, lora_r=0):
+def run_steps(dev=None, dtype=torch.float16, steps=3, seed=5, lora_r=0, rt_attrs=None):
     """`steps` eager optimizer steps of the tiny topology from seeded weights on a seeded batch; returns the final state.
     lora_r: config 5's trainable set (adapters on the attention projections, B randomised so that every gradient is non-zero)."""
     dev = dev or torch.device("cuda")
@@ -366,6 +366,9 @@ def run_steps(dev=None, dtype=torch.float16, steps=3, seed=5, lora_r=0):
                 p.data.copy_(torch.randn(p.shape, generator=gen) * 0.05)
     m.to(dev)
     tr = Trainer(m, dtype=dtype, lr=1e-3)
+    for name, val in (rt_attrs or {}).items():      # Runtime switches (ops.Runtime), set before the first step
+        assert hasattr(tr.rt, name), name
+        setattr(tr.rt, name, val)
     for _ in range(steps - 1):
         tr.step(batch)
     tr.rt.k.launch_log = log = []              # entry names of the last step's launches
@@ -383,20 +386,10 @@ def run_steps(dev=None, dtype=torch.float16, steps=3, seed=5, lora_r=0):
 
 def batched_vs_single_small_launches(dev=None, dtype=torch.float16, steps=2, lora_r=0):
     """The table-driven skinny launches (Runtime.batch_small: the cross-attention vector chain up front, its gradient chain and the
-    LayerNorm affine-gradient reductions at the end of the sweep) against one launch each (SVDX_BATCH_SMALL=0): identical bits after
+    LayerNorm affine-gradient reductions at the end of the sweep) against one launch each (batch_small=False): identical bits after
     `steps` optimizer steps, and the launches they save.  Returns (batched, single) run_steps results."""
-    import os
-    prev = os.environ.get("SVDX_BATCH_SMALL")
-    try:
-        os.environ["SVDX_BATCH_SMALL"] = "1"
-        a = run_steps(dev=dev, dtype=dtype, steps=steps, lora_r=lora_r)
-        os.environ["SVDX_BATCH_SMALL"] = "0"
-        b = run_steps(dev=dev, dtype=dtype, steps=steps, lora_r=lora_r)
-    finally:
-        if prev is None:
-            os.environ.pop("SVDX_BATCH_SMALL", None)
-        else:
-            os.environ["SVDX_BATCH_SMALL"] = prev
+    a = run_steps(dev=dev, dtype=dtype, steps=steps, lora_r=lora_r, rt_attrs=dict(batch_small=True))
+    b = run_steps(dev=dev, dtype=dtype, steps=steps, lora_r=lora_r, rt_attrs=dict(batch_small=False))
     return a, b
 
 

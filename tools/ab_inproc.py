@@ -4,7 +4,7 @@
 
 A CFG is a comma-separated list of settings applied on top of the defaults, `base` for none:
     batch_small=0              Runtime attribute (ops.Runtime) -- int / bool / float literal
-    SVDX_GEGLU_TILE=sweep      environment variable read at call time by the host code
+    SVDX_X=1                   environment variable (none selects a kernel since round 6; kept for one-off experiments)
     tuned                      the in-situ GEMM tuner's table (Trainer.tune_gemms, run once, staged candidates included)
 The model is built ONCE; every CFG gets its own hipGraph of the step (captured after two eager steps under that setting), then
 the graphs are replayed alternately, `--reps` times `--steps` steps each: box-to-box spread (+-5 %) and the cost of a fresh

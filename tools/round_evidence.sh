@@ -14,5 +14,5 @@ d = json.loads(open("$O/${tag}_bench_$f.json").read().strip().splitlines()[-1]);
 print("$f", round(d["ms_per_step"], 2), "ms", round(d["value"], 3), d["unit"], "loss", c["loss"], "steps", c["opt_steps"], "frac", r.get("frac"), (d.get("with_vae") or {}).get("ms_per_step"))
 PY
 done
-timeout 900 python tools/ab_inproc.py -- base tn_flat=1 fold_finite=0 batch_small=0 dvec_from_dw=0 SVDX_GEGLU_TILE=sweep fuse_tsa=0 fuse_gn_stats=0 defer_grad_finalize=0 > $O/${tag}_ab_c2.txt 2>&1; grep -v "^\[" $O/${tag}_ab_c2.txt | tail -n 10
+timeout 900 python tools/ab_inproc.py -- base fold_finite=0 batch_small=0 dvec_from_dw=0 fuse_tsa=0 fuse_gn_stats=0 defer_grad_finalize=0 > $O/${tag}_ab_c2.txt 2>&1; grep -v "^\[" $O/${tag}_ab_c2.txt | tail -n 10
 bash tools/collect_evidence.sh $tag > $O/${tag}_collect.log 2>&1; tail -n 4 $O/${tag}_collect.log
