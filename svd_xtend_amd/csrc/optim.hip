@@ -293,28 +293,39 @@ __global__ __launch_bounds__(256) void adamw_tiled_kernel(float* __restrict__ p,
     const int off = tl[0], ld = tl[1], rows = tl[2], cols = tl[3], wt_off = tl[4], ldwt = tl[5];
     const AdamScalars a = adam_scalars(st, lr, beta1, beta2, eps, wd, grad_mul, ref != 0);
     const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
+    // one pass over 12.6 GB that nothing re-reads before the next step: streaming loads and stores throughout.  All sixteen operand
+    // loads of the thread (four rows x p, g, m, v) are requested before the first is used (round 6: the row-at-a-time loop kept
+    // four in flight and drained them before every row's arithmetic -- two IEEE divisions and a square root per element).
+    f32x4 pv[4], gv[4], mv[4], vv[4];
+    bool live[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + 16 * i;
-        if (r < rows && c4 < cols) {
+        live[i] = r < rows && c4 < cols;
+        // threads beyond the tile read its first element group (in range, never stored): no branch between the loads
+        const long idx = live[i] ? (long)off + (long)r * ld + c4 : (long)off;
+        pv[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + idx));
+        gv[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + idx));
+        mv[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + idx));
+        vv[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + idx));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 16 * i;
+        if (live[i]) {
             const long idx = (long)off + (long)r * ld + c4;
-            // one pass over 12.6 GB that nothing re-reads before the next step: streaming loads and stores throughout
-            f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + idx));
-            const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + idx));
-            f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + idx));
-            f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + idx));
             Vec4<T> o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float pe = pv[e], me = mv[e], ve = vv[e];
-                if (ref) adamw_elem<true>(pe, gv[e], me, ve, a);
-                else adamw_elem<false>(pe, gv[e], me, ve, a);
-                pv[e] = pe; mv[e] = me; vv[e] = ve;
-                o.v[e] = from_f<T>(pv[e]);
+                float pe = pv[i][e], me = mv[i][e], ve = vv[i][e];
+                if (ref) adamw_elem<true>(pe, gv[i][e], me, ve, a);
+                else adamw_elem<false>(pe, gv[i][e], me, ve, a);
+                pv[i][e] = pe; mv[i][e] = me; vv[i][e] = ve;
+                o.v[e] = from_f<T>(pe);
             }
-            __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(p + idx));
-            __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m + idx));
-            __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + idx));
+            __builtin_nontemporal_store(pv[i], reinterpret_cast<f32x4*>(p + idx));
+            __builtin_nontemporal_store(mv[i], reinterpret_cast<f32x4*>(m + idx));
+            __builtin_nontemporal_store(vv[i], reinterpret_cast<f32x4*>(v + idx));
             if (p_act) *reinterpret_cast<Vec4<T>*>(p_act + idx) = o;
             if (wt_off >= 0) *reinterpret_cast<Vec4<T>*>(&tile[r][c4]) = o;
         }

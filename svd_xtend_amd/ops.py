@@ -351,6 +351,12 @@ def choose_cfg(rt: "Runtime", M: int, N: int, Kd: int, ldc: int, cin: int = 0, d
 @functools.lru_cache(maxsize=None)
 def _choose_cfg_v4(split_k: bool, M: int, N: int, Kd: int, ldc: int, cin: int, dual: bool):
     splittable = split_k and N % 4 == 0 and ldc % 4 == 0
+    if not dual and M >= 30000 and N % 128 == 0 and N % 160:
+        # the conditioners' convolutions (VAE widths 128 / 256 / 512 over 38400 - 2.46 M pixel rows; no UNet width is a multiple of 128 and
+        # not of 160): the cost model's rates were fitted to the UNet's shapes and picked tiles 3-17 % behind the fastest here.  In-situ
+        # sweep of round 6 (tools/cond_tune.py, profiles/r6k_cond_tune.txt): 256 x 256 tiles where two column tiles and >= 100 k rows
+        # exist, the two-stage eight-wave 128 x 128 tile elsewhere; VAE encode of 15 frames 16.08 -> 15.47 ms.
+        return 1, (18 if (M >= 100000 and N % 256 == 0) else 27)
     cands = _dual_candidates(M, N, Kd) if dual else _nt_candidates(M, N, Kd, splittable)
     if not cands:
         return choose_split(SimpleNamespace(split_k=split_k), M, N, Kd, ldc), 4

@@ -295,6 +295,8 @@ def test_gemm_config_rules_for_the_c2_shapes():
     assert choose_cfg(rt, 2240, 1280, 3840, 1280, 1280) == (1, 24)       # medium / short K: 24 x 10 = 240 four-wave ring tiles of 96 x 128, no split
     assert choose_cfg(rt, 2240, 1280, 1280, 1280) == (1, 24)             #   (128-row tiles: 180)
     assert choose_cfg(rt, 560, 1280, 3840, 1280, 1280) == (3, 24)        # 8x5 level: 6 x 10 tiles of 96 x 128, 3 slices
+    assert choose_cfg(rt, 2457600, 128, 1152, 128, 128) == (1, 27)       # conditioner widths (VAE): round 6's in-situ table, not the UNet-fitted model
+    assert choose_cfg(rt, 614400, 256, 2304, 256, 256) == (1, 18) and choose_cfg(rt, 38400, 512, 4608, 512, 512) == (1, 27)
     s, v = choose_cfg(rt, 560, 1280, 11520, 1280, 1280)
     assert v in (22, 23) and 6 <= s <= 10
     for (M, N, Kd) in [(560, 1280, 11520), (560, 1280, 1280), (2240, 640, 5760), (8960, 1920, 640), (300, 960, 192), (64, 640, 1280), (1000, 4, 576)]:
