@@ -43,6 +43,10 @@ struct GemmParams {
     // variant 4, activation output: GroupNorm statistics of the tensor this launch writes (sum, sum of squares per (sample, group) of the
     // ROUNDED values, in the fixed-point replica slots svdx_gn_apply reads) -- the norm that consumes C needs no pass of its own over it
     unsigned long long* gn_stats; int gn_rows, gn_cg; float gn_m0, gn_m1;
+    // variant 4 / 5: rows a row tile OWNS (= its stride over M).  Equal to the tile height except for the 144-row tile of variant 36,
+    // which steps 140 rows (35840 = 256 x 140, 8960 = 64 x 140: the grid fills every workgroup slot of the chip exactly); rows of a
+    // tile beyond its step are computed and not stored (they are the next tile's).
+    int m_step;
 };
 constexpr int GN_MAX_S = 8, GN_MAX_G = 36;               // samples / groups one output tile may touch (else the host runs svdx_gn_stats)
 constexpr int GN_LDS = GN_MAX_S * GN_MAX_G * 2 * 8;
@@ -866,6 +870,7 @@ __device__ __forceinline__ void v4_epilogue(const GemmParams& p, char* smem, f32
                                             int wm, int wn, int tid) {
     const int lane = tid & 63, fr = lane & 15, fg = lane >> 4;
     const int Fdim = p.aux_dim;
+    const int m_lim = min(p.M, m0 + p.m_step);          // first row this tile does not own
     auto brow = [&](int nl) __attribute__((always_inline)) { return v4_brow<BN3>(p, pid_n, n0, nl); };
     // ---- epilogue A (activation output): coalesced.  Each lane adds bias / row vector to its 4-column groups, rounds to the
     //      activation dtype and parks them in LDS (the stage buffers are free now); then every thread moves 16-byte row
@@ -916,7 +921,7 @@ __device__ __forceinline__ void v4_epilogue(const GemmParams& p, char* smem, f32
                 const int row = id / (NPAIR * 2), r2 = id - row * (NPAIR * 2);
                 const int pr = r2 >> 1, c2 = r2 & 1;
                 const int m = m0 + row;
-                if (m >= p.M) continue;
+                if (m >= m_lim) continue;
                 const Vec8<T> a8 = *reinterpret_cast<const Vec8<T>*>(smem + row * PITCH + (pr * 32 + c2 * 8) * 2);
                 const Vec8<T> g8 = *reinterpret_cast<const Vec8<T>*>(smem + row * PITCH + (pr * 32 + 16 + c2 * 8) * 2);
                 const int fc = pid_n * (BN3 / 2) + pr * 16 + c2 * 8;
@@ -941,7 +946,7 @@ __device__ __forceinline__ void v4_epilogue(const GemmParams& p, char* smem, f32
             for (int id = tid; id < BM4 * CPR; id += NT) {
                 const int row = id / CPR, c = id - row * CPR;
                 const int m = m0 + row;
-                if (m >= p.M) continue;
+                if (m >= m_lim) continue;
                 const Vec8<T> d8 = *reinterpret_cast<const Vec8<T>*>(smem + row * PITCH + c * 16);
                 const size_t po = (size_t)m * (2 * Fdim) + n0 + c * 8;
                 const Vec8<T> a8 = *reinterpret_cast<const Vec8<T>*>(pre + po);
@@ -993,7 +998,7 @@ __device__ __forceinline__ void v4_epilogue(const GemmParams& p, char* smem, f32
             if (tid < RPS * CPR) {
                 for (int row = tid / CPR; row < BM4; row += RPS) {
                     const int m = m0 + row;
-                    if (m >= p.M) break;
+                    if (m >= m_lim) break;
                     Vec8<T> o8 = *reinterpret_cast<const Vec8<T>*>(smem + row * PITCH + c * 16);
                     const size_t co = (size_t)m * p.ldc + n0 + c * 8;
                     if (R2) {
@@ -1015,7 +1020,7 @@ __device__ __forceinline__ void v4_epilogue(const GemmParams& p, char* smem, f32
                 if (cur_s >= 0) flush(cur_s);
             }
             __syncthreads();
-            const int ns_t = (min(m0 + BM4, p.M) - 1) / p.gn_rows - s_first + 1, ng_t = (min(n0 + BN3, p.N) - 1) / p.gn_cg - g_first + 1;
+            const int ns_t = (m_lim - 1) / p.gn_rows - s_first + 1, ng_t = (min(n0 + BN3, p.N) - 1) / p.gn_cg - g_first + 1;
             const int n_s = p.M / p.gn_rows, G = p.N / p.gn_cg;
             unsigned long long* out = p.gn_stats + (size_t)((pid_m + pid_n) % SVDX_GN_REPLICAS) * n_s * G * 2;
             for (int i = tid; i < ns_t * ng_t * 2; i += NT) {
@@ -1029,7 +1034,7 @@ __device__ __forceinline__ void v4_epilogue(const GemmParams& p, char* smem, f32
         for (int id = tid; id < BM4 * CPR; id += NT) {
             const int row = id / CPR, c = id - row * CPR;
             const int m = m0 + row;
-            if (m >= p.M) continue;
+            if (m >= m_lim) continue;
             const Vec8<T> t8 = *reinterpret_cast<const Vec8<T>*>(smem + row * PITCH + c * 16);
             const size_t co = (size_t)m * p.ldc + n0 + c * 8;
             if (R2) {
@@ -1061,7 +1066,7 @@ __device__ __forceinline__ void v4_epilogue(const GemmParams& p, char* smem, f32
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
         const int m = m0 + wm * WM4 + j * 16 + fr;
-        if (m >= p.M) continue;
+        if (m >= m_lim) continue;
         const float* rv = nullptr;
         if (lead && p.rowvec) rv = p.rowvec + (size_t)(p.rv_mod ? (m % p.rv_mod) : (m / p.rv_rpg)) * p.rv_ld;
 #pragma unroll
@@ -1159,7 +1164,7 @@ __global__ __launch_bounds__(128 * WGM, 2) void gemm_v4_kernel(GemmParams p) {  
     const int wm = wave >> 1, wn = wave & 1;
     int pid_m, pid_n, z;
     if (!v4_tile_of_block(p, pid_m, pid_n, z)) return;
-    const int m0 = pid_m * BM4, n0 = pid_n * BN3;
+    const int m0 = pid_m * p.m_step, n0 = pid_n * BN3;
     const int kt_total = p.K / KT;
     const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
     const int kt_begin = z * kt_per;
@@ -1391,7 +1396,7 @@ __global__ __launch_bounds__(512) void gemm_v5_kernel(GemmParams p) {
     const int wr = wave_u >> 2, wc = wave_u & 3;
     int pid_m, pid_n, z;
     if (!v4_tile_of_block(p, pid_m, pid_n, z)) return;
-    const int m0 = pid_m * BM5, n0 = pid_n * BN5;
+    const int m0 = pid_m * p.m_step, n0 = pid_n * BN5;
     const int kt_total = p.K / KT;
     const int kt_per = (kt_total + p.split_k - 1) / p.split_k;
     const int kt_begin = z * kt_per;
@@ -1898,11 +1903,11 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
 
 // Tile counts, vector-store eligibility and the XCD arrangement of a BMT x BNT tile grid (see v4_tile_of_block): the arrangement with the
 // least operand re-fetch among those that keep >= 90 % of the best tile balance; -> the launch grid.  Shared by the v4 and v5 launchers.
-static int arrange_nt_grid(GemmParams& p, int BMT, int BNT, dim3& grid) {
+static int arrange_nt_grid(GemmParams& p, int BMT, int BNT, dim3& grid, int rows_computed = 0) {      // BMT: rows a tile owns; rows_computed: its height when larger
     if (p.gn_stats) {
         // the statistics are taken in the coalesced store loop, which handles whole column tiles of 16-byte-aligned rows only
         const bool ok = p.N % BNT == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && (!p.res || (p.ldres % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
-                        (BMT - 1) / p.gn_rows + 2 <= GN_MAX_S && (BNT - 1) / p.gn_cg + 2 <= GN_MAX_G;
+                        ((rows_computed ? rows_computed : BMT) - 1) / p.gn_rows + 2 <= GN_MAX_S && (BNT - 1) / p.gn_cg + 2 <= GN_MAX_G;
         if (!ok) { svdx_set_error("svdx_gemm_gn: N=%d / ldc=%d / rows=%d / cg=%d do not fit the %dx%d tile's statistics path", p.N, p.ldc, p.gn_rows, p.gn_cg, BMT, BNT); return -2; }
     }
     p.tiles_m = cdiv(p.M, BMT);
@@ -1951,9 +1956,11 @@ static int arrange_nt_grid(GemmParams& p, int BMT, int BNT, dim3& grid) {
     return 0;
 }
 
-template <typename T, int NB, int MB, int WGM = 2, int NSTG = 2>
+template <typename T, int NB, int MB, int WGM = 2, int NSTG = 2, int MSTEP = 0>
 int launch_gemm_v4(GemmParams p, hipStream_t st) {
     constexpr int BMT = 16 * MB * WGM, BNT = 32 * NB;
+    constexpr int STEP = MSTEP ? MSTEP : BMT;                    // rows a tile owns (variant 36: 140 of its 144)
+    static_assert(STEP <= BMT && STEP > 0, "a tile cannot own more rows than it computes");
     constexpr int LDS_STG = NSTG * (BMT + BNT) * BK * 2, LDS_EPI = ((BMT * (BNT + 8) * 2 + 15) & ~15) + GN_LDS;      // K-loop stages | the rounded output tile parked for the coalesced stores (+ the GroupNorm statistics table behind it)
     constexpr int LDS = LDS_STG > LDS_EPI ? LDS_STG : LDS_EPI;
     static_assert(LDS <= 160 * 1024, "stages (and the epilogue tile parked in them) must fit the 160 KiB LDS");
@@ -1967,7 +1974,8 @@ int launch_gemm_v4(GemmParams p, hipStream_t st) {
     }
     if (p.K2 > 0 && !HAS_DUAL) { svdx_set_error("svdx_gemm_dual: this tile variant has no second-operand loop"); return -2; }
     dim3 grid;
-    if (int rc = arrange_nt_grid(p, BMT, BNT, grid)) return rc;
+    p.m_step = STEP;
+    if (int rc = arrange_nt_grid(p, STEP, BNT, grid, BMT)) return rc;
     if (p.K2 > 0) hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB, HAS_DUAL, WGM, NSTG>), grid, dim3(128 * WGM), LDS, st, p);
     else hipLaunchKernelGGL((gemm_v4_kernel<T, NB, MB, false, WGM, NSTG>), grid, dim3(128 * WGM), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm");
@@ -1988,6 +1996,7 @@ int launch_gemm_v5(GemmParams p, hipStream_t st) {
     }
     if (p.K2 > 0) { svdx_set_error("svdx_gemm_dual: this tile variant has no second-operand loop"); return -2; }
     dim3 grid;
+    p.m_step = BMT;
     if (int rc = arrange_nt_grid(p, BMT, BNT, grid)) return rc;
     hipLaunchKernelGGL((gemm_v5_kernel<T, MF, NF>), grid, dim3(512), LDS, st, p);
     SVDX_LAUNCH_CHECK("svdx_gemm");
@@ -2225,6 +2234,13 @@ static int gemm_entry(const void* A, const void* B, void* C, int M, int N, int K
                 if (variant == 32 && (epilogue == SVDX_EPI_NONE || n_cols % 256 == 0)) return launch_gemm_v5<T, 8, 4>(p, st);
                 if (variant == 34 && (epilogue == SVDX_EPI_NONE || n_cols % 320 == 0)) return launch_gemm_v5<T, 5, 5>(p, st);
                 if (variant == 32 || variant == 34) variant = 16;
+                // 36 (round 6): 144 x 160, SIX waves (3 x 2), two stages, two workgroups per CU, row tiles 140 apart -- the 64x40 level's
+                //     35840 rows are 256 x 140 and the 32x20 level's 8960 are 64 x 140, so N = 320 / 1280 give exactly 512 workgroups: every
+                //     slot of the chip, where the 160-row tile of variant 6 fills 448 of them.  160-wide only; no GEGLU-forward epilogue.
+                if (variant == 36) {
+                    if (nb5 && epilogue != SVDX_EPI_GEGLU_FWD) return launch_gemm_v4<T, 5, 3, 3, 2, 140>(p, st);
+                    variant = 28;
+                }
                 switch (variant) {
                     case 18: if (n_cols % 256 == 0) return launch_gemm_v4<T, 8, 4, 4, 2>(p, st);   // else: fall through to 256 x 128
                     case 16: case 17: return nb5 ? launch_gemm_v4<T, 5, 4, 4, 3>(p, st) : launch_gemm_v4<T, 4, 4, 4, 3>(p, st);

@@ -269,7 +269,13 @@ TILE_OF_VARIANT = {7: (128, 160, 2, 4), 6: (160, 160, 2, 4), 8: (128, 128, 2, 4)
 #   (8192^3: 1397 TF/s against 1297 for tile 18; the 64x40-level convolutions 5-20 % ahead of tile 6), inside the step they only TIE with
 #   the two-per-CU four-wave tiles (in-situ sweep: +-3 % per problem, one problem -10 %; cost-model selection +0.45 ms / step):
 #   profiles/r6e_tune_dump_reworked.txt, DESIGN.md 6.4.  A 160 x 320 two-role workgroup IS two 160 x 160 workgroups side by side.
-STAGED_TILES = {27: (128, 128, 2, 8), 28: (128, 160, 2, 8), 32: (256, 256, 2, 8), 34: (160, 320, 2, 8)}
+#   36: round 6's 144 x 160 SIX-wave two-stage tile whose row tiles are 140 apart (two workgroups per CU): 35840 = 256 x 140 and 8960 = 64 x 140,
+#   so N = 320 at the 64x40 level / N = 1280 at the 32x20 level launch exactly 512 workgroups -- every slot of the chip -- where the
+#   160-row tile of variant 6 fills 448.  The entry's first number is the row STEP (what tile counts follow); it computes 144 rows.
+#   Isolated it is 3-12 % ahead of tile 6 on the N = 320 problems of the 64x40 level (profiles/r6m_ring_time_tile36.txt); selected for every
+#   (1, 6) choice whose grid it fills in one round it moved the step by -0.07 ms (profiles/r6n_ab_tile36.txt: 48.01 against 48.08 ms) -- inside the
+#   step those launches wait for their cold operands, not for workgroup slots.  A tuner candidate only.
+STAGED_TILES = {27: (128, 128, 2, 8), 28: (128, 160, 2, 8), 32: (256, 256, 2, 8), 34: (160, 320, 2, 8), 36: (140, 160, 2, 6)}
 # TFLOP/s one CU sustains on a variant's K-loop when the CU is full (8192^3 runs of tools/ring_check.py divided by 256 CUs, trimmed by
 # the in-situ sweeps of bench.py --tune): the two-stage four-wave tiles need two workgroups per CU for it
 _TILE_RATE = {6: 4.05, 7: 3.5, 8: 3.5, 16: 4.4, 17: 4.0, 18: 3.6, 20: 2.75, 21: 2.5, 22: 3.8, 23: 3.8, 24: 2.4, 25: 2.05}
@@ -471,7 +477,7 @@ def gn_tile_ok(variant: int, N: int, rows: int, cg: int) -> bool:
     t = TILE_OF_VARIANT.get(variant) or STAGED_TILES.get(variant)
     if t is None:
         return False
-    bm, bn = t[0], t[1]
+    bm, bn = (144 if variant == 36 else t[0]), t[1]          # (variant 36 steps 140 rows and computes 144: the launcher checks the height)
     return N % bn == 0 and (bm - 1) // rows + 2 <= 8 and (bn - 1) // cg + 2 <= 36
 
 
@@ -534,7 +540,7 @@ def _tile_launched(variant: int, M: int, N: int) -> int:
             return 8
         t128, t160 = -(-M // 128) * (N // 160), -(-M // 160) * (N // 160)
         return 6 if (-(-t128 // 512) * 4 > -(-t160 // 512) * 5 and t160 >= 384) else 7
-    sib = {16: 17, 23: 22, 25: 24, 20: 21, 28: 27, 7: 8, 6: 8}
+    sib = {16: 17, 23: 22, 25: 24, 20: 21, 28: 27, 7: 8, 6: 8, 36: 27}
     if variant in sib and N % 160:
         return sib[variant]
     if variant == 18 and N % 256:

@@ -18,7 +18,7 @@ import emul  # noqa: E402
 import kernel_checks as kc  # noqa: E402
 from svd_xtend_amd import kernels as K  # noqa: E402
 
-NT_VARIANTS = (1, 4, 6, 7, 8, 16, 17, 18, 20, 21, 22, 23, 24, 25, 26, 27, 28)
+NT_VARIANTS = (1, 4, 6, 7, 8, 16, 17, 18, 20, 21, 22, 23, 24, 25, 26, 27, 28, 36)
 HEAD = 64
 
 

@@ -20,11 +20,11 @@ def groups(P, dt):
            "attention": lambda: kc.check_attention(P, dt), "temporal_attention": lambda: kc.check_temporal_attention(P, dt),
            "tsa": lambda: kc.check_tsa(P, dt), "encoders": lambda: kc.check_encoders(P, dt), "elementwise": lambda: kc.check_elementwise(P, dt),
            "optim": lambda: kc.check_optim(P, dt)}
-    for v in (4, 6, 8, 16, 18, 22, 23, 24, 26, 32, 34):
+    for v in (4, 6, 8, 16, 18, 22, 23, 24, 26, 32, 34, 36):
         fns[f"gemm_gn_v{v}"] = lambda v=v: kc.check_gemm_gn(P, dt, v)
     for v in (17, 18, 21, 26, 27, 32, 34):
         fns[f"gemm_geglu_v{v}"] = lambda v=v: kc.check_gemm_geglu(P, dt, v)
-    for v in (1, 4, 6, 16, 18, 20, 23, 25, 27, 28, 32, 34):
+    for v in (1, 4, 6, 16, 18, 20, 23, 25, 27, 28, 32, 34, 36):
         fns[f"gemm_plain_v{v}"] = lambda v=v: kc.check_gemm_plain(P, dt, v)
         fns[f"gemm_gather_v{v}"] = lambda v=v: kc.check_gemm_gather(P, dt, v)
     return fns

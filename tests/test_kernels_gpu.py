@@ -12,6 +12,7 @@ GROUPS = (["gemm_tn", "gemm_tn_s3", "gemm_tn_s4", "gemm_tn_v18", "gemm_geglu", "
           + [f"gemm_gn_v{v}" for v in (4, 6, 8, 16, 18, 22, 23, 24, 26)]     # svdx_gemm_gn: GroupNorm statistics from the store loop of every tile family
           + [f"gemm_{k}_v{v}" for v in (27, 28) for k in ("plain", "gather")] + ["gemm_geglu_v27"]     # tuner candidates (ops.STAGED_TILES)
           + [f"gemm_{k}_v{v}" for v in (32, 34) for k in ("plain", "gather", "gn", "geglu")]     # two-role eight-wave tiles (gemm_v5_kernel)
+          + [f"gemm_{k}_v36" for k in ("plain", "gather", "gn")]     # round 6: 144 x 160 six-wave tile stepping 140 rows
           + ["large_offsets", "small", "groupnorm", "layernorm", "attention", "temporal_attention", "tsa", "encoders", "elementwise", "optim"])
 
 
@@ -38,11 +39,11 @@ def test_kernel_group(pair, group, dt):
            "elementwise": lambda: kc.check_elementwise(pair, dt), "optim": lambda: kc.check_optim(pair, dt)}
     for v in (18,):
         fns[f"gemm_tn_v{v}"] = lambda v=v: kc.check_gemm_tn(pair, dt, v)
-    for v in (4, 6, 8, 16, 18, 22, 23, 24, 26, 32, 34):
+    for v in (4, 6, 8, 16, 18, 22, 23, 24, 26, 32, 34, 36):
         fns[f"gemm_gn_v{v}"] = lambda v=v: kc.check_gemm_gn(pair, dt, v)
     for v in (17, 18, 21, 26, 27, 32, 34):
         fns[f"gemm_geglu_v{v}"] = lambda v=v: kc.check_gemm_geglu(pair, dt, v)
-    for v in (4, 6, 27, 28, 32, 34) + RING:
+    for v in (4, 6, 27, 28, 32, 34, 36) + RING:
         fns[f"gemm_plain_v{v}"] = lambda v=v: kc.check_gemm_plain(pair, dt, v)
         fns[f"gemm_gather_v{v}"] = lambda v=v: kc.check_gemm_gather(pair, dt, v)
     bad = [(l, e, t) for l, e, t in fns[group]() if not (e <= t and math.isfinite(e))]
