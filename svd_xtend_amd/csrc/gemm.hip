@@ -949,8 +949,11 @@ __device__ __forceinline__ void v4_epilogue(const GemmParams& p, char* smem, f32
                 if (m >= m_lim) continue;
                 const Vec8<T> d8 = *reinterpret_cast<const Vec8<T>*>(smem + row * PITCH + c * 16);
                 const size_t po = (size_t)m * (2 * Fdim) + n0 + c * 8;
-                const Vec8<T> a8 = *reinterpret_cast<const Vec8<T>*>(pre + po);
-                const Vec8<T> g8 = *reinterpret_cast<const Vec8<T>*>(pre + po + Fdim);
+                // `pre` was written a whole forward sweep ago and is dead after this read: streaming loads, so that its 183 MB (64x40 level) do not
+                // push the d(pre) lines this launch writes -- the A operand of the next GEMM -- out of the Infinity Cache
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const Vec8<T> a8 = __builtin_bit_cast(Vec8<T>, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pre + po)));
+                const Vec8<T> g8 = __builtin_bit_cast(Vec8<T>, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pre + po + Fdim)));
                 Vec8<T> da, dg;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {

@@ -40,13 +40,18 @@ def rand_log_normal_reference(shape, loc: float = 0.0, scale: float = 1.0) -> to
 class TrainLoop:
     def __init__(self, trainer: Trainer, vae, image_encoder, conditioning_dropout_prob: Optional[float] = None, seed: int = 0,
                  use_graph: bool = True, ema=None, fps: int = 7, motion_bucket_id: int = 127, graph_conditioners: bool = True,
-                 reference_rng: bool = False):
+                 reference_rng: bool = False, overlap_clip: bool = True):
         """reference_rng: draw cond_sigmas (:954) and sigmas (:964) the reference's way -- on the host, from the process-global generator, in
         that order -- instead of on the device from this loop's generator: a run seeded with `torch.manual_seed` then walks the reference's
         sigma sequence.  (The Gaussian noise tensors stay device draws: the reference's come from the CUDA generator, which no other device
         reproduces.)  Costs two 4-byte host-to-device copies per micro-batch."""
         self.reference_rng = reference_rng
         self.tr, self.vae, self.enc = trainer, vae, image_encoder
+        # overlap_clip: the CLIP embed of the first frame (~300 launches of 5-25 us on <= 150 workgroups each: latency-bound, 3.5 ms) runs on a
+        # second stream BESIDE the VAE encode (chip-filling convolutions, 15.5 ms) instead of after it -- fork / join by events, also inside the
+        # captured conditioner graph.  Same arithmetic, same results; the two towers share nothing but the pixel clip.
+        self.overlap_clip = overlap_clip and trainer.dev.type == "cuda"
+        self._clip_stream = torch.cuda.Stream(device=trainer.dev) if self.overlap_clip else None
         self.p_drop = conditioning_dropout_prob
         self.use_graph = use_graph and trainer.dev.type == "cuda"
         self.ema = ema
@@ -93,12 +98,22 @@ class TrainLoop:
         cpix = d["n_cpix"] * cond_sigmas[:, None, None, None, None] + pix[:, 0:1]                 # :957-958
         # one encoder pass over the clip's T frames and the noise-augmented first frame (:948 and :959 are two calls there)
         frames = torch.cat([pix, cpix], dim=1)
+        ehs = None
+        if self.overlap_clip:
+            cur = torch.cuda.current_stream()
+            self._clip_stream.wait_stream(cur)                                                    # fork: the pixel clip is ready
+            with torch.cuda.stream(self._clip_stream):
+                ehs = encode_image(pix[:, 0], self.enc).to(torch.float32)                         # :975-976
+            ehs.record_stream(cur)
         dist_ = self.vae.encode(frames.reshape(bsz * (T + 1), *frames.shape[2:])).latent_dist    # tensor_to_vae_latent, :283-291
         z = (dist_.mean + dist_.std * d["eps"].reshape(dist_.mean.shape)).reshape(bsz, T + 1, *dist_.mean.shape[1:]) * self.vae.config.scaling_factor
         latents = z[:, :T]
         conditional_latents = z[:, T] / self.vae.config.scaling_factor                            # :959-960
         sigmas = d["sigmas"] if "sigmas" in d else log_normal(d["u_sig"], 0.7, 1.6)              # :964
-        ehs = encode_image(pix[:, 0], self.enc).to(torch.float32)                                 # :975-976
+        if ehs is None:
+            ehs = encode_image(pix[:, 0], self.enc).to(torch.float32)                             # :975-976
+        else:
+            torch.cuda.current_stream().wait_stream(self._clip_stream)                            # join
         ids = torch.stack([torch.full_like(noise_aug_strength, float(self.fps)), torch.full_like(noise_aug_strength, float(self.bucket)),
                            noise_aug_strength]).unsqueeze(0).repeat(bsz, 1)                       # :981-988 (fps passed as 7 there)
         if self.p_drop is not None:                                                               # :992-1011
