@@ -353,7 +353,7 @@ def real_loop_leg(args, trainer, dev, dt, world, rank, T):
     del pix, frames
     out = {"ms_per_step": el / K * 1e3, "value": world * ga * K / el, "unit": "samples/s", "steps": K,
            "conditioners_ms_alone": e0.elapsed_time(e1) / 5, "conditioners": cond,
-           "what": "TrainLoop.step: new pixel clip from pinned host memory -> VAE encode (T + 1 frames) + CLIP image embed + EDM noising on the "
+           "what": "TrainLoop.step: new pixel clip from pinned host memory -> VAE encode (T + 1 frames) with the CLIP image embed beside it on a second stream (serial with --serial-conditioners) + EDM noising on the "
                    "device, queued between this step's backward sweep and its optimizer (beside the gradient all-reduce when N > 1) -> batch copied "
                    "into the captured tensors -> hipGraph replay -> loss read on the host (one host sync per step)",
            "loss_first": losses[0], "loss_last": losses[-1], "losses_finite": all(l == l and abs(l) != float("inf") for l in losses),
