@@ -352,13 +352,17 @@ __device__ __forceinline__ desc4 hidden_desc(const void* p, unsigned bytes) {   
     const unsigned long a = (unsigned long)p;
     return desc4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
 }
-template <int SIZE>
+template <int SIZE, bool STREAM = false>
 __device__ __forceinline__ void hidden_dma(desc4 d, char* lds, unsigned voff) {     // lane l: SIZE bytes from d.base + voff -> lds + l * SIZE (0 beyond num_records)
     static_assert(SIZE == 16 || SIZE == 4, "dwordx4 or dword");
     /*SIM-BEGIN*/
     const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds);
     unsigned keep;
-    if (SIZE == 16)
+    if (SIZE == 16 && STREAM)          // nt (streaming policy).  Round 6 tried it on the X operand of the weight-gradient kernels (a saved activation, dead after the
+                                       // launch): +0.3 ms / step -- the tiles of a row slice share those lines through the L2 (profiles/r6q_ab_tn_nt_operand.txt); unused
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen nt lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(la), "v"(voff), "s"(d) : "memory");
+    else if (SIZE == 16)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "s"(la), "v"(voff), "s"(d) : "memory");
     else
