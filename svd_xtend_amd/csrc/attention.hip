@@ -97,20 +97,41 @@ __device__ __forceinline__ void store4(T* p, const f32x4& v, float mul) {
     *reinterpret_cast<Vec4<T>*>(p) = o;
 }
 
+// ---- which (128-row tile, head, sample) a workgroup computes.  Workgroup ids go round-robin to the 8 XCDs (id & 7), each with a private
+// 4 MiB L2, and every tile of one (head, sample) pair streams that pair's WHOLE K / V (forward, dQ) or Q / dO (dK/dV): a (tile, head, sample)
+// grid in dispatch order spread the 20 tiles of a pair over all eight XCDs, each of which then pulled the pair's operands over the fabric
+// for itself -- 403 MB read per forward launch at the 64x40 level where q, k, v are 69 MB (profiles/r5_pmc_traffic_by_grid.txt).  Round 6: a
+// 1-D grid of 8 * ceil(pairs / 8) * tiles workgroups; the j-th workgroup of XCD c is tile j % tiles of pair (j / tiles) * 8 + c, so the
+// tiles of a pair run side by side on ONE XCD (three pairs at a time fill its 64 workgroup slots: 2 MB of K / V in its L2).
+struct AttnWho { int tile, h, n; bool live; };
+__device__ __forceinline__ AttnWho attn_who(int tiles, int heads, int pairs) {
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int pl = slot / tiles, pair = pl * 8 + xcd;
+    AttnWho w;
+    w.tile = slot - pl * tiles;
+    w.live = pair < pairs;
+    w.n = pair / heads;
+    w.h = pair - w.n * heads;
+    return w;
+}
+static inline unsigned attn_grid(int tiles, int pairs) { return 8u * (unsigned)((pairs + 7) / 8) * (unsigned)tiles; }
+
 // ================================================================================================================
 // forward: block = (128 queries, head, frame); 4 waves x 32 queries; KV tiles of 64 keys
 // ================================================================================================================
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                        const T* __restrict__ v, T* __restrict__ o, float* __restrict__ lse,
-                                                       int heads, int S, int ld, int ld_o, float sl2) {
+                                                       int heads, int S, int ld, int ld_o, float sl2, int pairs) {
     typedef typename TT<T>::v8 v8;
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
     char* Ks = smem;
     char* Vs = smem + 64 * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const int h = blockIdx.y, n = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const AttnWho who = attn_who((S + 127) >> 7, heads, pairs);
+    if (!who.live) return;
+    const int h = who.h, n = who.n;
+    const int q0 = who.tile * 128 + wave * 32;
     const T* qb_ = q + (size_t)n * S * ld + h * 64;
     const T* kb_ = k + (size_t)n * S * ld + h * 64;
     const T* vb_ = v + (size_t)n * S * ld + h * 64;
@@ -260,14 +281,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* __restrict
                                                           const T* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ Dv,
                                                           T* __restrict__ dq, int heads, int S, int ld, int ld_o, int ld_d,
-                                                          float scale) {
+                                                          float scale, int pairs) {
     typedef typename TT<T>::v8 v8;
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
     char* Ks = smem;
     char* Vs = smem + 64 * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const int h = blockIdx.y, n = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const AttnWho who = attn_who((S + 127) >> 7, heads, pairs);
+    if (!who.live) return;
+    const int h = who.h, n = who.n;
+    const int q0 = who.tile * 128 + wave * 32;
     const float sl2 = scale * LOG2E;
     const T* qb_ = q + (size_t)n * S * ld + h * 64;
     const T* kb_ = k + (size_t)n * S * ld + h * 64;
@@ -378,15 +401,17 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                            const T* __restrict__ d_o, const float* __restrict__ lse,
                                                            const float* __restrict__ Dv, T* __restrict__ dk, T* __restrict__ dv,
-                                                           int heads, int S, int ld, int ld_o, int ld_d, float scale) {
+                                                           int heads, int S, int ld, int ld_o, int ld_d, float scale, int pairs) {
     typedef typename TT<T>::v8 v8;
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128 + 512];
     char* Qs = smem;
     char* dOs = smem + 64 * 128;
     float* Ls = reinterpret_cast<float*>(smem + 2 * 64 * 128);   // [64] -lse*log2e, then [64] -D
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const int h = blockIdx.y, n = blockIdx.z;
-    const int k0 = blockIdx.x * 128 + wave * 32;
+    const AttnWho who = attn_who((S + 127) >> 7, heads, pairs);
+    if (!who.live) return;
+    const int h = who.h, n = who.n;
+    const int k0 = who.tile * 128 + wave * 32;
     const float sl2 = scale * LOG2E;
     const T* qb_ = q + (size_t)n * S * ld + h * 64;
     const T* kb_ = k + (size_t)n * S * ld + h * 64;
@@ -519,9 +544,9 @@ extern "C" int svdx_attn_fwd(const void* q, const void* k, const void* v, void* 
     SVDX_CHECK_ARG(q && k && v && o && lse && nb > 0 && heads > 0 && S > 0, "svdx_attn_fwd: bad args");
     SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ld_o % 4 == 0 && (((uintptr_t)o) & 7) == 0,
                    "svdx_attn_fwd: alignment (ld=%d ld_o=%d)", ld, ld_o);
-    dim3 grid(cdiv(S, 128), heads, nb);
+    dim3 grid(attn_grid(cdiv(S, 128), heads * nb));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_fwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q, (const T*)k,
-                                             (const T*)v, (T*)o, lse, heads, S, ld, ld_o, scale * LOG2E));
+                                             (const T*)v, (T*)o, lse, heads, S, ld, ld_o, scale * LOG2E, heads * nb));
     SVDX_LAUNCH_CHECK("svdx_attn_fwd");
     return 0;
 }
@@ -541,10 +566,10 @@ extern "C" int svdx_attn_bwd_dkv(const void* q, const void* k, const void* v, co
     SVDX_CHECK_ARG(q && k && v && d_o && lse && D && dk && dv, "svdx_attn_bwd_dkv: null argument");
     SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ATTN_ARGS_OK(ld_o, d_o) && ld_d % 4 == 0,
                    "svdx_attn_bwd_dkv: alignment");
-    dim3 grid(cdiv(S, 128), heads, nb);
+    dim3 grid(attn_grid(cdiv(S, 128), heads * nb));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q,
                                              (const T*)k, (const T*)v, (const T*)d_o, lse, D, (T*)dk, (T*)dv, heads, S, ld, ld_o,
-                                             ld_d, scale));
+                                             ld_d, scale, heads * nb));
     SVDX_LAUNCH_CHECK("svdx_attn_bwd_dkv");
     return 0;
 }
@@ -555,10 +580,10 @@ extern "C" int svdx_attn_bwd_dq(const void* q, const void* k, const void* v, con
     SVDX_CHECK_ARG(q && k && v && d_o && lse && D && dq, "svdx_attn_bwd_dq: null argument");
     SVDX_CHECK_ARG(ATTN_ARGS_OK(ld, q) && ATTN_ARGS_OK(ld, k) && ATTN_ARGS_OK(ld, v) && ATTN_ARGS_OK(ld_o, d_o) && ld_d % 4 == 0,
                    "svdx_attn_bwd_dq: alignment");
-    dim3 grid(cdiv(S, 128), heads, nb);
+    dim3 grid(attn_grid(cdiv(S, 128), heads * nb));
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q,
                                              (const T*)k, (const T*)v, (const T*)d_o, lse, D, (T*)dq, heads, S, ld, ld_o, ld_d,
-                                             scale));
+                                             scale, heads * nb));
     SVDX_LAUNCH_CHECK("svdx_attn_bwd_dq");
     return 0;
 }
