@@ -1,6 +1,7 @@
 """End-to-end parity: MI355X-native UNet train step (HIP kernels) vs the CPU oracle on identical seeded
 weights / latents / sigmas.  Metric (BASELINE.json north_star): |loss_gpu - loss_cpu| / loss_cpu <= 1e-3 (fp16)."""
 import copy
+import json
 import os
 import time
 
@@ -89,6 +90,27 @@ def oracle_step(cfg, B, T, h, w, seed, lr, cross_dim, lora_r=0, orc=None, with_p
 BIG_REF_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "_big")
 
 
+def check_big_ref_fingerprint(tag, ref, rel=2e-5):
+    """Hold a big oracle reference (cached file or fresh computation) to the fingerprint this repository committed for it
+    (tests/golden/big_ref_fingerprints.json, written by tests/golden/make_big_fingerprint.py): loss, seeded-weight fingerprint, the L2 norm
+    of the prediction and of every gradient.  The cache itself is untracked (145 MB); what it must contain is not.  rel: fp32 oracle
+    results move in the last digits with the host's thread count (reduction order)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_ref_fingerprints.json")
+    if not os.path.exists(path):
+        return False
+    want = json.load(open(path)).get(tag.replace(" ", "_"))
+    if want is None:
+        return False
+    close = lambda a, b: abs(a - b) <= rel * max(abs(a), abs(b), 1e-30)      # noqa: E731
+    assert close(ref["loss"], want["loss"]), (tag, "loss", ref["loss"], want["loss"])
+    assert close(ref["sd0_fingerprint"], want["sd0_fingerprint"]), (tag, "seeded weights", ref["sd0_fingerprint"], want["sd0_fingerprint"])
+    assert close(float(ref["pred"].double().norm()), want["pred_l2"]), (tag, "prediction norm")
+    assert len(ref["grads"]) == want["n_grads"], (tag, len(ref["grads"]), want["n_grads"])
+    for k, v in ref["grads"].items():
+        assert close(float(v.double().norm()), want["grad_l2"][k]), (tag, k, float(v.double().norm()), want["grad_l2"][k])
+    return True
+
+
 def oracle_step_cached(tag, cfg, B, T, h, w, seed, lr, cross_dim):
     """`oracle_step` with its result kept on disk (tests/golden/_big/<tag>.pt: git-ignored, travels with the gpurun snapshot) for the
     cases whose CPU oracle takes minutes and tens of GB -- config 4's upper levels: computed once wherever there is a host for it
@@ -102,11 +124,13 @@ def oracle_step_cached(tag, cfg, B, T, h, w, seed, lr, cross_dim):
         sd0 = copy.deepcopy(orc.state_dict())
         fp = float(sum(v.double().abs().sum() for v in sd0.values()))
         if abs(fp - ref["sd0_fingerprint"]) <= 1e-9 * abs(fp):
+            check_big_ref_fingerprint(tag, ref)
             ref["sd0"] = sd0
             ref["cached"] = path
             return ref
         print(f"[e2e_checks] {path}: seeded weights differ from the stored fingerprint ({fp} vs {ref['sd0_fingerprint']}); recomputing", flush=True)
     ref = oracle_step(cfg, B, T, h, w, seed=seed, lr=lr, cross_dim=cross_dim)
+    check_big_ref_fingerprint(tag, dict(ref, sd0_fingerprint=float(sum(v.double().abs().sum() for v in ref["sd0"].values()))))
     if os.environ.get("SVDX_SAVE_BIG_REF") == "1":
         os.makedirs(BIG_REF_DIR, exist_ok=True)
         keep = {k: v for k, v in ref.items() if k != "sd0"}

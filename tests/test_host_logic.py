@@ -611,3 +611,27 @@ def test_trainer_reference_lora_dtype_keeps_bf16_parameters_and_state(emu_backen
         assert is_bf16(ref.p_flat[:n]) and is_bf16(ref.m_flat[:n]) and is_bf16(ref.v_flat[:n])
         assert torch.equal(ref.p_flat[:n], shadow.detach().float())
     assert float((ref.p_flat[:n] - dflt.p_flat[:n]).abs().max()) > 0
+
+
+def test_big_reference_fingerprint_is_enforced():
+    """tests/golden/big_ref_fingerprints.json (config 4's 9216-pixel level: loss, seeded-weight fingerprint, prediction norm, 104 gradient
+    norms) is what a cached or recomputed big oracle reference must reproduce: e2e_checks.check_big_ref_fingerprint accepts a reference
+    that carries these numbers and refuses one whose loss or one gradient moved."""
+    import json
+    import os
+    import pytest
+    import torch
+    import e2e_checks
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_ref_fingerprints.json")))
+    tag = "L0 320ch 72x128 T=25 seed=11"
+    w = want[tag.replace(" ", "_")]
+    assert w["n_grads"] == 104 and len(w["grad_l2"]) == 104 and abs(w["loss"] - 0.769970178604126) < 1e-12
+    unit = lambda n: torch.tensor([float(n)])                                            # noqa: E731  (a tensor whose L2 norm is n)
+    ref = dict(loss=w["loss"], sd0_fingerprint=w["sd0_fingerprint"], pred=unit(w["pred_l2"]), grads={k: unit(v) for k, v in w["grad_l2"].items()})
+    assert e2e_checks.check_big_ref_fingerprint(tag, ref)
+    assert not e2e_checks.check_big_ref_fingerprint("no such case", ref)
+    with pytest.raises(AssertionError):
+        e2e_checks.check_big_ref_fingerprint(tag, dict(ref, loss=w["loss"] * 1.001))
+    k0 = next(iter(w["grad_l2"]))
+    with pytest.raises(AssertionError):
+        e2e_checks.check_big_ref_fingerprint(tag, dict(ref, grads=dict(ref["grads"], **{k0: unit(w["grad_l2"][k0] * 1.01)})))
