@@ -406,8 +406,13 @@ def test_tile_table_matches_the_kernel_dispatch():
     # the two-role tiles: `if (variant == V && ...) return launch_gemm_v5<T, MF, NF>(p, st);` -> rows = 32 * MF, columns = 64 * NF, two K-tiles, eight waves
     for v, mf, nf in re.findall(r"if \(variant == (\d+) &&[^\n]*launch_gemm_v5<T, (\d+), (\d+)>", src):
         seen[int(v)] = [("v5", int(mf), int(nf))]
+    # variant 36: `if (variant == 36) { if (...) return launch_gemm_v4<T, NB, MB, WGM, NSTG, MSTEP>(p, st);`: the table holds the row STEP, the tile computes 16 MB WGM rows
+    m36 = re.search(r"if \(variant == 36\) \{\s*if \([^\n]*launch_gemm_v4<T, (\d+), (\d+), (\d+), (\d+), (\d+)>", src)
+    assert m36, "variant 36 dispatch not found"
+    nb, mb, wgm, nstg, mstep = (int(x) for x in m36.groups())
+    assert STAGED_TILES[36] == (mstep, 32 * nb, nstg, 2 * wgm) and mstep <= 16 * mb * wgm == 144
     assert not set(STAGED_TILES) & set(TILE_OF_VARIANT)
-    for v, (bm, bn, stages, waves) in list(TILE_OF_VARIANT.items()) + list(STAGED_TILES.items()):
+    for v, (bm, bn, stages, waves) in list(TILE_OF_VARIANT.items()) + [kv for kv in STAGED_TILES.items() if kv[0] != 36]:
         if v < 16:
             continue                                   # 6 / 7 / 8: the two-stage four-wave defaults of launch_gemm_v4<T, NB, MB>
         if seen[v][0][0] == "v5":
