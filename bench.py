@@ -286,7 +286,8 @@ def real_loop_leg(args, trainer, dev, dt, world, rank, T):
     host_clips = [(torch.rand(1, T, 3, args.height, args.width, generator=g) * 2 - 1).pin_memory() for _ in range(4)]
     ga = args.grad_accum
     pick = lambda i: [host_clips[(i * ga + j) % len(host_clips)] for j in range(ga)]           # noqa: E731
-    loop = TrainLoop(trainer, vae, enc, conditioning_dropout_prob=0.1, seed=99 + rank, use_graph=not args.no_graph, overlap_clip=not args.serial_conditioners)
+    loop = TrainLoop(trainer, vae, enc, conditioning_dropout_prob=0.1, seed=99 + rank, use_graph=not args.no_graph, overlap_clip=not args.serial_conditioners,
+                     overlap_optimizer=not args.serial_optimizer)
     loop.start(pick(0))
     it = 1
     for _ in range(3):
@@ -405,6 +406,7 @@ def main():
     ap.add_argument("--with-vae", action="store_true",
                     help="also time the step with the VAE encode of the next micro-batch (train_svd.py:948, 957-960) on a second "
                          "stream; reported as a second field, the headline metric stays UNet-only")
+    ap.add_argument("--serial-optimizer", action="store_true", help="real loop: the optimizer after the next clip's conditioners instead of beside them (A/B of TrainLoop(overlap_optimizer))")
     ap.add_argument("--serial-conditioners", action="store_true", help="real loop: CLIP embed after the VAE encode on one stream (A/B of TrainLoop(overlap_clip))")
     ap.add_argument("--no-real-loop", action="store_true",
                     help="skip the `real_loop` leg (the step inside svd_xtend_amd.loop.TrainLoop: a new pixel clip through VAE + CLIP + EDM prep every "

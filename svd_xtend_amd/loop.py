@@ -40,7 +40,7 @@ def rand_log_normal_reference(shape, loc: float = 0.0, scale: float = 1.0) -> to
 class TrainLoop:
     def __init__(self, trainer: Trainer, vae, image_encoder, conditioning_dropout_prob: Optional[float] = None, seed: int = 0,
                  use_graph: bool = True, ema=None, fps: int = 7, motion_bucket_id: int = 127, graph_conditioners: bool = True,
-                 reference_rng: bool = False, overlap_clip: bool = True):
+                 reference_rng: bool = False, overlap_clip: bool = True, overlap_optimizer: bool = True):
         """reference_rng: draw cond_sigmas (:954) and sigmas (:964) the reference's way -- on the host, from the process-global generator, in
         that order -- instead of on the device from this loop's generator: a run seeded with `torch.manual_seed` then walks the reference's
         sigma sequence.  (The Gaussian noise tensors stay device draws: the reference's come from the CUDA generator, which no other device
@@ -52,6 +52,9 @@ class TrainLoop:
         # captured conditioner graph.  Same arithmetic, same results; the two towers share nothing but the pixel clip.
         self.overlap_clip = overlap_clip and trainer.dev.type == "cuda"
         self._clip_stream = torch.cuda.Stream(device=trainer.dev) if self.overlap_clip else None
+        # overlap_optimizer: on one rank the captured optimizer (AdamW: HBM streaming, no matrix pipe) runs on a second stream beside the next
+        # clip's conditioners instead of after them (GraphedStep.opt_beside_side_work)
+        self.overlap_optimizer = overlap_optimizer
         self.p_drop = conditioning_dropout_prob
         self.use_graph = use_graph and trainer.dev.type == "cuda"
         self.ema = ema
@@ -177,6 +180,7 @@ class TrainLoop:
         if self.use_graph:
             # GraphedStep's warm-up pass is one real optimizer step on this batch; the loop counts it as step 1 (see step())
             self.graphed = GraphedStep(self.tr, self.batches)
+            self.graphed.opt_beside_side_work = self.overlap_optimizer
             self._after_step()
             self._warm = True
             if self.graph_conditioners:

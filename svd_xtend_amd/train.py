@@ -589,6 +589,8 @@ class GraphedStep:
         if len(batches) != trainer.grad_accum:
             raise ValueError(f"expected {trainer.grad_accum} micro-batch(es), got {len(batches)}")
         self.tr = trainer
+        self.opt_beside_side_work = True                 # __call__(side_work): the optimizer graph on a second stream beside the side work (one rank)
+        self._opt_stream = None
         self.graphs: List[torch.cuda.CUDAGraph] = []
         self.spans: List[list] = []                      # per graph segment: the flat-buffer slices whose gradients it completed
         tr = trainer
@@ -671,6 +673,20 @@ class GraphedStep:
             if multi and tr.overlap and i < len(self.spans):
                 for lo, hi in self.spans[i]:             # the gradient slices the segment just completed
                     tr._pending.append(((lo, hi), dist.all_reduce(tr.g_flat[lo:hi], op=dist.ReduceOp.SUM, group=tr.pg, async_op=True)))
+        if side_work is not None and not multi and self.opt_beside_side_work:
+            # one rank: nothing separates the optimizer from the side work (the next clip's frozen conditioners: they neither read nor write
+            # anything AdamW touches), and the two want different things of the chip -- AdamW streams 12.6 GB through HBM on no matrix pipe,
+            # the VAE encoder's convolutions live on the matrix pipes and the LDS.  The optimizer graph runs on a second stream beside
+            # the side work; the step ends when both have (round 6; TrainLoop(overlap_optimizer=False) / bench --serial-optimizer: in a row)
+            cur = torch.cuda.current_stream()
+            if self._opt_stream is None:
+                self._opt_stream = torch.cuda.Stream(device=tr.dev)
+            self._opt_stream.wait_stream(cur)
+            with torch.cuda.stream(self._opt_stream):
+                self.g_opt.replay()
+            side_work()
+            cur.wait_stream(self._opt_stream)
+            return
         tr.finish_grads(side_work)
         self.g_opt.replay()
 
