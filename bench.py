@@ -406,6 +406,7 @@ def main():
     ap.add_argument("--with-vae", action="store_true",
                     help="also time the step with the VAE encode of the next micro-batch (train_svd.py:948, 957-960) on a second "
                          "stream; reported as a second field, the headline metric stays UNet-only")
+    ap.add_argument("--rt", action="append", default=[], metavar="NAME=VALUE", help="set an ops.Runtime switch (developer A/B between two processes), e.g. --rt big_m_rules=0")
     ap.add_argument("--serial-optimizer", action="store_true", help="real loop: the optimizer after the next clip's conditioners instead of beside them (A/B of TrainLoop(overlap_optimizer))")
     ap.add_argument("--serial-conditioners", action="store_true", help="real loop: CLIP embed after the VAE encode on one stream (A/B of TrainLoop(overlap_clip))")
     ap.add_argument("--no-real-loop", action="store_true",
@@ -475,6 +476,11 @@ def main():
         with torch.device(dev):
             model.add_adapter(LoraConfig(r=args.lora_rank, lora_alpha=args.lora_rank, init_lora_weights="gaussian"))
     trainer = Trainer(model, dtype=dt, lr=1e-5, grad_accum=args.grad_accum, lora_param_dtype=args.lora_param_dtype)
+    for kv in args.rt:                                   # developer A/B of a Runtime switch between two processes (configurations whose two graphs
+        name, _, val = kv.partition("=")                 # do not fit one process: tools/ab_inproc.py is the same-process form)
+        if not hasattr(trainer.rt, name):
+            raise SystemExit(f"--rt {kv}: ops.Runtime has no attribute {name!r}")
+        setattr(trainer.rt, name, type(getattr(trainer.rt, name))(int(val)) if val.lstrip("-").isdigit() else val)
     trainer.rt.gemm_variant = args.gemm_variant
     schedules = {}
 
